@@ -1,0 +1,83 @@
+"""ctypes binding of libbfstark_hip.so (C ABI: include/bfstark.h).
+
+There is no CPU fallback: if the library is missing or a HIP call fails, the caller gets an exception.
+Error codes that correspond to the reference's `assert`s are raised as AssertionError with the reference's
+message, everything else as RuntimeError.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbfstark_hip.so")
+
+u64 = ctypes.c_uint64
+u32 = ctypes.c_uint32
+vp = ctypes.c_void_p
+sz = ctypes.c_size_t
+ci = ctypes.c_int
+
+BFS_OK = 0
+ASSERT_CODES = {1, 2, 3, 4, 5, 8, 9}
+
+_SIGNATURES = {
+    "bfs_version": (ci, []),
+    "bfs_last_error": (ctypes.c_char_p, []),
+    "bfs_device_count": (ci, [ctypes.POINTER(ci)]),
+    "bfs_set_device": (ci, [ci]),
+    "bfs_malloc": (ci, [ctypes.POINTER(vp), sz]),
+    "bfs_free": (ci, [vp]),
+    "bfs_memcpy_h2d": (ci, [vp, vp, sz, vp]),
+    "bfs_memcpy_d2h": (ci, [vp, vp, sz, vp]),
+    "bfs_memcpy_d2d": (ci, [vp, vp, sz, vp]),
+    "bfs_memset": (ci, [vp, ci, sz, vp]),
+    "bfs_stream_synchronize": (ci, [vp]),
+    "bfs_event_create": (ci, [ctypes.POINTER(vp)]),
+    "bfs_event_destroy": (ci, [vp]),
+    "bfs_event_record": (ci, [vp, vp]),
+    "bfs_event_elapsed_ms": (ci, [vp, vp, ctypes.POINTER(ctypes.c_float)]),
+    "bfs_gl_primitive_root": (u64, [u32]),
+    "bfs_gl_mul": (u64, [u64, u64]),
+    "bfs_gl_inv": (u64, [u64]),
+    "bfs_gl_pow": (u64, [u64, u64]),
+    "bfs_gl_ntt": (ci, [vp, u64, u64, vp, u64, u32, u32, u64, u64, u64, vp]),
+    "bfs_gl_scale": (ci, [vp, vp, u64, u64, u32, u64, vp]),
+    "bfs_gl_mul_pointwise": (ci, [vp, vp, vp, u64, vp]),
+    "bfs_gl_batch_inverse": (ci, [vp, vp, u64, vp]),
+}
+
+_lib = None
+
+
+class BackendUnavailable(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    """names include/bfstark.h declares (used by the CPU test that checks the .so exports all of them)."""
+    return sorted(_SIGNATURES)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BackendUnavailable(
+            "libbfstark_hip.so is not built (%s). Run `python -m stark_brainfuck_amd.build`; "
+            "there is no CPU fallback for the hot path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc == BFS_OK:
+        return
+    msg = load().bfs_last_error().decode("utf-8", "replace")
+    if rc in ASSERT_CODES:
+        raise AssertionError(msg)
+    raise RuntimeError("libbfstark_hip: error %d: %s" % (rc, msg))

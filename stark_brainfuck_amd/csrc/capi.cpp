@@ -1,0 +1,73 @@
+// capi.cpp -- extern "C" entry points of libbfstark_hip.so (declarations + reference citations: include/bfstark.h)
+#include "../../include/bfstark.h"
+
+#include "runtime.hpp"
+
+namespace bfs {
+int mul_pointwise_launch(const u64* a, const u64* b, u64* out, u64 n, hipStream_t stream);
+int batch_inverse_launch(const u64* in, u64* out, u64 n, hipStream_t stream);
+int scale_launch(const u64* in, u64* out, u64 n, u64 stride, u32 batch, u64 factor, hipStream_t stream);
+}
+
+using namespace bfs;
+
+extern "C" {
+
+int bfs_version(void) { return 1; }
+const char* bfs_last_error(void) { return last_error(); }
+
+int bfs_device_count(int* count) { BFS_HIP(hipGetDeviceCount(count)); return BFS_OK; }
+int bfs_set_device(int device) { BFS_HIP(hipSetDevice(device)); return BFS_OK; }
+int bfs_malloc(void** d_ptr, size_t bytes) { BFS_HIP(hipMalloc(d_ptr, bytes)); return BFS_OK; }
+int bfs_free(void* d_ptr) { BFS_HIP(hipFree(d_ptr)); return BFS_OK; }
+int bfs_memcpy_h2d(void* d, const void* h, size_t bytes, void* stream) {
+    BFS_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    BFS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return BFS_OK;
+}
+int bfs_memcpy_d2h(void* h, const void* d, size_t bytes, void* stream) {
+    BFS_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    BFS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return BFS_OK;
+}
+int bfs_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+    BFS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return BFS_OK;
+}
+int bfs_memset(void* d, int value, size_t bytes, void* stream) {
+    BFS_HIP(hipMemsetAsync(d, value, bytes, (hipStream_t)stream));
+    return BFS_OK;
+}
+int bfs_stream_synchronize(void* stream) { BFS_HIP(hipStreamSynchronize((hipStream_t)stream)); return BFS_OK; }
+int bfs_event_create(void** event) { hipEvent_t e; BFS_HIP(hipEventCreate(&e)); *event = (void*)e; return BFS_OK; }
+int bfs_event_destroy(void* event) { BFS_HIP(hipEventDestroy((hipEvent_t)event)); return BFS_OK; }
+int bfs_event_record(void* event, void* stream) { BFS_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream)); return BFS_OK; }
+int bfs_event_elapsed_ms(void* start, void* stop, float* ms) {
+    BFS_HIP(hipEventSynchronize((hipEvent_t)stop));
+    BFS_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return BFS_OK;
+}
+
+uint64_t bfs_gl_primitive_root(uint32_t log_n) { return gl_primitive_root(log_n); }
+uint64_t bfs_gl_mul(uint64_t a, uint64_t b) { return gl_mul(a % GL_P, b % GL_P); }
+uint64_t bfs_gl_inv(uint64_t a) { return gl_inv(a % GL_P); }
+uint64_t bfs_gl_pow(uint64_t a, uint64_t e) { return gl_pow(a % GL_P, e); }
+
+int bfs_gl_ntt(const uint64_t* d_in, uint64_t n_in, uint64_t in_stride, uint64_t* d_out, uint64_t out_stride, uint32_t log_n,
+               uint32_t batch, uint64_t root, uint64_t coset_shift, uint64_t post_scale, void* stream) {
+    return ntt_launch(d_in, n_in, in_stride, d_out, out_stride, log_n, batch, root, coset_shift, post_scale, (hipStream_t)stream);
+}
+
+int bfs_gl_scale(const uint64_t* d_in, uint64_t* d_out, uint64_t n, uint64_t stride, uint32_t batch, uint64_t factor, void* stream) {
+    return scale_launch(d_in, d_out, n, stride, batch, factor, (hipStream_t)stream);
+}
+
+int bfs_gl_mul_pointwise(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, uint64_t n, void* stream) {
+    return mul_pointwise_launch(d_a, d_b, d_out, n, (hipStream_t)stream);
+}
+
+int bfs_gl_batch_inverse(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void* stream) {
+    return batch_inverse_launch(d_in, d_out, n, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,115 @@
+// gl.hpp -- arithmetic in F_p, p = 2^64 - 2^32 + 1, and in F_p[X]/(X^3 - X + 1), for gfx950 device code
+// and for the host-side planner.  Replaces the reference's boxed-bigint element classes:
+//   BaseField.add/subtract/multiply/negate/inverse      /root/reference/code/algebra.py:89-108
+//   BaseFieldElement.__xor__ (square-and-multiply)       algebra.py:39-46
+//   ExtensionField.multiply/add/subtract/inverse         extension_field.py:65-86
+// All values are canonical residues in [0, p) stored as uint64_t; every function returns canonical values,
+// so results are bit-identical to the reference's Python ints.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define BFS_HD __host__ __device__ __forceinline__
+#else
+#define BFS_HD inline
+#endif
+
+namespace bfs {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+typedef unsigned __int128 u128;
+
+constexpr u64 GL_P = 0xFFFFFFFF00000001ULL;
+constexpr u64 GL_EPS = 0xFFFFFFFFULL;  // 2^64 mod p = 2^32 - 1
+
+BFS_HD u64 gl_add(u64 a, u64 b) {
+    u64 s = a + b;
+    // a, b < p: either the 64-bit add wrapped (then s + EPS is the canonical value) or s may be >= p
+    if (s < a) return s + GL_EPS;
+    return s >= GL_P ? s - GL_P : s;
+}
+
+BFS_HD u64 gl_sub(u64 a, u64 b) {
+    u64 d = a - b;
+    return a < b ? d - GL_EPS : d;  // borrow: add p (== subtract EPS in wrapped arithmetic)
+}
+
+BFS_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
+
+// reduce a 128-bit value hi*2^64 + lo.  2^64 = 2^32 - 1, 2^96 = -1 (mod p).
+BFS_HD u64 gl_reduce128(u64 hi, u64 lo) {
+    u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
+    u64 t0 = lo - hi_hi;
+    if (lo < hi_hi) t0 -= GL_EPS;          // borrow -> +p ; no second borrow: t0 wrapped >= 2^64 - 2^32 + 1
+    u64 t1 = hi_lo * GL_EPS;               // (hi_lo << 32) - hi_lo, fits 64 bits
+    u64 r = t0 + t1;
+    if (r < t1) r += GL_EPS;               // carry -> +2^64 = +EPS ; cannot carry twice
+    return r >= GL_P ? r - GL_P : r;
+}
+
+BFS_HD u64 gl_mul(u64 a, u64 b) {
+    u128 z = (u128)a * b;
+    return gl_reduce128((u64)(z >> 64), (u64)z);
+}
+
+BFS_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
+
+BFS_HD u64 gl_pow(u64 a, u64 e) {
+    u64 acc = 1;
+    while (e) {
+        if (e & 1) acc = gl_mul(acc, a);
+        a = gl_sqr(a);
+        e >>= 1;
+    }
+    return acc;
+}
+
+// a^(p-2); inverse(0) = 0, which is also what the reference's xgcd-based inverse returns (algebra.py:101-103)
+BFS_HD u64 gl_inv(u64 a) { return gl_pow(a, GL_P - 2); }
+
+// ---- cubic extension, X^3 = X - 1.  Limbs low degree first (c0, c1, c2). ----
+struct Xfe {
+    u64 c[3];
+};
+
+BFS_HD Xfe xfe_add(const Xfe& a, const Xfe& b) { return Xfe{{gl_add(a.c[0], b.c[0]), gl_add(a.c[1], b.c[1]), gl_add(a.c[2], b.c[2])}}; }
+BFS_HD Xfe xfe_sub(const Xfe& a, const Xfe& b) { return Xfe{{gl_sub(a.c[0], b.c[0]), gl_sub(a.c[1], b.c[1]), gl_sub(a.c[2], b.c[2])}}; }
+BFS_HD Xfe xfe_scale(const Xfe& a, u64 s) { return Xfe{{gl_mul(a.c[0], s), gl_mul(a.c[1], s), gl_mul(a.c[2], s)}}; }
+
+// schoolbook 3x3 then fold X^3 -> X - 1, X^4 -> X^2 - X:  r0 = d0 - d3, r1 = d1 + d3 - d4, r2 = d2 + d4
+BFS_HD Xfe xfe_mul(const Xfe& a, const Xfe& b) {
+    u64 d0 = gl_mul(a.c[0], b.c[0]);
+    u64 d1 = gl_add(gl_mul(a.c[0], b.c[1]), gl_mul(a.c[1], b.c[0]));
+    u64 d2 = gl_add(gl_add(gl_mul(a.c[0], b.c[2]), gl_mul(a.c[1], b.c[1])), gl_mul(a.c[2], b.c[0]));
+    u64 d3 = gl_add(gl_mul(a.c[1], b.c[2]), gl_mul(a.c[2], b.c[1]));
+    u64 d4 = gl_mul(a.c[2], b.c[2]);
+    return Xfe{{gl_sub(d0, d3), gl_sub(gl_add(d1, d3), d4), gl_add(d2, d4)}};
+}
+
+// inverse by solving the 3x3 system (a * b = 1); host-side use only (Fiat-Shamir scalars), not a hot loop
+inline Xfe xfe_inv(const Xfe& a) {
+    Xfe x{{1, 0, 0}}, X1{{0, 1, 0}};
+    u64 m[3][3];  // m[i][j] = coefficient i of a * X^j
+    for (int j = 0; j < 3; ++j) {
+        Xfe col = xfe_mul(a, x);
+        for (int i = 0; i < 3; ++i) m[i][j] = col.c[i];
+        x = xfe_mul(x, X1);
+    }
+    u64 c00 = gl_sub(gl_mul(m[1][1], m[2][2]), gl_mul(m[1][2], m[2][1]));
+    u64 c01 = gl_sub(gl_mul(m[1][2], m[2][0]), gl_mul(m[1][0], m[2][2]));
+    u64 c02 = gl_sub(gl_mul(m[1][0], m[2][1]), gl_mul(m[1][1], m[2][0]));
+    u64 det = gl_add(gl_add(gl_mul(m[0][0], c00), gl_mul(m[0][1], c01)), gl_mul(m[0][2], c02));
+    u64 di = gl_inv(det);
+    return Xfe{{gl_mul(c00, di), gl_mul(c01, di), gl_mul(c02, di)}};
+}
+
+// algebra.py:122-136: the reference's fixed 2^32-th root of unity squared down to order 2^log_n
+inline u64 gl_primitive_root(u32 log_n) {
+    u64 r = 1753635133440165772ULL;
+    for (u32 k = 32; k > log_n; --k) r = gl_sqr(r);
+    return r;
+}
+
+}  // namespace bfs

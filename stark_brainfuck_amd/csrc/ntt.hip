@@ -1,0 +1,179 @@
+// ntt.hip -- gfx950 kernels and launcher for bfs_gl_ntt() (algorithm and reference citations: ntt_core.hpp)
+#include "runtime.hpp"
+
+namespace bfs {
+
+template <int B1, int B2, int B3>
+__global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) u64 smem[];
+    ntt_stage1<B1, B2, B3>(a, smem, threadIdx.x, blockIdx.x, blockIdx.y);
+    if constexpr (B2 > 0) {
+        __syncthreads();
+        ntt_stage2<B1, B2, B3>(a, smem, threadIdx.x, blockIdx.x, blockIdx.y);
+    }
+    if constexpr (B3 > 0) {
+        __syncthreads();
+        ntt_stage3<B1, B2, B3>(a, smem, threadIdx.x, blockIdx.x, blockIdx.y);
+    }
+}
+
+__global__ void ntt_small_kernel(const SmallArgs a) { ntt_small_body(a, threadIdx.x, blockIdx.y); }
+
+template <int B1, int B2, int B3>
+static int launch_tile(const PassArgs& a, u32 grid_x, u32 batch, hipStream_t stream) {
+    constexpr u32 S = B1 + B2 + B3;
+    const u32 threads = ((1u << S) << a.logC) >> 4;
+    const size_t lds = (B2 > 0) ? tile_lds_elems(S, a.logC, a.pad_shift, a.pad_amount) * sizeof(u64) : 0;
+    hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3>), dim3(grid_x, batch), dim3(threads), lds, stream, a);
+    BFS_HIP(hipGetLastError());
+    return BFS_OK;
+}
+
+static int dispatch_tile(const PassArgs& a, u32 S, u32 grid_x, u32 batch, hipStream_t stream) {
+    switch (S) {
+        case 4: return launch_tile<4, 0, 0>(a, grid_x, batch, stream);
+        case 5: return launch_tile<4, 1, 0>(a, grid_x, batch, stream);
+        case 6: return launch_tile<4, 2, 0>(a, grid_x, batch, stream);
+        case 7: return launch_tile<4, 3, 0>(a, grid_x, batch, stream);
+        case 8: return launch_tile<4, 4, 0>(a, grid_x, batch, stream);
+        case 9: return launch_tile<4, 4, 1>(a, grid_x, batch, stream);
+        case 10: return launch_tile<4, 4, 2>(a, grid_x, batch, stream);
+        case 11: return launch_tile<4, 4, 3>(a, grid_x, batch, stream);
+        case 12: return launch_tile<4, 4, 4>(a, grid_x, batch, stream);
+    }
+    set_error("internal: no tile kernel for a %u-bit digit", S);
+    return BFS_ERR_BAD_ARG;
+}
+
+enum { TBL_W_LO = 1, TBL_W_HI, TBL_T_IN, TBL_T_IN_LAST, TBL_S_LO, TBL_S_HI };
+
+static int get_tables(const NttPlan& p, u64 root, u64 shift, u64 post_scale, NttTables& tb) {
+    tb = NttTables{};
+    tb.lo_bits = p.lo_bits;
+    tb.t_in_log = p.t_in_log;
+    const u64 kb = ((u64)p.log_n << 8);
+    bool have = cached_table_lookup(root, kb | TBL_W_LO, 0, &tb.w_lo) && cached_table_lookup(root, kb | TBL_W_HI, 0, &tb.w_hi) &&
+                cached_table_lookup(root, kb | TBL_T_IN, 0, &tb.t_in) &&
+                cached_table_lookup(root, kb | TBL_T_IN_LAST, post_scale, &tb.t_in_last);
+    if (!have) {
+        NttHostTables ht;
+        ntt_build_tables(p, root, post_scale, ht);
+        BFS_TRY(cached_table(root, kb | TBL_W_LO, 0, ht.w_lo.data(), ht.w_lo.size(), &tb.w_lo));
+        BFS_TRY(cached_table(root, kb | TBL_W_HI, 0, ht.w_hi.data(), ht.w_hi.size(), &tb.w_hi));
+        BFS_TRY(cached_table(root, kb | TBL_T_IN, 0, ht.t_in.data(), ht.t_in.size(), &tb.t_in));
+        BFS_TRY(cached_table(root, kb | TBL_T_IN_LAST, post_scale, ht.t_in_last.data(), ht.t_in_last.size(), &tb.t_in_last));
+    }
+    if (shift != 1) {
+        if (!(cached_table_lookup(shift, kb | TBL_S_LO, 0, &tb.s_lo) && cached_table_lookup(shift, kb | TBL_S_HI, 0, &tb.s_hi))) {
+            CosetHostTables ct;
+            ntt_build_coset_tables(p, shift, ct);
+            BFS_TRY(cached_table(shift, kb | TBL_S_LO, 0, ct.s_lo.data(), ct.s_lo.size(), &tb.s_lo));
+            BFS_TRY(cached_table(shift, kb | TBL_S_HI, 0, ct.s_hi.data(), ct.s_hi.size(), &tb.s_hi));
+        }
+    }
+    return BFS_OK;
+}
+
+int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_stride, u32 log_n, u32 batch, u64 root,
+               u64 shift, u64 post_scale, hipStream_t stream) {
+    if (log_n > 32) { set_error("field has no 2^%u-th root of unity (algebra.py:124-125)", log_n); return BFS_ERR_BAD_ARG; }
+    const u64 n = 1ull << log_n;
+    if (n_in > n) { set_error("more coefficients (%llu) than the evaluation order (%llu)", (unsigned long long)n_in, (unsigned long long)n); return BFS_ERR_TOO_MANY_COEFFS; }
+    if (batch == 0) return BFS_OK;
+    if (batch > 65535) { set_error("batch %u exceeds 65535", batch); return BFS_ERR_BAD_ARG; }
+    int rc = ntt_check_root(root, log_n);
+    if (rc == BFS_ERR_NOT_ROOT) { set_error("primitive root must be nth root of unity, where n is %llu", (unsigned long long)n); return rc; }
+    if (rc == BFS_ERR_NOT_PRIMITIVE) { set_error("primitive root %llu is not primitive nth root of unity, where n is %llu", (unsigned long long)root, (unsigned long long)n); return rc; }
+    NttPlan p;
+    if (!ntt_make_plan(log_n, root, p)) { set_error("no NTT plan for log_n = %u", log_n); return BFS_ERR_BAD_ARG; }
+    if (p.npass == 0) {
+        SmallArgs a{d_in, d_out, in_stride, out_stride, n_in, log_n, root, shift, post_scale};
+        hipLaunchKernelGGL(ntt_small_kernel, dim3(1, batch), dim3(64), 0, stream, a);
+        BFS_HIP(hipGetLastError());
+        return BFS_OK;
+    }
+    NttTables tb;
+    BFS_TRY(get_tables(p, root, shift, post_scale, tb));
+    u64* ws = nullptr;
+    if (p.npass > 1) {
+        void* w = nullptr;
+        BFS_TRY(workspace(0, (size_t)n * batch * sizeof(u64), stream, &w));
+        ws = (u64*)w;
+    }
+    for (u32 t = 0; t < p.npass; ++t) {
+        const bool first = t == 0, last = t + 1 == p.npass;
+        PassArgs a = ntt_pass_args(p, t, first ? d_in : ws, last ? d_out : ws, first ? in_stride : n, last ? out_stride : n,
+                                   first ? n_in : n, tb, shift != 1, shift, post_scale);
+        u32 grid_x = (u32)((n >> p.pass_bits[t]) >> p.logC[t]);
+        BFS_TRY(dispatch_tile(a, p.pass_bits[t], grid_x, batch, stream));
+    }
+    return BFS_OK;
+}
+
+// ---- element-wise kernels (ntt.py:76, ntt.py:177-188, univariate.py:168-169) ----
+__global__ void gl_mul_pointwise_kernel(const u64* a, const u64* b, u64* out, u64 n) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) out[i] = gl_mul(a[i], b[i]);
+}
+
+__global__ void gl_inverse_kernel(const u64* in, u64* out, u64 n, unsigned int* zero_flag) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        u64 v = in[i];
+        if (v == 0) atomicOr(zero_flag, 1u);
+        out[i] = gl_inv(v);
+    }
+}
+
+__global__ void gl_scale_kernel(const u64* in, u64* out, u64 n, u64 stride, const u64* s_lo, const u64* s_hi, u32 lo_bits) {
+    const u64 b = blockIdx.y;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x)
+        out[b * stride + i] = gl_mul(in[b * stride + i], tw_pow(s_lo, s_hi, lo_bits, i));
+}
+
+static u32 grid_for(u64 n, u32 block) {
+    u64 g = (n + block - 1) / block;
+    return (u32)(g > 2048 ? 2048 : (g ? g : 1));
+}
+
+int mul_pointwise_launch(const u64* a, const u64* b, u64* out, u64 n, hipStream_t stream) {
+    if (!n) return BFS_OK;
+    hipLaunchKernelGGL(gl_mul_pointwise_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, a, b, out, n);
+    BFS_HIP(hipGetLastError());
+    return BFS_OK;
+}
+
+int batch_inverse_launch(const u64* in, u64* out, u64 n, hipStream_t stream) {
+    if (!n) return BFS_OK;
+    void* w = nullptr;
+    BFS_TRY(workspace(1, 256, stream, &w));
+    BFS_HIP(hipMemsetAsync(w, 0, 4, stream));
+    hipLaunchKernelGGL(gl_inverse_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, in, out, n, (unsigned int*)w);
+    BFS_HIP(hipGetLastError());
+    unsigned int flag = 0;
+    BFS_HIP(hipMemcpyAsync(&flag, w, 4, hipMemcpyDeviceToHost, stream));
+    BFS_HIP(hipStreamSynchronize(stream));
+    if (flag) { set_error("batch inverse does not work when input contains a zero"); return BFS_ERR_ZERO_IN_BATCH_INVERSE; }
+    return BFS_OK;
+}
+
+int scale_launch(const u64* in, u64* out, u64 n, u64 stride, u32 batch, u64 factor, hipStream_t stream) {
+    if (!n || !batch) return BFS_OK;
+    u32 log_n = 0;
+    while ((1ull << log_n) < n) ++log_n;
+    // power tables of `factor` split at lo_bits, not cached (arbitrary factors would pile up)
+    u32 lo_bits = (log_n + 1) / 2, hi_bits = log_n - lo_bits;
+    std::vector<u64> lo, hi;
+    fill_powers(lo, 1ull << lo_bits, factor, 1);
+    fill_powers(hi, 1ull << hi_bits, gl_pow(factor, 1ull << lo_bits), 1);
+    void* w = nullptr;
+    BFS_TRY(workspace(2, (lo.size() + hi.size()) * sizeof(u64), stream, &w));
+    u64* d_lo = (u64*)w;
+    u64* d_hi = d_lo + lo.size();
+    BFS_HIP(hipMemcpyAsync(d_lo, lo.data(), lo.size() * sizeof(u64), hipMemcpyHostToDevice, stream));
+    BFS_HIP(hipMemcpyAsync(d_hi, hi.data(), hi.size() * sizeof(u64), hipMemcpyHostToDevice, stream));
+    BFS_HIP(hipStreamSynchronize(stream));  // lo/hi are pageable host vectors about to go out of scope
+    hipLaunchKernelGGL(gl_scale_kernel, dim3(grid_for(n, 256), batch), dim3(256), 0, stream, in, out, n, stride, d_lo, d_hi, lo_bits);
+    BFS_HIP(hipGetLastError());
+    return BFS_OK;
+}
+
+}  // namespace bfs

@@ -1,0 +1,154 @@
+// ntt_plan.hpp -- host-side planning for bfs_gl_ntt(): pass split, tile shapes, twiddle tables.
+// Pure C++ (no HIP calls) so that the planner is also exercised by the host emulation test.
+// Validation mirrors the reference's asserts: /root/reference/code/ntt.py:5-6 (power of two),
+// :13-14 (w^n == 1), :15-16 (w^(n/2) != 1).
+#pragma once
+#include <vector>
+
+#include "../../include/bfstark.h"
+#include "ntt_core.hpp"
+
+namespace bfs {
+
+
+constexpr u32 NTT_TILE_LOG = 12;      // 4096 elements (32 KiB) per tile in the multi-pass regime
+constexpr u32 NTT_MAX_PASS_BITS = 8;  // digits of a multi-pass plan are <= 2^8 so tiles keep >= 16 columns (128 B segments)
+constexpr u32 NTT_SMALL_LOG = 3;      // n <= 8 goes through the direct small kernel
+
+struct NttPlan {
+    u32 log_n = 0;
+    u32 npass = 0;
+    u32 pass_bits[4] = {0, 0, 0, 0};
+    u32 logC[4] = {0, 0, 0, 0};
+    u32 uinv = 1;
+    u32 lo_bits = 0;
+    u32 t_in_log = 0;
+};
+
+inline int ntt_check_root(u64 root, u32 log_n) {
+    if (log_n == 0) return BFS_OK;  // ntt.py:8-9: length <= 1 returns its input unchecked
+    if (gl_pow(root, 1ull << log_n) != 1) return BFS_ERR_NOT_ROOT;
+    if (gl_pow(root, 1ull << (log_n - 1)) == 1) return BFS_ERR_NOT_PRIMITIVE;
+    return BFS_OK;
+}
+
+// u with root^(n/16) = 2^(12u); returns u^-1 mod 16
+inline u32 ntt_uinv(u64 root, u32 log_n) {
+    if (log_n < 4) return 1;
+    u64 w16 = gl_pow(root, 1ull << (log_n - 4));
+    u64 c = cx_pow2(12), acc = 1;
+    u32 u = 0;
+    for (u32 i = 1; i < 16; ++i) {
+        acc = gl_mul(acc, c);
+        if (acc == w16) { u = i; break; }
+    }
+    for (u32 v = 1; v < 16; v += 2)
+        if (((u * v) & 15) == 1) return v;
+    return 1;
+}
+
+inline bool ntt_make_plan(u32 log_n, u64 root, NttPlan& p) {
+    p = NttPlan();
+    p.log_n = log_n;
+    p.uinv = ntt_uinv(root, log_n);
+    p.lo_bits = (log_n + 1) / 2;
+    p.t_in_log = log_n < 12 ? log_n : 12;
+    if (log_n <= NTT_SMALL_LOG) { p.npass = 0; return true; }
+    if (log_n <= NTT_TILE_LOG) {
+        p.npass = 1; p.pass_bits[0] = log_n; p.logC[0] = 0;
+        return true;
+    }
+    u32 m = (log_n + NTT_MAX_PASS_BITS - 1) / NTT_MAX_PASS_BITS;
+    if (m > 4) return false;
+    // enumerate splits S_0..S_{m-1} in [4,8]; keep tiles at 4096 elements; pick the most balanced feasible one
+    u32 best[4] = {0, 0, 0, 0};
+    u32 best_score = ~0u;
+    u32 s[4];
+    u32 total = 1;
+    for (u32 i = 0; i < m; ++i) total *= 5;
+    for (u32 code = 0; code < total; ++code) {
+        u32 c = code, sum = 0, mx = 0, mn = 99;
+        for (u32 i = 0; i < m; ++i) { s[i] = 4 + c % 5; c /= 5; sum += s[i]; mx = s[i] > mx ? s[i] : mx; mn = s[i] < mn ? s[i] : mn; }
+        if (sum != log_n) continue;
+        bool ok = true;
+        u32 done = 0;
+        for (u32 t = 0; t + 1 < m && ok; ++t) {
+            done += s[t];
+            if (NTT_TILE_LOG - s[t] > log_n - done) ok = false;  // C_t <= L_t
+        }
+        if (NTT_TILE_LOG - s[m - 1] > s[0]) ok = false;          // final pass: C <= n_1
+        if (!ok) continue;
+        u32 score = (mx - mn) * 16 + (8 - s[m - 1]);             // balanced first, then a long last digit
+        if (score < best_score) { best_score = score; for (u32 i = 0; i < m; ++i) best[i] = s[i]; }
+    }
+    if (best_score == ~0u) return false;
+    p.npass = m;
+    for (u32 i = 0; i < m; ++i) { p.pass_bits[i] = best[i]; p.logC[i] = NTT_TILE_LOG - best[i]; }
+    return true;
+}
+
+// powers table helper: out[i] = base^i * scale
+inline void fill_powers(std::vector<u64>& out, size_t count, u64 base, u64 scale) {
+    out.resize(count);
+    u64 v = scale;
+    for (size_t i = 0; i < count; ++i) { out[i] = v; v = gl_mul(v, base); }
+}
+
+struct NttHostTables {
+    std::vector<u64> w_lo, w_hi, t_in, t_in_last;
+};
+
+inline void ntt_build_tables(const NttPlan& p, u64 root, u64 post_scale, NttHostTables& t) {
+    u32 hi_bits = p.log_n - p.lo_bits;
+    fill_powers(t.w_lo, 1ull << p.lo_bits, root, 1);
+    fill_powers(t.w_hi, 1ull << hi_bits, gl_pow(root, 1ull << p.lo_bits), 1);
+    u64 omega = gl_pow(root, 1ull << (p.log_n - p.t_in_log));
+    fill_powers(t.t_in, 1ull << p.t_in_log, omega, 1);
+    fill_powers(t.t_in_last, 1ull << p.t_in_log, omega, post_scale);
+}
+
+struct CosetHostTables {
+    std::vector<u64> s_lo, s_hi;
+};
+
+inline void ntt_build_coset_tables(const NttPlan& p, u64 shift, CosetHostTables& t) {
+    u32 hi_bits = p.log_n - p.lo_bits;
+    fill_powers(t.s_lo, 1ull << p.lo_bits, shift, 1);
+    fill_powers(t.s_hi, 1ull << hi_bits, gl_pow(shift, 1ull << p.lo_bits), 1);
+}
+
+// default LDS padding for a pass (tuned per configuration in ntt.hip; see DESIGN.md "LDS layout")
+inline void ntt_default_padding(u32 /*S*/, u32 /*logC*/, u32 /*mode*/, u32& pad_shift, u32& pad_amount) {
+    pad_shift = 8;
+    pad_amount = 2;
+}
+
+// fill the per-pass kernel arguments (pointers are whatever address space the caller runs in)
+inline PassArgs ntt_pass_args(const NttPlan& p, u32 t, const u64* in, u64* out, u64 in_stride, u64 out_stride,
+                              u64 n_in, const NttTables& tb, bool has_coset, u64 shift, u64 post_scale) {
+    PassArgs a{};
+    a.in = in; a.out = out;
+    a.in_batch_stride = in_stride; a.out_batch_stride = out_stride;
+    a.n_in = n_in;
+    a.log_n = p.log_n;
+    a.mode = (t + 1 == p.npass) ? PASS_FINAL : PASS_COLUMN;
+    a.logC = p.logC[t];
+    a.pass_index = t;
+    a.npass = p.npass;
+    a.pass_bits = p.pass_bits[0] | (p.pass_bits[1] << 8) | (p.pass_bits[2] << 16) | (p.pass_bits[3] << 24);
+    a.uinv = p.uinv;
+    a.has_coset = (t == 0 && has_coset) ? 1 : 0;
+    a.post_scale = (a.mode == PASS_FINAL) ? post_scale : 1;
+    a.tb = tb;
+    if (a.has_coset) {
+        u32 S = p.pass_bits[0];
+        u32 b1 = S < 4 ? S : 4;
+        u32 sh1 = S - b1;
+        u64 stride = (a.mode == PASS_COLUMN) ? ((1ull << (p.log_n - S)) << sh1) : (1ull << sh1);
+        a.coset_delta = gl_pow(shift, stride);
+    }
+    ntt_default_padding(p.pass_bits[t], a.logC, a.mode, a.pad_shift, a.pad_amount);
+    return a;
+}
+
+}  // namespace bfs

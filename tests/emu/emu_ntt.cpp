@@ -1,0 +1,82 @@
+// Host emulation of the NTT tile kernels (TEST INFRASTRUCTURE, never part of the product path).
+// Compiles stark_brainfuck_amd/csrc/ntt_core.hpp for the host and runs every (block, thread) of every pass
+// sequentially, stage by stage -- __syncthreads() becomes "finish the stage for all threads of the block".
+// Lets tests/test_emulation.py check the planner and all index/twiddle arithmetic against the oracle on CPU.
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../stark_brainfuck_amd/csrc/ntt_plan.hpp"
+
+using namespace bfs;
+
+template <int B1, int B2, int B3>
+static void run_pass(const PassArgs& a, u32 grid_x, u32 batch) {
+    const u32 S = B1 + B2 + B3;
+    const u32 W = ((1u << S) << a.logC) >> 4;
+    std::vector<u64> smem(tile_lds_elems(S, a.logC, a.pad_shift, a.pad_amount));
+    for (u32 by = 0; by < batch; ++by)
+        for (u32 bx = 0; bx < grid_x; ++bx) {
+            for (u32 t = 0; t < W; ++t) ntt_stage1<B1, B2, B3>(a, smem.data(), t, bx, by);
+            if (B2 > 0) for (u32 t = 0; t < W; ++t) ntt_stage2<B1, B2, B3>(a, smem.data(), t, bx, by);
+            if (B3 > 0) for (u32 t = 0; t < W; ++t) ntt_stage3<B1, B2, B3>(a, smem.data(), t, bx, by);
+        }
+}
+
+static void dispatch(const PassArgs& a, u32 S, u32 grid_x, u32 batch) {
+    switch (S) {
+        case 4: run_pass<4, 0, 0>(a, grid_x, batch); break;
+        case 5: run_pass<4, 1, 0>(a, grid_x, batch); break;
+        case 6: run_pass<4, 2, 0>(a, grid_x, batch); break;
+        case 7: run_pass<4, 3, 0>(a, grid_x, batch); break;
+        case 8: run_pass<4, 4, 0>(a, grid_x, batch); break;
+        case 9: run_pass<4, 4, 1>(a, grid_x, batch); break;
+        case 10: run_pass<4, 4, 2>(a, grid_x, batch); break;
+        case 11: run_pass<4, 4, 3>(a, grid_x, batch); break;
+        case 12: run_pass<4, 4, 4>(a, grid_x, batch); break;
+        default: abort();
+    }
+}
+
+extern "C" int emu_gl_ntt(const u64* in, u64 n_in, u64 in_stride, u64* out, u64 out_stride, u32 log_n, u32 batch,
+                          u64 root, u64 shift, u64 post_scale) {
+    int rc = ntt_check_root(root, log_n);
+    if (rc) return rc;
+    const u64 n = 1ull << log_n;
+    if (n_in > n) return BFS_ERR_TOO_MANY_COEFFS;
+    NttPlan p;
+    if (!ntt_make_plan(log_n, root, p)) return BFS_ERR_BAD_ARG;
+    if (p.npass == 0) {
+        SmallArgs a{in, out, in_stride, out_stride, n_in, log_n, root, shift, post_scale};
+        for (u32 b = 0; b < batch; ++b)
+            for (u32 k = 0; k < n; ++k) ntt_small_body(a, k, b);
+        return 0;
+    }
+    NttHostTables ht;
+    ntt_build_tables(p, root, post_scale, ht);
+    CosetHostTables ct;
+    const bool coset = shift != 1;
+    if (coset) ntt_build_coset_tables(p, shift, ct);
+    NttTables tb{ht.w_lo.data(), ht.w_hi.data(), p.lo_bits, p.t_in_log, ht.t_in.data(), ht.t_in_last.data(),
+                 coset ? ct.s_lo.data() : nullptr, coset ? ct.s_hi.data() : nullptr};
+    std::vector<u64> ws;
+    if (p.npass > 1) ws.resize((size_t)n * batch);
+    for (u32 t = 0; t < p.npass; ++t) {
+        const bool first = t == 0, last = t + 1 == p.npass;
+        const u64* src = first ? in : ws.data();
+        u64* dst = last ? out : ws.data();
+        PassArgs a = ntt_pass_args(p, t, src, dst, first ? in_stride : n, last ? out_stride : n, first ? n_in : n, tb,
+                                   coset, shift, post_scale);
+        u32 grid_x = (u32)((n >> p.pass_bits[t]) >> p.logC[t]);
+        dispatch(a, p.pass_bits[t], grid_x, batch);
+    }
+    return 0;
+}
+
+extern "C" int emu_plan(u32 log_n, u64 root, u32* npass, u32* bits, u32* logc, u32* uinv) {
+    NttPlan p;
+    if (!ntt_make_plan(log_n, root, p)) return 1;
+    *npass = p.npass; *uinv = p.uinv;
+    for (int i = 0; i < 4; ++i) { bits[i] = p.pass_bits[i]; logc[i] = p.logC[i]; }
+    return 0;
+}
