@@ -90,6 +90,89 @@ int bfs_gl_scale(const uint64_t* d_in, uint64_t* d_out, uint64_t n, uint64_t str
 int bfs_gl_mul_pointwise(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, uint64_t n, void* stream);
 int bfs_gl_batch_inverse(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void* stream);
 
+/* ---- proof stream / Fiat-Shamir (host) -------------------------------------------------------------------- */
+/*
+ * ProofStream of the reference (ip.py:4-30): a list of Python objects, serialised with pickle.dumps and hashed
+ * with SHAKE256.  Objects are built through handles (opaque, valid for the lifetime of the stream); building the
+ * same handle into several containers reproduces Python's shared-object memoisation.
+ *   bfs_ps_obj_xfe  : ExtensionFieldElement whose coefficients live in the xfield's own BaseField (extension_field.py:88-98)
+ *   bfs_ps_obj_bfe  : BaseFieldElement; internal_field != 0 -> same BaseField instance as the xfield's coefficients
+ *   bfs_ps_push                ProofStream.push                ip.py:9-10
+ *   bfs_ps_serialize(count)    pickle.dumps(objects[:count])   ip.py:18-19,24-25 (count >= #objects: the whole stream);
+ *                              two-call pattern: pass out = NULL to query *length
+ *   bfs_ps_fiat_shamir(count)  shake_256(serialize).digest(n)  ip.py:21-25
+ */
+void* bfs_ps_new(void);
+void bfs_ps_free(void* ps);
+uint64_t bfs_ps_obj_bytes(void* ps, const uint8_t* data, size_t len);
+uint64_t bfs_ps_obj_int(void* ps, uint64_t value);
+uint64_t bfs_ps_obj_xfe(void* ps, const uint64_t limbs[3]);
+uint64_t bfs_ps_obj_bfe(void* ps, uint64_t value, int internal_field);
+uint64_t bfs_ps_obj_list(void* ps, const uint64_t* handles, size_t n);
+uint64_t bfs_ps_obj_tuple(void* ps, const uint64_t* handles, size_t n);
+int bfs_ps_push(void* ps, uint64_t handle);
+size_t bfs_ps_num_objects(void* ps);
+uint64_t bfs_ps_object_at(void* ps, size_t index);
+int bfs_ps_serialize(void* ps, size_t count, uint8_t* out, size_t capacity, size_t* length);
+int bfs_ps_fiat_shamir(void* ps, size_t count, uint8_t* out, size_t num_bytes);
+/* pickle.dumps(obj) of one object on its own (leaf preimages: merkle.py:30, salted_merkle.py:32-33); two-call pattern */
+int bfs_ps_obj_dumps(void* ps, uint64_t handle, uint8_t* out, size_t capacity, size_t* length);
+/* introspection (to hand objects created by bfs_fri_prove back to the host language):
+ * kind: 0 bytes, 1 int, 3 list, 4 tuple, 100 extension element, 101 base element */
+int bfs_ps_obj_kind(void* ps, uint64_t handle);
+size_t bfs_ps_obj_len(void* ps, uint64_t handle);
+uint64_t bfs_ps_obj_item(void* ps, uint64_t handle, size_t i);
+int bfs_ps_obj_get_bytes(void* ps, uint64_t handle, uint8_t* out, size_t capacity);
+int bfs_ps_obj_get_limbs(void* ps, uint64_t handle, uint64_t limbs[3]);
+/* BaseField.sample / ExtensionField.sample: big-endian bytes -> element        algebra.py:138-142, extension_field.py:100-111 */
+uint64_t bfs_gl_sample(const uint8_t* bytes, size_t len);
+void bfs_xfe_sample(const uint8_t* bytes, size_t len, uint64_t out[3]);
+
+/* ---- Merkle trees ------------------------------------------------------------------------------------------- */
+/*
+ * Tree layout = the reference's `nodes` list (merkle.py:26-44): 2*npo2 digests of 64 bytes, npo2 = next power of
+ * two >= n, leaf i at index npo2 + i, parent k = BLAKE2b-512(nodes[2k] || nodes[2k+1]), root at index 1.  Index 0
+ * and the slots of absent leaves are not written (the reference keeps 32 zero bytes there; the parent of an absent
+ * leaf hashes those 32 zero bytes, which these kernels reproduce).  d_nodes must hold 2*npo2*64 bytes.
+ *   bfs_merkle_build_xfe   Merkle(codeword) over ExtensionFieldElement leaves   merkle.py:8-41 (leaf = blake2b(pickle.dumps(e)))
+ *   bfs_merkle_build_bfe   same over BaseFieldElement leaves (stand-alone BaseField instance)
+ *   bfs_merkle_build_bytes same over caller-pickled leaves: message i = lengths[i] bytes at d_data + 8*word_offsets[i]
+ *                          (arbitrary picklable leaves, merkle.py:30; salted leaves, salted_merkle.py:32-35)
+ *   bfs_merkle_open        Merkle.open(index): `depth` sibling digests, leaf level first      merkle.py:46-52 (synchronous)
+ */
+int bfs_merkle_build_xfe(const uint64_t* d_limbs, uint64_t limb_stride, uint64_t n, uint8_t* d_nodes, void* stream);
+int bfs_merkle_build_bfe(const uint64_t* d_values, uint64_t n, uint8_t* d_nodes, void* stream);
+int bfs_merkle_build_bytes(const uint8_t* d_data, const uint64_t* d_word_offsets, const uint32_t* d_lengths, uint64_t n,
+                           uint8_t* d_nodes, void* stream);
+int bfs_merkle_open(const uint8_t* d_nodes, uint32_t depth, uint64_t index, uint8_t* h_path, void* stream);
+
+/* ---- FRI ---------------------------------------------------------------------------------------------------- */
+/*
+ * bfs_xfe_fold: one split-and-fold round (fri.py:127-128) of a limb-major extension codeword of length 2^log_n:
+ *     out[i] = 2^-1 * ((1 + alpha/(offset*omega^i)) * in[i] + (1 - alpha/(offset*omega^i)) * in[n/2 + i]),  i < n/2
+ * bfs_fri_commit : Fri.commit (fri.py:91-139) -- per round Merkle tree, root -> transcript (not for round 0),
+ *                  alpha = xfield.sample(prover_fiat_shamir()), fold; pushes the last codeword.  Keeps the round
+ *                  codewords and trees in HBM inside `session`.
+ * bfs_fri_query  : sample_indices + Fri.query / Fri.query_last (fri.py:62-86, 141-176, 186-197); writes the
+ *                  top-level indices (Fri.prove's return value) to h_top_level_indices[num_colinearity_tests].
+ * bfs_fri_prove  : Fri.prove(codeword, proof_stream) (fri.py:178-199) = commit + query with a temporary session.
+ * The codeword is limb-major in HBM (limb k at d_codeword + k*limb_stride); `ps` is a bfs_ps_new() stream, possibly
+ * already holding earlier objects.  These calls synchronise `stream` (each round needs the root on the host).
+ * Errors: BFS_ERR_NOT_ROOT ("omega does not have the right order", fri.py:104-105), BFS_ERR_TOO_MANY_INDICES (fri.py:69-70).
+ */
+int bfs_xfe_fold(const uint64_t* d_in, uint64_t in_stride, uint64_t* d_out, uint64_t out_stride, uint32_t log_n,
+                 const uint64_t alpha[3], uint64_t offset, uint64_t omega, void* stream);
+void* bfs_fri_session_new(void);
+void bfs_fri_session_free(void* session);
+int bfs_fri_commit(void* session, void* ps, const uint64_t* d_codeword, uint64_t limb_stride, uint32_t log_n, uint64_t offset,
+                   uint64_t omega, uint32_t expansion_factor, void* stream);
+int bfs_fri_query(void* session, void* ps, uint32_t num_colinearity_tests, uint64_t* h_top_level_indices, void* stream);
+int bfs_fri_prove(void* ps, const uint64_t* d_codeword, uint64_t limb_stride, uint32_t log_n, uint64_t offset, uint64_t omega,
+                  uint32_t expansion_factor, uint32_t num_colinearity_tests, uint64_t* h_top_level_indices, void* stream);
+uint32_t bfs_fri_session_rounds(void* session);
+int bfs_fri_session_round(void* session, uint32_t round, const uint64_t** d_codeword, uint64_t* length, uint64_t* limb_stride,
+                          const uint8_t** d_nodes, uint8_t h_root[64]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,39 @@ _SIGNATURES = {
     "bfs_gl_scale": (ci, [vp, vp, u64, u64, u32, u64, vp]),
     "bfs_gl_mul_pointwise": (ci, [vp, vp, vp, u64, vp]),
     "bfs_gl_batch_inverse": (ci, [vp, vp, u64, vp]),
+    "bfs_ps_new": (vp, []),
+    "bfs_ps_free": (None, [vp]),
+    "bfs_ps_obj_bytes": (u64, [vp, ctypes.c_char_p, sz]),
+    "bfs_ps_obj_int": (u64, [vp, u64]),
+    "bfs_ps_obj_xfe": (u64, [vp, ctypes.POINTER(u64)]),
+    "bfs_ps_obj_bfe": (u64, [vp, u64, ci]),
+    "bfs_ps_obj_list": (u64, [vp, ctypes.POINTER(u64), sz]),
+    "bfs_ps_obj_tuple": (u64, [vp, ctypes.POINTER(u64), sz]),
+    "bfs_ps_push": (ci, [vp, u64]),
+    "bfs_ps_num_objects": (sz, [vp]),
+    "bfs_ps_object_at": (u64, [vp, sz]),
+    "bfs_ps_serialize": (ci, [vp, sz, vp, sz, ctypes.POINTER(sz)]),
+    "bfs_ps_fiat_shamir": (ci, [vp, sz, vp, sz]),
+    "bfs_ps_obj_dumps": (ci, [vp, u64, vp, sz, ctypes.POINTER(sz)]),
+    "bfs_ps_obj_kind": (ci, [vp, u64]),
+    "bfs_ps_obj_len": (sz, [vp, u64]),
+    "bfs_ps_obj_item": (u64, [vp, u64, sz]),
+    "bfs_ps_obj_get_bytes": (ci, [vp, u64, vp, sz]),
+    "bfs_ps_obj_get_limbs": (ci, [vp, u64, ctypes.POINTER(u64)]),
+    "bfs_gl_sample": (u64, [ctypes.c_char_p, sz]),
+    "bfs_xfe_sample": (None, [ctypes.c_char_p, sz, ctypes.POINTER(u64)]),
+    "bfs_merkle_build_xfe": (ci, [vp, u64, u64, vp, vp]),
+    "bfs_merkle_build_bfe": (ci, [vp, u64, vp, vp]),
+    "bfs_merkle_build_bytes": (ci, [vp, vp, vp, u64, vp, vp]),
+    "bfs_merkle_open": (ci, [vp, u32, u64, vp, vp]),
+    "bfs_xfe_fold": (ci, [vp, u64, vp, u64, u32, ctypes.POINTER(u64), u64, u64, vp]),
+    "bfs_fri_session_new": (vp, []),
+    "bfs_fri_session_free": (None, [vp]),
+    "bfs_fri_commit": (ci, [vp, vp, vp, u64, u32, u64, u64, u32, vp]),
+    "bfs_fri_query": (ci, [vp, vp, u32, ctypes.POINTER(u64), vp]),
+    "bfs_fri_prove": (ci, [vp, vp, u64, u32, u64, u64, u32, u32, ctypes.POINTER(u64), vp]),
+    "bfs_fri_session_rounds": (u32, [vp]),
+    "bfs_fri_session_round": (ci, [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(vp), vp]),
 }
 
 _lib = None

@@ -7,6 +7,9 @@ namespace bfs {
 int mul_pointwise_launch(const u64* a, const u64* b, u64* out, u64 n, hipStream_t stream);
 int batch_inverse_launch(const u64* in, u64* out, u64 n, hipStream_t stream);
 int scale_launch(const u64* in, u64* out, u64 n, u64 stride, u32 batch, u64 factor, hipStream_t stream);
+int merkle_build_xfe_launch(const u64* d_limbs, u64 limb_stride, u64 n, u64* d_nodes, hipStream_t stream);
+int merkle_build_bfe_launch(const u64* d_values, u64 n, u64* d_nodes, hipStream_t stream);
+int merkle_build_bytes_launch(const u64* d_data, const u64* d_offsets, const u32* d_lengths, u64 n, u64* d_nodes, hipStream_t stream);
 }
 
 using namespace bfs;
@@ -68,6 +71,24 @@ int bfs_gl_mul_pointwise(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_o
 
 int bfs_gl_batch_inverse(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void* stream) {
     return batch_inverse_launch(d_in, d_out, n, (hipStream_t)stream);
+}
+
+int bfs_merkle_build_xfe(const uint64_t* d_limbs, uint64_t limb_stride, uint64_t n, uint8_t* d_nodes, void* stream) {
+    return merkle_build_xfe_launch(d_limbs, limb_stride, n, (u64*)d_nodes, (hipStream_t)stream);
+}
+int bfs_merkle_build_bfe(const uint64_t* d_values, uint64_t n, uint8_t* d_nodes, void* stream) {
+    return merkle_build_bfe_launch(d_values, n, (u64*)d_nodes, (hipStream_t)stream);
+}
+int bfs_merkle_build_bytes(const uint8_t* d_data, const uint64_t* d_word_offsets, const uint32_t* d_lengths, uint64_t n, uint8_t* d_nodes, void* stream) {
+    return merkle_build_bytes_launch((const u64*)d_data, d_word_offsets, d_lengths, n, (u64*)d_nodes, (hipStream_t)stream);
+}
+int bfs_merkle_open(const uint8_t* d_nodes, uint32_t depth, uint64_t index, uint8_t* h_path, void* stream) {
+    // merkle.py:46-52: walk from the leaf to the root collecting siblings; one small copy per level
+    uint64_t k = (1ull << depth) | index;
+    for (uint32_t lvl = 0; k > 1; k >>= 1, ++lvl)
+        BFS_HIP(hipMemcpyAsync(h_path + 64 * (size_t)lvl, d_nodes + 64 * (k ^ 1), 64, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    BFS_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return BFS_OK;
 }
 
 }  // extern "C"

@@ -1,0 +1,306 @@
+// fri.hip -- the FRI prover loop on gfx950.  Replaces Fri.commit / Fri.query / Fri.query_last / Fri.prove of the
+// reference (/root/reference/code/fri.py:91-199): per round a Merkle tree over the codeword (GPU), the root to the
+// host, the Fiat-Shamir challenge from the transcript (host: pickle + SHAKE256, ip.py:21-22), the split-and-fold
+// step (GPU, fri.py:127-128); then index sampling (fri.py:62-86) and one batched gather of every revealed leaf and
+// authentication-path node.
+#include <map>
+#include <vector>
+
+#include "../../include/bfstark.h"
+#include "blake2b.hpp"
+#include "refpickle.hpp"
+#include "runtime.hpp"
+
+namespace bfs {
+
+int merkle_build_xfe_launch(const u64* d_limbs, u64 limb_stride, u64 n, u64* d_nodes, hipStream_t stream);
+int ntt_power_tables(u64 root, u32 log_n, const u64** lo, const u64** hi, u32* lo_bits);
+
+BFS_HD u64 gl_half(u64 x) { return (x >> 1) + ((x & 1) ? 0x7FFFFFFF80000001ULL : 0); }  // x / 2 mod p
+
+// fri.py:127-128:  out[i] = 2^-1 * ((1 + alpha/x_i) * a + (1 - alpha/x_i) * b),  x_i = offset * omega^i
+//                         = (a + b)/2 + alpha * (2^-1 * offset^-1 * omega^-i) * (a - b)
+// winv_*: two-level powers of the ROUND-0 omega^-1 (exponent i << round_shift); scal = 2^-1 * offset_r^-1
+__global__ void fri_fold_kernel(const u64* in, u64 in_stride, u64* out, u64 out_stride, u64 half, Xfe alpha, u64 scal,
+                                const u64* winv_lo, const u64* winv_hi, u32 lo_bits, u32 round_shift) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < half; i += (u64)gridDim.x * blockDim.x) {
+        Xfe a{{in[i], in[in_stride + i], in[2 * in_stride + i]}};
+        Xfe b{{in[half + i], in[in_stride + half + i], in[2 * in_stride + half + i]}};
+        u64 s = gl_mul(scal, tw_pow(winv_lo, winv_hi, lo_bits, i << round_shift));
+        Xfe beta = xfe_scale(alpha, s);
+        Xfe sum = xfe_add(a, b), diff = xfe_sub(a, b);
+        Xfe prod = xfe_mul(beta, diff);
+        out[i] = gl_add(gl_half(sum.c[0]), prod.c[0]);
+        out[out_stride + i] = gl_add(gl_half(sum.c[1]), prod.c[1]);
+        out[2 * out_stride + i] = gl_add(gl_half(sum.c[2]), prod.c[2]);
+    }
+}
+
+__global__ void gather_words_kernel(const u64* const* src, u64 count, u64* out) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (u64)gridDim.x * blockDim.x) out[i] = *src[i];
+}
+
+struct FriRound {
+    const u64* cw = nullptr;  // limb-major codeword
+    u64 stride = 0, length = 0;
+    u64* nodes = nullptr;     // 2*length digests of 8 words
+    unsigned char root[64];
+};
+
+struct FriSession {
+    std::vector<FriRound> rounds;
+    void* block = nullptr;  // device allocation owned by the session
+    u32 log_n = 0;
+    std::map<std::pair<u32, u64>, rp::Ref> elements;  // (round, index) -> the element object (identity!)
+    std::map<std::pair<u32, u64>, rp::Ref> nodes;     // (round, node index) -> bytes object
+    std::vector<uint64_t> last_handles;
+    ~FriSession() { if (block) (void)hipFree(block); }
+};
+
+static u32 fri_num_rounds(u64 length, u32 expansion) {  // fri.py:54-60
+    u32 r = 0;
+    while (length > expansion) { length /= 2; ++r; }
+    return r;
+}
+
+int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u32 log_n, u64 offset, u64 omega,
+               u32 expansion, hipStream_t stream) {
+    const u64 N = 1ull << log_n;
+    const u32 R = fri_num_rounds(N, expansion);
+    if (R < 1) { set_error("cannot do FRI with less than one round"); return BFS_ERR_BAD_ARG; }
+    if (gl_pow(omega, N) != 1 || (log_n && gl_pow(omega, N / 2) == 1)) {
+        set_error("error in commit: omega does not have the right order!");
+        return BFS_ERR_NOT_ROOT;
+    }
+    S.log_n = log_n;
+    S.rounds.assign(R, FriRound());
+    // one allocation: nodes of every round + codewords of rounds >= 1
+    size_t words = 0;
+    for (u32 r = 0; r < R; ++r) words += (size_t)16 * (N >> r) + (r ? (size_t)3 * (N >> r) : 0);
+    BFS_HIP(hipMalloc(&S.block, words * sizeof(u64)));
+    u64* p = (u64*)S.block;
+    for (u32 r = 0; r < R; ++r) {
+        FriRound& fr = S.rounds[r];
+        fr.length = N >> r;
+        fr.nodes = p; p += 16 * fr.length;
+        if (r == 0) { fr.cw = d_cw; fr.stride = stride; }
+        else { fr.cw = p; fr.stride = fr.length; p += 3 * fr.length; }
+    }
+    const u64 *winv_lo = nullptr, *winv_hi = nullptr;
+    u32 lo_bits = 0;
+    BFS_TRY(ntt_power_tables(gl_inv(omega), log_n, &winv_lo, &winv_hi, &lo_bits));
+    const u64 half_inv = gl_inv(2);
+    u64 g = offset;
+    for (u32 r = 0; r < R; ++r) {
+        FriRound& fr = S.rounds[r];
+        BFS_TRY(merkle_build_xfe_launch(fr.cw, fr.stride, fr.length, fr.nodes, stream));  // fri.py:108
+        BFS_HIP(hipMemcpyAsync(fr.root, fr.nodes + 8, 64, hipMemcpyDeviceToHost, stream));
+        BFS_HIP(hipStreamSynchronize(stream));
+        if (r > 0) ps.objects.push_back(rp::mk_bytes(fr.root, 64));  // fri.py:112-113
+        if (r == R - 1) break;                                       // fri.py:116-117
+        unsigned char seed[32];
+        ps.fiat_shamir(ps.objects.size(), seed, 32);                 // fri.py:120
+        Xfe alpha = rp::sample_xfe(seed, 32);
+        FriRound& nx = S.rounds[r + 1];
+        const u64 half = fr.length / 2;
+        u32 grid = (u32)((half + 255) / 256);
+        if (grid > 4096) grid = 4096;
+        hipLaunchKernelGGL(fri_fold_kernel, dim3(grid), dim3(256), 0, stream, fr.cw, fr.stride, (u64*)nx.cw, nx.stride, half, alpha,
+                           gl_mul(half_inv, gl_inv(g)), winv_lo, winv_hi, lo_bits, r);
+        BFS_HIP(hipGetLastError());
+        g = gl_sqr(g);  // fri.py:130-131 (omega is squared implicitly through round_shift)
+    }
+    // fri.py:134: the last codeword goes into the transcript as a list of element objects
+    FriRound& last = S.rounds[R - 1];
+    std::vector<u64> host(3 * last.length);
+    for (int k = 0; k < 3; ++k)
+        BFS_HIP(hipMemcpyAsync(host.data() + k * last.length, last.cw + k * last.stride, last.length * sizeof(u64), hipMemcpyDeviceToHost, stream));
+    BFS_HIP(hipStreamSynchronize(stream));
+    std::vector<rp::Ref> items;
+    for (u64 j = 0; j < last.length; ++j) {
+        u64 l[3] = {host[j], host[last.length + j], host[2 * last.length + j]};
+        rp::Ref e = ps.world.xfe(l);
+        S.elements[{R - 1, j}] = e;
+        items.push_back(e);
+    }
+    ps.objects.push_back(rp::mk_list(items));
+    return BFS_OK;
+}
+
+// fri.py:62-86
+static int sample_indices(const unsigned char seed[32], u64 size, u64 reduced_size, u32 number, std::vector<u64>& out) {
+    if (number > reduced_size) {
+        set_error("cannot sample more indices than available in last codeword; requested: %u, available: %llu", number, (unsigned long long)reduced_size);
+        return BFS_ERR_TOO_MANY_INDICES;
+    }
+    out.clear();
+    std::vector<u64> reduced;
+    std::vector<unsigned char> msg(seed, seed + 32);
+    while (out.size() < number) {
+        unsigned char digest[64];
+        blake2b_host(msg.data(), msg.size(), digest);  // blake2b(seed + bytes(counter)): `counter` zero bytes
+        msg.push_back(0);
+        u128 acc = 0;
+        for (int i = 0; i < 64; ++i) acc = ((acc << 8) | digest[i]) % size;
+        u64 index = (u64)acc, red = index % reduced_size;
+        bool seen = false;
+        for (u64 x : reduced) seen |= (x == red);
+        if (!seen) { out.push_back(index); reduced.push_back(red); }
+    }
+    return BFS_OK;
+}
+
+int fri_query(FriSession& S, rp::Transcript& ps, u32 t, u64* h_top, hipStream_t stream) {
+    const u32 R = (u32)S.rounds.size();
+    if (R < 2) { set_error("Fri.prove needs at least two rounds (fri.py:186 indexes codewords[1])"); return BFS_ERR_BAD_ARG; }
+    unsigned char seed[32];
+    ps.fiat_shamir(ps.objects.size(), seed, 32);
+    std::vector<u64> top;
+    BFS_TRY(sample_indices(seed, S.rounds[1].length, S.rounds[R - 1].length, t, top));  // fri.py:186-187
+    for (u32 s = 0; s < t; ++s) h_top[s] = top[s];
+
+    // plan every opening first (fri.py:191-197), then fetch everything with one gather
+    std::vector<std::vector<u64>> layer_idx;  // c indices per layer
+    std::vector<u64> idx = top;
+    for (u32 i = 0; i + 2 < R; ++i) {  // len(trees) - 1 = R - 2 layers use query()
+        for (auto& x : idx) x %= S.rounds[i].length / 2;
+        layer_idx.push_back(idx);
+    }
+    for (auto& x : idx) x %= S.rounds[R - 1].length;
+    layer_idx.push_back(idx);  // query_last
+
+    typedef std::pair<u32, u64> Key;
+    std::vector<const u64*> src;                 // one device address per gathered 64-bit word
+    std::vector<std::pair<int, Key>> order;      // what the words are: (0 = element | 1 = tree node, key)
+    auto need_element = [&](u32 r, u64 j) {
+        Key key{r, j};
+        if (S.elements.count(key)) return;       // same Python object in the reference -> same node here
+        S.elements[key] = rp::Ref();
+        order.push_back({0, key});
+        const FriRound& fr = S.rounds[r];
+        for (int k = 0; k < 3; ++k) src.push_back(fr.cw + k * fr.stride + j);
+    };
+    auto need_path = [&](u32 r, u64 leaf) {      // merkle.py:46-52
+        const FriRound& fr = S.rounds[r];
+        for (u64 k = fr.length | leaf; k > 1; k >>= 1) {
+            Key key{r, k ^ 1};
+            if (S.nodes.count(key)) continue;
+            S.nodes[key] = rp::Ref();
+            order.push_back({1, key});
+            for (int w = 0; w < 8; ++w) src.push_back(fr.nodes + (k ^ 1) * 8 + w);
+        }
+    };
+    for (u32 i = 0; i < (u32)layer_idx.size(); ++i) {
+        const bool lastq = (i + 1 == layer_idx.size());
+        const u32 cur = lastq ? R - 2 : i;
+        const u64 half = S.rounds[cur].length / 2;
+        for (u32 s = 0; s < t; ++s) {
+            u64 c = layer_idx[i][s];
+            need_element(cur, c); need_element(cur, c + half); need_element(cur + 1, c);
+            need_path(cur, c); need_path(cur, c + half);
+            if (!lastq) need_path(cur + 1, c);
+        }
+    }
+    std::vector<u64> words(src.size());
+    if (!src.empty()) {
+        void* w = nullptr;
+        BFS_TRY(workspace(3, src.size() * 16, stream, &w));
+        const u64** d_src = (const u64**)w;
+        u64* d_out = (u64*)w + src.size();
+        BFS_HIP(hipMemcpyAsync(d_src, src.data(), src.size() * 8, hipMemcpyHostToDevice, stream));
+        u32 grid = (u32)((src.size() + 255) / 256);
+        hipLaunchKernelGGL(gather_words_kernel, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, stream, (const u64* const*)d_src, (u64)src.size(), d_out);
+        BFS_HIP(hipGetLastError());
+        BFS_HIP(hipMemcpyAsync(words.data(), d_out, src.size() * 8, hipMemcpyDeviceToHost, stream));
+        BFS_HIP(hipStreamSynchronize(stream));
+    }
+    size_t pos = 0;
+    for (auto& o : order) {
+        if (o.first == 0) {
+            u64 l[3] = {words[pos], words[pos + 1], words[pos + 2]};
+            pos += 3;
+            S.elements[o.second] = ps.world.xfe(l);
+        } else {
+            S.nodes[o.second] = rp::mk_bytes(&words[pos], 64);
+            pos += 8;
+        }
+    }
+    auto path_obj = [&](u32 r, u64 leaf) {
+        std::vector<rp::Ref> items;
+        for (u64 k = S.rounds[r].length | leaf; k > 1; k >>= 1) items.push_back(S.nodes[{r, k ^ 1}]);
+        return rp::mk_list(items);
+    };
+    // push in the reference's order: per layer, t leaf triples then the authentication paths (fri.py:147-156, 166-174)
+    for (u32 i = 0; i < (u32)layer_idx.size(); ++i) {
+        const bool lastq = (i + 1 == layer_idx.size());
+        const u32 cur = lastq ? R - 2 : i;
+        const u64 half = S.rounds[cur].length / 2;
+        for (u32 s = 0; s < t; ++s) {
+            u64 c = layer_idx[i][s];
+            ps.objects.push_back(rp::mk_tuple({S.elements[{cur, c}], S.elements[{cur, c + half}], S.elements[{cur + 1, c}]}));
+        }
+        for (u32 s = 0; s < t; ++s) {
+            u64 c = layer_idx[i][s];
+            ps.objects.push_back(path_obj(cur, c));
+            ps.objects.push_back(path_obj(cur, c + half));
+            if (!lastq) ps.objects.push_back(path_obj(cur + 1, c));
+        }
+    }
+    return BFS_OK;
+}
+
+}  // namespace bfs
+
+using namespace bfs;
+
+extern "C" {
+
+void* bfs_fri_session_new(void) { return new FriSession(); }
+void bfs_fri_session_free(void* s) { delete (FriSession*)s; }
+
+int bfs_fri_commit(void* session, void* ps, const uint64_t* d_codeword, uint64_t limb_stride, uint32_t log_n, uint64_t offset,
+                   uint64_t omega, uint32_t expansion_factor, void* stream) {
+    return fri_commit(*(FriSession*)session, *(rp::Transcript*)ps, d_codeword, limb_stride, log_n, offset, omega, expansion_factor, (hipStream_t)stream);
+}
+
+int bfs_fri_query(void* session, void* ps, uint32_t num_colinearity_tests, uint64_t* h_top_level_indices, void* stream) {
+    return fri_query(*(FriSession*)session, *(rp::Transcript*)ps, num_colinearity_tests, h_top_level_indices, (hipStream_t)stream);
+}
+
+int bfs_fri_prove(void* ps, const uint64_t* d_codeword, uint64_t limb_stride, uint32_t log_n, uint64_t offset, uint64_t omega,
+                  uint32_t expansion_factor, uint32_t num_colinearity_tests, uint64_t* h_top_level_indices, void* stream) {
+    FriSession S;
+    BFS_TRY(fri_commit(S, *(rp::Transcript*)ps, d_codeword, limb_stride, log_n, offset, omega, expansion_factor, (hipStream_t)stream));
+    return fri_query(S, *(rp::Transcript*)ps, num_colinearity_tests, h_top_level_indices, (hipStream_t)stream);
+}
+
+uint32_t bfs_fri_session_rounds(void* session) { return (uint32_t)((FriSession*)session)->rounds.size(); }
+
+int bfs_fri_session_round(void* session, uint32_t r, const uint64_t** d_codeword, uint64_t* length, uint64_t* limb_stride,
+                          const uint8_t** d_nodes, uint8_t h_root[64]) {
+    FriSession* S = (FriSession*)session;
+    if (r >= S->rounds.size()) { set_error("round %u out of range", r); return BFS_ERR_BAD_ARG; }
+    const FriRound& fr = S->rounds[r];
+    *d_codeword = fr.cw; *length = fr.length; *limb_stride = fr.stride; *d_nodes = (const uint8_t*)fr.nodes;
+    memcpy(h_root, fr.root, 64);
+    return BFS_OK;
+}
+
+int bfs_xfe_fold(const uint64_t* d_in, uint64_t in_stride, uint64_t* d_out, uint64_t out_stride, uint32_t log_n, const uint64_t alpha[3],
+                 uint64_t offset, uint64_t omega, void* stream) {
+    const u64 N = 1ull << log_n;
+    if (log_n == 0) { set_error("cannot fold a codeword of length 1"); return BFS_ERR_BAD_ARG; }
+    if (gl_pow(omega, N) != 1 || gl_pow(omega, N / 2) == 1) { set_error("error in commit: omega does not have the right order!"); return BFS_ERR_NOT_ROOT; }
+    const u64 *lo = nullptr, *hi = nullptr;
+    u32 lo_bits = 0;
+    BFS_TRY(ntt_power_tables(gl_inv(omega), log_n, &lo, &hi, &lo_bits));
+    Xfe a{{alpha[0] % GL_P, alpha[1] % GL_P, alpha[2] % GL_P}};
+    const u64 half = N / 2;
+    u32 grid = (u32)((half + 255) / 256);
+    hipLaunchKernelGGL(fri_fold_kernel, dim3(grid > 4096 ? 4096 : grid), dim3(256), 0, (hipStream_t)stream, d_in, in_stride, d_out, out_stride, half, a,
+                       gl_mul(gl_inv(2), gl_inv(offset % GL_P)), lo, hi, lo_bits, 0u);
+    BFS_HIP(hipGetLastError());
+    return BFS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,135 @@
+// merkle.hip -- BLAKE2b-512 Merkle trees on gfx950.  Replaces Merkle.__init__ of the reference
+// (/root/reference/code/merkle.py:8-41): leaf hashing `blake2b(pickle.dumps(leaf))` (:29-32) and the level-by-level
+// parent hashing (:35-41).  One thread hashes one leaf (preimage synthesised in LDS, <= 4 compressions) or one
+// parent (one compression); the top 9 levels run in a single workgroup.
+#include "merkle_core.hpp"
+#include "runtime.hpp"
+
+namespace bfs {
+
+constexpr int LEAF_THREADS = 64;  // one wavefront per workgroup: the staging area is 52 words x 64 lanes = 26 KiB
+
+__global__ void __launch_bounds__(LEAF_THREADS) merkle_leaves_xfe_kernel(const u64* limbs, u64 limb_stride, u64 n, u64* leaf_digests) {
+    __shared__ u64 stage[XFE_LEAF_MAX_WORDS * LEAF_THREADS];
+    const u64 i = (u64)blockIdx.x * LEAF_THREADS + threadIdx.x;
+    if (i >= n) return;
+    u64 d[8];
+    merkle_leaf_xfe_body(limbs, limb_stride, i, stage + threadIdx.x, LEAF_THREADS, d);
+    u64* out = leaf_digests + i * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = d[j];
+}
+
+__global__ void __launch_bounds__(LEAF_THREADS) merkle_leaves_bfe_kernel(const u64* values, u64 n, u64* leaf_digests) {
+    __shared__ u64 stage[BFE_LEAF_MAX_WORDS * LEAF_THREADS];
+    const u64 i = (u64)blockIdx.x * LEAF_THREADS + threadIdx.x;
+    if (i >= n) return;
+    u64 d[8];
+    merkle_leaf_bfe_body(values, i, stage + threadIdx.x, LEAF_THREADS, d);
+    u64* out = leaf_digests + i * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = d[j];
+}
+
+// generic byte strings: message i occupies words [offsets[i], offsets[i] + ceil(len/8)) of `data`, lengths[i] bytes
+__global__ void blake2b_batch_kernel(const u64* data, const u64* offsets, const u32* lengths, u64 n, u64* digests) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    u64 h[8];
+    blake2b_staged(data + offsets[i], 1, lengths[i], h);
+    u64* out = digests + i * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = h[j];
+}
+
+// one level: parents [first, first+count) from children [2*first, ...).  present_children counts the child slots
+// (from the start of the child level) that hold digests; only smaller than 2*count directly above a ragged leaf level.
+__global__ void merkle_parents_kernel(u64* nodes, u64 first, u64 count, u64 present_children) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const u64 k = first + t;
+    const u64 c = 2 * t;
+    int present = c + 1 < present_children ? 2 : (c < present_children ? 1 : 0);
+    u64 out[8];
+    merkle_parent_body(nodes + (2 * k) * 8, nodes + (2 * k + 1) * 8, present, out);
+    u64* dst = nodes + k * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dst[j] = out[j];
+}
+
+// the top of the tree in one workgroup: levels with `width` <= 256 parents down to the root, through LDS
+__global__ void __launch_bounds__(256) merkle_top_kernel(u64* nodes, u32 width, u64 present_children) {
+    __shared__ u64 lvl[512 * 8];
+    const u32 t = threadIdx.x;
+    for (u32 i = t; i < 2 * width * 8; i += 256) lvl[i] = nodes[(u64)2 * width * 8 + i];
+    __syncthreads();
+    u64 present = present_children;
+    for (u32 w = width; w >= 1; w >>= 1) {
+        u64 out[8];
+        if (t < w) {
+            const u64 c = 2 * (u64)t;
+            int pr = c + 1 < present ? 2 : (c < present ? 1 : 0);
+            merkle_parent_body(lvl + (2 * t) * 8, lvl + (2 * t + 1) * 8, pr, out);
+        }
+        __syncthreads();
+        if (t < w) {
+            u64* dst = nodes + ((u64)w + t) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { lvl[t * 8 + j] = out[j]; dst[j] = out[j]; }
+        }
+        __syncthreads();
+        present = 2 * (u64)w;  // every computed level is complete
+    }
+}
+
+// build all inner nodes above a leaf level of npo2 = 2^depth slots of which n_leaves hold digests
+int merkle_inner_launch(u64* d_nodes, u32 depth, u64 n_leaves, hipStream_t stream) {
+    if (depth == 0) return BFS_OK;  // single leaf: root = leaf digest (merkle.py:43 nodes[1])
+    u64 present = n_leaves;
+    for (u32 lvl = depth; lvl-- > 0;) {
+        const u64 count = 1ull << lvl;
+        if (count <= 256) {
+            hipLaunchKernelGGL(merkle_top_kernel, dim3(1), dim3(256), 0, stream, d_nodes, (u32)count, present);
+            BFS_HIP(hipGetLastError());
+            return BFS_OK;
+        }
+        hipLaunchKernelGGL(merkle_parents_kernel, dim3((u32)((count + 255) / 256)), dim3(256), 0, stream, d_nodes, count, count, present);
+        BFS_HIP(hipGetLastError());
+        present = 2 * count;
+    }
+    return BFS_OK;
+}
+
+int merkle_build_xfe_launch(const u64* d_limbs, u64 limb_stride, u64 n, u64* d_nodes, hipStream_t stream) {
+    if (n == 0) return BFS_OK;
+    u32 depth = 0;
+    while ((1ull << depth) < n) ++depth;
+    const u64 npo2 = 1ull << depth;
+    hipLaunchKernelGGL(merkle_leaves_xfe_kernel, dim3((u32)((n + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0, stream,
+                       d_limbs, limb_stride, n, d_nodes + npo2 * 8);
+    BFS_HIP(hipGetLastError());
+    return merkle_inner_launch(d_nodes, depth, n, stream);
+}
+
+int merkle_build_bfe_launch(const u64* d_values, u64 n, u64* d_nodes, hipStream_t stream) {
+    if (n == 0) return BFS_OK;
+    u32 depth = 0;
+    while ((1ull << depth) < n) ++depth;
+    const u64 npo2 = 1ull << depth;
+    hipLaunchKernelGGL(merkle_leaves_bfe_kernel, dim3((u32)((n + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0, stream,
+                       d_values, n, d_nodes + npo2 * 8);
+    BFS_HIP(hipGetLastError());
+    return merkle_inner_launch(d_nodes, depth, n, stream);
+}
+
+int merkle_build_bytes_launch(const u64* d_data, const u64* d_offsets, const u32* d_lengths, u64 n, u64* d_nodes, hipStream_t stream) {
+    if (n == 0) return BFS_OK;
+    u32 depth = 0;
+    while ((1ull << depth) < n) ++depth;
+    const u64 npo2 = 1ull << depth;
+    hipLaunchKernelGGL(blake2b_batch_kernel, dim3((u32)((n + 63) / 64)), dim3(64), 0, stream, d_data, d_offsets, d_lengths, n, d_nodes + npo2 * 8);
+    BFS_HIP(hipGetLastError());
+    return merkle_inner_launch(d_nodes, depth, n, stream);
+}
+
+}  // namespace bfs

@@ -74,6 +74,16 @@ static int get_tables(const NttPlan& p, u64 root, u64 shift, u64 post_scale, Ntt
     return BFS_OK;
 }
 
+// two-level power tables of `root` (order 2^log_n): root^e = lo[e & mask] * hi[e >> lo_bits]; shared with the fold kernel
+int ntt_power_tables(u64 root, u32 log_n, const u64** lo, const u64** hi, u32* lo_bits) {
+    NttPlan p;
+    if (!ntt_make_plan(log_n, root, p)) { set_error("no table plan for log_n = %u", log_n); return BFS_ERR_BAD_ARG; }
+    NttTables tb;
+    BFS_TRY(get_tables(p, root, 1, 1, tb));
+    *lo = tb.w_lo; *hi = tb.w_hi; *lo_bits = tb.lo_bits;
+    return BFS_OK;
+}
+
 int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_stride, u32 log_n, u32 batch, u64 root,
                u64 shift, u64 post_scale, hipStream_t stream) {
     if (log_n > 32) { set_error("field has no 2^%u-th root of unity (algebra.py:124-125)", log_n); return BFS_ERR_BAD_ARG; }

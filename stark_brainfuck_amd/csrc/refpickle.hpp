@@ -1,0 +1,313 @@
+// refpickle.hpp -- host-side transcript of the reference's proof stream, byte for byte.
+//
+// The reference's ProofStream is a Python list; its serialisation is pickle.dumps(list) and the Fiat-Shamir
+// challenge is shake_256 of those bytes (/root/reference/code/ip.py:18-25).  The bytes depend on CPython's
+// pickler: memoisation by object identity, opcode choice, batching and 64 KiB framing.  This file re-creates
+// that for the object kinds the hot path pushes (bytes, ints, lists, tuples, field elements) by
+//   (1) building the same object GRAPH the reference would hold -- classes, interned attribute-name strings,
+//       the shared BaseField / ExtensionField instances, one node per Python object, identity = node address;
+//   (2) walking it with a small pickler that follows Modules/_pickle.c (protocol 4): save(), memo_get/put,
+//       save_long, save_bytes, save_unicode, save_tuple, batch_list_exact, batch_dict_exact, save_global,
+//       save_reduce(copyreg.__newobj__), _Pickler_OpcodeBoundary / _Pickler_CommitFrame.
+// Pinned by tests against pickle byte strings captured from the reference (tests/golden/pickle.json, fri_*_stream.bin).
+#pragma once
+#include <stdint.h>
+#include <string.h>
+
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "gl.hpp"
+#include "keccak.hpp"
+
+namespace bfs {
+namespace rp {
+
+enum Kind { K_BYTES = 0, K_INT = 1, K_STR = 2, K_LIST = 3, K_TUPLE = 4, K_DICT = 5, K_CLASS = 6, K_INSTANCE = 7 };
+enum Role { R_NONE = 0, R_XFE = 1, R_BFE = 2 };  // what an INSTANCE node stands for (for reading values back)
+
+struct Node;
+typedef std::shared_ptr<Node> Ref;
+
+struct Node {
+    Kind kind = K_INT;
+    Role role = R_NONE;
+    std::string data;        // BYTES / STR payload
+    u64 ival = 0;            // INT (0 <= v < 2^64)
+    std::vector<Ref> items;  // LIST / TUPLE elements; DICT: k0 v0 k1 v1 ...; CLASS: module, qualname
+    Ref cls, state;          // INSTANCE
+    u64 limbs[3] = {0, 0, 0};  // R_XFE: value; R_BFE: limbs[0]
+};
+
+inline Ref mk(Kind k) { Ref n = std::make_shared<Node>(); n->kind = k; return n; }
+inline Ref mk_int(u64 v) { Ref n = mk(K_INT); n->ival = v; return n; }
+inline Ref mk_str(const char* s) { Ref n = mk(K_STR); n->data = s; return n; }
+inline Ref mk_bytes(const void* p, size_t len) { Ref n = mk(K_BYTES); n->data.assign((const char*)p, len); return n; }
+inline Ref mk_list(const std::vector<Ref>& it) { Ref n = mk(K_LIST); n->items = it; return n; }
+inline Ref mk_tuple(const std::vector<Ref>& it) { Ref n = mk(K_TUPLE); n->items = it; return n; }
+inline Ref mk_class(const Ref& module, const Ref& name) { Ref n = mk(K_CLASS); n->items = {module, name}; return n; }
+inline Ref mk_instance(const Ref& cls, const std::vector<Ref>& kv) {
+    Ref n = mk(K_INSTANCE);
+    n->cls = cls;
+    n->state = mk(K_DICT);
+    n->state->items = kv;
+    return n;
+}
+
+// The shared part of the reference's object graph: what `ExtensionField.main()` creates once
+// (extension_field.py:88-98) plus the classes and the interned attribute names.
+struct World {
+    Ref s_value, s_field, s_p, s_coefficients, s_polynomial, s_modulus;
+    Ref c_bfe, c_bf, c_poly, c_xfe, c_xf;
+    Ref bf_internal;    // the BaseField instance inside the ExtensionField's modulus ("variant A")
+    Ref bf_standalone;  // a BaseField.main() of its own (pure base-field leaves)
+    Ref xfield;
+
+    World() {
+        Ref m_alg = mk_str("algebra"), m_uni = mk_str("univariate"), m_ext = mk_str("extension_field");
+        s_value = mk_str("value"); s_field = mk_str("field"); s_p = mk_str("p");
+        s_coefficients = mk_str("coefficients"); s_polynomial = mk_str("polynomial"); s_modulus = mk_str("modulus");
+        c_bfe = mk_class(m_alg, mk_str("BaseFieldElement"));
+        c_bf = mk_class(m_alg, mk_str("BaseField"));
+        c_poly = mk_class(m_uni, mk_str("Polynomial"));
+        c_xfe = mk_class(m_ext, mk_str("ExtensionFieldElement"));
+        c_xf = mk_class(m_ext, mk_str("ExtensionField"));
+        bf_internal = mk_instance(c_bf, {s_p, mk_int(GL_P)});
+        bf_standalone = mk_instance(c_bf, {s_p, mk_int(GL_P)});
+        Ref one = bfe(1, true), minus_one = bfe(GL_P - 1, true), zero = bfe(0, true);
+        Ref modulus = mk_instance(c_poly, {s_coefficients, mk_list({one, minus_one, zero, one})});  // same `one` twice
+        xfield = mk_instance(c_xf, {s_modulus, modulus});
+    }
+
+    // BaseFieldElement(value, field)  algebra.py:15-18
+    Ref bfe(u64 v, bool internal) const {
+        Ref n = mk_instance(c_bfe, {s_value, mk_int(v), s_field, internal ? bf_internal : bf_standalone});
+        n->role = R_BFE;
+        n->limbs[0] = v;
+        return n;
+    }
+
+    // ExtensionFieldElement(Polynomial(coeffs trimmed of trailing zeros), xfield)  extension_field.py:5-9
+    Ref xfe(const u64 limbs[3]) const {
+        int k = limbs[2] ? 3 : (limbs[1] ? 2 : (limbs[0] ? 1 : 0));
+        std::vector<Ref> coeffs;
+        for (int i = 0; i < k; ++i) coeffs.push_back(bfe(limbs[i], true));
+        Ref poly = mk_instance(c_poly, {s_coefficients, mk_list(coeffs)});
+        Ref n = mk_instance(c_xfe, {s_polynomial, poly, s_field, xfield});
+        n->role = R_XFE;
+        for (int i = 0; i < 3; ++i) n->limbs[i] = limbs[i];
+        return n;
+    }
+};
+
+class Pickler {
+   public:
+    std::string dumps(const Ref& root) {
+        out_.clear();
+        memo_.clear();
+        frame_start_ = NPOS;
+        framing_ = false;
+        const unsigned char proto[2] = {0x80, 4};
+        write(proto, 2);
+        framing_ = true;
+        save(root.get());
+        op(0x2e);  // STOP
+        commit_frame();
+        framing_ = false;
+        return out_;
+    }
+
+   private:
+    static constexpr size_t NPOS = (size_t)-1;
+    static constexpr size_t FRAME_HEADER = 9, FRAME_MIN = 4, FRAME_TARGET = 64 * 1024, BATCH = 1000;
+    std::string out_;
+    std::unordered_map<const Node*, uint32_t> memo_;
+    size_t frame_start_ = NPOS;
+    bool framing_ = false;
+
+    void write(const void* p, size_t n) {  // _Pickler_Write
+        if (framing_ && frame_start_ == NPOS) {
+            frame_start_ = out_.size();
+            out_.append(FRAME_HEADER, (char)0xFE);
+        }
+        out_.append((const char*)p, n);
+    }
+    void op(unsigned char c) { write(&c, 1); }
+    void commit_frame() {  // _Pickler_CommitFrame
+        if (!framing_ || frame_start_ == NPOS) return;
+        size_t len = out_.size() - frame_start_ - FRAME_HEADER;
+        if (len >= FRAME_MIN) {
+            out_[frame_start_] = (char)0x95;
+            uint64_t l = len;
+            memcpy(&out_[frame_start_ + 1], &l, 8);
+        } else {
+            out_.erase(frame_start_, FRAME_HEADER);
+        }
+        frame_start_ = NPOS;
+    }
+    void opcode_boundary() {  // _Pickler_OpcodeBoundary
+        if (!framing_ || frame_start_ == NPOS) return;
+        if (out_.size() - frame_start_ - FRAME_HEADER >= FRAME_TARGET) commit_frame();
+    }
+    void memo_put(const Node* n) {
+        uint32_t idx = (uint32_t)memo_.size();
+        memo_[n] = idx;
+        op(0x94);  // MEMOIZE
+    }
+    void memo_get(uint32_t idx) {
+        if (idx < 256) { unsigned char b[2] = {0x68, (unsigned char)idx}; write(b, 2); }
+        else { unsigned char b[5] = {0x6a}; memcpy(b + 1, &idx, 4); write(b, 5); }
+    }
+
+    void save_long(u64 v) {
+        unsigned char b[12];
+        if (v < (1ull << 31)) {
+            uint32_t x = (uint32_t)v;
+            if (x >> 16) { b[0] = 0x4a; memcpy(b + 1, &x, 4); write(b, 5); }
+            else if (x >> 8) { b[0] = 0x4d; b[1] = (unsigned char)x; b[2] = (unsigned char)(x >> 8); write(b, 3); }
+            else { b[0] = 0x4b; b[1] = (unsigned char)x; write(b, 2); }
+            return;
+        }
+        int bits = 64 - __builtin_clzll(v);
+        int nn = bits / 8 + 1;
+        b[0] = 0x8a; b[1] = (unsigned char)nn;
+        memset(b + 2, 0, 10);
+        memcpy(b + 2, &v, 8);
+        write(b, 2 + (size_t)nn);
+    }
+
+    void save(const Node* n) {
+        opcode_boundary();
+        if (n->kind == K_INT) { save_long(n->ival); return; }
+        auto it = memo_.find(n);
+        if (it != memo_.end()) { memo_get(it->second); return; }
+        switch (n->kind) {
+            case K_BYTES: {
+                size_t len = n->data.size();
+                if (len < 256) { unsigned char h[2] = {0x43, (unsigned char)len}; write(h, 2); }
+                else { unsigned char h[5] = {0x42}; uint32_t l = (uint32_t)len; memcpy(h + 1, &l, 4); write(h, 5); }
+                write(n->data.data(), len);
+                memo_put(n);
+                break;
+            }
+            case K_STR: {
+                size_t len = n->data.size();
+                if (len < 256) { unsigned char h[2] = {0x8c, (unsigned char)len}; write(h, 2); }
+                else { unsigned char h[5] = {0x58}; uint32_t l = (uint32_t)len; memcpy(h + 1, &l, 4); write(h, 5); }
+                write(n->data.data(), len);
+                memo_put(n);
+                break;
+            }
+            case K_LIST: {
+                op(0x5d);  // EMPTY_LIST
+                memo_put(n);
+                size_t len = n->items.size();
+                if (len == 1) { save(n->items[0].get()); op(0x61); }  // APPEND
+                else if (len > 1) {
+                    size_t total = 0;
+                    do {
+                        size_t batch = 0;
+                        op(0x28);  // MARK
+                        while (total < len) {
+                            save(n->items[total].get());
+                            ++total;
+                            if (++batch == BATCH) break;
+                        }
+                        op(0x65);  // APPENDS
+                    } while (total < len);
+                }
+                break;
+            }
+            case K_TUPLE: {
+                size_t len = n->items.size();
+                if (len == 0) { op(0x29); break; }  // EMPTY_TUPLE, not memoised
+                if (len <= 3) {
+                    for (auto& x : n->items) save(x.get());
+                    op((unsigned char)(0x84 + len));  // TUPLE1/2/3
+                } else {
+                    op(0x28);
+                    for (auto& x : n->items) save(x.get());
+                    op(0x74);  // TUPLE
+                }
+                memo_put(n);
+                break;
+            }
+            case K_DICT: {
+                op(0x7d);  // EMPTY_DICT
+                memo_put(n);
+                size_t pairs = n->items.size() / 2;
+                if (pairs == 1) { save(n->items[0].get()); save(n->items[1].get()); op(0x73); }  // SETITEM
+                else if (pairs > 1) {
+                    size_t i = 0;
+                    while (i < pairs) {
+                        size_t batch = 0;
+                        op(0x28);
+                        while (i < pairs) {
+                            save(n->items[2 * i].get());
+                            save(n->items[2 * i + 1].get());
+                            ++i;
+                            if (++batch == BATCH) break;
+                        }
+                        op(0x75);  // SETITEMS
+                    }
+                }
+                break;
+            }
+            case K_CLASS: {  // save_global, protocol 4
+                save(n->items[0].get());
+                save(n->items[1].get());
+                op(0x93);  // STACK_GLOBAL
+                memo_put(n);
+                break;
+            }
+            case K_INSTANCE: {  // save_reduce with copyreg.__newobj__(cls), state = __dict__
+                save(n->cls.get());
+                op(0x29);  // args[1:] == ()
+                op(0x81);  // NEWOBJ
+                memo_put(n);
+                save(n->state.get());
+                op(0x62);  // BUILD
+                break;
+            }
+            default: break;
+        }
+    }
+};
+
+// ProofStream (ip.py:4-30): a list of objects, serialised as one pickle; handles are indices into an arena
+struct Transcript {
+    World world;
+    std::vector<Ref> arena;    // every object ever created through the C ABI (handle = index + 1)
+    std::vector<Ref> objects;  // the pushed objects, in order
+
+    uint64_t add(const Ref& r) { arena.push_back(r); return arena.size(); }
+    Ref get(uint64_t h) const { return (h >= 1 && h <= arena.size()) ? arena[h - 1] : Ref(); }
+
+    std::string serialize(size_t count) const {
+        Ref lst = mk(K_LIST);
+        lst->items.assign(objects.begin(), objects.begin() + (count < objects.size() ? count : objects.size()));
+        Pickler p;
+        return p.dumps(lst);
+    }
+    void fiat_shamir(size_t count, unsigned char* out, size_t num_bytes) const {
+        std::string s = serialize(count);
+        shake256(s.data(), s.size(), out, num_bytes);
+    }
+};
+
+// BaseField.sample (algebra.py:138-142): big-endian bytes -> integer mod p
+inline u64 sample_base(const unsigned char* b, size_t len) {
+    u128 acc = 0;
+    for (size_t i = 0; i < len; ++i) acc = ((acc << 8) | b[i]) % GL_P;
+    return (u64)acc;
+}
+// ExtensionField.sample (extension_field.py:100-111): three chunks of len//3 bytes
+inline Xfe sample_xfe(const unsigned char* b, size_t len) {
+    size_t c = len / 3;
+    return Xfe{{sample_base(b, c), sample_base(b + c, c), sample_base(b + 2 * c, c)}};
+}
+
+}  // namespace rp
+}  // namespace bfs

@@ -1,0 +1,127 @@
+// transcript.cpp -- C ABI over rp::Transcript (proof stream / Fiat-Shamir, host side).
+// Declarations and reference citations: include/bfstark.h ("proof stream").
+#include "../../include/bfstark.h"
+#include "refpickle.hpp"
+#include "runtime.hpp"
+
+using namespace bfs;
+using bfs::rp::Ref;
+using bfs::rp::Transcript;
+
+static Transcript* T(void* ps) { return (Transcript*)ps; }
+
+static int bad_handle(uint64_t h) {
+    set_error("invalid proof-stream object handle %llu", (unsigned long long)h);
+    return BFS_ERR_BAD_ARG;
+}
+
+extern "C" {
+
+void* bfs_ps_new(void) { return new Transcript(); }
+void bfs_ps_free(void* ps) { delete T(ps); }
+
+uint64_t bfs_ps_obj_bytes(void* ps, const uint8_t* data, size_t len) { return T(ps)->add(rp::mk_bytes(data, len)); }
+uint64_t bfs_ps_obj_int(void* ps, uint64_t value) { return T(ps)->add(rp::mk_int(value)); }
+uint64_t bfs_ps_obj_xfe(void* ps, const uint64_t limbs[3]) {
+    uint64_t l[3] = {limbs[0] % GL_P, limbs[1] % GL_P, limbs[2] % GL_P};
+    return T(ps)->add(T(ps)->world.xfe(l));
+}
+uint64_t bfs_ps_obj_bfe(void* ps, uint64_t value, int internal_field) { return T(ps)->add(T(ps)->world.bfe(value % GL_P, internal_field != 0)); }
+
+static uint64_t make_seq(void* ps, rp::Kind kind, const uint64_t* handles, size_t n) {
+    std::vector<Ref> items;
+    items.reserve(n);
+    for (size_t i = 0; i < n; ++i) {
+        Ref r = T(ps)->get(handles[i]);
+        if (!r) { bad_handle(handles[i]); return 0; }
+        items.push_back(r);
+    }
+    Ref node = rp::mk(kind);
+    node->items = items;
+    return T(ps)->add(node);
+}
+uint64_t bfs_ps_obj_list(void* ps, const uint64_t* handles, size_t n) { return make_seq(ps, rp::K_LIST, handles, n); }
+uint64_t bfs_ps_obj_tuple(void* ps, const uint64_t* handles, size_t n) { return make_seq(ps, rp::K_TUPLE, handles, n); }
+
+int bfs_ps_push(void* ps, uint64_t handle) {
+    Ref r = T(ps)->get(handle);
+    if (!r) return bad_handle(handle);
+    T(ps)->objects.push_back(r);
+    return BFS_OK;
+}
+size_t bfs_ps_num_objects(void* ps) { return T(ps)->objects.size(); }
+
+uint64_t bfs_ps_object_at(void* ps, size_t index) {
+    Transcript* t = T(ps);
+    if (index >= t->objects.size()) { set_error("proof stream has %zu objects, asked for %zu", t->objects.size(), index); return 0; }
+    const rp::Node* want = t->objects[index].get();
+    // pushed objects always come from the arena; search from the back (recent objects are the common case)
+    for (size_t i = t->arena.size(); i-- > 0;)
+        if (t->arena[i].get() == want) return i + 1;
+    return t->add(t->objects[index]);
+}
+
+int bfs_ps_serialize(void* ps, size_t count, uint8_t* out, size_t capacity, size_t* length) {
+    std::string s = T(ps)->serialize(count);
+    *length = s.size();
+    if (out && capacity >= s.size()) memcpy(out, s.data(), s.size());
+    return BFS_OK;
+}
+
+int bfs_ps_obj_dumps(void* ps, uint64_t handle, uint8_t* out, size_t capacity, size_t* length) {
+    Ref r = T(ps)->get(handle);
+    if (!r) return bad_handle(handle);
+    rp::Pickler p;
+    std::string s = p.dumps(r);
+    *length = s.size();
+    if (out && capacity >= s.size()) memcpy(out, s.data(), s.size());
+    return BFS_OK;
+}
+
+int bfs_ps_fiat_shamir(void* ps, size_t count, uint8_t* out, size_t num_bytes) {
+    T(ps)->fiat_shamir(count, out, num_bytes);
+    return BFS_OK;
+}
+
+int bfs_ps_obj_kind(void* ps, uint64_t handle) {
+    Ref r = T(ps)->get(handle);
+    if (!r) return -1;
+    if (r->kind == rp::K_INSTANCE) return r->role == rp::R_XFE ? 100 : (r->role == rp::R_BFE ? 101 : 102);
+    return (int)r->kind;
+}
+size_t bfs_ps_obj_len(void* ps, uint64_t handle) {
+    Ref r = T(ps)->get(handle);
+    if (!r) return 0;
+    return (r->kind == rp::K_BYTES || r->kind == rp::K_STR) ? r->data.size() : r->items.size();
+}
+uint64_t bfs_ps_obj_item(void* ps, uint64_t handle, size_t i) {
+    Transcript* t = T(ps);
+    Ref r = t->get(handle);
+    if (!r || i >= r->items.size()) return 0;
+    const rp::Node* want = r->items[i].get();
+    for (size_t k = t->arena.size(); k-- > 0;)
+        if (t->arena[k].get() == want) return k + 1;
+    return t->add(r->items[i]);
+}
+int bfs_ps_obj_get_bytes(void* ps, uint64_t handle, uint8_t* out, size_t capacity) {
+    Ref r = T(ps)->get(handle);
+    if (!r || capacity < r->data.size()) return bad_handle(handle);
+    memcpy(out, r->data.data(), r->data.size());
+    return BFS_OK;
+}
+int bfs_ps_obj_get_limbs(void* ps, uint64_t handle, uint64_t limbs[3]) {
+    Ref r = T(ps)->get(handle);
+    if (!r) return bad_handle(handle);
+    if (r->kind == rp::K_INT) { limbs[0] = r->ival; limbs[1] = limbs[2] = 0; return BFS_OK; }
+    for (int i = 0; i < 3; ++i) limbs[i] = r->limbs[i];
+    return BFS_OK;
+}
+
+/* BaseField.sample / ExtensionField.sample (algebra.py:138-142, extension_field.py:100-111) */
+uint64_t bfs_gl_sample(const uint8_t* bytes, size_t len) { return rp::sample_base(bytes, len); }
+void bfs_xfe_sample(const uint8_t* bytes, size_t len, uint64_t out[3]) {
+    Xfe x = rp::sample_xfe(bytes, len);
+    for (int i = 0; i < 3; ++i) out[i] = x.c[i];
+}
+
+}  // extern "C"

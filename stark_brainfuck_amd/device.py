@@ -58,10 +58,10 @@ class DeviceBuffer:
 
 def device_ptr(x):
     """device pointer of a DeviceBuffer, a torch CUDA tensor of 64-bit integers, or a raw int."""
-    if isinstance(x, DeviceBuffer):
-        return x.ptr
     if isinstance(x, int):
         return x
+    if hasattr(x, "ptr") and not hasattr(x, "data_ptr"):
+        return x.ptr          # DeviceBuffer, or a borrowed view into a native allocation
     if hasattr(x, "data_ptr") and hasattr(x, "is_cuda"):
         if not x.is_cuda:
             raise ValueError("expected a tensor in HBM (cuda device)")

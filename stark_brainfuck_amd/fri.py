@@ -1,0 +1,292 @@
+"""FRI low-degree test, prover on the GPU -- mirror of the reference's `fri.py` (/root/reference/code/fri.py:13-319).
+
+    Fri(offset, omega, initial_domain_length, expansion_factor, num_colinearity_tests, xfield)
+      .domain   Fri.Domain: offset, omega, length, __call__, list, evaluate, xevaluate, interpolate, xinterpolate
+      .num_rounds()  .sample_indices(...)  .commit(...)  .query(...)  .query_last(...)  .prove(...)  .verify(...)
+
+`prove` / `commit` run the whole round loop natively (csrc/fri.hip): Merkle trees, folding and openings on the GPU,
+Fiat-Shamir on the host in C++.  `codeword` may be a Python list of ExtensionFieldElement (as in the reference) or an
+XArray already in HBM.  `verify` is the verifier: host-side, as in the reference.
+"""
+import ctypes
+from hashlib import blake2b
+
+from . import _lib
+from .arrays import BaseArray, XArray
+from .device import current_stream
+from .ip import NativeTranscript, ProofStream
+from .merkle import Merkle
+from .ntt import _base_value, _transform, fast_coset_interpolate
+from .univariate import Polynomial, colinear
+
+_u64 = ctypes.c_uint64
+
+
+class _Codeword:
+    """a round codeword living in HBM that behaves like the reference's list of elements (lazy, identity-stable)."""
+
+    def __init__(self, xarray):
+        self.array = xarray
+        self._items = None
+
+    def __len__(self):
+        return self.array.n
+
+    def _all(self):
+        if self._items is None:
+            self._items = self.array.to_elements()
+        return self._items
+
+    def __getitem__(self, i):
+        return self._all()[i]
+
+    def __iter__(self):
+        return iter(self._all())
+
+
+class Fri:
+    class Domain:
+        def __init__(self, offset, omega, length):
+            self.offset = offset
+            self.omega = omega
+            self.length = length
+
+        def __call__(self, index):
+            return (self.omega ^ index) * self.offset
+
+        def list(self):
+            out, x = [], self.offset
+            for _ in range(self.length):
+                out.append(x)
+                x = x * self.omega
+            return out
+
+        def _evaluate(self, polynomial, as_array):
+            coeffs = polynomial.coefficients if isinstance(polynomial, Polynomial) else polynomial
+            if isinstance(coeffs, (XArray, BaseArray)):
+                src, n_in = coeffs, len(coeffs)
+            else:
+                assert len(coeffs) <= self.length, "polynomial has more coefficients than the domain has points"
+                if not coeffs:
+                    return [self.omega.field.zero() for _ in range(self.length)]
+                from .extension_field import ExtensionFieldElement
+                src = XArray.from_elements(coeffs) if isinstance(coeffs[0], ExtensionFieldElement) else BaseArray.from_elements(coeffs)
+                n_in = len(coeffs)
+            out = _transform(src, n_in, self.length, _base_value(self.omega), _base_value(self.offset), 1)
+            return out if as_array else out.to_elements()
+
+        def evaluate(self, polynomial, as_array=False):
+            """coset evaluation of a base-field polynomial (fri.py:26-30)."""
+            return self._evaluate(polynomial, as_array)
+
+        def xevaluate(self, polynomial, xfield=None, as_array=False):
+            """coset evaluation of an extension-field polynomial (fri.py:32-37): three limb transforms."""
+            if xfield is None and isinstance(polynomial, Polynomial):
+                assert len(polynomial.coefficients) != 0, "trying to xevaluate zero polynomial with no target field"
+            return self._evaluate(polynomial, as_array)
+
+        def interpolate(self, values):
+            return fast_coset_interpolate(self.offset, self.omega, values)
+
+        def xinterpolate(self, values):
+            return fast_coset_interpolate(self.offset, self.omega, values)
+
+    def __init__(self, offset, omega, initial_domain_length, expansion_factor, num_colinearity_tests, xfield):
+        self.domain = Fri.Domain(offset, omega, initial_domain_length)
+        self.field = xfield
+        self.expansion_factor = expansion_factor
+        self.num_colinearity_tests = num_colinearity_tests
+        assert self.num_rounds() >= 1, "cannot do FRI with less than one round"
+
+    def num_rounds(self):
+        length, rounds = self.domain.length, 0
+        while length > self.expansion_factor:
+            length //= 2
+            rounds += 1
+        return rounds
+
+    @staticmethod
+    def sample_index(byte_array, size):
+        return int.from_bytes(bytes(byte_array), "big") % size
+
+    def sample_indices(self, seed, size, reduced_size, number):
+        assert number <= reduced_size, \
+            f"cannot sample more indices than available in last codeword; requested: {number}, available: {reduced_size}"
+        assert number <= 2 * reduced_size, "not enough entropy in indices wrt last codeword"
+        indices, reduced, counter = [], set(), 0
+        while len(indices) < number:
+            index = Fri.sample_index(blake2b(seed + bytes(counter)).digest(), size)
+            counter += 1
+            if index % reduced_size not in reduced:
+                indices.append(index)
+                reduced.add(index % reduced_size)
+        return indices
+
+    def eval_domain(self):
+        return self.domain.list()
+
+    # ------------------------------------------------------------------ prover (GPU)
+    def _as_xarray(self, codeword):
+        if isinstance(codeword, _Codeword):
+            return codeword.array
+        return codeword if isinstance(codeword, XArray) else XArray.from_elements(list(codeword))
+
+    def _run_native(self, codeword, proof_stream, with_query):
+        lib, stream = _lib.load(), current_stream()
+        arr = self._as_xarray(codeword)
+        n = len(arr)
+        assert n & (n - 1) == 0, "codeword length must be a power of two"
+        transcript = NativeTranscript()
+        transcript.xfield = self.field
+        for o in proof_stream.objects:
+            transcript.push(o)
+        before = transcript.num_objects()
+        session = lib.bfs_fri_session_new()
+        try:
+            _lib.check(lib.bfs_fri_commit(session, transcript.handle, arr.ptr, arr.stride, n.bit_length() - 1,
+                                          _base_value(self.domain.offset), _base_value(self.domain.omega), self.expansion_factor, stream))
+            top = None
+            if with_query:
+                out = (_u64 * self.num_colinearity_tests)()
+                _lib.check(lib.bfs_fri_query(session, transcript.handle, self.num_colinearity_tests, out, stream))
+                top = [int(x) for x in out]
+            for i in range(before, transcript.num_objects()):
+                proof_stream.push(transcript.to_python(lib.bfs_ps_object_at(transcript.handle, i), self.field))
+            rounds = []
+            for r in range(lib.bfs_fri_session_rounds(session)):
+                cw, nodes = ctypes.c_void_p(), ctypes.c_void_p()
+                length, stride = _u64(), _u64()
+                root = ctypes.create_string_buffer(64)
+                _lib.check(lib.bfs_fri_session_round(session, r, ctypes.byref(cw), ctypes.byref(length), ctypes.byref(stride), ctypes.byref(nodes), root))
+                rounds.append((cw.value, length.value, stride.value, nodes.value, root.raw))
+            return top, rounds, session, arr
+        except Exception:
+            lib.bfs_fri_session_free(session)
+            raise
+
+    def commit(self, codeword, proof_stream, round_index=0):
+        """fri.py:91-139 -> (codewords, trees); both stay in HBM and are materialised lazily."""
+        lib = _lib.load()
+        _, rounds, session, arr = self._run_native(codeword, proof_stream, with_query=False)
+        keeper = _SessionKeeper(lib, session, arr)
+        codewords, trees = [], []
+        for r, (cw, length, stride, nodes, _root) in enumerate(rounds):
+            view = _Codeword(XArray(_Borrowed(cw, keeper), length, self.field, stride))
+            if r == 0 and isinstance(codeword, list):
+                view._items = codeword
+            codewords.append(view)
+            if r + 1 < len(rounds):
+                trees.append(Merkle(view, _device_nodes=_Borrowed(nodes, keeper)))
+        return codewords, trees
+
+    def query(self, current_tree, next_tree, c_indices, proof_stream):
+        """fri.py:141-158"""
+        half = len(current_tree.leafs) // 2
+        a_indices, b_indices = list(c_indices), [i + half for i in c_indices]
+        for s in range(self.num_colinearity_tests):
+            proof_stream.push((current_tree.leafs[a_indices[s]], current_tree.leafs[b_indices[s]], next_tree.leafs[c_indices[s]]))
+        for s in range(self.num_colinearity_tests):
+            proof_stream.push(current_tree.open(a_indices[s]))
+            proof_stream.push(current_tree.open(b_indices[s]))
+            proof_stream.push(next_tree.open(c_indices[s]))
+        return a_indices + b_indices
+
+    def query_last(self, current_tree, last_codeword, c_indices, proof_stream):
+        """fri.py:160-176"""
+        half = len(current_tree.leafs) // 2
+        a_indices, b_indices = list(c_indices), [i + half for i in c_indices]
+        for s in range(self.num_colinearity_tests):
+            proof_stream.push((current_tree.leafs[a_indices[s]], current_tree.leafs[b_indices[s]], last_codeword[c_indices[s]]))
+        for s in range(self.num_colinearity_tests):
+            proof_stream.push(current_tree.open(a_indices[s]))
+            proof_stream.push(current_tree.open(b_indices[s]))
+        return a_indices + b_indices
+
+    def prove(self, codeword, proof_stream):
+        """fri.py:178-199: commit + query in one native call; returns the top-level indices."""
+        assert self.domain.length == len(codeword), "initial codeword length does not match length of initial codeword"
+        top, _, session, _ = self._run_native(codeword, proof_stream, with_query=True)
+        _lib.load().bfs_fri_session_free(session)
+        return top
+
+    # ------------------------------------------------------------------ verifier (host, fri.py:201-319)
+    def verify(self, proof_stream, root):
+        omega = self.field.lift(self.domain.omega)
+        offset = self.field.lift(self.domain.offset)
+        rounds, t, N = self.num_rounds(), self.num_colinearity_tests, self.domain.length
+        roots, alphas = [root], []
+        for r in range(rounds):
+            if r > 0:
+                roots.append(proof_stream.pull())
+            alphas.append(self.field.sample(proof_stream.verifier_fiat_shamir()))
+        last_codeword = proof_stream.pull()
+        if roots[-1] != Merkle(last_codeword).root():
+            print("last codeword is not well formed")
+            return False
+        degree = (len(last_codeword) // self.expansion_factor) - 1
+        last_omega, last_offset = omega ^ (1 << (rounds - 1)), offset ^ (1 << (rounds - 1))
+        assert last_omega.inverse() == last_omega ^ (len(last_codeword) - 1), "omega does not have right order"
+        last_domain = [last_offset * (last_omega ^ i) for i in range(len(last_codeword))]
+        poly = Polynomial.interpolate_domain(last_domain, last_codeword)
+        assert poly.evaluate_domain(last_domain) == last_codeword, "re-evaluated codeword does not match original!"
+        if poly.degree() > degree:
+            return False
+        top_level_indices = self.sample_indices(proof_stream.verifier_fiat_shamir(), N >> 1, N >> (rounds - 1), t)
+        for r in range(rounds - 1):
+            half = N >> (r + 1)
+            c_indices = [i % half for i in top_level_indices]
+            a_indices, b_indices = list(c_indices), [i + half for i in c_indices]
+            aa, bb, cc = [], [], []
+            for s in range(t):
+                ay, by, cy = proof_stream.pull()
+                aa.append(ay); bb.append(by); cc.append(cy)
+                ax, bx = offset * (omega ^ a_indices[s]), offset * (omega ^ b_indices[s])
+                if not colinear([(ax, ay), (bx, by), (alphas[r], cy)]):
+                    print("colinearity check failure")
+                    return False
+            for i in range(t):
+                if not Merkle.verify(roots[r], a_indices[i], proof_stream.pull(), aa[i]):
+                    print("merkle authentication path verification fails for aa")
+                    return False
+                if not Merkle.verify(roots[r], b_indices[i], proof_stream.pull(), bb[i]):
+                    print("merkle authentication path verification fails for bb")
+                    return False
+                if r + 1 != rounds - 1:
+                    if not Merkle.verify(roots[r + 1], c_indices[i], proof_stream.pull(), cc[i]):
+                        print("merkle authentication path verification fails for cc")
+                        return False
+            if r + 1 == rounds - 1:
+                for i in range(t):
+                    if cc[i] != last_codeword[c_indices[i]]:
+                        print("leafs in last round do not correspond to last codeword")
+                        return False
+            omega, offset = omega ^ 2, offset ^ 2
+        return True
+
+
+class _SessionKeeper:
+    """keeps a native FRI session (and the round-0 codeword) alive while views into its HBM block exist."""
+
+    def __init__(self, lib, session, arr):
+        self.lib, self.session, self.arr = lib, session, arr
+
+    def __del__(self):
+        try:
+            self.lib.bfs_fri_session_free(self.session)
+        except Exception:
+            pass
+
+
+class _Borrowed:
+    """a device pointer owned by someone else, shaped like DeviceBuffer for reads."""
+
+    def __init__(self, ptr, keeper):
+        self.ptr, self._keeper = ptr, keeper
+
+    def to_numpy(self, count, offset=0, stream=None):
+        import numpy as np
+        out = np.empty(count, dtype=np.uint64)
+        if count:
+            _lib.check(_lib.load().bfs_memcpy_d2h(out.ctypes.data, self.ptr + 8 * offset, count * 8,
+                                                  stream if stream is not None else current_stream()))
+        return out

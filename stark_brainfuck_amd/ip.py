@@ -1,0 +1,180 @@
+"""Proof stream / Fiat-Shamir -- mirror of the reference's `ip.py` (/root/reference/code/ip.py:4-30).
+
+`objects` is a plain Python list, as in the reference.  The byte stream the reference obtains from
+`pickle.dumps(self.objects)` is produced by the native transcript code (csrc/refpickle.hpp) from an equivalent
+object graph: elements of this package's classes are emitted exactly as the reference's `algebra.*`,
+`univariate.*`, `extension_field.*` instances would be, shared Python objects stay shared (pickle memoises by
+identity), and SHAKE256 is applied to those bytes.
+"""
+import ctypes
+import io
+import pickle
+
+from . import _lib
+from .algebra import BaseField, BaseFieldElement
+from .extension_field import ExtensionField, ExtensionFieldElement
+from .univariate import Polynomial
+
+_u64 = ctypes.c_uint64
+
+
+class NativeTranscript:
+    """owns a bfs_ps_* handle and the two-way mapping between Python objects and native object handles."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self.handle = self.lib.bfs_ps_new()
+        self._by_id = {}     # id(python object) -> native handle
+        self._keep = []      # keeps those python objects alive so ids stay unique
+        self._by_handle = {}  # native handle -> python object (identity of objects created natively)
+        self.xfield = None
+
+    def __del__(self):
+        try:
+            self.lib.bfs_ps_free(self.handle)
+        except Exception:
+            pass
+
+    # ---- python -> native
+    def to_native(self, obj):
+        key = id(obj)
+        if key in self._by_id:
+            return self._by_id[key]
+        lib, h = self.lib, self.handle
+        if isinstance(obj, (bytes, bytearray)):
+            n = lib.bfs_ps_obj_bytes(h, bytes(obj), len(obj))
+        elif isinstance(obj, ExtensionFieldElement):
+            if self.xfield is None:
+                self.xfield = obj.field
+            n = lib.bfs_ps_obj_xfe(h, (_u64 * 3)(*obj.limbs()))
+        elif isinstance(obj, BaseFieldElement):
+            internal = self.xfield is not None and obj.field is self.xfield.modulus.coefficients[0].field
+            n = lib.bfs_ps_obj_bfe(h, obj.value, 1 if internal else 0)
+        elif isinstance(obj, bool):
+            raise TypeError("bool objects are not supported in the native transcript")
+        elif isinstance(obj, int):
+            if not 0 <= obj < 1 << 64:
+                raise TypeError("only integers in [0, 2^64) are supported in the native transcript")
+            return lib.bfs_ps_obj_int(h, obj)            # ints are never memoised by pickle
+        elif isinstance(obj, (list, tuple)):
+            items = [self.to_native(x) for x in obj]
+            arr = (_u64 * len(items))(*items)
+            n = (lib.bfs_ps_obj_list if isinstance(obj, list) else lib.bfs_ps_obj_tuple)(h, arr, len(items))
+        else:
+            raise TypeError("cannot put a %s into the native proof stream" % type(obj).__name__)
+        if n == 0:
+            _lib.check(6)
+        self._by_id[key] = n
+        self._keep.append(obj)
+        self._by_handle[n] = obj
+        return n
+
+    # ---- native -> python
+    def to_python(self, n, xfield):
+        if n in self._by_handle:
+            return self._by_handle[n]
+        lib, h = self.lib, self.handle
+        kind = lib.bfs_ps_obj_kind(h, n)
+        if kind == 0:
+            buf = ctypes.create_string_buffer(max(lib.bfs_ps_obj_len(h, n), 1))
+            _lib.check(lib.bfs_ps_obj_get_bytes(h, n, buf, len(buf)))
+            obj = buf.raw[:lib.bfs_ps_obj_len(h, n)]
+        elif kind in (1, 100, 101):
+            limbs = (_u64 * 3)()
+            _lib.check(lib.bfs_ps_obj_get_limbs(h, n, limbs))
+            if kind == 1:
+                return int(limbs[0])
+            obj = xfield.from_limbs(list(limbs)) if kind == 100 else BaseFieldElement(int(limbs[0]), xfield.modulus.coefficients[0].field)
+        elif kind in (3, 4):
+            items = [self.to_python(lib.bfs_ps_obj_item(h, n, i), xfield) for i in range(lib.bfs_ps_obj_len(h, n))]
+            obj = items if kind == 3 else tuple(items)
+        else:
+            raise RuntimeError("unexpected native object kind %d" % kind)
+        self._by_handle[n] = obj
+        self._by_id[id(obj)] = n
+        self._keep.append(obj)
+        return obj
+
+    def push(self, obj):
+        _lib.check(self.lib.bfs_ps_push(self.handle, self.to_native(obj)))
+
+    def serialize(self, count=None):
+        lib = self.lib
+        count = (1 << 62) if count is None else count
+        n = ctypes.c_size_t()
+        _lib.check(lib.bfs_ps_serialize(self.handle, count, None, 0, ctypes.byref(n)))
+        buf = ctypes.create_string_buffer(max(n.value, 1))
+        _lib.check(lib.bfs_ps_serialize(self.handle, count, buf, n.value, ctypes.byref(n)))
+        return buf.raw[:n.value]
+
+    def dumps(self, obj):
+        """pickle.dumps(obj) for one object on its own (leaf preimages)."""
+        lib = self.lib
+        h = self.to_native(obj)
+        n = ctypes.c_size_t()
+        _lib.check(lib.bfs_ps_obj_dumps(self.handle, h, None, 0, ctypes.byref(n)))
+        buf = ctypes.create_string_buffer(max(n.value, 1))
+        _lib.check(lib.bfs_ps_obj_dumps(self.handle, h, buf, n.value, ctypes.byref(n)))
+        return buf.raw[:n.value]
+
+    def fiat_shamir(self, count, num_bytes):
+        out = ctypes.create_string_buffer(num_bytes)
+        _lib.check(self.lib.bfs_ps_fiat_shamir(self.handle, (1 << 62) if count is None else count, out, num_bytes))
+        return out.raw
+
+    def num_objects(self):
+        return self.lib.bfs_ps_num_objects(self.handle)
+
+
+def reference_pickle(obj):
+    """bytes of the reference's `pickle.dumps(obj)` for an object made of this package's element classes,
+    bytes, ints, lists and tuples."""
+    return NativeTranscript().dumps(obj)
+
+
+class ProofStream:
+    def __init__(self):
+        self.objects = []
+        self.read_index = 0
+
+    def push(self, obj):
+        self.objects += [obj]
+
+    def pull(self):
+        assert self.read_index < len(self.objects), "ProofStream: cannot pull object; queue empty."
+        obj = self.objects[self.read_index]
+        self.read_index += 1
+        return obj
+
+    def _native(self, count=None):
+        t = NativeTranscript()
+        for o in (self.objects if count is None else self.objects[:count]):
+            t.push(o)
+        return t
+
+    def serialize(self):
+        return self._native().serialize()
+
+    def prover_fiat_shamir(self, num_bytes=32):
+        return self._native().fiat_shamir(None, num_bytes)
+
+    def verifier_fiat_shamir(self, num_bytes=32):
+        return self._native(self.read_index).fiat_shamir(None, num_bytes)
+
+    def deserialize(self, bb):
+        ps = ProofStream()
+        ps.objects = _ReferenceUnpickler(io.BytesIO(bb)).load()
+        return ps
+
+
+class _ReferenceUnpickler(pickle.Unpickler):
+    """reads a stream written by the reference (or by serialize()) into this package's classes."""
+    _CLASSES = {("algebra", "BaseField"): BaseField, ("algebra", "BaseFieldElement"): BaseFieldElement,
+                ("univariate", "Polynomial"): Polynomial, ("extension_field", "ExtensionField"): ExtensionField,
+                ("extension_field", "ExtensionFieldElement"): ExtensionFieldElement}
+
+    def find_class(self, module, name):
+        try:
+            return self._CLASSES[(module, name)]
+        except KeyError:
+            raise pickle.UnpicklingError("refusing to load %s.%s from a proof stream" % (module, name))

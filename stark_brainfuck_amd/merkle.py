@@ -1,0 +1,137 @@
+"""BLAKE2b-512 Merkle trees built on the GPU -- mirror of the reference's `merkle.py`
+(/root/reference/code/merkle.py:7-63): `Merkle(data_array)`, `.root()`, `.open(index)`, `Merkle.verify(...)`,
+attributes `num_leafs`, `depth`, `leafs`, `nodes`.
+
+Leaf hashing and all inner levels run in HIP kernels (csrc/merkle.hip).  When the leaves are field elements (or an
+XArray / BaseArray in HBM) the pickle preimage of every leaf is synthesised on the GPU from the limbs; arbitrary
+picklable leaves are pickled on the host, exactly like the reference does, and hashed on the GPU in one batch.
+"""
+import ctypes
+import pickle
+from hashlib import blake2b
+
+import numpy as np
+
+from . import _lib
+from .algebra import BaseFieldElement
+from .arrays import BaseArray, XArray
+from .device import DeviceBuffer, current_stream, synchronize
+from .extension_field import ExtensionFieldElement
+from .ip import NativeTranscript
+
+
+def leaf_bytes(element, transcript=None):
+    """the reference's pickle.dumps(element): native emitter for this package's element classes (and containers
+    of them), CPython's pickle for everything else."""
+    try:
+        return (transcript or NativeTranscript()).dumps(element)
+    except TypeError:
+        return pickle.dumps(element, protocol=4)
+
+
+def _tree_shape(n):
+    npo2 = 1
+    while npo2 < n:
+        npo2 <<= 1
+    if n == 0:
+        npo2 = 0
+    return npo2, max(npo2.bit_length() - 1, 0)
+
+
+class Merkle:
+    def __init__(self, data_array, _device_nodes=None):
+        self.num_leafs = len(data_array)
+        self._npo2, self.depth = _tree_shape(self.num_leafs)
+        self._data = data_array
+        self._leafs = None
+        self._nodes_host = None
+        if _device_nodes is not None:            # tree already built in HBM (Fri.commit)
+            self._nodes = _device_nodes
+            return
+        self._nodes = DeviceBuffer(max(2 * self._npo2, 2) * 8)
+        if self.num_leafs:
+            self._build(data_array)
+
+    # ---- construction
+    def _build(self, data):
+        lib, stream = _lib.load(), current_stream()
+        n = self.num_leafs
+        if isinstance(data, XArray):
+            _lib.check(lib.bfs_merkle_build_xfe(data.ptr, data.stride, n, self._nodes.ptr, stream))
+        elif isinstance(data, BaseArray):
+            _lib.check(lib.bfs_merkle_build_bfe(data.ptr, n, self._nodes.ptr, stream))
+        elif all(isinstance(e, ExtensionFieldElement) for e in data):
+            arr = XArray.from_elements(data)
+            _lib.check(lib.bfs_merkle_build_xfe(arr.ptr, arr.stride, n, self._nodes.ptr, stream))
+            synchronize(stream)
+        elif all(isinstance(e, BaseFieldElement) for e in data) and len({id(e.field) for e in data}) == 1:
+            arr = BaseArray.from_elements(data)
+            _lib.check(lib.bfs_merkle_build_bfe(arr.ptr, n, self._nodes.ptr, stream))
+            synchronize(stream)
+        else:
+            self._build_from_bytes([leaf_bytes(e) for e in data])
+
+    def _build_from_bytes(self, preimages):
+        lib, stream = _lib.load(), current_stream()
+        n = len(preimages)
+        lengths = np.fromiter((len(b) for b in preimages), dtype=np.uint32, count=n)
+        words = (lengths.astype(np.uint64) + 7) // 8
+        offsets = np.zeros(n, dtype=np.uint64)
+        np.cumsum(words[:-1], out=offsets[1:])
+        total = int(words.sum())
+        blob = bytearray(max(total, 1) * 8)
+        for b, off in zip(preimages, offsets):
+            blob[int(off) * 8:int(off) * 8 + len(b)] = b
+        d_data = DeviceBuffer.from_numpy(np.frombuffer(bytes(blob), dtype=np.uint64))
+        d_off = DeviceBuffer.from_numpy(offsets)
+        d_len = DeviceBuffer.from_numpy(np.frombuffer(np.ascontiguousarray(np.concatenate([lengths, np.zeros(n % 2, np.uint32)])).tobytes(), dtype=np.uint64))
+        _lib.check(lib.bfs_merkle_build_bytes(d_data.ptr, d_off.ptr, d_len.ptr, n, self._nodes.ptr, stream))
+        synchronize(stream)
+
+    # ---- reference attributes
+    @property
+    def leafs(self):
+        if self._leafs is None:
+            d = self._data
+            self._leafs = d.to_elements() if isinstance(d, (XArray, BaseArray)) else [leaf for leaf in d]
+        return self._leafs
+
+    @property
+    def nodes(self):
+        """the reference's `nodes` list: 2*npo2 entries, 32 zero bytes where the reference never writes a digest."""
+        if self._nodes_host is None:
+            npo2, n = self._npo2, self.num_leafs
+            raw = self._nodes.to_numpy(2 * npo2 * 8).tobytes() if npo2 else b""
+            nodes = [raw[64 * i:64 * i + 64] for i in range(2 * npo2)]
+            for i in range(npo2 + n, 2 * npo2):
+                nodes[i] = bytes(32)                                     # merkle.py:26
+            if npo2:
+                nodes[0] = blake2b(bytes(32) + nodes[1]).digest()        # merkle.py:35-41 runs down to index 0
+            self._nodes_host = nodes
+        return self._nodes_host
+
+    def root(self):
+        if self._nodes_host is not None:
+            return self._nodes_host[1]
+        synchronize()
+        return self._nodes.to_numpy(8, offset=8).tobytes()
+
+    def open(self, index):
+        if self.depth == 0:
+            return []
+        buf = ctypes.create_string_buffer(64 * self.depth)
+        _lib.check(_lib.load().bfs_merkle_open(self._nodes.ptr, self.depth, index, buf, current_stream()))
+        path = [buf.raw[64 * i:64 * i + 64] for i in range(self.depth)]
+        sibling = ((1 << self.depth) | index) ^ 1
+        if sibling >= self._npo2 + self.num_leafs:
+            path[0] = bytes(32)              # absent leaf slot: the reference keeps 32 zero bytes there (merkle.py:26)
+        return path
+
+    @staticmethod
+    def verify(root, index, path, element):
+        """verifier side (host, hashlib -- as in the reference, merkle.py:54-63)."""
+        running = blake2b(leaf_bytes(element)).digest()
+        for node in path:
+            running = blake2b(running + node).digest() if index % 2 == 0 else blake2b(node + running).digest()
+            index >>= 1
+        return running == root

@@ -1,0 +1,199 @@
+"""Fast polynomial arithmetic on the GPU -- the mirror of the reference's `ntt.py` (/root/reference/code/ntt.py).
+
+Same functions, argument order, results and AssertionErrors:
+
+    ntt(primitive_root, values)            ntt.py:4-23      intt(primitive_root, values)            ntt.py:26-42
+    fast_multiply(lhs, rhs, root, order)   ntt.py:45-79     fast_coset_evaluate(poly, offset, g, n) ntt.py:164-168
+    fast_coset_interpolate(offset, g, v)   ntt.py:171-174   batch_inverse(array)                    ntt.py:177-188
+    fast_coset_divide(l, r, offset, g, n)  ntt.py:191-235
+
+`values` may be a Python list of BaseFieldElement / ExtensionFieldElement objects (a new list of new objects comes
+back, as in the reference) or a BaseArray / XArray living in HBM (an array of the same kind comes back, nothing is
+copied to the host).  Every transform runs in the HIP kernels behind bfs_gl_ntt; there is no CPU fallback.
+"""
+import numpy as np
+
+from . import _lib
+from .algebra import BaseFieldElement
+from .arrays import BaseArray, XArray, raw_ntt
+from .device import current_stream
+from .extension_field import ExtensionFieldElement
+from .univariate import Polynomial
+
+
+def _base_value(x):
+    """int value of a root/offset given as int, BaseFieldElement or a lifted ExtensionFieldElement."""
+    if isinstance(x, int):
+        return x
+    if isinstance(x, BaseFieldElement):
+        return x.value
+    if isinstance(x, ExtensionFieldElement):
+        c = x.polynomial.coefficients
+        if len(c) > 1:
+            raise NotImplementedError("transform roots / offsets must lie in the base field (fri.py:37 lifts them)")
+        return c[0].value if c else 0
+    raise TypeError("not a field element: %r" % type(x))
+
+
+def _log2(n):
+    assert n & (n - 1) == 0, "cannot compute ntt of non-power-of-two sequence"
+    return n.bit_length() - 1
+
+
+def _is_x(values):
+    return isinstance(values, XArray) or (isinstance(values, list) and len(values) and isinstance(values[0], ExtensionFieldElement))
+
+
+def _to_array(values):
+    if isinstance(values, (BaseArray, XArray)):
+        return values
+    return XArray.from_elements(values) if _is_x(values) else BaseArray.from_elements(values)
+
+
+def _transform(arr, n_in, n, root, shift, post_scale):
+    """run bfs_gl_ntt on a BaseArray (batch rows) or XArray (3 limb planes) -> new array of length n."""
+    log_n = _log2(n)
+    if isinstance(arr, XArray):
+        out = XArray.empty(n, arr.field)
+        raw_ntt(arr.ptr, n_in, arr.stride, out.ptr, n, log_n, 3, root, shift, post_scale)
+    else:
+        out = BaseArray.empty(n, arr.field, arr.batch)
+        raw_ntt(arr.ptr, n_in, arr.n, out.ptr, n, log_n, arr.batch, root, shift, post_scale)
+    return out
+
+
+def _pow(v, e):
+    return _lib.load().bfs_gl_pow(v, e)
+
+
+def ntt(primitive_root, values):
+    n = len(values)
+    assert n & (n - 1) == 0, "cannot compute ntt of non-power-of-two sequence"
+    if n <= 1:
+        return values                                       # ntt.py:8-9 returns its argument
+    as_list = isinstance(values, list)
+    out = _transform(_to_array(values), n, n, _base_value(primitive_root), 1, 1)
+    return out.to_elements() if as_list else out
+
+
+def intt(primitive_root, values):
+    n = len(values)
+    assert n & (n - 1) == 0, "cannot compute intt of non-power-of-two sequence"
+    w = _base_value(primitive_root)
+    assert _pow(w, n) == 1, "supplied root does not have supplied order"
+    if n == 1:
+        return values
+    assert _pow(w, n // 2) != 1, "supplied root is not primitive root of supplied order"
+    lib = _lib.load()
+    as_list = isinstance(values, list)
+    out = _transform(_to_array(values), n, n, lib.bfs_gl_inv(w), 1, lib.bfs_gl_inv(n))
+    return out.to_elements() if as_list else out
+
+
+def _check_root(primitive_root, root_order):
+    w = _base_value(primitive_root)
+    assert _pow(w, root_order) == 1, "supplied root does not have supplied order"
+    assert _pow(w, root_order // 2) != 1, "supplied root is not primitive root of supplied order"
+    return w
+
+
+def _coeff_array(coeffs, order, field):
+    """zero-padded device array of the first len(coeffs) coefficients (list of elements)."""
+    if coeffs and isinstance(coeffs[0], ExtensionFieldElement):
+        return XArray.from_elements(coeffs)
+    return BaseArray.from_elements(coeffs)
+
+
+def fast_multiply(lhs, rhs, primitive_root, root_order):
+    w = _check_root(primitive_root, root_order)
+    if lhs.is_zero() or rhs.is_zero():
+        return Polynomial([])
+    degree = lhs.degree() + rhs.degree()
+    if degree < 8:
+        return lhs * rhs                                    # ntt.py:59-60
+    order = root_order
+    while degree < order // 2:
+        w, order = _lib.load().bfs_gl_mul(w, w), order // 2
+    lib = _lib.load()
+    la = _coeff_array(lhs.coefficients[:lhs.degree() + 1], order, None)
+    ra = _coeff_array(rhs.coefficients[:rhs.degree() + 1], order, None)
+    if isinstance(la, XArray) or isinstance(ra, XArray):
+        raise NotImplementedError("fast_multiply over the extension field is not on the hot path")
+    lc = _transform(la, la.n, order, w, 1, 1)
+    rc = _transform(ra, ra.n, order, w, 1, 1)
+    _lib.check(lib.bfs_gl_mul_pointwise(lc.ptr, rc.ptr, lc.ptr, order, current_stream()))
+    prod = _transform(lc, order, order, lib.bfs_gl_inv(w), 1, lib.bfs_gl_inv(order))
+    return Polynomial(prod.to_elements()[:degree + 1])
+
+
+def fast_coset_evaluate(polynomial, offset, generator, order):
+    coeffs = polynomial.coefficients
+    assert len(coeffs) <= order, "polynomial has more coefficients than the evaluation domain has points"
+    if not coeffs:
+        return [offset.field.zero() for _ in range(order)]  # ntt of `order` zeros (ntt.py:166-167)
+    src = _coeff_array(coeffs, order, None)
+    out = _transform(src, len(coeffs), order, _base_value(generator), _base_value(offset), 1)
+    return out.to_elements()
+
+
+def fast_coset_interpolate(offset, generator, values):
+    n = len(values)
+    assert n & (n - 1) == 0, "cannot compute intt of non-power-of-two sequence"
+    w = _base_value(generator)
+    assert _pow(w, n) == 1, "supplied root does not have supplied order"
+    as_list = isinstance(values, list)
+    if n == 1:
+        coeffs = values if as_list else values.to_elements()
+        return Polynomial(coeffs)
+    assert _pow(w, n // 2) != 1, "supplied root is not primitive root of supplied order"
+    lib = _lib.load()
+    # intt followed by scale(offset^-1)  ==  one inverse transform whose outputs are multiplied by offset^-k:
+    # done as intt, then a coset "scale" pass (bfs_gl_scale)
+    arr = _to_array(values)
+    out = _transform(arr, n, n, lib.bfs_gl_inv(w), 1, lib.bfs_gl_inv(n))
+    oinv = lib.bfs_gl_inv(_base_value(offset))
+    batch = 3 if isinstance(out, XArray) else out.batch
+    _lib.check(lib.bfs_gl_scale(out.ptr, out.ptr, n, n, batch, oinv, current_stream()))
+    return Polynomial(out.to_elements())
+
+
+def batch_inverse(array):
+    if isinstance(array, BaseArray):
+        out = BaseArray.empty(array.n, array.field, array.batch)
+        _lib.check(_lib.load().bfs_gl_batch_inverse(array.ptr, out.ptr, array.n * array.batch, current_stream()))
+        return out
+    assert all(not a.is_zero() for a in array), "batch inverse does not work when input contains a zero"
+    if not array:
+        return []
+    if isinstance(array[0], ExtensionFieldElement):
+        return [a.inverse() for a in array]                 # not on the hot path
+    src = BaseArray.from_elements(array)
+    out = BaseArray.empty(src.n, src.field)
+    _lib.check(_lib.load().bfs_gl_batch_inverse(src.ptr, out.ptr, src.n, current_stream()))
+    return out.to_elements()
+
+
+def fast_coset_divide(lhs, rhs, offset, primitive_root, root_order):
+    """exact division on a coset (ntt.py:191-235)."""
+    w = _check_root(primitive_root, root_order)
+    assert not rhs.is_zero(), "cannot divide by zero polynomial"
+    if lhs.is_zero():
+        return Polynomial([])
+    assert rhs.degree() <= lhs.degree(), "cannot divide by polynomial of larger degree"
+    degree = max(lhs.degree(), rhs.degree())
+    if degree < 8:
+        return lhs / rhs
+    lib = _lib.load()
+    order = root_order
+    while degree < order // 2:
+        w, order = lib.bfs_gl_mul(w, w), order // 2
+    off = _base_value(offset)
+    la = BaseArray.from_elements(lhs.coefficients[:lhs.degree() + 1])
+    ra = BaseArray.from_elements(rhs.coefficients[:rhs.degree() + 1])
+    lc = _transform(la, la.n, order, w, off, 1)
+    rc = _transform(ra, ra.n, order, w, off, 1)
+    _lib.check(lib.bfs_gl_batch_inverse(rc.ptr, rc.ptr, order, current_stream()))
+    _lib.check(lib.bfs_gl_mul_pointwise(lc.ptr, rc.ptr, lc.ptr, order, current_stream()))
+    quo = _transform(lc, order, order, lib.bfs_gl_inv(w), 1, lib.bfs_gl_inv(order))
+    _lib.check(lib.bfs_gl_scale(quo.ptr, quo.ptr, order, order, 1, lib.bfs_gl_inv(off), current_stream()))
+    return Polynomial(quo.to_elements()[:lhs.degree() - rhs.degree() + 1])
