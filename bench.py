@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X backend on BASELINE.json's metric: Goldilocks NTT field-elements/s (+ FRI.prove ms).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (config 5 of BASELINE.json, weak scaling): every GPU holds `--columns` (default 8) independent trace
+columns of 2^24 base-field elements resident in HBM; one step = the forward NTT of all its columns
+(one bfs_gl_ntt call, batch = columns).  value = total field elements transformed per second over all ranks,
+timed over exactly K steps between barrier + device synchronisation on both sides, max over ranks.
+Extra keys on the same JSON line:
+    roofline      dominant kernel (the NTT tile kernel) vs the 8 TB/s HBM roofline, from HIP events on the kernel's stream
+    cpu_baseline  the CPU oracle (oracle/gl_oracle.c, plain C port of ntt.py, 1 core) on a bounded sample, rank 0, N=1 only
+    fri_prove_ms  Fri.prove on a random degree-2^18 codeword, expansion 4 (config 3), through the C ABI, median of 5
+Nothing here reads /root/reference.
+"""
+import argparse
+import ctypes
+import json
+import os
+import statistics
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+P = (1 << 64) - (1 << 32) + 1
+SEED = 0x5EED
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def felt_array(seed, start, n):
+    """felt(seed, i) = splitmix64(seed + i) mod p  (SURVEY.md 8d), vectorised."""
+    with np.errstate(over="ignore"):
+        x = (np.arange(start, start + n, dtype=np.uint64) + np.uint64(seed & 0xFFFFFFFFFFFFFFFF)) + np.uint64(0x9E3779B97F4A7C15)
+        z = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z % np.uint64(P)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=24)
+    ap.add_argument("--columns", type=int, default=8, help="columns per GPU")
+    ap.add_argument("--no-fri", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run --nproc-per-node N" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the hot path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from stark_brainfuck_amd import _lib, shard
+    from stark_brainfuck_amd.device import DeviceBuffer
+    lib = _lib.load()
+    _lib.check(lib.bfs_set_device(local_rank))
+
+    log_n, cols = args.log_n, args.columns
+    n = 1 << log_n
+    root = lib.bfs_gl_primitive_root(log_n)
+    total_cols = cols * world
+    my_cols = [rank * cols + j for j in range(cols)]        # weak scaling: every rank owns `cols` columns
+    host_in = np.concatenate([felt_array(SEED + (c << 32), 0, n) for c in my_cols])
+    d_in = DeviceBuffer.from_numpy(host_in)
+    d_out = DeviceBuffer(n * cols)
+    stream = 0
+
+    def step():
+        _lib.check(lib.bfs_gl_ntt(d_in.ptr, n, n, d_out.ptr, n, log_n, cols, root, 1, 1, stream))
+
+    def sync_all():
+        _lib.check(lib.bfs_stream_synchronize(stream))
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ev0, ev1 = ctypes.c_void_p(), ctypes.c_void_p()
+    lib.bfs_event_create(ctypes.byref(ev0)); lib.bfs_event_create(ctypes.byref(ev1))
+    sync_all()
+    t0 = time.perf_counter()
+    lib.bfs_event_record(ev0, stream)
+    for _ in range(args.steps):
+        step()
+    lib.bfs_event_record(ev1, stream)
+    sync_all()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    kern_ms = ctypes.c_float()
+    _lib.check(lib.bfs_event_elapsed_ms(ev0, ev1, ctypes.byref(kern_ms)))
+    if dist is not None:
+        t = torch.tensor([elapsed, kern_ms.value], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, kern = float(t[0]), float(t[1])
+    else:
+        kern = kern_ms.value
+
+    # ---- after the timed region: correctness guard + the one collective of the design (roots of all columns)
+    from stark_brainfuck_amd.arrays import BaseArray
+    from stark_brainfuck_amd.merkle import Merkle
+    inv = DeviceBuffer(n)
+    _lib.check(lib.bfs_gl_ntt(d_out.ptr, n, n, inv.ptr, n, log_n, 1, lib.bfs_gl_inv(root), 1, lib.bfs_gl_inv(n), stream))
+    back = inv.to_numpy()
+    assert (back == host_in[:n]).all(), "intt(ntt(x)) != x on the bench data"
+    small = 1 << 12                                          # commit to a 4096-element prefix of each output column
+    local_roots = {}
+    for j, c in enumerate(my_cols):
+        pref = BaseArray(DeviceBuffer.from_numpy(d_out.to_numpy(small, offset=j * n)), small)
+        local_roots[c] = Merkle(pref).root()
+    if world > 1:
+        width = cols
+        send = torch.from_numpy(np.frombuffer(b"".join(local_roots[c] for c in my_cols), dtype=np.uint8).copy()).cuda()
+        recv = [torch.empty_like(send) for _ in range(world)]
+        dist.all_gather(recv, send)                           # RCCL over xGMI: 64-byte roots only
+        all_roots = b"".join(r.cpu().numpy().tobytes() for r in recv)
+        assert len(all_roots) == 64 * total_cols and all_roots[64 * rank * width:64 * (rank + 1) * width] == send.cpu().numpy().tobytes()
+
+    elems = n * cols * world * args.steps
+    value = elems / elapsed
+    line = {
+        "metric": "goldilocks_ntt_field_elements_per_sec",
+        "value": value,
+        "unit": "elements/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64 (mod 2^64-2^32+1)",
+        "data": "synthetic (splitmix64 mod p, seed 0x5EED)",
+        "config": {"workload": "forward NTT, 2^%d-point base-field columns, %d columns per GPU resident in HBM (BASELINE config 5 shape)" % (log_n, cols),
+                   "log_n": log_n, "columns_per_gpu": cols, "parallelism": "columns sharded %d-way, no data-path collective" % world},
+        "algorithmic_GBps": 16.0 * elems / elapsed / 1e9,
+    }
+    if rank == 0:
+        # dominant kernel = ntt_tile_kernel (npass launches per step); algorithmic bytes of one launch =
+        # 16 B/element * n * columns / npass (DESIGN.md "Roofline accounting"); HIP events bracket exactly K steps
+        npass = 1 if log_n <= 12 else (log_n + 7) // 8
+        launches = npass * args.steps
+        avg_launch_s = kern * 1e-3 / launches
+        bytes_per_launch = 16.0 * n * cols / npass
+        achieved = bytes_per_launch / avg_launch_s / 1e9
+        line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                            "traffic": None, "kernel": "ntt_tile_kernel<4,4,0>", "launches_per_step": npass,
+                            "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch}
+        if not args.no_fri:
+            line["fri_prove"] = bench_fri(lib, _lib, stream)
+            line["fri_prove_ms"] = line["fri_prove"]["ms"]
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(log_n)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def bench_fri(lib, _lib, stream):
+    """config 3: Fri.prove on a degree-2^18 extension codeword, expansion 4, 4 colinearity tests, fresh proof stream."""
+    from stark_brainfuck_amd.device import DeviceBuffer
+    log_d, expansion, t = 18, 4, 4
+    d, N = 1 << log_d, (1 << log_d) * expansion
+    log_N = N.bit_length() - 1
+    omega = lib.bfs_gl_primitive_root(log_N)
+    coeffs = felt_array(SEED, 0, 3 * d).reshape(d, 3).T.copy()
+    d_coef = DeviceBuffer.from_numpy(coeffs.reshape(-1))
+    d_cw = DeviceBuffer(3 * N)
+    _lib.check(lib.bfs_gl_ntt(d_coef.ptr, d, d, d_cw.ptr, N, log_N, 3, omega, 7, 1, stream))     # Domain.xevaluate
+    _lib.check(lib.bfs_stream_synchronize(stream))
+    times, idx = [], None
+    for rep in range(6):
+        ps = lib.bfs_ps_new()
+        out = (ctypes.c_uint64 * t)()
+        t0 = time.perf_counter()
+        _lib.check(lib.bfs_fri_prove(ps, d_cw.ptr, N, log_N, 7, omega, expansion, t, out, stream))
+        _lib.check(lib.bfs_stream_synchronize(stream))
+        times.append(time.perf_counter() - t0)
+        idx = [int(x) for x in out]
+        nobj = lib.bfs_ps_num_objects(ps)
+        lib.bfs_ps_free(ps)
+    ms = statistics.median(times[1:]) * 1e3
+    return {"ms": ms, "N": N, "expansion": expansion, "colinearity_tests": t, "rounds": log_N - 2, "objects": nobj,
+            "top_level_indices": idx, "algorithmic_GBps": 376.0 * N / (ms * 1e-3) / 1e9,
+            "note": "bfs_fri_prove through the C ABI, codeword resident in HBM, includes host Fiat-Shamir round trips and D2H of openings"}
+
+
+def cpu_baseline(log_n):
+    """the oracle's C restatement of ntt.py (recursive radix-2, one core) on a bounded sample of the same workload."""
+    from oracle import ref_oracle as o
+    n = 1 << log_n
+    sample_cols = 2 if log_n >= 24 else 4
+    w = o.primitive_nth_root(n)
+    t = 0.0
+    for c in range(sample_cols):
+        v = felt_array(SEED + (c << 32), 0, n)
+        t0 = time.perf_counter()
+        o.ntt(w, v)
+        t += time.perf_counter() - t0
+    return {"value": n * sample_cols / t, "unit": "elements/s", "cores": 1, "kind": "port",
+            "sample": "%d column(s) of 2^%d elements, forward NTT, oracle/gl_oracle.c (gcc -O2), %.1f s" % (sample_cols, log_n, t),
+            "host_cpus": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

@@ -174,6 +174,8 @@ class Fri:
             view = _Codeword(XArray(_Borrowed(cw, keeper), length, self.field, stride))
             if r == 0 and isinstance(codeword, list):
                 view._items = codeword
+            if r + 1 == len(rounds):
+                view._items = proof_stream.objects[-1]      # fri.py:134 pushes this very list: keep object identity
             codewords.append(view)
             if r + 1 < len(rounds):
                 trees.append(Merkle(view, _device_nodes=_Borrowed(nodes, keeper)))

@@ -126,6 +126,18 @@ class NativeTranscript:
         return self.lib.bfs_ps_num_objects(self.handle)
 
 
+def _find_xfield(obj):
+    """the ExtensionField of the first extension element inside obj (None if there is none)."""
+    if isinstance(obj, ExtensionFieldElement):
+        return obj.field
+    if isinstance(obj, (list, tuple)):
+        for x in obj:
+            f = _find_xfield(x)
+            if f is not None:
+                return f
+    return None
+
+
 def reference_pickle(obj):
     """bytes of the reference's `pickle.dumps(obj)` for an object made of this package's element classes,
     bytes, ints, lists and tuples."""
@@ -148,7 +160,9 @@ class ProofStream:
 
     def _native(self, count=None):
         t = NativeTranscript()
-        for o in (self.objects if count is None else self.objects[:count]):
+        objs = self.objects if count is None else self.objects[:count]
+        t.xfield = _find_xfield(objs)     # decides which BaseField instance a bare BaseFieldElement refers to
+        for o in objs:
             t.push(o)
         return t
 

@@ -38,6 +38,12 @@ def _tree_shape(n):
     return npo2, max(npo2.bit_length() - 1, 0)
 
 
+def _walk(k):
+    while k > 1:
+        yield k
+        k >>= 1
+
+
 class Merkle:
     def __init__(self, data_array, _device_nodes=None):
         self.num_leafs = len(data_array)
@@ -45,6 +51,7 @@ class Merkle:
         self._data = data_array
         self._leafs = None
         self._nodes_host = None
+        self._node_cache = {}
         if _device_nodes is not None:            # tree already built in HBM (Fri.commit)
             self._nodes = _device_nodes
             return
@@ -107,6 +114,8 @@ class Merkle:
                 nodes[i] = bytes(32)                                     # merkle.py:26
             if npo2:
                 nodes[0] = blake2b(bytes(32) + nodes[1]).digest()        # merkle.py:35-41 runs down to index 0
+            for k, obj in self._node_cache.items():
+                nodes[k] = obj                                           # keep the identity of nodes already handed out
             self._nodes_host = nodes
         return self._nodes_host
 
@@ -117,14 +126,22 @@ class Merkle:
         return self._nodes.to_numpy(8, offset=8).tobytes()
 
     def open(self, index):
+        """sibling digests from the leaf level up (merkle.py:46-52).  A node is always returned as the SAME bytes
+        object, like the reference's `nodes` list: pickle memoises by identity, so this is visible in proof streams."""
         if self.depth == 0:
             return []
+        if self._nodes_host is not None:
+            nodes = self._nodes_host
+            return [nodes[k ^ 1] for k in _walk((1 << self.depth) | index)]
         buf = ctypes.create_string_buffer(64 * self.depth)
         _lib.check(_lib.load().bfs_merkle_open(self._nodes.ptr, self.depth, index, buf, current_stream()))
-        path = [buf.raw[64 * i:64 * i + 64] for i in range(self.depth)]
-        sibling = ((1 << self.depth) | index) ^ 1
-        if sibling >= self._npo2 + self.num_leafs:
-            path[0] = bytes(32)              # absent leaf slot: the reference keeps 32 zero bytes there (merkle.py:26)
+        path = []
+        for lvl, k in enumerate(_walk((1 << self.depth) | index)):
+            sib = k ^ 1
+            if sib not in self._node_cache:
+                absent = sib >= self._npo2 + self.num_leafs       # the reference keeps 32 zero bytes there (merkle.py:26)
+                self._node_cache[sib] = bytes(32) if absent else buf.raw[64 * lvl:64 * lvl + 64]
+            path.append(self._node_cache[sib])
         return path
 
     @staticmethod

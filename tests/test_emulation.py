@@ -1,0 +1,126 @@
+"""CPU checks of the product's DEVICE code compiled for the host (tests/emu/*.cpp): the NTT planner and every
+index / twiddle computation of the tile kernels, the pickle-exact leaf encoder, BLAKE2b, SHAKE256 and the Merkle
+bodies -- against the oracle and the reference goldens.  The emulation library is test infrastructure; the product
+never executes these paths on the CPU."""
+import ctypes
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+SEED = 0x5EED
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+u64, vp = ctypes.c_uint64, ctypes.c_void_p
+
+
+@pytest.fixture(scope="session")
+def emu():
+    so = os.path.join(EMU_DIR, "libbfs_emu.so")
+    srcs = [os.path.join(EMU_DIR, f) for f in ("emu_ntt.cpp", "emu_merkle.cpp")]
+    deps = srcs + [os.path.join(ROOT, "stark_brainfuck_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "stark_brainfuck_amd", "csrc")) if f.endswith(".hpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so] + srcs)
+    lib = ctypes.CDLL(so)
+    lib.emu_gl_ntt.argtypes = [vp, u64, u64, vp, u64, ctypes.c_uint32, ctypes.c_uint32, u64, u64, u64]
+    lib.emu_plan.argtypes = [ctypes.c_uint32, u64, vp, vp, vp, vp]
+    lib.emu_merkle_xfe.argtypes = [vp, u64, u64, vp]
+    return lib
+
+
+def emu_ntt(lib, v, logn, root, shift=1, scale=1, n_in=None, batch=1):
+    n = 1 << logn
+    v = np.ascontiguousarray(v, dtype=np.uint64)
+    n_in = n if n_in is None else n_in
+    out = np.zeros(n * batch, dtype=np.uint64)
+    rc = lib.emu_gl_ntt(v.ctypes.data, n_in, n_in, out.ctypes.data, n, logn, batch, root, shift, scale)
+    assert rc == 0, rc
+    return out
+
+
+@pytest.mark.parametrize("logn", list(range(0, 15)) + [16, 17])
+def test_tile_kernels_match_oracle(emu, oracle, logn):
+    n = 1 << logn
+    v = oracle.felt_array(SEED, 0, n)
+    w = oracle.primitive_nth_root(n)
+    assert (emu_ntt(emu, v, logn, w) == oracle.ntt(w, v)).all()
+    assert (emu_ntt(emu, v, logn, oracle.inv(w), 1, oracle.inv(n)) == oracle.intt(w, v)).all()
+    d = max(1, n // 4)
+    assert (emu_ntt(emu, v[:d], logn, w, 7, 1, n_in=d) == oracle.fast_coset_evaluate(v[:d], 7, w, n)).all()
+
+
+def test_tile_kernels_batch_and_other_roots(emu, oracle):
+    logn, n = 13, 1 << 13
+    w = oracle.power(oracle.primitive_nth_root(n), 5)          # another primitive root (odd power)
+    v = oracle.felt_array(SEED + 9, 0, 3 * n)
+    got = emu_ntt(emu, v, logn, w, batch=3).reshape(3, n)
+    for b in range(3):
+        assert (got[b] == oracle.ntt(w, v[b * n:(b + 1) * n])).all()
+
+
+def test_golden_ntt_through_emulation(emu):
+    c = load_golden("ntt.json")["cases"]["10"]
+    import oracle.ref_oracle as o
+    v = o.felt_array(SEED, 0, 1024)
+    assert emu_ntt(emu, v, 10, c["root"]).tolist() == c["ntt"]
+
+
+def test_planner(emu, oracle):
+    for logn in range(4, 33):
+        npass, uinv = ctypes.c_uint32(), ctypes.c_uint32()
+        bits, logc = (ctypes.c_uint32 * 4)(), (ctypes.c_uint32 * 4)()
+        root = oracle.primitive_nth_root(1 << logn)
+        assert emu.emu_plan(logn, root, ctypes.byref(npass), bits, logc, ctypes.byref(uinv)) == 0
+        assert sum(bits[:npass.value]) == logn
+        if npass.value > 1:
+            assert all(4 <= b <= 8 for b in bits[:npass.value])
+            assert all(bits[i] + logc[i] == 12 for i in range(npass.value))
+        # the radix-16 root of the reference is 2^(12u): u * uinv == 1 (mod 16)
+        w16 = oracle.power(root, (1 << logn) // 16)
+        u = [k for k in range(1, 16, 2) if pow(2, 12 * k, oracle.P) == w16][0]
+        assert (u * uinv.value) % 16 == 1
+
+
+def test_leaf_encoder_matches_reference_pickles(emu):
+    g = load_golden("pickle.json")
+    for r in g["xfe_leaves"]:
+        l = r["limbs"] + [0] * (3 - len(r["limbs"]))
+        buf = ctypes.create_string_buffer(424)
+        n = emu.emu_xfe_leaf_pickle((u64 * 3)(*l), buf)
+        assert buf.raw[:n].hex() == r["pickle"], r["limbs"]
+    for r in g["bfe_leaves"]:
+        buf = ctypes.create_string_buffer(136)
+        n = emu.emu_bfe_leaf_pickle(u64(r["limbs"][0]), buf)
+        assert buf.raw[:n].hex() == r["pickle"]
+        d = ctypes.create_string_buffer(64)
+        emu.emu_blake2b(buf.raw[:n], ctypes.c_size_t(n), d)
+        assert d.raw.hex() == r["blake2b"]
+
+
+def test_hashes_match_hashlib(emu):
+    for ln in [0, 1, 63, 64, 127, 128, 129, 255, 256, 300, 409, 1000]:
+        data = bytes((i * 7 + 3) & 255 for i in range(ln))
+        d = ctypes.create_string_buffer(64)
+        emu.emu_blake2b(data, ctypes.c_size_t(ln), d)
+        assert d.raw == hashlib.blake2b(data).digest()
+        for ol in (32, 136, 200):
+            o = ctypes.create_string_buffer(ol)
+            emu.emu_shake256(data, ctypes.c_size_t(ln), o, ctypes.c_size_t(ol))
+            assert o.raw == hashlib.shake_256(data).digest(ol)
+
+
+def test_merkle_bodies_match_reference_trees(emu, oracle):
+    for t in load_golden("merkle.json")["xfe_trees"]:
+        n = t["n"]
+        soa = np.array([[oracle.felt(SEED + t["seed_offset"], 3 * i + k) for i in range(n)] for k in range(3)], dtype=np.uint64)
+        npo2 = 1
+        while npo2 < n:
+            npo2 *= 2
+        nodes = np.zeros(2 * npo2 * 8, dtype=np.uint64)
+        emu.emu_merkle_xfe(soa.ctypes.data, n, n, nodes.ctypes.data)
+        got = [nodes[i * 8:(i + 1) * 8].tobytes().hex() for i in range(2 * npo2)]
+        for i in range(1, npo2 + n):
+            assert got[i] == t["nodes"][i], (n, i)

@@ -1,0 +1,457 @@
+"""Parity tests proper: the HIP path (through the C ABI / the Python mirror) against the CPU oracle on the same
+seeded inputs, against the golden fixtures captured from the reference, and -- at BASELINE.json's full sizes --
+through size-independent properties.  Everything here needs the MI355X (`-m gpu`).  Bit-exact throughout: the
+path is integer arithmetic mod p and byte hashing; there is no tolerance."""
+import ctypes
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, golden_bytes, load_golden
+
+pytestmark = pytest.mark.gpu
+SEED = 0x5EED
+
+
+@pytest.fixture(scope="module")
+def sb():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    import stark_brainfuck_amd
+    from stark_brainfuck_amd import _lib
+    _lib.load()            # raises BackendUnavailable if the HIP library is missing: no fallback
+    return stark_brainfuck_amd
+
+
+def sha_u64(a):
+    return hashlib.sha256(np.ascontiguousarray(a, dtype="<u8").tobytes()).hexdigest()
+
+
+def addmod(a, b):
+    """(a + b) mod p on uint64 arrays of canonical residues."""
+    P, EPS = np.uint64(0xFFFFFFFF00000001), np.uint64(0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        s = a + b
+        return np.where(s < a, s + EPS, np.where(s >= P, s - P, s))
+
+
+def raw_ntt(sb, v, logn, root, shift=1, scale=1, n_in=None, batch=1):
+    """straight through the C ABI: bfs_gl_ntt on device buffers."""
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.device import DeviceBuffer, synchronize
+    n = 1 << logn
+    n_in = n if n_in is None else n_in
+    din, dout = DeviceBuffer.from_numpy(v), DeviceBuffer(n * batch)
+    _lib.check(_lib.load().bfs_gl_ntt(din.ptr, n_in, n_in, dout.ptr, n, logn, batch, root, shift, scale, 0))
+    synchronize(0)
+    return dout.to_numpy()
+
+
+# ------------------------------------------------------------------------------------------------ NTT
+@pytest.mark.parametrize("logn", list(range(0, 21)))
+def test_ntt_intt_coset_vs_oracle(sb, oracle, logn):
+    n = 1 << logn
+    v = oracle.felt_array(SEED, 0, n)
+    w = oracle.primitive_nth_root(n)
+    assert (raw_ntt(sb, v, logn, w) == oracle.ntt(w, v)).all()
+    assert (raw_ntt(sb, v, logn, oracle.inv(w), 1, oracle.inv(n)) == oracle.intt(w, v)).all()
+    d = max(1, n // 4)
+    assert (raw_ntt(sb, v[:d], logn, w, 7, 1, n_in=d) == oracle.fast_coset_evaluate(v[:d], 7, w, n)).all()
+
+
+def test_ntt_golden_vectors(sb):
+    g = load_golden("ntt.json")
+    import oracle.ref_oracle as o
+    for logn, c in g["cases"].items():
+        n = 1 << int(logn)
+        v = o.felt_array(SEED, 0, n)
+        fw = raw_ntt(sb, v, int(logn), c["root"])
+        assert sha_u64(fw) == c["sha_ntt"], logn
+        if "ntt" in c:
+            assert fw.tolist() == c["ntt"]
+        if n > 1:
+            iv = raw_ntt(sb, v, int(logn), o.inv(c["root"]), 1, o.inv(n))
+            assert sha_u64(iv) == c["sha_intt"], logn
+
+
+def test_config2_2p20_forward_inverse_golden(sb, oracle):
+    """BASELINE config 2: 2^20-point forward + inverse NTT, bit-exact vs the reference's ntt.py (ntt20.json)."""
+    c = load_golden("ntt20.json")
+    v = oracle.felt_array(SEED, 0, 1 << 20)
+    assert sha_u64(v) == c["sha_in"]
+    fw = raw_ntt(sb, v, 20, c["root"])
+    assert sha_u64(fw) == c["sha_ntt"] and fw[:4].tolist() == c["ntt_head"] and fw[-4:].tolist() == c["ntt_tail"]
+    iv = raw_ntt(sb, v, 20, oracle.inv(c["root"]), 1, oracle.inv(1 << 20))
+    assert sha_u64(iv) == c["sha_intt"]
+    assert (raw_ntt(sb, fw, 20, oracle.inv(c["root"]), 1, oracle.inv(1 << 20)) == v).all()
+
+
+def test_config5_2p24_columns(sb, oracle):
+    """BASELINE config 5 shape: 2^24-point columns.  Column 0 against the oracle, the batch through round trip and
+    linearity (size-independent properties)."""
+    logn, n, cols = 24, 1 << 24, 3
+    w = oracle.primitive_nth_root(n)
+    v = np.concatenate([oracle.felt_array(SEED + (c << 32), 0, n) for c in range(cols)])
+    fw = raw_ntt(sb, v, logn, w, batch=cols)
+    assert (fw[:n] == oracle.ntt(w, v[:n])).all()
+    back = raw_ntt(sb, fw, logn, oracle.inv(w), 1, oracle.inv(n), batch=cols)
+    assert (back == v).all()
+    # linearity: NTT(a + b) = NTT(a) + NTT(b) (mod p), on columns 1 and 2
+    assert (raw_ntt(sb, addmod(v[n:2 * n], v[2 * n:]), logn, w) == addmod(fw[n:2 * n], fw[2 * n:])).all()
+
+
+def test_ntt_other_roots_and_batches(sb, oracle):
+    for logn in (6, 11, 13, 17):
+        n = 1 << logn
+        w = oracle.power(oracle.primitive_nth_root(n), 3)
+        v = oracle.felt_array(SEED + logn, 0, 4 * n)
+        got = raw_ntt(sb, v, logn, w, batch=4).reshape(4, n)
+        for b in range(4):
+            assert (got[b] == oracle.ntt(w, v[b * n:(b + 1) * n])).all()
+
+
+def test_ntt_error_behaviour(sb):
+    g = load_golden("ntt.json")["errors"]
+    F = sb.BaseField.main()
+    w8 = F.primitive_nth_root(8)
+    with pytest.raises(AssertionError) as e:
+        sb.ntt(w8, [F(1)] * 6)
+    assert str(e.value) == g["non_pow2"]
+    with pytest.raises(AssertionError) as e:
+        sb.ntt(F(3), [F(1)] * 8)
+    assert str(e.value) == g["not_root"]
+    with pytest.raises(AssertionError) as e:
+        sb.ntt(F.primitive_nth_root(4), [F(1)] * 8)
+    assert str(e.value).startswith("primitive root 281474976710656 is not primitive nth root of unity, where n is 8")
+    with pytest.raises(AssertionError) as e:
+        sb.intt(w8, [F(1)] * 6)
+    assert str(e.value) == g["intt_non_pow2"]
+    with pytest.raises(AssertionError) as e:
+        sb.intt(F(3), [F(1)] * 8)
+    assert str(e.value) == g["intt_not_root"]
+    one = [F(5)]
+    assert sb.ntt(w8, one) is one            # ntt.py:8-9 returns its argument for length <= 1
+
+
+# ---- the reference's own test_ntt.py, restated against this API (object lists in, object lists out)
+def test_reference_test_ntt(sb):
+    F = sb.BaseField.main()
+    n = 1 << 8
+    w = F.primitive_nth_root(n)
+    coeffs = [F.sample(os.urandom(17)) for _ in range(n)]
+    values = sb.ntt(w, coeffs)
+    assert values == sb.Polynomial(coeffs).evaluate_domain([w ^ i for i in range(n)])
+
+
+def test_reference_test_intt(sb):
+    F = sb.BaseField.main()
+    for logn in range(1, 8):
+        n = 1 << logn
+        w = F.primitive_nth_root(n)
+        values = [F.sample(os.urandom(1)) for _ in range(n)]
+        coeffs = sb.intt(w, values)
+        assert sb.ntt(w, coeffs) == values
+        poly = sb.Polynomial(coeffs)
+        assert [poly.evaluate(w ^ i) for i in range(n)] == values
+
+
+def test_reference_test_multiply_and_divide(sb):
+    F = sb.BaseField.main()
+    n = 64
+    w = F.primitive_nth_root(n)
+    for _ in range(20):
+        ld, rd = os.urandom(1)[0] % (n // 2), os.urandom(1)[0] % (n // 2)
+        lhs = sb.Polynomial([F.sample(os.urandom(17)) for _ in range(ld + 1)])
+        rhs = sb.Polynomial([F.sample(os.urandom(17)) for _ in range(rd + 1)])
+        prod = sb.fast_multiply(lhs, rhs, w, n)
+        assert prod == lhs * rhs
+        assert sb.fast_coset_divide(prod, lhs, F.generator(), w, n) == rhs
+
+
+def test_fast_multiply_and_coset_goldens(sb):
+    g = load_golden("poly.json")
+    F = sb.BaseField.main()
+    w = F.primitive_nth_root(64)
+    P = lambda c: sb.Polynomial([F(x) for x in c])
+    for c in g["fast_multiply_n64"]:
+        prod = sb.fast_multiply(P(c["lhs"]), P(c["rhs"]), w, 64)
+        assert [x.value for x in prod.coefficients] == c["product"]
+        if "quotient_by_lhs" in c:
+            q = sb.fast_coset_divide(prod, P(c["lhs"]), F.generator(), w, 64)
+            assert [x.value for x in q.coefficients] == c["quotient_by_lhs"]
+    for c in g["coset"]:
+        gen = F.primitive_nth_root(c["order"])
+        vals = sb.fast_coset_evaluate(P(c["coefficients"]), F(c["offset"]), gen, c["order"])
+        assert [x.value for x in vals] == c["values"]
+        back = sb.fast_coset_interpolate(F(c["offset"]), gen, vals)
+        assert [x.value for x in back.coefficients] == c["interpolated"]
+    b = g["batch_inverse"]
+    assert [x.value for x in sb.batch_inverse([F(x) for x in b["in"]])] == b["out"]
+    with pytest.raises(AssertionError) as e:
+        sb.batch_inverse([F(1), F(0)])
+    assert str(e.value) == b["zero_message"]
+
+
+def test_reference_test_coset_evaluate_and_batch_inverse(sb):
+    F = sb.BaseField.main()
+    n = 512
+    w = F.primitive_nth_root(n)
+    two = F(2)
+    degree = ((os.urandom(1)[0] * 256 + os.urandom(1)[0]) % n) - 1
+    poly = sb.Polynomial([F.sample(os.urandom(17)) for _ in range(degree + 1)])
+    fast = sb.fast_coset_evaluate(poly, two, w, n)
+    assert all(f == poly.evaluate(two * (w ^ i)) for i, f in enumerate(fast))
+    arr = [F.sample(os.urandom(8)) for _ in range(100)]
+    arr = [a if not a.is_zero() else F(1) for a in arr]
+    assert all((i * a) == F.one() for i, a in zip(sb.batch_inverse(arr), arr))
+
+
+def test_domain_and_extension_transforms(sb):
+    g = load_golden("poly.json")["domain64"]
+    XF = sb.ExtensionField.main()
+    BF = XF.modulus.coefficients[0].field
+    dom = sb.Fri.Domain(BF.generator(), BF.primitive_nth_root(64), 64)
+    assert dom(5).value == g["call_5"] and [e.value for e in dom.list()[:4]] == g["list_head"]
+    ev = dom.evaluate(sb.Polynomial([BF(v) for v in g["coefficients"]]))
+    assert [e.value for e in ev] == g["evaluate"]
+    assert [c.value for c in dom.interpolate(ev).coefficients] == g["interpolate"]
+    xev = dom.xevaluate(sb.Polynomial([XF.from_limbs(l) for l in g["xcoefficients"]]))
+    assert [e.limbs() for e in xev] == g["xevaluate"]
+    assert [c.limbs() for c in dom.xinterpolate(xev).coefficients] == g["xinterpolate"]
+    x = load_golden("ntt.json")["xfe_ntt_64"]
+    w = XF.lift(BF.primitive_nth_root(64))
+    vals = [XF.from_limbs(l) for l in x["in"]]
+    assert [e.limbs() for e in sb.ntt(w, vals)] == x["ntt"]
+    assert [e.limbs() for e in sb.intt(w, vals)] == x["intt"]
+
+
+# ------------------------------------------------------------------------------------------------ Merkle
+def test_merkle_goldens(sb, oracle):
+    g = load_golden("merkle.json")
+    XF = sb.ExtensionField.main()
+    for t in g["xfe_trees"]:
+        n = t["n"]
+        leaves = [XF.from_limbs([oracle.felt(SEED + t["seed_offset"], 3 * i + k) for k in range(3)]) for i in range(n)]
+        tree = sb.Merkle(leaves)
+        assert (tree.num_leafs, tree.depth) == (n, t["depth"])
+        assert tree.root().hex() == t["root"]
+        assert [x.hex() for x in tree.nodes] == t["nodes"]
+        for i in range(n):
+            path = tree.open(i)
+            assert [x.hex() for x in path] == t["paths"][i]
+            assert sb.Merkle.verify(tree.root(), i, path, leaves[i])
+    F = sb.BaseField.main()
+    t = g["bfe_tree"]
+    tree = sb.Merkle([F(oracle.felt(SEED + t["seed_offset"], i)) for i in range(t["n"])])
+    assert tree.root().hex() == t["root"] and [x.hex() for x in tree.nodes] == t["nodes"]
+
+
+def test_merkle_generic_leaves_like_reference_test(sb):
+    """test_merkle.py:58-100 restated: arbitrary picklable leaves, positive and negative openings."""
+    from conftest import load_golden as lg
+    g = lg("merkle.json")["generic_tree"]
+    M64 = (1 << 64) - 1
+
+    def splitmix(x):
+        x = (x + 0x9E3779B97F4A7C15) & M64
+        z = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M64
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+        return z ^ (z >> 31)
+    leaves = [[bytes((splitmix(i * 1000 + j) & 0xFF) for j in range(splitmix(i) % 200)),
+               bytes((splitmix(i * 2000 + j) & 0xFF) for j in range(splitmix(i + 64) % 200))] for i in range(16)]
+    tree = sb.Merkle(leaves)
+    assert tree.root().hex() == g["root"] and [x.hex() for x in tree.open(5)] == g["path_5"]
+    n = 64
+    elements = [[os.urandom(os.urandom(1)[0]), os.urandom(os.urandom(1)[0])] for _ in range(n)]
+    tree = sb.Merkle(elements)
+    root = tree.root()
+    for i in range(n):
+        path = tree.open(i)
+        assert sb.Merkle.verify(root, i, path, elements[i])
+        assert not sb.Merkle.verify(root, i, path, os.urandom(51))
+        j = (i + 1 + os.urandom(1)[0] % (n - 1)) % n
+        assert not sb.Merkle.verify(root, i, path, elements[j])
+        assert not sb.Merkle.verify(root, j, path, elements[i])
+        assert not sb.Merkle.verify(os.urandom(32), i, path, elements[i])
+        for k in range(len(path)):
+            assert not sb.Merkle.verify(root, i, path[:k] + [os.urandom(32)] + path[k + 1:], elements[i])
+
+
+def test_salted_merkle(sb, oracle, monkeypatch):
+    g = load_golden("merkle.json")["salted_tree"]
+    from stark_brainfuck_amd import salted_merkle
+    ctr = [0]
+
+    def fake_urandom(k):
+        ctr[0] += 1
+        return hashlib.shake_256(b"salt" + ctr[0].to_bytes(8, "little")).digest(k)
+    monkeypatch.setattr(salted_merkle, "urandom", fake_urandom)
+    XF = sb.ExtensionField.main()
+    leaves = [XF.from_limbs([oracle.felt(SEED + g["seed_offset"], 3 * i + k) for k in range(3)]) for i in range(g["n"])]
+    tree = sb.SaltedMerkle(leaves)
+    assert [l[1].hex() for l in tree.leafs] == g["salts"]
+    assert tree.root().hex() == g["root"] and [x.hex() for x in tree.nodes] == g["nodes"]
+    salt, path = tree.open(3)
+    assert salt.hex() == g["open3_salt"] and [x.hex() for x in path] == g["open3_path"]
+    assert sb.SaltedMerkle.verify(tree.root(), 3, salt, path, leaves[3])
+    assert not sb.SaltedMerkle.verify(tree.root(), 3, os.urandom(24), path, leaves[3])
+    assert not sb.SaltedMerkle.verify(tree.root(), 2, salt, path, leaves[3])
+
+
+def test_merkle_large_vs_oracle(sb, oracle):
+    n = 1 << 12
+    soa = oracle.felt_array(SEED + 5, 0, 3 * n).reshape(3, n)
+    soa[:, 17] = 0                       # zero element (different pickle template)
+    soa[1:, 18] = 0                      # base-field-like element (one stored coefficient)
+    soa[2, 19] = 0
+    soa[0, 20] = 3                       # short integer opcodes
+    tree = sb.Merkle(sb.XArray.from_numpy(soa))
+    ref, _ = oracle.xfe_merkle(soa)
+    assert tree.root() == ref.root()
+    assert tree.nodes[1:] == ref.nodes[1:]
+    assert tree.open(1234) == ref.open(1234)
+
+
+# ------------------------------------------------------------------------------------------------ FRI
+def _codeword(sb, oracle, rec, tag):
+    d = 1 << rec["log_degree"]
+    if tag.startswith("test_fri"):
+        coeffs = np.zeros((3, d), dtype=np.uint64)
+        coeffs[0] = np.arange(d, dtype=np.uint64)
+    else:
+        coeffs = oracle.felt_array(SEED, 0, 3 * d).reshape(d, 3).T.copy()
+    XF = sb.ExtensionField.main()
+    BF = XF.modulus.coefficients[0].field
+    fri = sb.Fri(BF.generator(), BF.primitive_nth_root(rec["N"]), rec["N"], rec["expansion"], rec["num_colinearity_tests"], XF)
+    assert (fri.domain.offset.value, fri.domain.omega.value) == (rec["offset"], rec["omega"])
+    cw = fri.domain.xevaluate(sb.XArray.from_numpy(coeffs), as_array=True)
+    soa = cw.to_numpy()
+    if rec.get("disturb"):
+        for i in rec["disturb"]:
+            soa[:, i] = 0
+        cw = sb.XArray.from_numpy(soa)
+    assert sha_u64(soa) == rec["codeword_sha"]
+    return fri, cw, soa, XF
+
+
+@pytest.mark.parametrize("tag", ["d16_t2", "d64_t8", "d1024_t4", "test_fri_valid", "test_fri_disturbed", "d16_t2_prepushed"])
+def test_fri_prove_goldens(sb, oracle, tag):
+    rec = load_golden("fri.json")[tag]
+    fri, cw, soa, XF = _codeword(sb, oracle, rec, tag)
+    ps = sb.ProofStream()
+    if rec["num_prepushed"]:
+        r = [hashlib.blake2b(bytes([i])).digest() for i in range(2)]
+        e = [XF.from_limbs([oracle.felt(SEED + 88, 3 * i + k) for k in range(3)]) for i in range(3)]
+        for ob in [r[0], (e[0], e[1], e[2]), [r[1]]]:
+            ps.push(ob)
+    npre = rec["num_prepushed"]
+    root0 = sb.Merkle(cw).root()
+    assert root0.hex() == rec["roots"][0]
+    idx = fri.prove(cw, ps)
+    assert idx == rec["indices"]
+    assert len(ps.objects) == rec["num_objects"]
+    assert [x.hex() for x in ps.objects[npre:npre + rec["rounds"] - 1]] == rec["roots"][1:]
+    assert [[c.value for c in el.polynomial.coefficients] for el in ps.objects[npre + rec["rounds"] - 1]] == rec["last_codeword"]
+    ser = ps.serialize()
+    assert hashlib.sha256(ser).hexdigest() == rec["serialize_sha256"]
+    assert ser == golden_bytes("fri_%s_stream.bin" % tag)
+    assert ps.prover_fiat_shamir().hex() == rec["final_fiat_shamir"]
+    vs = sb.ProofStream()
+    vs.objects, vs.read_index = list(ps.objects), npre
+    assert fri.verify(vs, root0) == rec["verify"]
+
+
+def test_fri_commit_codewords_and_trees(sb, oracle):
+    rec = load_golden("fri.json")["d64_t8"]
+    fri, cw, soa, XF = _codeword(sb, oracle, rec, "d64_t8")
+    ps = sb.ProofStream()
+    codewords, trees = fri.commit(cw, ps)
+    assert len(codewords) == rec["rounds"] and len(trees) == rec["rounds"] - 1
+    assert [sha_u64(c.array.to_numpy()) for c in codewords] == rec["codeword_shas"]
+    assert [t.root().hex() for t in trees] == rec["roots"][:-1]
+    # fold kernel on its own (bfs_xfe_fold) against the oracle's restatement of fri.py:127-128
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.device import DeviceBuffer, synchronize
+    out = DeviceBuffer(3 * (rec["N"] // 2))
+    alpha = rec["alphas"][0]
+    _lib.check(_lib.load().bfs_xfe_fold(cw.ptr, cw.stride, out.ptr, rec["N"] // 2, rec["N"].bit_length() - 1,
+                                        (ctypes.c_uint64 * 3)(*alpha), rec["offset"], rec["omega"], 0))
+    synchronize(0)
+    assert (out.to_numpy().reshape(3, -1) == oracle.fri_fold(soa, alpha, rec["offset"], rec["omega"])).all()
+    # Fri.query / query_last on the HBM-resident trees reproduce the transcript prove() writes
+    ps2 = sb.ProofStream()
+    ps2.objects = list(ps.objects)
+    top = fri.sample_indices(ps2.prover_fiat_shamir(), len(codewords[1]), len(codewords[-1]), fri.num_colinearity_tests)
+    assert top == rec["indices"]
+    indices = list(top)
+    for i in range(len(trees) - 1):
+        indices = [x % (len(codewords[i]) // 2) for x in indices]
+        fri.query(trees[i], trees[i + 1], indices, ps2)
+    indices = [x % len(codewords[-1]) for x in indices]
+    fri.query_last(trees[-1], codewords[-1], indices, ps2)
+    assert len(ps2.objects) == rec["num_objects"]
+    assert hashlib.sha256(ps2.serialize()).hexdigest() == rec["serialize_sha256"]
+
+
+def test_fri_vs_oracle_mid_size(sb, oracle):
+    """N = 2^14 (oracle finishes in seconds): every round root, alpha-dependent codeword and the full transcript."""
+    log_d, expansion, t = 12, 4, 4
+    d, N = 1 << log_d, (1 << log_d) * 4
+    coeffs = oracle.felt_array(SEED + 3, 0, 3 * d).reshape(d, 3).T.copy()
+    XF = sb.ExtensionField.main()
+    BF = XF.modulus.coefficients[0].field
+    fri = sb.Fri(BF.generator(), BF.primitive_nth_root(N), N, expansion, t, XF)
+    cw = fri.domain.xevaluate(sb.XArray.from_numpy(coeffs), as_array=True)
+    soa = cw.to_numpy()
+    ref = oracle.fri_prove(soa, 7, oracle.primitive_nth_root(N), expansion, t)
+    ps = sb.ProofStream()
+    assert fri.prove(cw, ps) == ref["indices"]
+    assert ps.serialize() == ref["proof_stream"].serialize()
+
+
+def test_config3_fri_2p20(sb, oracle):
+    """BASELINE config 3: FRI.prove on a degree-2^18 codeword, expansion 4.  Against the reference's own run when its
+    fixture exists (fri20.json), and always through verify() and the round-0 root."""
+    log_d, expansion, t = 18, 4, 4
+    d, N = 1 << log_d, (1 << log_d) * 4
+    coeffs = oracle.felt_array(SEED, 0, 3 * d).reshape(d, 3).T.copy()
+    XF = sb.ExtensionField.main()
+    BF = XF.modulus.coefficients[0].field
+    fri = sb.Fri(BF.generator(), BF.primitive_nth_root(N), N, expansion, t, XF)
+    cw = fri.domain.xevaluate(sb.XArray.from_numpy(coeffs), as_array=True)
+    root0 = sb.Merkle(cw).root()
+    ps = sb.ProofStream()
+    idx = fri.prove(cw, ps)
+    assert len(set(i % 8 for i in idx)) == t and all(0 <= i < N // 2 for i in idx)
+    vs = sb.ProofStream()
+    vs.objects = list(ps.objects)
+    assert fri.verify(vs, root0)
+    bad = sb.ProofStream()
+    bad.objects = list(ps.objects)
+    bad.objects[0] = bytes(64)           # a wrong round-1 root changes every later challenge
+    assert not fri.verify(bad, root0)
+    path = os.path.join(GOLDEN, "fri20.json")
+    if os.path.exists(path):
+        rec = load_golden("fri20.json")
+        assert sha_u64(cw.to_numpy()) == rec["codeword_sha"]
+        assert root0.hex() == rec["roots"][0]
+        assert [x.hex() for x in ps.objects[:rec["rounds"] - 1]] == rec["roots"][1:]
+        assert idx == rec["indices"] and len(ps.objects) == rec["num_objects"]
+        ser = ps.serialize()
+        assert (len(ser), hashlib.sha256(ser).hexdigest()) == (rec["serialize_len"], rec["serialize_sha256"])
+
+
+def test_fri_length_assert(sb):
+    XF = sb.ExtensionField.main()
+    BF = XF.modulus.coefficients[0].field
+    fri = sb.Fri(BF.generator(), BF.primitive_nth_root(64), 64, 4, 2, XF)
+    with pytest.raises(AssertionError) as e:
+        fri.prove([XF.zero()] * 32, sb.ProofStream())
+    assert str(e.value) == load_golden("fri.json")["errors"]["length_mismatch"]
+
+
+def test_smoke_entry_point(sb):
+    import __graft_entry__
+    __graft_entry__.smoke()

@@ -1,0 +1,178 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every declared symbol, the scalar object
+model, the native pickle emitter / SHAKE256 transcript (against reference byte strings), index sampling."""
+import ctypes
+import hashlib
+import os
+import re
+
+import pytest
+
+from conftest import GOLDEN, ROOT, golden_bytes, load_golden
+
+SEED = 0x5EED
+
+
+@pytest.fixture(scope="session")
+def sb():
+    from stark_brainfuck_amd import build
+    build.build_library()
+    import stark_brainfuck_amd
+    return stark_brainfuck_amd
+
+
+def test_library_exports_every_declared_symbol(sb):
+    from stark_brainfuck_amd import _lib
+    header = open(os.path.join(ROOT, "include", "bfstark.h")).read()
+    declared = set(re.findall(r"\b(bfs_[a-z0-9_]+)\s*\(", header))
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libbfstark_hip.so does not export %s" % name
+    assert declared == set(_lib.exported_symbols()), declared ^ set(_lib.exported_symbols())
+    assert _lib.load().bfs_version() >= 1
+
+
+def test_no_gpu_means_loud_failure(sb):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    F = sb.BaseField.main()
+    with pytest.raises(RuntimeError):
+        sb.ntt(F.primitive_nth_root(4), [F(1), F(2), F(3), F(4)])
+
+
+def test_scalar_model_against_reference(sb):
+    g = load_golden("field.json")
+    F, XF = sb.BaseField.main(), sb.ExtensionField.main()
+    for r in g["base_ops"]:
+        a, b = F(r["a"]), F(r["b"])
+        assert ((a + b).value, (a - b).value, (a * b).value, (-a).value, (a ^ r["e"]).value) == (r["add"], r["sub"], r["mul"], r["neg"], r["pow"])
+        if "inv" in r:
+            assert a.inverse().value == r["inv"] and (b / a).value == r["b_div_a"]
+    xl = lambda e: [c.value for c in e.polynomial.coefficients]
+    for r in g["xfe_ops"]:
+        a, b = XF.from_limbs(r["a"]), XF.from_limbs(r["b"])
+        assert (xl(a + b), xl(a - b), xl(a * b), xl(-a), xl(a ^ r["e"])) == (r["add"], r["sub"], r["mul"], r["neg"], r["pow"])
+        if "inv" in r:
+            assert xl(a.inverse()) == r["inv"] and xl(b / a) == r["b_div_a"]
+    for r in g["base_sample"]:
+        assert F.sample(bytes.fromhex(r["bytes"])).value == r["value"]
+    for r in g["xfe_sample"]:
+        assert xl(XF.sample(bytes.fromhex(r["bytes"]))) == r["value"]
+    for k, v in g["roots"].items():
+        assert F.primitive_nth_root(1 << int(k)).value == v
+    for k, v in g["xfe_call"].items():
+        assert xl(XF(int(k))) == v
+    assert F.generator().value == g["generator"]
+
+
+def test_host_scalar_entry_points(sb):
+    from stark_brainfuck_amd import _lib
+    lib = _lib.load()
+    g = load_golden("field.json")
+    for r in g["base_ops"]:
+        assert lib.bfs_gl_mul(r["a"], r["b"]) == r["mul"] and lib.bfs_gl_pow(r["a"], r["e"]) == r["pow"]
+        if "inv" in r:
+            assert lib.bfs_gl_inv(r["a"]) == r["inv"]
+    for k, v in g["roots"].items():
+        assert lib.bfs_gl_primitive_root(int(k)) == v
+    for r in g["xfe_sample"]:
+        out = (ctypes.c_uint64 * 3)()
+        b = bytes.fromhex(r["bytes"])
+        lib.bfs_xfe_sample(b, len(b), out)
+        assert [x for x in list(out)][:len(r["value"])] == r["value"]
+
+
+def test_polynomial_helpers(sb):
+    F = sb.BaseField.main()
+    P = sb.Polynomial
+    a = P([F(3), F(0), F(5), F(7)])
+    b = P([F(2), F(1)])
+    q, r = P.divide(a, b)
+    assert q * b + r == a and r.degree() < b.degree()
+    assert (a * b) / b == a
+    x, y, g = P.xgcd(a, b)
+    assert x * a + y * b == g
+    dom = [F(1), F(2), F(5), F(9)]
+    vals = a.evaluate_domain(dom)
+    assert P.interpolate_domain(dom, vals) == a
+    assert P.zerofier_domain(dom).evaluate_domain(dom) == [F(0)] * 4
+    assert a.scale(F(3)).evaluate(F(2)) == a.evaluate(F(6))
+    assert sb.colinear([(F(1), F(2)), (F(2), F(4)), (F(3), F(6))]) and not sb.colinear([(F(1), F(2)), (F(2), F(4)), (F(3), F(7))])
+
+
+def test_reference_pickle_of_elements(sb):
+    g = load_golden("pickle.json")
+    XF, F = sb.ExtensionField.main(), sb.BaseField.main()
+    for r in g["xfe_leaves"]:
+        assert sb.reference_pickle(XF.from_limbs(r["limbs"])).hex() == r["pickle"]
+    for r in g["bfe_leaves"][:8]:
+        assert sb.reference_pickle(F(r["limbs"][0])).hex() == r["pickle"]
+    # arbitrary picklable leaves go through CPython's own pickle, like the reference
+    from stark_brainfuck_amd.merkle import leaf_bytes
+    import pickle
+    leaf = [b"abc", bytes(range(200))]
+    assert leaf_bytes(leaf) == pickle.dumps(leaf, protocol=4)
+
+
+def test_proof_stream_known_answers(sb):
+    g = load_golden("pickle.json")
+    XF = sb.ExtensionField.main()
+    ps = sb.ProofStream()
+    assert ps.serialize() == bytes.fromhex("80045d942e")                 # empty list
+    alpha0 = XF.sample(ps.prover_fiat_shamir())
+    assert alpha0.limbs() == [12226376460829714024, 16869843892243676816, 17476883614840174052]
+    for rec in g["root_lists"]:
+        ps = sb.ProofStream()
+        for x in rec["roots"]:
+            ps.push(bytes.fromhex(x))
+        assert ps.serialize().hex() == rec["pickle"] and ps.prover_fiat_shamir().hex() == rec["shake256_32"]
+    from oracle.ref_oracle import felt
+    r = [hashlib.blake2b(bytes([i])).digest() for i in range(4)]
+    e = [XF.from_limbs([felt(SEED + 88, 3 * i + k) for k in range(3)]) for i in range(6)]
+    z, salt = XF.zero(), bytes(range(24))
+    B = lambda v: sb.BaseFieldElement(v, XF.modulus.coefficients[0].field)
+    recipes = {
+        "roots_then_codeword": [r[0], r[1], [e[0], e[1], e[2]]],
+        "shared_objects": [r[0], [e[0], e[1], e[2], z], (e[0], e[3], e[1]), [r[2], r[3], r[2]]],
+        "tuples_first": [(e[4], e[5], e[4]), [r[1]], (z, XF.from_limbs([5]), XF.from_limbs([0, 6]))],
+        "with_bfe_and_salt": [B(5), r[0], (B(6), e[0]), [salt, [r[1]]]],
+    }
+    for rec in g["transcripts"]:
+        ps = sb.ProofStream()
+        for o in recipes[rec["name"]]:
+            ps.push(o)
+        assert ps.serialize().hex() == rec["pickle"], rec["name"]
+        assert ps.prover_fiat_shamir().hex() == rec["fiat_shamir"]
+    ps.read_index = 2
+    t2 = sb.ProofStream()
+    t2.objects = ps.objects[:2]
+    assert ps.verifier_fiat_shamir() == t2.prover_fiat_shamir()
+
+
+@pytest.mark.parametrize("tag", ["d16_t2", "d64_t8", "d1024_t4", "test_fri_valid", "test_fri_disturbed", "d16_t2_prepushed"])
+def test_reference_streams_round_trip(sb, tag):
+    """load a proof stream written by the reference into this package's classes and serialise it again with the
+    native emitter: must reproduce the reference's bytes (memoisation, opcodes, 64 KiB framing)."""
+    blob = golden_bytes("fri_%s_stream.bin" % tag)
+    rec = load_golden("fri.json")[tag]
+    ps = sb.ProofStream().deserialize(blob)
+    assert len(ps.objects) == rec["num_objects"]
+    assert ps.serialize() == blob
+    assert ps.prover_fiat_shamir().hex() == rec["final_fiat_shamir"]
+    xl = lambda el: [c.value for c in el.polynomial.coefficients]
+    last = ps.objects[rec["num_prepushed"] + rec["rounds"] - 1]
+    assert [xl(el) for el in last] == rec["last_codeword"]
+
+
+def test_sample_indices(sb):
+    XF = sb.ExtensionField.main()
+    F = XF.modulus.coefficients[0].field
+    fri = sb.Fri(F.generator(), F.primitive_nth_root(64), 64, 4, 2, XF)
+    g = load_golden("fri.json")
+    for r in g["sample_indices"]:
+        assert fri.sample_indices(bytes.fromhex(r["seed"]), r["size"], r["reduced_size"], r["number"]) == r["indices"]
+    with pytest.raises(AssertionError, match="cannot sample more indices"):
+        fri.sample_indices(b"s", 32, 8, 9)
+    assert fri.num_rounds() == 4
+    with pytest.raises(AssertionError, match="less than one round"):
+        sb.Fri(F.generator(), F.primitive_nth_root(4), 4, 4, 1, XF)
