@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbfstark_hip.so")
+LIB_PATH = os.environ.get("BFS_LIB_PATH") or os.path.join(_HERE, "libbfstark_hip.so")   # override: development builds only
 
 u64 = ctypes.c_uint64
 u32 = ctypes.c_uint32

@@ -15,6 +15,12 @@
 #define BFS_HD inline
 #endif
 
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BFS_UNROLL _Pragma("unroll")
+#else
+#define BFS_UNROLL
+#endif
+
 namespace bfs {
 
 typedef uint64_t u64;
@@ -24,6 +30,42 @@ typedef unsigned __int128 u128;
 constexpr u64 GL_P = 0xFFFFFFFF00000001ULL;
 constexpr u64 GL_EPS = 0xFFFFFFFFULL;  // 2^64 mod p = 2^32 - 1
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- gfx950 code generation notes (measured with tools/microbench, DESIGN.md "modular arithmetic") ----
+// 64-bit compares / selects cost twice a 32-bit VALU op and hipcc recomputes carries with v_cmp_*_u64; the
+// __builtin_subc / __builtin_addc forms below compile to v_sub_co_u32 / v_subb_co_u32 carry chains instead
+// (5 VALU instructions for a canonical modular subtraction).
+BFS_HD u64 gl_sub(u64 a, u64 b) {
+    u32 bl, bh, b2;
+    u32 dlo = __builtin_subc((u32)a, (u32)b, 0u, &bl);
+    u32 dhi = __builtin_subc((u32)(a >> 32), (u32)(b >> 32), bl, &bh);
+    u32 t = 0u - bh;                                   // EPS when the subtraction borrowed, else 0
+    u32 rlo = __builtin_subc(dlo, t, 0u, &b2);
+    u32 rhi = dhi - b2;
+    return ((u64)rhi << 32) | rlo;
+}
+BFS_HD u64 gl_add(u64 a, u64 b) { return gl_sub(a, GL_P - b); }   // b < p, so p - b is in [1, p]: still exact
+
+// hi*2^64 + lo  ->  canonical residue
+BFS_HD u64 gl_reduce128(u64 hi, u64 lo) {
+    u32 hh = (u32)(hi >> 32), hl = (u32)hi;
+    u32 bl, bh, b2;
+    u32 dlo = __builtin_subc((u32)lo, hh, 0u, &bl);    // t0 = lo - hi_hi  (2^96 = -1)
+    u32 dhi = __builtin_subc((u32)(lo >> 32), 0u, bl, &bh);
+    u32 t = 0u - bh;
+    u32 t0lo = __builtin_subc(dlo, t, 0u, &b2);
+    u32 t0hi = dhi - b2;
+    u64 t0 = ((u64)t0hi << 32) | t0lo;
+    u64 r = (u64)hl * 0xFFFFFFFFu + t0;                // + hi_lo * (2^32 - 1)  (2^64 = 2^32 - 1): one v_mad_u64_u32
+    u32 c = r < t0, c2, c3;
+    u32 rlo = __builtin_addc((u32)r, 0u - c, 0u, &c2); // wrapped: + EPS (cannot wrap twice)
+    u32 rhi = (u32)(r >> 32) + c2;
+    // canonical form: r >= p  <=>  r + EPS carries out of 64 bits
+    u32 ulo = __builtin_addc(rlo, 0xFFFFFFFFu, 0u, &c2);
+    u32 uhi = __builtin_addc(rhi, 0u, c2, &c3);
+    return c3 ? (((u64)uhi << 32) | ulo) : (((u64)rhi << 32) | rlo);
+}
+#else
 BFS_HD u64 gl_add(u64 a, u64 b) {
     u64 s = a + b;
     // a, b < p: either the 64-bit add wrapped (then s + EPS is the canonical value) or s may be >= p
@@ -36,8 +78,6 @@ BFS_HD u64 gl_sub(u64 a, u64 b) {
     return a < b ? d - GL_EPS : d;  // borrow: add p (== subtract EPS in wrapped arithmetic)
 }
 
-BFS_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
-
 // reduce a 128-bit value hi*2^64 + lo.  2^64 = 2^32 - 1, 2^96 = -1 (mod p).
 BFS_HD u64 gl_reduce128(u64 hi, u64 lo) {
     u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
@@ -48,6 +88,9 @@ BFS_HD u64 gl_reduce128(u64 hi, u64 lo) {
     if (r < t1) r += GL_EPS;               // carry -> +2^64 = +EPS ; cannot carry twice
     return r >= GL_P ? r - GL_P : r;
 }
+#endif
+
+BFS_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
 
 BFS_HD u64 gl_mul(u64 a, u64 b) {
     u128 z = (u128)a * b;

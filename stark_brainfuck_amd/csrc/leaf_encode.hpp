@@ -13,12 +13,6 @@
 
 namespace bfs {
 
-#if defined(__HIP_DEVICE_COMPILE__)
-#define BFS_UNROLL _Pragma("unroll")
-#else
-#define BFS_UNROLL
-#endif
-
 constexpr int XFE_LEAF_MAX_BYTES = 11 + tpl::XFE_PRE_A_LEN + 1 + tpl::XFE_PRE_B_LEN + 11 + tpl::XFE_MID_A_LEN + 11 + tpl::XFE_MID_B_LEN + 11 + tpl::XFE_POST3_LEN;
 constexpr int XFE_LEAF_MAX_WORDS = (XFE_LEAF_MAX_BYTES + 7) / 8;  // 52
 constexpr int BFE_LEAF_MAX_BYTES = 11 + tpl::BFE_PRE_LEN + 11 + tpl::BFE_POST_LEN;

@@ -3,17 +3,42 @@
 
 namespace bfs {
 
-template <int B1, int B2, int B3>
-__global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a) {
+// Persistent tile kernel: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and issues the (16-byte,
+// paired-lane) global loads of the next tile before computing on the current one.  LDS = tile + inner twiddle table.
+template <int B1, int B2, int B3, bool WIDE>
+__global__ void __launch_bounds__(256, 4) ntt_tile_kernel(const PassArgs a, u32 grid_x, u32 total_tiles, u32 tw_offset) {
     extern __shared__ __attribute__((aligned(16))) u64 smem[];
-    ntt_stage1<B1, B2, B3>(a, smem, threadIdx.x, blockIdx.x, blockIdx.y);
-    if constexpr (B2 > 0) {
+    typedef TileCfg<B1, B2, B3> Cfg;
+    u64* tw = smem + tw_offset;
+    if constexpr (Cfg::U >= 2) {
+        // dense copy of the stage-1 -> stage-2 twiddles w_M^e, M = 2^(B1+B2) <= 256 (n^-1 folded in when it is the last one)
+        const u64* tab = (Cfg::U == 2 && a.mode == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;
+        for (u32 i = threadIdx.x; i < (1u << (B1 + B2)); i += blockDim.x) tw[i] = tab[(u64)i << (a.tb.t_in_log - (B1 + B2))];
         __syncthreads();
-        ntt_stage2<B1, B2, B3>(a, smem, threadIdx.x, blockIdx.x, blockIdx.y);
     }
-    if constexpr (B3 > 0) {
-        __syncthreads();
-        ntt_stage3<B1, B2, B3>(a, smem, threadIdx.x, blockIdx.x, blockIdx.y);
+    constexpr bool wide = WIDE;
+    RawTile cur, nxt;
+    u32 t = blockIdx.x;
+    if (wide && t < total_tiles) ntt_prefetch<B1, B2, B3>(a, threadIdx.x, t % grid_x, t / grid_x, cur);
+    for (; t < total_tiles; t += gridDim.x) {
+        const u32 tn = t + gridDim.x;
+        if (wide && tn < total_tiles) ntt_prefetch<B1, B2, B3>(a, threadIdx.x, tn % grid_x, tn / grid_x, nxt);
+        const u32 bx = t % grid_x, by = t / grid_x;
+        // opaque copy of the thread id: keeps the compiler from hoisting every tid-derived address, digit and twiddle
+        // out of the tile loop (that costs > 200 VGPRs and spills; recomputing them per tile is a few dozen SALU/VALU ops)
+        u32 tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        ntt_stage1<B1, B2, B3, WIDE>(a, smem, tw, tid, bx, by, cur);
+        if constexpr (B2 > 0) {
+            __syncthreads();
+            ntt_stage2<B1, B2, B3>(a, smem, tid, bx, by);
+        }
+        if constexpr (B3 > 0) {
+            __syncthreads();
+            ntt_stage3<B1, B2, B3>(a, smem, tid, bx, by);
+        }
+        if constexpr (B2 > 0) __syncthreads();   // the next tile's stage 1 overwrites the LDS tile
+        if constexpr (WIDE) cur = nxt;
     }
 }
 
@@ -23,8 +48,17 @@ template <int B1, int B2, int B3>
 static int launch_tile(const PassArgs& a, u32 grid_x, u32 batch, hipStream_t stream) {
     constexpr u32 S = B1 + B2 + B3;
     const u32 threads = ((1u << S) << a.logC) >> 4;
-    const size_t lds = (B2 > 0) ? tile_lds_elems(S, a.logC, a.pad_shift, a.pad_amount) * sizeof(u64) : 0;
-    hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3>), dim3(grid_x, batch), dim3(threads), lds, stream, a);
+    const u32 tile = (B2 > 0) ? tile_lds_elems(S, a.logC, a.pad_shift, a.pad_amount) : 0;
+    const u32 tw_offset = (tile + 1) & ~1u;
+    const size_t lds = (B2 > 0) ? (tw_offset + (1u << (B1 + B2))) * sizeof(u64) : 0;
+    const u64 total = (u64)grid_x * batch;
+    if (total > 0xFFFFFFFFull) { set_error("too many tiles"); return BFS_ERR_BAD_ARG; }
+    // persistent grid: enough workgroups to fill the 256 CUs at the residency the 34 KiB LDS tile allows (4 per CU)
+    u32 grid = total < 1024 ? (u32)total : 1024;
+    if (!(B1 == 4 && a.wide_load)) grid = (u32)total;   // without prefetch there is nothing to gain from persistence
+    const bool wide = B1 == 4 && a.wide_load && (a.mode == PASS_COLUMN ? a.logC >= 1 : (B2 + B3) >= 1);
+    if (wide) hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, true>), dim3(grid), dim3(threads), lds, stream, a, grid_x, (u32)total, tw_offset);
+    else hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, false>), dim3(grid), dim3(threads), lds, stream, a, grid_x, (u32)total, tw_offset);
     BFS_HIP(hipGetLastError());
     return BFS_OK;
 }

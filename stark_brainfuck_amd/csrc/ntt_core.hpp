@@ -32,13 +32,16 @@ constexpr u64 cx_pow2(int k) {
     return r;
 }
 
+// x * 2^K mod p.  Written as a multiplication by the compile-time constant 2^K mod p: hipcc drops the partial products of
+// the constant's zero limbs (1-2 v_mad_u64_u32 instead of 4), which measured fewer instructions than an explicit
+// shift-and-fold formulation (tools/microbench, DESIGN.md "modular arithmetic").
 template <int K>
 BFS_HD u64 mul_pow2(u64 x) {
     if constexpr (K == 0) {
         return x;
     } else {
         constexpr u64 c = cx_pow2(K);
-        return gl_mul(x, c);  // constant operand: the compiler drops the zero partial products
+        return gl_mul(x, c);
     }
 }
 
@@ -65,7 +68,9 @@ BFS_HD void dif(u64* x) {
 
 BFS_HD u32 bitrev(u32 v, int bits) {
     u32 r = 0;
-    for (int i = 0; i < bits; ++i) r |= ((v >> i) & 1u) << (bits - 1 - i);
+    BFS_UNROLL
+    for (int i = 0; i < 4; ++i)
+        if (i < bits) r |= ((v >> i) & 1u) << (bits - 1 - i);
     return r;
 }
 
@@ -99,6 +104,8 @@ struct PassArgs {
     u64 post_scale;      // multiplied in at the final store when the final pass has a single stage
     u32 pad_shift;       // LDS padding: phys = lin + (lin >> pad_shift) * pad_amount
     u32 pad_amount;
+    u32 wide_load;       // 16-byte paired-lane loads allowed (pointer / stride alignment checked on the host)
+    u32 wide_store;
     NttTables tb;
 };
 
@@ -107,6 +114,24 @@ BFS_HD u64 tw_pow(const u64* lo, const u64* hi, u32 lo_bits, u64 e) {
     u64 b = hi[e >> lo_bits];
     return gl_mul(a, b);
 }
+
+// exchange a 64-bit value with the neighbouring lane (lane ^ 1): two DPP moves, no LDS traffic.
+// Used to turn two 8-byte accesses of adjacent lanes into one 16-byte access per lane (HBM efficiency of the tile
+// passes: 4.4 TB/s with 16 B per lane against 3.2 TB/s with 8 B per lane, tools/microbench/mem.hip).
+BFS_HD u64 lane_swap1(u64 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 lo = (u32)v, hi = (u32)(v >> 32);
+    lo = (u32)__builtin_amdgcn_update_dpp((int)lo, (int)lo, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
+    hi = (u32)__builtin_amdgcn_update_dpp((int)hi, (int)hi, 0xB1, 0xF, 0xF, true);
+    return ((u64)hi << 32) | lo;
+#else
+    return v;
+#endif
+}
+
+struct alignas(16) U64x2 {
+    u64 x, y;
+};
 
 BFS_HD u32 lds_phys(const PassArgs& a, u32 lin) { return lin + (lin >> a.pad_shift) * a.pad_amount; }
 
@@ -197,23 +222,86 @@ struct TileCfg {
 
 // store the 16 registers of the last stage.  f_lo / f_mid are the already-final lower digits of k_pass.
 template <int B1, int B2, int B3, int BQ>
-BFS_HD void final_store(const PassArgs& a, const TileGeom& g, const u64* x, u32 sub, u32 klow, int kshift, u32 c) {
+BFS_HD void final_store(const PassArgs& a, const TileGeom& g, const u64* x, u32 sub, u32 klow, int kshift, u32 c, u32 G) {
     typedef TileCfg<B1, B2, B3> Cfg;
     u64* out = a.out + g.out_base;
     constexpr int Q = 1 << BQ;
     const bool scale = (Cfg::U == 1) && a.post_scale != 1;
+    u64 v[Q];
+    BFS_UNROLL
+    for (int m = 0; m < Q; ++m) v[m] = scale ? gl_mul(x[sub * Q + m], a.post_scale) : x[sub * Q + m];
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (Q >= 2 && a.wide_store && a.logC >= 1) {
+        // lanes 2i / 2i+1 hold adjacent columns: the even lane stores both columns of outputs m < Q/2, the odd lane
+        // those of m >= Q/2, as one 16-byte store each
+        constexpr int H = Q / 2 ? Q / 2 : 1;
+        const u32 par = G & 1;
+        BFS_UNROLL
+        for (int mm = 0; mm < H; ++mm) {
+            u64 keep = par ? v[H + mm] : v[mm];
+            u64 send = par ? v[mm] : v[H + mm];
+            u64 recv = lane_swap1(send);
+            u32 kd = perm_digit((u32)(par ? H + mm : mm), BQ, a.uinv);
+            u32 kpass = klow + (kd << kshift);
+            U64x2 pr;
+            pr.x = par ? recv : keep;
+            pr.y = par ? keep : recv;
+            *reinterpret_cast<U64x2*>(out + out_index<Cfg::S>(a, g, kpass, c & ~1u)) = pr;
+        }
+        return;
+    }
+#endif
+    BFS_UNROLL
     for (int m = 0; m < Q; ++m) {
         u32 kd = perm_digit((u32)m, BQ, a.uinv);
         u32 kpass = klow + (kd << kshift);
-        u64 v = x[sub * Q + m];
-        if (scale) v = gl_mul(v, a.post_scale);
-        out[out_index<Cfg::S>(a, g, kpass, c)] = v;
+        out[out_index<Cfg::S>(a, g, kpass, c)] = v[m];
+    }
+}
+
+// raw 16-byte pieces of one tile as fetched by a thread (paired-lane wide loads); lets the kernel issue the loads of
+// the NEXT tile before it starts computing on the current one (software prefetch: HBM latency hides under the VALU work)
+struct RawTile {
+    U64x2 pr[8];
+};
+
+template <int B1, int B2, int B3>
+BFS_HD bool wide_load_possible(const PassArgs& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return B1 == 4 && a.wide_load && (a.mode == PASS_COLUMN ? a.logC >= 1 : TileCfg<B1, B2, B3>::SH1 >= 1);
+#else
+    return false;
+#endif
+}
+
+// issue the global loads of tile (bid_x, bid_y) for this thread; only valid when wide_load_possible()
+template <int B1, int B2, int B3>
+BFS_HD void ntt_prefetch(const PassArgs& a, u32 tid, u32 bid_x, u32 bid_y, RawTile& raw) {
+    typedef TileCfg<B1, B2, B3> Cfg;
+    const TileGeom g = tile_geom<Cfg::S>(a, bid_x, bid_y);
+    const u64* in = a.in + g.in_base;
+    const u32 G = tid;
+    u32 o, c;
+    if (a.mode == PASS_COLUMN) { c = G & ((1u << a.logC) - 1); o = G >> a.logC; }
+    else { o = G & ((1u << Cfg::SH1) - 1); c = G >> Cfg::SH1; }
+    const u32 par = G & 1;
+    const u32 oe = (a.mode == PASS_COLUMN) ? o : (o & ~1u);
+    const u32 ce = (a.mode == PASS_COLUMN) ? (c & ~1u) : c;
+    BFS_UNROLL
+    for (int dd = 0; dd < 8; ++dd) {
+        u32 d = par ? (u32)(8 + dd) : (u32)dd;
+        u64 idx = in_index<Cfg::S>(a, g, (d << Cfg::SH1) | oe, ce);
+        U64x2 pr;
+        if (a.pass_index > 0 || idx + 1 < a.n_in) pr = *reinterpret_cast<const U64x2*>(in + idx);
+        else { pr.x = idx < a.n_in ? in[idx] : 0; pr.y = 0; }
+        raw.pr[dd] = pr;
     }
 }
 
 // ---- stage 1: global load (+ coset / inter-pass twiddle), first radix, inner twiddle, LDS write (or final store)
-template <int B1, int B2, int B3>
-BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid_y) {
+// tw: dense inner-twiddle table for the stage 1 -> 2 exchange (2^(B1+B2) entries, in LDS on the GPU)
+template <int B1, int B2, int B3, bool PRE>
+BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, const u64* tw, u32 tid, u32 bid_x, u32 bid_y, const RawTile& pre) {
     typedef TileCfg<B1, B2, B3> Cfg;
     constexpr int Q = 1 << B1, SG = 16 / Q;
     const u32 W = ((1u << Cfg::S) << a.logC) >> 4;
@@ -222,17 +310,37 @@ BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid
     const u64 n = 1ull << a.log_n;
     const bool twiddle = a.pass_index > 0;
     u64 x[16];
+    BFS_UNROLL
     for (int s = 0; s < SG; ++s) {
         u32 G = (u32)s * W + tid;
         u32 o, c;
         if (a.mode == PASS_COLUMN) { c = G & ((1u << a.logC) - 1); o = G >> a.logC; }
         else { o = G & ((1u << Cfg::SH1) - 1); c = G >> Cfg::SH1; }
-        for (int d = 0; d < Q; ++d) {
-            u32 r = ((u32)d << Cfg::SH1) | o;
-            u64 idx = in_index<Cfg::S>(a, g, r, c);
-            x[s * Q + d] = (a.pass_index > 0 || idx < a.n_in) ? in[idx] : 0;
+        if constexpr (PRE) {
+            // paired lanes (adjacent columns in a column pass, adjacent rows in the final pass) fetched 16 bytes each:
+            // the even lane the first half of the register index d, the odd lane the second half; now they swap
+            const u32 par = G & 1;
+            BFS_UNROLL
+            for (int dd = 0; dd < 8; ++dd) {
+                U64x2 pr = pre.pr[dd];
+                u64 keep = par ? pr.y : pr.x;
+                u64 recv = lane_swap1(par ? pr.x : pr.y);
+                x[dd] = par ? recv : keep;
+                x[8 + dd] = par ? keep : recv;
+            }
+        } else {
+            BFS_UNROLL
+            for (int d = 0; d < Q; ++d) {
+                u32 r = ((u32)d << Cfg::SH1) | o;
+                u64 idx = in_index<Cfg::S>(a, g, r, c);
+                x[s * Q + d] = (a.pass_index > 0 || idx < a.n_in) ? in[idx] : 0;
+            }
         }
+#ifdef BFS_ABL_NO_CHAIN
+        if (false) {
+#else
         if (twiddle || a.has_coset) {
+#endif
             u64 gam, del;
             if (twiddle) {
                 u64 ks = (a.mode == PASS_COLUMN) ? g.kstep : ((g.c0 + c) + (g.kmid << g.n1_bits));
@@ -243,21 +351,28 @@ BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid
                 del = a.coset_delta;
             }
             u64 f = gam;
+            BFS_UNROLL
             for (int d = 0; d < Q; ++d) {
                 x[s * Q + d] = gl_mul(x[s * Q + d], f);
                 f = gl_mul(f, del);
             }
         }
+#ifndef BFS_ABL_NO_DIF
         dif<Q>(x + s * Q);
+#endif
         if constexpr (Cfg::U == 1) {
-            final_store<B1, B2, B3, B1>(a, g, x, (u32)s, 0, 0, c);
+            final_store<B1, B2, B3, B1>(a, g, x, (u32)s, 0, 0, c, G);
         } else {
-            const u64* tab = (Cfg::U == 2 && a.mode == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;
             u32 i2 = o >> B3;
+            BFS_UNROLL
             for (int m = 0; m < Q; ++m) {
                 u32 k1 = perm_digit((u32)m, B1, a.uinv);
                 u32 e = (i2 * k1) & ((1u << (B1 + B2)) - 1);
-                u64 v = gl_mul(x[s * Q + m], tab[(u64)e << (a.tb.t_in_log - (B1 + B2))]);
+#ifdef BFS_ABL_NO_INNER
+                u64 v = x[s * Q + m] + e;
+#else
+                u64 v = gl_mul(x[s * Q + m], tw[e]);
+#endif
                 u32 r = (k1 << Cfg::SH1) | o;
                 smem[lds_phys(a, (r << a.logC) + c)] = v;
             }
@@ -274,20 +389,25 @@ BFS_HD void ntt_stage2(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid
         const u32 W = ((1u << Cfg::S) << a.logC) >> 4;
         const TileGeom g = tile_geom<Cfg::S>(a, bid_x, bid_y);
         u64 x[16];
-        for (int s = 0; s < SG; ++s) {
+        BFS_UNROLL
+    for (int s = 0; s < SG; ++s) {
             u32 G = (u32)s * W + tid;
             u32 c = G & ((1u << a.logC) - 1);
             u32 rest = G >> a.logC;
             u32 f1 = rest & ((1u << B1) - 1), f3 = rest >> B1;
+            BFS_UNROLL
             for (int d = 0; d < Q; ++d) {
                 u32 r = (f1 << Cfg::SH1) | ((u32)d << Cfg::SH2) | f3;
                 x[s * Q + d] = smem[lds_phys(a, (r << a.logC) + c)];
             }
+#ifndef BFS_ABL_NO_DIF
             dif<Q>(x + s * Q);
+#endif
             if constexpr (Cfg::U == 2) {
-                final_store<B1, B2, B3, B2>(a, g, x, (u32)s, f1, B1, c);
+                final_store<B1, B2, B3, B2>(a, g, x, (u32)s, f1, B1, c, G);
             } else {
                 const u64* tab = (a.mode == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;
+                BFS_UNROLL
                 for (int m = 0; m < Q; ++m) {
                     u32 k2 = perm_digit((u32)m, B2, a.uinv);
                     u32 e = (f3 * (f1 + (k2 << B1))) & ((1u << Cfg::S) - 1);
@@ -309,17 +429,19 @@ BFS_HD void ntt_stage3(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid
         const u32 W = ((1u << Cfg::S) << a.logC) >> 4;
         const TileGeom g = tile_geom<Cfg::S>(a, bid_x, bid_y);
         u64 x[16];
-        for (int s = 0; s < SG; ++s) {
+        BFS_UNROLL
+    for (int s = 0; s < SG; ++s) {
             u32 G = (u32)s * W + tid;
             u32 c = G & ((1u << a.logC) - 1);
             u32 rest = G >> a.logC;
             u32 f1 = rest & ((1u << B1) - 1), f2 = rest >> B1;
+            BFS_UNROLL
             for (int d = 0; d < Q; ++d) {
                 u32 r = (f1 << Cfg::SH1) | (f2 << Cfg::SH2) | (u32)d;
                 x[s * Q + d] = smem[lds_phys(a, (r << a.logC) + c)];
             }
             dif<Q>(x + s * Q);
-            final_store<B1, B2, B3, B3>(a, g, x, (u32)s, f1 + (f2 << B1), B1 + B2, c);
+            final_store<B1, B2, B3, B3>(a, g, x, (u32)s, f1 + (f2 << B1), B1 + B2, c, G);
         }
     }
 }

@@ -13,7 +13,10 @@ namespace bfs {
 
 constexpr u32 NTT_TILE_LOG = 12;      // 4096 elements (32 KiB) per tile in the multi-pass regime
 constexpr u32 NTT_MAX_PASS_BITS = 8;  // digits of a multi-pass plan are <= 2^8 so tiles keep >= 16 columns (128 B segments)
-constexpr u32 NTT_SMALL_LOG = 3;      // n <= 8 goes through the direct small kernel
+constexpr u32 NTT_SMALL_LOG = 3;
+#ifndef NTT_WIDE_ACCESS
+#define NTT_WIDE_ACCESS 0
+#endif      // n <= 8 goes through the direct small kernel
 
 struct NttPlan {
     u32 log_n = 0;
@@ -148,6 +151,10 @@ inline PassArgs ntt_pass_args(const NttPlan& p, u32 t, const u64* in, u64* out, 
         a.coset_delta = gl_pow(shift, stride);
     }
     ntt_default_padding(p.pass_bits[t], a.logC, a.mode, a.pad_shift, a.pad_amount);
+    // 16-byte paired-lane accesses raise the HBM rate of a pass from 3.2 to 4.4 TB/s but cost ~200 VALU instructions per
+    // tile; the kernels are VALU-bound today (74 % VALU busy, profiles/r01), so they are switched on by NTT_WIDE_ACCESS only
+    a.wide_load = (NTT_WIDE_ACCESS && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (in_stride & 1) == 0) ? 1 : 0;
+    a.wide_store = (NTT_WIDE_ACCESS && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (out_stride & 1) == 0) ? 1 : 0;
     return a;
 }
 

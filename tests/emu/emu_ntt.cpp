@@ -15,9 +15,14 @@ static void run_pass(const PassArgs& a, u32 grid_x, u32 batch) {
     const u32 S = B1 + B2 + B3;
     const u32 W = ((1u << S) << a.logC) >> 4;
     std::vector<u64> smem(tile_lds_elems(S, a.logC, a.pad_shift, a.pad_amount));
+    // dense stage-1 -> stage-2 twiddle table, as the kernel builds it in LDS
+    std::vector<u64> tw(1u << (B1 + B2));
+    const u64* tab = (B2 > 0 && B3 == 0 && a.mode == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;
+    if (B2 > 0) for (u32 i = 0; i < tw.size(); ++i) tw[i] = tab[(u64)i << (a.tb.t_in_log - (B1 + B2))];
     for (u32 by = 0; by < batch; ++by)
         for (u32 bx = 0; bx < grid_x; ++bx) {
-            for (u32 t = 0; t < W; ++t) ntt_stage1<B1, B2, B3>(a, smem.data(), t, bx, by);
+            RawTile none{};
+            for (u32 t = 0; t < W; ++t) ntt_stage1<B1, B2, B3, false>(a, smem.data(), tw.data(), t, bx, by, none);
             if (B2 > 0) for (u32 t = 0; t < W; ++t) ntt_stage2<B1, B2, B3>(a, smem.data(), t, bx, by);
             if (B3 > 0) for (u32 t = 0; t < W; ++t) ntt_stage3<B1, B2, B3>(a, smem.data(), t, bx, by);
         }
