@@ -7,7 +7,7 @@ namespace bfs {
 int mul_pointwise_launch(const u64* a, const u64* b, u64* out, u64 n, hipStream_t stream);
 int batch_inverse_launch(const u64* in, u64* out, u64 n, hipStream_t stream);
 int scale_launch(const u64* in, u64* out, u64 n, u64 stride, u32 batch, u64 factor, hipStream_t stream);
-int merkle_build_xfe_launch(const u64* d_limbs, u64 limb_stride, u64 n, u64* d_nodes, hipStream_t stream);
+int merkle_build_xfe_launch(const u64* d_limbs, u64 limb_stride, u64 n, u64* d_nodes, hipStream_t stream, u64* root_out = nullptr, u64 seq = 0);
 int merkle_build_bfe_launch(const u64* d_values, u64 n, u64* d_nodes, hipStream_t stream);
 int merkle_build_bytes_launch(const u64* d_data, const u64* d_offsets, const u32* d_lengths, u64 n, u64* d_nodes, hipStream_t stream);
 }

@@ -13,7 +13,7 @@
 
 namespace bfs {
 
-int merkle_build_xfe_launch(const u64* d_limbs, u64 limb_stride, u64 n, u64* d_nodes, hipStream_t stream);
+int merkle_build_xfe_launch(const u64* d_limbs, u64 limb_stride, u64 n, u64* d_nodes, hipStream_t stream, u64* root_out = nullptr, u64 seq = 0);
 int ntt_power_tables(u64 root, u32 log_n, const u64** lo, const u64** hi, u32* lo_bits);
 
 BFS_HD u64 gl_half(u64 x) { return (x >> 1) + ((x & 1) ? 0x7FFFFFFF80000001ULL : 0); }  // x / 2 mod p
@@ -36,9 +36,37 @@ __global__ void fri_fold_kernel(const u64* in, u64 in_stride, u64* out, u64 out_
     }
 }
 
-__global__ void gather_words_kernel(const u64* const* src, u64 count, u64* out) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (u64)gridDim.x * blockDim.x) out[i] = *src[i];
+// one request = `nwords` 64-bit words at base, base + stride, ...; requests and results live in pinned host memory that the
+// GPU reads / writes directly (no copy commands: the openings of a proof are a few thousand scattered words)
+struct GatherReq {
+    const u64* base;
+    u32 nwords, stride;
+    u64 out_offset;
+};
+__global__ void gather_requests_kernel(const GatherReq* req, u32 count, u64* out) {
+    for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < count; i += gridDim.x * blockDim.x) {
+        const GatherReq r = req[i];
+        for (u32 w = 0; w < r.nwords; ++w) out[r.out_offset + w] = r.base[(u64)w * r.stride];
+    }
 }
+
+// pinned staging area shared by the prover calls of this process (grow-only)
+struct PinnedArea {
+    void* host = nullptr;
+    void* dev = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return BFS_OK;
+        if (host) (void)hipHostFree(host);
+        host = dev = nullptr; bytes = 0;
+        size_t sz = need < (1u << 20) ? (1u << 20) : need * 2;
+        BFS_HIP(hipHostMalloc(&host, sz, hipHostMallocMapped | hipHostMallocCoherent));
+        BFS_HIP(hipHostGetDevicePointer(&dev, host, 0));
+        bytes = sz;
+        return BFS_OK;
+    }
+};
+static PinnedArea g_req_area, g_res_area;
 
 struct FriRound {
     const u64* cw = nullptr;  // limb-major codeword
@@ -47,9 +75,26 @@ struct FriRound {
     unsigned char root[64];
 };
 
+// pinned, host-visible mailbox the tree kernel drops each round's root into (9 words: digest + sequence flag)
+struct RootMailbox {
+    u64* host = nullptr;
+    u64* dev = nullptr;
+    u64 seq = 0;
+    int init() {
+        if (host) return BFS_OK;
+        BFS_HIP(hipHostMalloc((void**)&host, 16 * sizeof(u64), hipHostMallocMapped | hipHostMallocCoherent));
+        memset(host, 0, 16 * sizeof(u64));
+        BFS_HIP(hipHostGetDevicePointer((void**)&dev, host, 0));
+        return BFS_OK;
+    }
+    ~RootMailbox() { if (host) (void)hipHostFree(host); }
+};
+
 struct FriSession {
     std::vector<FriRound> rounds;
-    void* block = nullptr;  // device allocation owned by the session
+    void* block = nullptr;  // device allocation owned by the session (null when it borrows the cached workspace)
+    bool use_workspace = false;
+    RootMailbox mailbox;
     u32 log_n = 0;
     std::map<std::pair<u32, u64>, rp::Ref> elements;  // (round, index) -> the element object (identity!)
     std::map<std::pair<u32, u64>, rp::Ref> nodes;     // (round, node index) -> bytes object
@@ -77,8 +122,16 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
     // one allocation: nodes of every round + codewords of rounds >= 1
     size_t words = 0;
     for (u32 r = 0; r < R; ++r) words += (size_t)16 * (N >> r) + (r ? (size_t)3 * (N >> r) : 0);
-    BFS_HIP(hipMalloc(&S.block, words * sizeof(u64)));
-    u64* p = (u64*)S.block;
+    u64* p = nullptr;
+    if (S.use_workspace) {
+        void* w = nullptr;
+        BFS_TRY(workspace(4, words * sizeof(u64), stream, &w));   // bfs_fri_prove: nothing outlives the call
+        p = (u64*)w;
+    } else {
+        BFS_HIP(hipMalloc(&S.block, words * sizeof(u64)));
+        p = (u64*)S.block;
+    }
+    BFS_TRY(S.mailbox.init());
     for (u32 r = 0; r < R; ++r) {
         FriRound& fr = S.rounds[r];
         fr.length = N >> r;
@@ -93,9 +146,26 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
     u64 g = offset;
     for (u32 r = 0; r < R; ++r) {
         FriRound& fr = S.rounds[r];
-        BFS_TRY(merkle_build_xfe_launch(fr.cw, fr.stride, fr.length, fr.nodes, stream));  // fri.py:108
-        BFS_HIP(hipMemcpyAsync(fr.root, fr.nodes + 8, 64, hipMemcpyDeviceToHost, stream));
-        BFS_HIP(hipStreamSynchronize(stream));
+        if (fr.length >= 2) {
+            // the tree kernel writes the root straight into pinned host memory; poll the sequence flag instead of
+            // paying a copy command + stream synchronisation per round
+            const u64 seq = ++S.mailbox.seq;
+            BFS_TRY(merkle_build_xfe_launch(fr.cw, fr.stride, fr.length, fr.nodes, stream, S.mailbox.dev, seq));  // fri.py:108
+            volatile u64* flag = S.mailbox.host + 8;
+            u64 spins = 0;
+            while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+                if (++spins > (1ull << 22)) {   // ~ms: fall back to a real synchronisation (also surfaces kernel errors)
+                    BFS_HIP(hipStreamSynchronize(stream));
+                    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) { set_error("root mailbox was not written"); return BFS_ERR_HIP; }
+                    break;
+                }
+            }
+            memcpy(fr.root, S.mailbox.host, 64);
+        } else {
+            BFS_TRY(merkle_build_xfe_launch(fr.cw, fr.stride, fr.length, fr.nodes, stream));
+            BFS_HIP(hipMemcpyAsync(fr.root, fr.nodes + 8, 64, hipMemcpyDeviceToHost, stream));
+            BFS_HIP(hipStreamSynchronize(stream));
+        }
         if (r > 0) ps.objects.push_back(rp::mk_bytes(fr.root, 64));  // fri.py:112-113
         if (r == R - 1) break;                                       // fri.py:116-117
         unsigned char seed[32];
@@ -113,8 +183,12 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
     // fri.py:134: the last codeword goes into the transcript as a list of element objects
     FriRound& last = S.rounds[R - 1];
     std::vector<u64> host(3 * last.length);
-    for (int k = 0; k < 3; ++k)
-        BFS_HIP(hipMemcpyAsync(host.data() + k * last.length, last.cw + k * last.stride, last.length * sizeof(u64), hipMemcpyDeviceToHost, stream));
+    if (last.stride == last.length) {
+        BFS_HIP(hipMemcpyAsync(host.data(), last.cw, 3 * last.length * sizeof(u64), hipMemcpyDeviceToHost, stream));
+    } else {
+        for (int k = 0; k < 3; ++k)
+            BFS_HIP(hipMemcpyAsync(host.data() + k * last.length, last.cw + k * last.stride, last.length * sizeof(u64), hipMemcpyDeviceToHost, stream));
+    }
     BFS_HIP(hipStreamSynchronize(stream));
     std::vector<rp::Ref> items;
     for (u64 j = 0; j < last.length; ++j) {
@@ -170,15 +244,18 @@ int fri_query(FriSession& S, rp::Transcript& ps, u32 t, u64* h_top, hipStream_t 
     layer_idx.push_back(idx);  // query_last
 
     typedef std::pair<u32, u64> Key;
-    std::vector<const u64*> src;                 // one device address per gathered 64-bit word
-    std::vector<std::pair<int, Key>> order;      // what the words are: (0 = element | 1 = tree node, key)
+    std::vector<GatherReq> reqs;                 // what to fetch
+    std::vector<std::pair<int, Key>> order;      // what the fetched words are: (0 = element | 1 = tree node, key)
+    reqs.reserve(4096); order.reserve(4096);
+    u64 nwords = 0;
     auto need_element = [&](u32 r, u64 j) {
         Key key{r, j};
         if (S.elements.count(key)) return;       // same Python object in the reference -> same node here
         S.elements[key] = rp::Ref();
         order.push_back({0, key});
         const FriRound& fr = S.rounds[r];
-        for (int k = 0; k < 3; ++k) src.push_back(fr.cw + k * fr.stride + j);
+        reqs.push_back(GatherReq{fr.cw + j, 3u, (u32)fr.stride, nwords});
+        nwords += 3;
     };
     auto need_path = [&](u32 r, u64 leaf) {      // merkle.py:46-52
         const FriRound& fr = S.rounds[r];
@@ -187,7 +264,8 @@ int fri_query(FriSession& S, rp::Transcript& ps, u32 t, u64* h_top, hipStream_t 
             if (S.nodes.count(key)) continue;
             S.nodes[key] = rp::Ref();
             order.push_back({1, key});
-            for (int w = 0; w < 8; ++w) src.push_back(fr.nodes + (k ^ 1) * 8 + w);
+            reqs.push_back(GatherReq{fr.nodes + (k ^ 1) * 8, 8u, 1u, nwords});
+            nwords += 8;
         }
     };
     for (u32 i = 0; i < (u32)layer_idx.size(); ++i) {
@@ -201,18 +279,16 @@ int fri_query(FriSession& S, rp::Transcript& ps, u32 t, u64* h_top, hipStream_t 
             if (!lastq) need_path(cur + 1, c);
         }
     }
-    std::vector<u64> words(src.size());
-    if (!src.empty()) {
-        void* w = nullptr;
-        BFS_TRY(workspace(3, src.size() * 16, stream, &w));
-        const u64** d_src = (const u64**)w;
-        u64* d_out = (u64*)w + src.size();
-        BFS_HIP(hipMemcpyAsync(d_src, src.data(), src.size() * 8, hipMemcpyHostToDevice, stream));
-        u32 grid = (u32)((src.size() + 255) / 256);
-        hipLaunchKernelGGL(gather_words_kernel, dim3(grid > 1024 ? 1024 : grid), dim3(256), 0, stream, (const u64* const*)d_src, (u64)src.size(), d_out);
+    const u64* words = nullptr;
+    if (!reqs.empty()) {
+        BFS_TRY(g_req_area.ensure(reqs.size() * sizeof(GatherReq)));
+        BFS_TRY(g_res_area.ensure(nwords * sizeof(u64)));
+        memcpy(g_req_area.host, reqs.data(), reqs.size() * sizeof(GatherReq));
+        u32 grid = (u32)((reqs.size() + 255) / 256);
+        hipLaunchKernelGGL(gather_requests_kernel, dim3(grid), dim3(256), 0, stream, (const GatherReq*)g_req_area.dev, (u32)reqs.size(), (u64*)g_res_area.dev);
         BFS_HIP(hipGetLastError());
-        BFS_HIP(hipMemcpyAsync(words.data(), d_out, src.size() * 8, hipMemcpyDeviceToHost, stream));
         BFS_HIP(hipStreamSynchronize(stream));
+        words = (const u64*)g_res_area.host;
     }
     size_t pos = 0;
     for (auto& o : order) {
@@ -221,7 +297,7 @@ int fri_query(FriSession& S, rp::Transcript& ps, u32 t, u64* h_top, hipStream_t 
             pos += 3;
             S.elements[o.second] = ps.world.xfe(l);
         } else {
-            S.nodes[o.second] = rp::mk_bytes(&words[pos], 64);
+            S.nodes[o.second] = rp::mk_bytes(words + pos, 64);
             pos += 8;
         }
     }
@@ -270,6 +346,7 @@ int bfs_fri_query(void* session, void* ps, uint32_t num_colinearity_tests, uint6
 int bfs_fri_prove(void* ps, const uint64_t* d_codeword, uint64_t limb_stride, uint32_t log_n, uint64_t offset, uint64_t omega,
                   uint32_t expansion_factor, uint32_t num_colinearity_tests, uint64_t* h_top_level_indices, void* stream) {
     FriSession S;
+    S.use_workspace = true;
     BFS_TRY(fri_commit(S, *(rp::Transcript*)ps, d_codeword, limb_stride, log_n, offset, omega, expansion_factor, (hipStream_t)stream));
     return fri_query(S, *(rp::Transcript*)ps, num_colinearity_tests, h_top_level_indices, (hipStream_t)stream);
 }

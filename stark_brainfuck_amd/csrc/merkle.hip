@@ -58,7 +58,9 @@ __global__ void merkle_parents_kernel(u64* nodes, u64 first, u64 count, u64 pres
 }
 
 // the top of the tree in one workgroup: levels with `width` <= 256 parents down to the root, through LDS
-__global__ void __launch_bounds__(256) merkle_top_kernel(u64* nodes, u32 width, u64 present_children) {
+// root_out (optional): pinned, host-visible memory; the root is written there followed by a sequence flag (word 8), so the
+// host can pick it up without a copy command (FRI needs the root of every round on the host, fri.py:108-120)
+__global__ void __launch_bounds__(256) merkle_top_kernel(u64* nodes, u32 width, u64 present_children, u64* root_out, u64 seq) {
     __shared__ u64 lvl[512 * 8];
     const u32 t = threadIdx.x;
     for (u32 i = t; i < 2 * width * 8; i += 256) lvl[i] = nodes[(u64)2 * width * 8 + i];
@@ -76,6 +78,11 @@ __global__ void __launch_bounds__(256) merkle_top_kernel(u64* nodes, u32 width, 
             u64* dst = nodes + ((u64)w + t) * 8;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { lvl[t * 8 + j] = out[j]; dst[j] = out[j]; }
+            if (w == 1 && root_out != nullptr) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) __hip_atomic_store(root_out + j, out[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(root_out + 8, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         __syncthreads();
         present = 2 * (u64)w;  // every computed level is complete
@@ -83,13 +90,13 @@ __global__ void __launch_bounds__(256) merkle_top_kernel(u64* nodes, u32 width, 
 }
 
 // build all inner nodes above a leaf level of npo2 = 2^depth slots of which n_leaves hold digests
-int merkle_inner_launch(u64* d_nodes, u32 depth, u64 n_leaves, hipStream_t stream) {
+int merkle_inner_launch(u64* d_nodes, u32 depth, u64 n_leaves, hipStream_t stream, u64* root_out = nullptr, u64 seq = 0) {
     if (depth == 0) return BFS_OK;  // single leaf: root = leaf digest (merkle.py:43 nodes[1])
     u64 present = n_leaves;
     for (u32 lvl = depth; lvl-- > 0;) {
         const u64 count = 1ull << lvl;
         if (count <= 256) {
-            hipLaunchKernelGGL(merkle_top_kernel, dim3(1), dim3(256), 0, stream, d_nodes, (u32)count, present);
+            hipLaunchKernelGGL(merkle_top_kernel, dim3(1), dim3(256), 0, stream, d_nodes, (u32)count, present, root_out, seq);
             BFS_HIP(hipGetLastError());
             return BFS_OK;
         }
@@ -100,7 +107,7 @@ int merkle_inner_launch(u64* d_nodes, u32 depth, u64 n_leaves, hipStream_t strea
     return BFS_OK;
 }
 
-int merkle_build_xfe_launch(const u64* d_limbs, u64 limb_stride, u64 n, u64* d_nodes, hipStream_t stream) {
+int merkle_build_xfe_launch(const u64* d_limbs, u64 limb_stride, u64 n, u64* d_nodes, hipStream_t stream, u64* root_out, u64 seq) {
     if (n == 0) return BFS_OK;
     u32 depth = 0;
     while ((1ull << depth) < n) ++depth;
@@ -108,7 +115,7 @@ int merkle_build_xfe_launch(const u64* d_limbs, u64 limb_stride, u64 n, u64* d_n
     hipLaunchKernelGGL(merkle_leaves_xfe_kernel, dim3((u32)((n + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0, stream,
                        d_limbs, limb_stride, n, d_nodes + npo2 * 8);
     BFS_HIP(hipGetLastError());
-    return merkle_inner_launch(d_nodes, depth, n, stream);
+    return merkle_inner_launch(d_nodes, depth, n, stream, root_out, seq);
 }
 
 int merkle_build_bfe_launch(const u64* d_values, u64 n, u64* d_nodes, hipStream_t stream) {
