@@ -2,6 +2,7 @@
 // (/root/reference/code/merkle.py:8-41): leaf hashing `blake2b(pickle.dumps(leaf))` (:29-32) and the level-by-level
 // parent hashing (:35-41).  One thread hashes one leaf (preimage synthesised in LDS, <= 4 compressions) or one
 // parent (one compression); the top 9 levels run in a single workgroup.
+#include "blake2b_quad.hpp"
 #include "merkle_core.hpp"
 #include "runtime.hpp"
 
@@ -89,6 +90,114 @@ __global__ void __launch_bounds__(256) merkle_top_kernel(u64* nodes, u32 width, 
     }
 }
 
+// ---- latency-oriented variants: four lanes per hash (blake2b_quad.hpp), used when a level has few hashes ----
+
+// parents [first, first+count) with one QUAD per parent; 64 parents per 256-thread workgroup, messages staged in LDS
+__global__ void __launch_bounds__(256) merkle_parents_quad_kernel(u64* nodes, u64 first, u64 count, u64 present_children) {
+#if defined(__HIP_DEVICE_COMPILE__)   // DPP builtins exist only in the device pass
+    __shared__ u64 msg[64 * 16];
+    const u32 q = threadIdx.x >> 2, j = threadIdx.x & 3;
+    const u64 t = (u64)blockIdx.x * 64 + q;
+    const QuadLane ql = quad_lane(threadIdx.x);
+    if (t < count) {
+        const u64 k = first + t, c = 2 * t;
+        const int present = c + 1 < present_children ? 2 : (c < present_children ? 1 : 0);
+        const u64* child = nodes + (2 * k) * 8;      // the two children are adjacent: 16 words
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int idx = 4 * j + w;
+            msg[q * 16 + idx] = (idx < 8 * present) ? child[idx] : 0;
+        }
+        u64 hl, hh;
+        blake2b_init_quad(ql, hl, hh);
+        blake2b_compress_quad(ql, hl, hh, msg + q * 16, (u64)(64 * present + 32 * (2 - present)), true);
+        nodes[k * 8 + j] = hl;
+        nodes[k * 8 + 4 + j] = hh;
+    }
+#endif
+}
+
+// top of the tree (levels of width <= 256 down to the root) in one 1024-thread workgroup, one quad per parent,
+// ping-pong level buffers in LDS
+__global__ void __launch_bounds__(1024) merkle_top_quad_kernel(u64* nodes, u32 width, u64 present_children, u64* root_out, u64 seq) {
+#if defined(__HIP_DEVICE_COMPILE__)   // DPP builtins exist only in the device pass
+    __shared__ u64 bufA[512 * 8];
+    __shared__ u64 bufB[256 * 8];
+    const u32 tid = threadIdx.x, q = tid >> 2, j = tid & 3;
+    const QuadLane ql = quad_lane(tid);
+    for (u32 i = tid; i < 2 * width * 8; i += 1024) bufA[i] = nodes[(u64)2 * width * 8 + i];
+    __syncthreads();
+    u64* src = bufA;
+    u64* dst = bufB;
+    u64 present = present_children;
+    for (u32 w = width; w >= 1; w >>= 1) {
+        if (q < w) {
+            const u64 c = 2 * (u64)q;
+            const int pr = c + 1 < present ? 2 : (c < present ? 1 : 0);
+            u64* m = src + q * 16;
+            if (pr < 2) {                            // ragged leaf level only: absent children are zero bytes
+#pragma unroll
+                for (int wd = 0; wd < 4; ++wd) { const int idx = 4 * j + wd; if (idx >= 8 * pr) m[idx] = 0; }
+            }
+            u64 hl, hh;
+            blake2b_init_quad(ql, hl, hh);
+            blake2b_compress_quad(ql, hl, hh, m, (u64)(64 * pr + 32 * (2 - pr)), true);
+            dst[q * 8 + j] = hl;
+            dst[q * 8 + 4 + j] = hh;
+            u64* g = nodes + ((u64)w + q) * 8;
+            g[j] = hl;
+            g[4 + j] = hh;
+            if (w == 1 && root_out != nullptr) {
+                __hip_atomic_store(root_out + j, hl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(root_out + 4 + j, hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        __syncthreads();
+        u64* tmp = src; src = dst; dst = tmp;
+        present = 2 * (u64)w;
+    }
+    if (tid == 0 && root_out != nullptr) {
+        __threadfence_system();
+        __hip_atomic_store(root_out + 8, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+#endif
+}
+
+// leaves with one quad per leaf (small codewords: late FRI rounds): lane 0 of the quad assembles the preimage in LDS,
+// the four lanes hash it
+__global__ void __launch_bounds__(256) merkle_leaves_xfe_quad_kernel(const u64* limbs, u64 limb_stride, u64 n, u64* leaf_digests) {
+#if defined(__HIP_DEVICE_COMPILE__)   // DPP builtins exist only in the device pass
+    constexpr int WORDS = 64;                        // 4 blocks of 16 words per leaf (409 bytes max)
+    __shared__ u64 stage[64 * WORDS];
+    const u32 q = threadIdx.x >> 2, j = threadIdx.x & 3;
+    const u64 i = (u64)blockIdx.x * 64 + q;
+    const QuadLane ql = quad_lane(threadIdx.x);
+    if (i >= n) return;
+    u64* m = stage + q * WORDS;
+    u32 total = 0;
+    if (j == 0) {
+        LeafWriter w;
+        w.init(m, 1);
+        total = encode_xfe_leaf(w, limbs[i], limbs[limb_stride + i], limbs[2 * limb_stride + i]);
+        const u32 nblk = (total + 127) / 128;
+        for (u32 k = w.wpos; k < nblk * 16; ++k) m[k] = 0;   // zero padding of the final block
+    }
+    total = __shfl(total, (threadIdx.x & 63) & ~3u);
+    const u32 nblk = (total + 127) / 128;
+    u64 hl, hh;
+    blake2b_init_quad(ql, hl, hh);
+    for (u32 b = 0; b < nblk; ++b) {
+        const bool last = b + 1 == nblk;
+        blake2b_compress_quad(ql, hl, hh, m + 16 * b, last ? (u64)total : (u64)(b + 1) * 128, last);
+    }
+    leaf_digests[i * 8 + j] = hl;
+    leaf_digests[i * 8 + 4 + j] = hh;
+#endif
+}
+
+constexpr u64 QUAD_PARENTS_MAX = 8192;   // levels with at most this many parents use one quad per hash
+constexpr u64 QUAD_LEAVES_MAX = 8192;
+
 // build all inner nodes above a leaf level of npo2 = 2^depth slots of which n_leaves hold digests
 int merkle_inner_launch(u64* d_nodes, u32 depth, u64 n_leaves, hipStream_t stream, u64* root_out = nullptr, u64 seq = 0) {
     if (depth == 0) return BFS_OK;  // single leaf: root = leaf digest (merkle.py:43 nodes[1])
@@ -96,11 +205,14 @@ int merkle_inner_launch(u64* d_nodes, u32 depth, u64 n_leaves, hipStream_t strea
     for (u32 lvl = depth; lvl-- > 0;) {
         const u64 count = 1ull << lvl;
         if (count <= 256) {
-            hipLaunchKernelGGL(merkle_top_kernel, dim3(1), dim3(256), 0, stream, d_nodes, (u32)count, present, root_out, seq);
+            hipLaunchKernelGGL(merkle_top_quad_kernel, dim3(1), dim3(1024), 0, stream, d_nodes, (u32)count, present, root_out, seq);
             BFS_HIP(hipGetLastError());
             return BFS_OK;
         }
-        hipLaunchKernelGGL(merkle_parents_kernel, dim3((u32)((count + 255) / 256)), dim3(256), 0, stream, d_nodes, count, count, present);
+        if (count <= QUAD_PARENTS_MAX)
+            hipLaunchKernelGGL(merkle_parents_quad_kernel, dim3((u32)((count + 63) / 64)), dim3(256), 0, stream, d_nodes, count, count, present);
+        else
+            hipLaunchKernelGGL(merkle_parents_kernel, dim3((u32)((count + 255) / 256)), dim3(256), 0, stream, d_nodes, count, count, present);
         BFS_HIP(hipGetLastError());
         present = 2 * count;
     }
@@ -112,8 +224,11 @@ int merkle_build_xfe_launch(const u64* d_limbs, u64 limb_stride, u64 n, u64* d_n
     u32 depth = 0;
     while ((1ull << depth) < n) ++depth;
     const u64 npo2 = 1ull << depth;
-    hipLaunchKernelGGL(merkle_leaves_xfe_kernel, dim3((u32)((n + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0, stream,
-                       d_limbs, limb_stride, n, d_nodes + npo2 * 8);
+    if (n <= QUAD_LEAVES_MAX)
+        hipLaunchKernelGGL(merkle_leaves_xfe_quad_kernel, dim3((u32)((n + 63) / 64)), dim3(256), 0, stream, d_limbs, limb_stride, n, d_nodes + npo2 * 8);
+    else
+        hipLaunchKernelGGL(merkle_leaves_xfe_kernel, dim3((u32)((n + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0, stream,
+                           d_limbs, limb_stride, n, d_nodes + npo2 * 8);
     BFS_HIP(hipGetLastError());
     return merkle_inner_launch(d_nodes, depth, n, stream, root_out, seq);
 }
