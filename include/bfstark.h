@@ -169,6 +169,9 @@ int bfs_fri_commit(void* session, void* ps, const uint64_t* d_codeword, uint64_t
 int bfs_fri_query(void* session, void* ps, uint32_t num_colinearity_tests, uint64_t* h_top_level_indices, void* stream);
 int bfs_fri_prove(void* ps, const uint64_t* d_codeword, uint64_t limb_stride, uint32_t log_n, uint64_t offset, uint64_t omega,
                   uint32_t expansion_factor, uint32_t num_colinearity_tests, uint64_t* h_top_level_indices, void* stream);
+/* wall-clock breakdown (ms) of the last commit/query on the calling thread: rounds, last codeword, Fiat-Shamir + sampling,
+ * planning the openings, gather + sync, building transcript objects */
+void bfs_fri_last_timing(double out[6]);
 uint32_t bfs_fri_session_rounds(void* session);
 int bfs_fri_session_round(void* session, uint32_t round, const uint64_t** d_codeword, uint64_t* length, uint64_t* limb_stride,
                           const uint8_t** d_nodes, uint8_t h_root[64]);

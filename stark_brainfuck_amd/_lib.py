@@ -74,6 +74,7 @@ _SIGNATURES = {
     "bfs_fri_commit": (ci, [vp, vp, vp, u64, u32, u64, u64, u32, vp]),
     "bfs_fri_query": (ci, [vp, vp, u32, ctypes.POINTER(u64), vp]),
     "bfs_fri_prove": (ci, [vp, vp, u64, u32, u64, u64, u32, u32, ctypes.POINTER(u64), vp]),
+    "bfs_fri_last_timing": (None, [ctypes.POINTER(ctypes.c_double)]),
     "bfs_fri_session_rounds": (u32, [vp]),
     "bfs_fri_session_round": (ci, [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(vp), vp]),
 }

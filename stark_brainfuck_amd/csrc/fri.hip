@@ -3,7 +3,9 @@
 // host, the Fiat-Shamir challenge from the transcript (host: pickle + SHAKE256, ip.py:21-22), the split-and-fold
 // step (GPU, fri.py:127-128); then index sampling (fri.py:62-86) and one batched gather of every revealed leaf and
 // authentication-path node.
+#include <chrono>
 #include <map>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/bfstark.h"
@@ -68,6 +70,10 @@ struct PinnedArea {
 };
 static PinnedArea g_req_area, g_res_area;
 
+// wall-clock breakdown of the last bfs_fri_commit / bfs_fri_query on this thread (ms): see bfs_fri_last_timing
+static thread_local double g_fri_timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 struct FriRound {
     const u64* cw = nullptr;  // limb-major codeword
     u64 stride = 0, length = 0;
@@ -96,8 +102,15 @@ struct FriSession {
     bool use_workspace = false;
     RootMailbox mailbox;
     u32 log_n = 0;
-    std::map<std::pair<u32, u64>, rp::Ref> elements;  // (round, index) -> the element object (identity!)
-    std::map<std::pair<u32, u64>, rp::Ref> nodes;     // (round, node index) -> bytes object
+    // (round, index) -> the element / tree-node object.  One object per key: the reference pushes the same Python object
+    // again when an index recurs, and pickle memoises by identity.
+    struct Key {
+        u64 v;
+        Key(u32 round, u64 index) : v(((u64)round << 48) | index) {}
+        bool operator==(const Key& o) const { return v == o.v; }
+    };
+    struct KeyHash { size_t operator()(const Key& k) const { return (size_t)(k.v * 0x9E3779B97F4A7C15ULL >> 16); } };
+    std::unordered_map<Key, rp::Ref, KeyHash> elements, nodes;
     std::vector<uint64_t> last_handles;
     ~FriSession() { if (block) (void)hipFree(block); }
 };
@@ -110,6 +123,7 @@ static u32 fri_num_rounds(u64 length, u32 expansion) {  // fri.py:54-60
 
 int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u32 log_n, u64 offset, u64 omega,
                u32 expansion, hipStream_t stream) {
+    const double t_begin = now_ms();
     const u64 N = 1ull << log_n;
     const u32 R = fri_num_rounds(N, expansion);
     if (R < 1) { set_error("cannot do FRI with less than one round"); return BFS_ERR_BAD_ARG; }
@@ -180,6 +194,7 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
         BFS_HIP(hipGetLastError());
         g = gl_sqr(g);  // fri.py:130-131 (omega is squared implicitly through round_shift)
     }
+    g_fri_timing[0] = now_ms() - t_begin;   // rounds: trees, roots, challenges, folds
     // fri.py:134: the last codeword goes into the transcript as a list of element objects
     FriRound& last = S.rounds[R - 1];
     std::vector<u64> host(3 * last.length);
@@ -193,11 +208,12 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
     std::vector<rp::Ref> items;
     for (u64 j = 0; j < last.length; ++j) {
         u64 l[3] = {host[j], host[last.length + j], host[2 * last.length + j]};
-        rp::Ref e = ps.world.xfe(l);
-        S.elements[{R - 1, j}] = e;
+        rp::Ref e = ps.world.xfe_compact(l);
+        S.elements[FriSession::Key(R - 1, j)] = e;
         items.push_back(e);
     }
     ps.objects.push_back(rp::mk_list(items));
+    g_fri_timing[1] = now_ms() - t_begin - g_fri_timing[0];   // last codeword to the host
     return BFS_OK;
 }
 
@@ -227,6 +243,7 @@ static int sample_indices(const unsigned char seed[32], u64 size, u64 reduced_si
 int fri_query(FriSession& S, rp::Transcript& ps, u32 t, u64* h_top, hipStream_t stream) {
     const u32 R = (u32)S.rounds.size();
     if (R < 2) { set_error("Fri.prove needs at least two rounds (fri.py:186 indexes codewords[1])"); return BFS_ERR_BAD_ARG; }
+    const double t_begin = now_ms();
     unsigned char seed[32];
     ps.fiat_shamir(ps.objects.size(), seed, 32);
     std::vector<u64> top;
@@ -243,13 +260,15 @@ int fri_query(FriSession& S, rp::Transcript& ps, u32 t, u64* h_top, hipStream_t 
     for (auto& x : idx) x %= S.rounds[R - 1].length;
     layer_idx.push_back(idx);  // query_last
 
-    typedef std::pair<u32, u64> Key;
+    g_fri_timing[2] = now_ms() - t_begin;   // Fiat-Shamir + index sampling
+    typedef FriSession::Key Key;
+    S.elements.reserve(1024); S.nodes.reserve(8192);
     std::vector<GatherReq> reqs;                 // what to fetch
     std::vector<std::pair<int, Key>> order;      // what the fetched words are: (0 = element | 1 = tree node, key)
     reqs.reserve(4096); order.reserve(4096);
     u64 nwords = 0;
     auto need_element = [&](u32 r, u64 j) {
-        Key key{r, j};
+        Key key(r, j);
         if (S.elements.count(key)) return;       // same Python object in the reference -> same node here
         S.elements[key] = rp::Ref();
         order.push_back({0, key});
@@ -260,7 +279,7 @@ int fri_query(FriSession& S, rp::Transcript& ps, u32 t, u64* h_top, hipStream_t 
     auto need_path = [&](u32 r, u64 leaf) {      // merkle.py:46-52
         const FriRound& fr = S.rounds[r];
         for (u64 k = fr.length | leaf; k > 1; k >>= 1) {
-            Key key{r, k ^ 1};
+            Key key(r, k ^ 1);
             if (S.nodes.count(key)) continue;
             S.nodes[key] = rp::Ref();
             order.push_back({1, key});
@@ -279,6 +298,8 @@ int fri_query(FriSession& S, rp::Transcript& ps, u32 t, u64* h_top, hipStream_t 
             if (!lastq) need_path(cur + 1, c);
         }
     }
+    g_fri_timing[3] = now_ms() - t_begin - g_fri_timing[2];   // planning the openings
+    const double t_gather = now_ms();
     const u64* words = nullptr;
     if (!reqs.empty()) {
         BFS_TRY(g_req_area.ensure(reqs.size() * sizeof(GatherReq)));
@@ -290,12 +311,14 @@ int fri_query(FriSession& S, rp::Transcript& ps, u32 t, u64* h_top, hipStream_t 
         BFS_HIP(hipStreamSynchronize(stream));
         words = (const u64*)g_res_area.host;
     }
+    g_fri_timing[4] = now_ms() - t_gather;   // gather kernel + synchronisation
+    const double t_build = now_ms();
     size_t pos = 0;
     for (auto& o : order) {
         if (o.first == 0) {
             u64 l[3] = {words[pos], words[pos + 1], words[pos + 2]};
             pos += 3;
-            S.elements[o.second] = ps.world.xfe(l);
+            S.elements[o.second] = ps.world.xfe_compact(l);
         } else {
             S.nodes[o.second] = rp::mk_bytes(words + pos, 64);
             pos += 8;
@@ -303,7 +326,7 @@ int fri_query(FriSession& S, rp::Transcript& ps, u32 t, u64* h_top, hipStream_t 
     }
     auto path_obj = [&](u32 r, u64 leaf) {
         std::vector<rp::Ref> items;
-        for (u64 k = S.rounds[r].length | leaf; k > 1; k >>= 1) items.push_back(S.nodes[{r, k ^ 1}]);
+        for (u64 k = S.rounds[r].length | leaf; k > 1; k >>= 1) items.push_back(S.nodes[Key(r, k ^ 1)]);
         return rp::mk_list(items);
     };
     // push in the reference's order: per layer, t leaf triples then the authentication paths (fri.py:147-156, 166-174)
@@ -313,7 +336,7 @@ int fri_query(FriSession& S, rp::Transcript& ps, u32 t, u64* h_top, hipStream_t 
         const u64 half = S.rounds[cur].length / 2;
         for (u32 s = 0; s < t; ++s) {
             u64 c = layer_idx[i][s];
-            ps.objects.push_back(rp::mk_tuple({S.elements[{cur, c}], S.elements[{cur, c + half}], S.elements[{cur + 1, c}]}));
+            ps.objects.push_back(rp::mk_tuple({S.elements[Key(cur, c)], S.elements[Key(cur, c + half)], S.elements[Key(cur + 1, c)]}));
         }
         for (u32 s = 0; s < t; ++s) {
             u64 c = layer_idx[i][s];
@@ -322,6 +345,7 @@ int fri_query(FriSession& S, rp::Transcript& ps, u32 t, u64* h_top, hipStream_t 
             if (!lastq) ps.objects.push_back(path_obj(cur + 1, c));
         }
     }
+    g_fri_timing[5] = now_ms() - t_build;   // building the transcript objects
     return BFS_OK;
 }
 
@@ -350,6 +374,8 @@ int bfs_fri_prove(void* ps, const uint64_t* d_codeword, uint64_t limb_stride, ui
     BFS_TRY(fri_commit(S, *(rp::Transcript*)ps, d_codeword, limb_stride, log_n, offset, omega, expansion_factor, (hipStream_t)stream));
     return fri_query(S, *(rp::Transcript*)ps, num_colinearity_tests, h_top_level_indices, (hipStream_t)stream);
 }
+
+void bfs_fri_last_timing(double out[6]) { for (int i = 0; i < 6; ++i) out[i] = g_fri_timing[i]; }
 
 uint32_t bfs_fri_session_rounds(void* session) { return (uint32_t)((FriSession*)session)->rounds.size(); }
 

@@ -25,7 +25,8 @@
 namespace bfs {
 namespace rp {
 
-enum Kind { K_BYTES = 0, K_INT = 1, K_STR = 2, K_LIST = 3, K_TUPLE = 4, K_DICT = 5, K_CLASS = 6, K_INSTANCE = 7 };
+enum Kind { K_BYTES = 0, K_INT = 1, K_STR = 2, K_LIST = 3, K_TUPLE = 4, K_DICT = 5, K_CLASS = 6, K_INSTANCE = 7,
+            K_XFE = 8 /* ExtensionFieldElement kept as three limbs; the pickler expands it (one allocation instead of ~12) */ };
 enum Role { R_NONE = 0, R_XFE = 1, R_BFE = 2 };  // what an INSTANCE node stands for (for reading values back)
 
 struct Node;
@@ -89,6 +90,14 @@ struct World {
         return n;
     }
 
+    // compact form of xfe(): same pickle bytes, built lazily by Pickler::save_xfe
+    Ref xfe_compact(const u64 limbs[3]) const {
+        Ref n = mk(K_XFE);
+        n->role = R_XFE;
+        for (int i = 0; i < 3; ++i) n->limbs[i] = limbs[i];
+        return n;
+    }
+
     // ExtensionFieldElement(Polynomial(coeffs trimmed of trailing zeros), xfield)  extension_field.py:5-9
     Ref xfe(const u64 limbs[3]) const {
         int k = limbs[2] ? 3 : (limbs[1] ? 2 : (limbs[0] ? 1 : 0));
@@ -104,6 +113,7 @@ struct World {
 
 class Pickler {
    public:
+    explicit Pickler(const World* world = nullptr) : world_(world) {}
     std::string dumps(const Ref& root) {
         out_.clear();
         memo_.clear();
@@ -120,6 +130,7 @@ class Pickler {
     }
 
    private:
+    const World* world_;
     static constexpr size_t NPOS = (size_t)-1;
     static constexpr size_t FRAME_HEADER = 9, FRAME_MIN = 4, FRAME_TARGET = 64 * 1024, BATCH = 1000;
     std::string out_;
@@ -156,6 +167,45 @@ class Pickler {
         memo_[n] = idx;
         op(0x94);  // MEMOIZE
     }
+    void memo_skip() {   // an inner object of a compact element: takes a memo slot, can never be referenced again
+        uint32_t idx = (uint32_t)memo_.size();
+        memo_[reinterpret_cast<const Node*>(&dummy_) + 1 + idx] = idx;
+        op(0x94);
+    }
+    char dummy_ = 0;
+
+    // byte-for-byte what save() emits for World::xfe(limbs): instance -> dict{polynomial: instance(dict{coefficients:
+    // [BaseFieldElement...]}), field: xfield}; inner objects only consume memo indices
+    void save_xfe(const Node* n) {
+        const World& w = *world_;
+        const int k = n->limbs[2] ? 3 : (n->limbs[1] ? 2 : (n->limbs[0] ? 1 : 0));
+        save(w.c_xfe.get()); op(0x29); op(0x81); memo_put(n);
+        opcode_boundary(); op(0x7d); memo_skip();                       // state dict of the element
+        op(0x28);
+        save(w.s_polynomial.get());
+        opcode_boundary(); save(w.c_poly.get()); op(0x29); op(0x81); memo_skip();   // Polynomial instance
+        opcode_boundary(); op(0x7d); memo_skip();                       // its dict (one item -> SETITEM)
+        save(w.s_coefficients.get());
+        opcode_boundary(); op(0x5d); memo_skip();                       // coefficient list
+        if (k > 1) op(0x28);
+        for (int i = 0; i < k; ++i) {
+            opcode_boundary(); save(w.c_bfe.get()); op(0x29); op(0x81); memo_skip();   // BaseFieldElement
+            opcode_boundary(); op(0x7d); memo_skip();
+            op(0x28);
+            save(w.s_value.get());
+            opcode_boundary(); save_long(n->limbs[i]);
+            save(w.s_field.get());
+            save(w.bf_internal.get());
+            op(0x75); op(0x62);                                         // SETITEMS, BUILD
+            if (k == 1) op(0x61);                                       // APPEND (single item)
+        }
+        if (k > 1) op(0x65);                                            // APPENDS
+        op(0x73); op(0x62);                                             // SETITEM (coefficients), BUILD (Polynomial)
+        save(w.s_field.get());
+        save(w.xfield.get());
+        op(0x75); op(0x62);                                             // SETITEMS, BUILD (element)
+    }
+
     void memo_get(uint32_t idx) {
         if (idx < 256) { unsigned char b[2] = {0x68, (unsigned char)idx}; write(b, 2); }
         else { unsigned char b[5] = {0x6a}; memcpy(b + 1, &idx, 4); write(b, 5); }
@@ -184,6 +234,7 @@ class Pickler {
         auto it = memo_.find(n);
         if (it != memo_.end()) { memo_get(it->second); return; }
         switch (n->kind) {
+            case K_XFE: save_xfe(n); break;
             case K_BYTES: {
                 size_t len = n->data.size();
                 if (len < 256) { unsigned char h[2] = {0x43, (unsigned char)len}; write(h, 2); }
@@ -288,7 +339,7 @@ struct Transcript {
     std::string serialize(size_t count) const {
         Ref lst = mk(K_LIST);
         lst->items.assign(objects.begin(), objects.begin() + (count < objects.size() ? count : objects.size()));
-        Pickler p;
+        Pickler p(&world);
         return p.dumps(lst);
     }
     void fiat_shamir(size_t count, unsigned char* out, size_t num_bytes) const {

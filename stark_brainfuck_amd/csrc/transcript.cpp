@@ -24,7 +24,7 @@ uint64_t bfs_ps_obj_bytes(void* ps, const uint8_t* data, size_t len) { return T(
 uint64_t bfs_ps_obj_int(void* ps, uint64_t value) { return T(ps)->add(rp::mk_int(value)); }
 uint64_t bfs_ps_obj_xfe(void* ps, const uint64_t limbs[3]) {
     uint64_t l[3] = {limbs[0] % GL_P, limbs[1] % GL_P, limbs[2] % GL_P};
-    return T(ps)->add(T(ps)->world.xfe(l));
+    return T(ps)->add(T(ps)->world.xfe_compact(l));
 }
 uint64_t bfs_ps_obj_bfe(void* ps, uint64_t value, int internal_field) { return T(ps)->add(T(ps)->world.bfe(value % GL_P, internal_field != 0)); }
 
@@ -71,7 +71,7 @@ int bfs_ps_serialize(void* ps, size_t count, uint8_t* out, size_t capacity, size
 int bfs_ps_obj_dumps(void* ps, uint64_t handle, uint8_t* out, size_t capacity, size_t* length) {
     Ref r = T(ps)->get(handle);
     if (!r) return bad_handle(handle);
-    rp::Pickler p;
+    rp::Pickler p(&T(ps)->world);
     std::string s = p.dumps(r);
     *length = s.size();
     if (out && capacity >= s.size()) memcpy(out, s.data(), s.size());
@@ -86,6 +86,7 @@ int bfs_ps_fiat_shamir(void* ps, size_t count, uint8_t* out, size_t num_bytes) {
 int bfs_ps_obj_kind(void* ps, uint64_t handle) {
     Ref r = T(ps)->get(handle);
     if (!r) return -1;
+    if (r->kind == rp::K_XFE) return 100;
     if (r->kind == rp::K_INSTANCE) return r->role == rp::R_XFE ? 100 : (r->role == rp::R_BFE ? 101 : 102);
     return (int)r->kind;
 }
