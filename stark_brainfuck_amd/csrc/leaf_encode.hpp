@@ -119,6 +119,44 @@ BFS_HD u32 encode_xfe_leaf(LeafWriter& w, u64 c0, u64 c1, u64 c2) {
     return w.finish();
 }
 
+// ---- midstate form ---------------------------------------------------------------------------------------------
+// The first 128 bytes of a non-zero leaf are constant except for the length field, so BLAKE2b's state after the first
+// block is tabulated per (class, body length) on the host (merkle_core.hpp: leaf_midstates).  The kernels then only
+// assemble and hash the bytes from offset 128 on: 3 compressions instead of 4, 36 staging words instead of 52.
+constexpr int XFE_TAIL_MAX_WORDS = (XFE_LEAF_MAX_BYTES - 128 + 7) / 8;   // 36
+
+BFS_HD u32 xfe_leaf_k(u64 c0, u64 c1, u64 c2) { return c2 ? 3u : (c1 ? 2u : (c0 ? 1u : 0u)); }
+
+// body length (total - 11) of the pickle of a non-zero element
+BFS_HD u32 xfe_leaf_body_len(u32 k, u64 c0, u64 c1, u64 c2) {
+    u32 body = tpl::XFE_PRE_A_LEN + tpl::XFE_PRE_B_LEN + pickle_int_len(c0);
+    if (k == 1) return body + tpl::XFE_POST1_LEN;
+    body += 1 + tpl::XFE_MID_A_LEN + pickle_int_len(c1);
+    return body + ((k == 2) ? tpl::XFE_POST2_LEN : tpl::XFE_MID_B_LEN + pickle_int_len(c2) + tpl::XFE_POST3_LEN);
+}
+
+// bytes [128, total) of the leaf pickle for k >= 1; returns how many were written
+BFS_HD u32 encode_xfe_leaf_tail(LeafWriter& w, u32 k, u64 c0, u64 c1, u64 c2) {
+    if (k == 1) {
+        w.put_const<tpl::XFE_PRE_B4_LEN>(tpl::XFE_PRE_B4);
+        w.put_int(c0);
+        w.put_const<tpl::XFE_POST1_LEN>(tpl::XFE_POST1);
+    } else {
+        w.put_const<tpl::XFE_PRE_B3_LEN>(tpl::XFE_PRE_B3);
+        w.put_int(c0);
+        w.put_const<tpl::XFE_MID_A_LEN>(tpl::XFE_MID_A);
+        w.put_int(c1);
+        if (k == 2) {
+            w.put_const<tpl::XFE_POST2_LEN>(tpl::XFE_POST2);
+        } else {
+            w.put_const<tpl::XFE_MID_B_LEN>(tpl::XFE_MID_B);
+            w.put_int(c2);
+            w.put_const<tpl::XFE_POST3_LEN>(tpl::XFE_POST3);
+        }
+    }
+    return w.finish();
+}
+
 // pickle.dumps(BaseFieldElement) with a stand-alone BaseField instance (algebra.py:110-115)
 BFS_HD u32 encode_bfe_leaf(LeafWriter& w, u64 v) {
     put_frame_header(w, tpl::BFE_PRE_LEN + pickle_int_len(v) + tpl::BFE_POST_LEN);

@@ -4,18 +4,20 @@
 // parent (one compression); the top 9 levels run in a single workgroup.
 #include "blake2b_quad.hpp"
 #include "merkle_core.hpp"
+#include <vector>
+
 #include "runtime.hpp"
 
 namespace bfs {
 
 constexpr int LEAF_THREADS = 64;  // one wavefront per workgroup: the staging area is 52 words x 64 lanes = 26 KiB
 
-__global__ void __launch_bounds__(LEAF_THREADS) merkle_leaves_xfe_kernel(const u64* limbs, u64 limb_stride, u64 n, u64* leaf_digests) {
-    __shared__ u64 stage[XFE_LEAF_MAX_WORDS * LEAF_THREADS];
+__global__ void __launch_bounds__(LEAF_THREADS) merkle_leaves_xfe_kernel(const u64* limbs, u64 limb_stride, u64 n, u64* leaf_digests, const u64* midstates) {
+    __shared__ u64 stage[XFE_TAIL_MAX_WORDS * LEAF_THREADS];
     const u64 i = (u64)blockIdx.x * LEAF_THREADS + threadIdx.x;
     if (i >= n) return;
     u64 d[8];
-    merkle_leaf_xfe_body(limbs, limb_stride, i, stage + threadIdx.x, LEAF_THREADS, d);
+    merkle_leaf_xfe_body(limbs, limb_stride, i, stage + threadIdx.x, LEAF_THREADS, d, midstates);
     u64* out = leaf_digests + i * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) out[j] = d[j];
@@ -165,30 +167,37 @@ __global__ void __launch_bounds__(1024) merkle_top_quad_kernel(u64* nodes, u32 w
 
 // leaves with one quad per leaf (small codewords: late FRI rounds): lane 0 of the quad assembles the preimage in LDS,
 // the four lanes hash it
-__global__ void __launch_bounds__(256) merkle_leaves_xfe_quad_kernel(const u64* limbs, u64 limb_stride, u64 n, u64* leaf_digests) {
+__global__ void __launch_bounds__(256) merkle_leaves_xfe_quad_kernel(const u64* limbs, u64 limb_stride, u64 n, u64* leaf_digests, const u64* midstates) {
 #if defined(__HIP_DEVICE_COMPILE__)   // DPP builtins exist only in the device pass
-    constexpr int WORDS = 64;                        // 4 blocks of 16 words per leaf (409 bytes max)
+    constexpr int WORDS = 48;                        // 3 blocks of 16 words per leaf (bytes 128..409)
     __shared__ u64 stage[64 * WORDS];
     const u32 q = threadIdx.x >> 2, j = threadIdx.x & 3;
     const u64 i = (u64)blockIdx.x * 64 + q;
     const QuadLane ql = quad_lane(threadIdx.x);
     if (i >= n) return;
     u64* m = stage + q * WORDS;
-    u32 total = 0;
-    if (j == 0) {
-        LeafWriter w;
-        w.init(m, 1);
-        total = encode_xfe_leaf(w, limbs[i], limbs[limb_stride + i], limbs[2 * limb_stride + i]);
-        const u32 nblk = (total + 127) / 128;
-        for (u32 k = w.wpos; k < nblk * 16; ++k) m[k] = 0;   // zero padding of the final block
-    }
-    total = __shfl(total, (threadIdx.x & 63) & ~3u);
-    const u32 nblk = (total + 127) / 128;
+    const u64 c0 = limbs[i], c1 = limbs[limb_stride + i], c2 = limbs[2 * limb_stride + i];
+    const u32 k = xfe_leaf_k(c0, c1, c2);
     u64 hl, hh;
-    blake2b_init_quad(ql, hl, hh);
-    for (u32 b = 0; b < nblk; ++b) {
-        const bool last = b + 1 == nblk;
-        blake2b_compress_quad(ql, hl, hh, m + 16 * b, last ? (u64)total : (u64)(b + 1) * 128, last);
+    if (k == 0) {
+        hl = midstates[(size_t)2 * LEAF_MS_LEN * 8 + j];
+        hh = midstates[(size_t)2 * LEAF_MS_LEN * 8 + 4 + j];
+    } else {
+        const u32 body = xfe_leaf_body_len(k, c0, c1, c2), total = body + 11;
+        const u32 nblk = (total + 127) / 128;
+        const u64* ms = midstates + ((size_t)(k == 1 ? 0 : 1) * LEAF_MS_LEN + body) * 8;
+        hl = ms[j];
+        hh = ms[4 + j];
+        if (j == 0) {
+            LeafWriter w;
+            w.init(m, 1);
+            encode_xfe_leaf_tail(w, k, c0, c1, c2);
+            for (u32 x = w.wpos; x < (nblk - 1) * 16; ++x) m[x] = 0;   // zero padding of the final block
+        }
+        for (u32 b = 1; b < nblk; ++b) {
+            const bool last = b + 1 == nblk;
+            blake2b_compress_quad(ql, hl, hh, m + 16 * (b - 1), last ? (u64)total : (u64)(b + 1) * 128, last);
+        }
     }
     leaf_digests[i * 8 + j] = hl;
     leaf_digests[i * 8 + 4 + j] = hh;
@@ -219,16 +228,25 @@ int merkle_inner_launch(u64* d_nodes, u32 depth, u64 n_leaves, hipStream_t strea
     return BFS_OK;
 }
 
+static int get_leaf_midstates(const u64** d_table) {
+    if (cached_table_lookup(0x6D696473ULL, 1, 0, d_table)) return BFS_OK;
+    std::vector<u64> host(LEAF_MS_WORDS);
+    leaf_midstates(host.data());
+    return cached_table(0x6D696473ULL, 1, 0, host.data(), host.size(), d_table);
+}
+
 int merkle_build_xfe_launch(const u64* d_limbs, u64 limb_stride, u64 n, u64* d_nodes, hipStream_t stream, u64* root_out, u64 seq) {
     if (n == 0) return BFS_OK;
+    const u64* d_ms = nullptr;
+    BFS_TRY(get_leaf_midstates(&d_ms));
     u32 depth = 0;
     while ((1ull << depth) < n) ++depth;
     const u64 npo2 = 1ull << depth;
     if (n <= QUAD_LEAVES_MAX)
-        hipLaunchKernelGGL(merkle_leaves_xfe_quad_kernel, dim3((u32)((n + 63) / 64)), dim3(256), 0, stream, d_limbs, limb_stride, n, d_nodes + npo2 * 8);
+        hipLaunchKernelGGL(merkle_leaves_xfe_quad_kernel, dim3((u32)((n + 63) / 64)), dim3(256), 0, stream, d_limbs, limb_stride, n, d_nodes + npo2 * 8, d_ms);
     else
         hipLaunchKernelGGL(merkle_leaves_xfe_kernel, dim3((u32)((n + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0, stream,
-                           d_limbs, limb_stride, n, d_nodes + npo2 * 8);
+                           d_limbs, limb_stride, n, d_nodes + npo2 * 8, d_ms);
     BFS_HIP(hipGetLastError());
     return merkle_inner_launch(d_nodes, depth, n, stream, root_out, seq);
 }

@@ -24,13 +24,66 @@ BFS_HD void blake2b_staged(const u64* base, u32 stride, u32 total, u64 h[8]) {
     }
 }
 
+// ---- leaf midstates: BLAKE2b state after the constant first block, per (class, body length) ----
+// layout: [0, 512*8): class k = 1 indexed by body length; [512*8, 1024*8): class k >= 2; [1024*8, 1025*8): digest of the zero element
+constexpr int LEAF_MS_LEN = 512;
+constexpr int LEAF_MS_WORDS = (2 * LEAF_MS_LEN + 1) * 8;
+
+inline void leaf_midstates(u64* table /* LEAF_MS_WORDS */) {
+    for (int cls = 0; cls < 2; ++cls)
+        for (int body = 0; body < LEAF_MS_LEN; ++body) {
+            unsigned char block[128];
+            const u64 hdr = 0x80ull | (0x04ull << 8) | (0x95ull << 16) | ((u64)body << 24);
+            memcpy(block, &hdr, 8);
+            memset(block + 8, 0, 3);
+            memcpy(block + 11, tpl::XFE_PRE_A, tpl::XFE_PRE_A_LEN);
+            if (cls == 0) memcpy(block + 124, tpl::XFE_PRE_B, 4);                        // k = 1: no MARK
+            else { block[124] = 0x28; memcpy(block + 125, tpl::XFE_PRE_B, 3); }           // k >= 2
+            u64 m[16], h[8];
+            memcpy(m, block, 128);
+            blake2b_init(h);
+            blake2b_compress(h, m, 128, false);
+            memcpy(table + ((size_t)cls * LEAF_MS_LEN + body) * 8, h, 64);
+        }
+    unsigned char d[64];
+    blake2b_host(tpl::XFE_K0, tpl::XFE_K0_LEN, d);
+    memcpy(table + (size_t)2 * LEAF_MS_LEN * 8, d, 64);
+}
+
+// BLAKE2b of a message whose first 128 bytes are already absorbed into h; tail words at base[w*stride], `total` = full length
+BFS_HD void blake2b_staged_tail(const u64* base, u32 stride, u32 total, u64 h[8]) {
+    const u32 nwords = (total - 128 + 7) / 8;
+    const u32 nblk = (total + 127) / 128;          // >= 2 for every non-zero leaf
+    for (u32 b = 1; b < nblk; ++b) {
+        u64 m[16];
+        BFS_UNROLL
+        for (int j = 0; j < 16; ++j) {
+            u32 w = (b - 1) * 16 + (u32)j;
+            m[j] = w < nwords ? base[(size_t)w * stride] : 0;
+        }
+        const bool last = (b + 1 == nblk);
+        blake2b_compress(h, m, last ? (u64)total : (u64)(b + 1) * 128, last);
+    }
+}
+
 // leaf i of an extension-field codeword stored limb-major; digest -> nodes[(npo2 + i)]
-BFS_HD void merkle_leaf_xfe_body(const u64* limbs, u64 limb_stride, u64 i, u64* stage, u32 stride, u64* digest_out) {
-    LeafWriter w;
-    w.init(stage, stride);
-    u32 total = encode_xfe_leaf(w, limbs[i], limbs[limb_stride + i], limbs[2 * limb_stride + i]);
+BFS_HD void merkle_leaf_xfe_body(const u64* limbs, u64 limb_stride, u64 i, u64* stage, u32 stride, u64* digest_out, const u64* midstates) {
+    const u64 c0 = limbs[i], c1 = limbs[limb_stride + i], c2 = limbs[2 * limb_stride + i];
+    const u32 k = xfe_leaf_k(c0, c1, c2);
     u64 h[8];
-    blake2b_staged(stage, stride, total, h);
+    if (k == 0) {
+        BFS_UNROLL
+        for (int j = 0; j < 8; ++j) h[j] = midstates[(size_t)2 * LEAF_MS_LEN * 8 + j];
+    } else {
+        const u32 body = xfe_leaf_body_len(k, c0, c1, c2);
+        const u64* ms = midstates + ((size_t)(k == 1 ? 0 : 1) * LEAF_MS_LEN + body) * 8;
+        BFS_UNROLL
+        for (int j = 0; j < 8; ++j) h[j] = ms[j];
+        LeafWriter w;
+        w.init(stage, stride);
+        encode_xfe_leaf_tail(w, k, c0, c1, c2);
+        blake2b_staged_tail(stage, stride, body + 11, h);
+    }
     BFS_UNROLL
     for (int j = 0; j < 8; ++j) digest_out[j] = h[j];
 }

@@ -34,8 +34,9 @@ extern "C" void emu_merkle_xfe(const u64* limbs, u64 stride, u64 n, u64* nodes /
     u32 depth = 0;
     while ((1ull << depth) < n) ++depth;
     const u64 npo2 = 1ull << depth;
-    std::vector<u64> stage(XFE_LEAF_MAX_WORDS * 64);
-    for (u64 i = 0; i < n; ++i) merkle_leaf_xfe_body(limbs, stride, i, stage.data() + (i % 64), 64, nodes + (npo2 + i) * 8);
+    std::vector<u64> stage(XFE_TAIL_MAX_WORDS * 64), ms(LEAF_MS_WORDS);
+    leaf_midstates(ms.data());
+    for (u64 i = 0; i < n; ++i) merkle_leaf_xfe_body(limbs, stride, i, stage.data() + (i % 64), 64, nodes + (npo2 + i) * 8, ms.data());
     u64 present = n;
     for (u32 lvl = depth; lvl-- > 0;) {
         const u64 count = 1ull << lvl;

@@ -171,7 +171,10 @@ with open(OUT, "w") as f:
             "// (see SURVEY.md Appendix A; replaces pickle.dumps at /root/reference/code/merkle.py:30)\n"
             "#pragma once\n#include \"gl.hpp\"\n\nnamespace bfs {\nnamespace tpl {\n\n"
             "#if defined(__HIP_DEVICE_COMPILE__)\n#define BFS_TPL_CONST __constant__ const\n#else\n#define BFS_TPL_CONST static const\n#endif\n\n")
-    for name, bs in (("XFE_K0", k0), ("XFE_PRE_A", pre_a), ("XFE_PRE_B", pre_b), ("XFE_POST1", post1), ("XFE_MID_A", mid_a),
+    # first BLAKE2b block of a leaf = 11-byte header + PRE_A (113) + [MARK] + the first 3 (k >= 2) or 4 (k = 1) bytes of PRE_B:
+    # constant up to the length field, so its compression is tabulated per length (merkle_core.hpp leaf_midstates)
+    assert 11 + len(pre_a) + 1 + 3 == 128 and 11 + len(pre_a) + 4 == 128
+    for name, bs in (("XFE_K0", k0), ("XFE_PRE_A", pre_a), ("XFE_PRE_B", pre_b), ("XFE_PRE_B3", pre_b[3:]), ("XFE_PRE_B4", pre_b[4:]), ("XFE_POST1", post1), ("XFE_MID_A", mid_a),
                      ("XFE_POST2", post2), ("XFE_MID_B", mid_b), ("XFE_POST3", post3), ("BFE_PRE", bfe_pre), ("BFE_POST", bfe_post)):
         f.write(emit(name, bs))
     f.write("\n}  // namespace tpl\n}  // namespace bfs\n")
