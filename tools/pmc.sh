@@ -10,7 +10,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_
            "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM" \
            "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_SCA SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/raw$i" -o p -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --no-cpu --no-fri "$@" > "$OUT/log$i.txt" 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$OUT/raw$i" -o p -- python "$GRAFT_REPO_ROOT/bench.py" --steps 3 --warmup 1 --no-cpu --no-fri --no-check "$@" > "$OUT/log$i.txt" 2>&1
   f=$(find "$OUT/raw$i" -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then python3 - "$f" <<'PY'
 import csv, sys, collections
