@@ -14,7 +14,7 @@ from .univariate import Polynomial, colinear, test_colinearity
 from .extension_field import ExtensionField, ExtensionFieldElement
 from .arrays import BaseArray, XArray
 from .ntt import (ntt, intt, fast_multiply, fast_coset_evaluate, fast_coset_interpolate, batch_inverse,
-                  fast_coset_divide)
+                  fast_coset_divide, fast_zerofier, fast_evaluate, fast_interpolate)
 from .merkle import Merkle
 from .salted_merkle import SaltedMerkle
 from .ip import ProofStream, reference_pickle

@@ -197,3 +197,48 @@ def fast_coset_divide(lhs, rhs, offset, primitive_root, root_order):
     quo = _transform(lc, order, order, lib.bfs_gl_inv(w), 1, lib.bfs_gl_inv(order))
     _lib.check(lib.bfs_gl_scale(quo.ptr, quo.ptr, order, order, 1, lib.bfs_gl_inv(off), current_stream()))
     return Polynomial(quo.to_elements()[:lhs.degree() - rhs.degree() + 1])
+
+
+# ---- subproduct-tree routines (ntt.py:82-161): zerofier, multi-point evaluation, interpolation over an arbitrary domain.
+# Same divide-and-conquer as the reference; every product of degree >= 8 goes through fast_multiply (GPU transforms).
+def fast_zerofier(domain, primitive_root, root_order):
+    _check_root(primitive_root, root_order)
+    if len(domain) == 0:
+        return Polynomial([])
+    if len(domain) == 1:
+        return Polynomial([-domain[0], primitive_root.field.one()])
+    half = len(domain) // 2
+    return fast_multiply(fast_zerofier(domain[:half], primitive_root, root_order),
+                         fast_zerofier(domain[half:], primitive_root, root_order), primitive_root, root_order)
+
+
+def fast_evaluate(polynomial, domain, primitive_root, root_order):
+    _check_root(primitive_root, root_order)
+    if len(domain) == 0:
+        return []
+    if len(domain) == 1:
+        return [polynomial.evaluate(domain[0])]
+    half = len(domain) // 2
+    lz = fast_zerofier(domain[:half], primitive_root, root_order)
+    rz = fast_zerofier(domain[half:], primitive_root, root_order)
+    return (fast_evaluate(polynomial % lz, domain[:half], primitive_root, root_order) +
+            fast_evaluate(polynomial % rz, domain[half:], primitive_root, root_order))
+
+
+def fast_interpolate(domain, values, primitive_root, root_order):
+    _check_root(primitive_root, root_order)
+    assert len(domain) == len(values), "cannot interpolate over domain of different length than values list"
+    if len(domain) == 0:
+        return Polynomial([])
+    if len(domain) == 1:
+        return Polynomial([values[0]])
+    half = len(domain) // 2
+    lz = fast_zerofier(domain[:half], primitive_root, root_order)
+    rz = fast_zerofier(domain[half:], primitive_root, root_order)
+    left_offset = fast_evaluate(rz, domain[:half], primitive_root, root_order)
+    right_offset = fast_evaluate(lz, domain[half:], primitive_root, root_order)
+    left_targets = [v / d for v, d in zip(values[:half], left_offset)]
+    right_targets = [v / d for v, d in zip(values[half:], right_offset)]
+    li = fast_interpolate(domain[:half], left_targets, primitive_root, root_order)
+    ri = fast_interpolate(domain[half:], right_targets, primitive_root, root_order)
+    return li * rz + ri * lz

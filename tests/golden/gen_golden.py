@@ -253,6 +253,26 @@ def gen_poly():
     dump("poly.json", out)
 
 
+def gen_poly2():
+    """fast_zerofier / fast_evaluate / fast_interpolate (ntt.py:82-161), the rows SURVEY 8f-3 lists as next."""
+    out = {"cases": []}
+    n = 64
+    w = BF2.primitive_nth_root(n)
+    for N in (1, 2, 5, 13, 24, 31):
+        dom = [felt(SEED + 700 + N, i) for i in range(N)]
+        vals = [felt(SEED + 800 + N, i) for i in range(N)]
+        D, V = [B(v) for v in dom], [B(v) for v in vals]
+        z = refntt.fast_zerofier(D, w, n)
+        poly = refntt.fast_interpolate(D, V, w, n)
+        ev = refntt.fast_evaluate(poly, D, w, n)
+        pc = [felt(SEED + 900 + N, i) for i in range(N + 3)]
+        ev2 = refntt.fast_evaluate(Polynomial([B(v) for v in pc]), D, w, n)
+        out["cases"].append({"N": N, "root_order": n, "domain": dom, "values": vals, "zerofier": [c.value for c in z.coefficients],
+                             "interpolant": [c.value for c in poly.coefficients], "interpolant_degree": poly.degree(),
+                             "evaluated_back": [e.value for e in ev], "poly": pc, "poly_evaluated": [e.value for e in ev2]})
+    dump("poly2.json", out)
+
+
 def leaf_record(obj, limbs):
     bs = pickle.dumps(obj)
     return {"limbs": limbs, "pickle": bs.hex(), "blake2b": hashlib.blake2b(bs).hexdigest()}
@@ -477,7 +497,7 @@ def gen_fri20():
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "small"
     if what == "small":
-        gen_field(); gen_ntt(); gen_poly(); gen_pickle(); gen_merkle(); gen_fri()
+        gen_field(); gen_ntt(); gen_poly(); gen_poly2(); gen_pickle(); gen_merkle(); gen_fri()
     else:
         {"field": gen_field, "ntt": gen_ntt, "poly": gen_poly, "pickle": gen_pickle, "merkle": gen_merkle,
-         "fri": gen_fri, "ntt20": gen_ntt20, "fri20": gen_fri20}[what]()
+         "fri": gen_fri, "ntt20": gen_ntt20, "fri20": gen_fri20, "poly2": gen_poly2}[what]()

@@ -194,6 +194,28 @@ def test_fast_multiply_and_coset_goldens(sb):
     assert str(e.value) == b["zero_message"]
 
 
+def test_subproduct_tree_goldens_and_reference_test_interpolate(sb):
+    """fast_zerofier / fast_evaluate / fast_interpolate (ntt.py:82-161) against the reference's outputs, then
+    test_ntt.py:90-114 restated (smaller n)."""
+    F = sb.BaseField.main()
+    for c in load_golden("poly2.json")["cases"]:
+        w = F.primitive_nth_root(c["root_order"])
+        D, V = [F(v) for v in c["domain"]], [F(v) for v in c["values"]]
+        assert [x.value for x in sb.fast_zerofier(D, w, c["root_order"]).coefficients] == c["zerofier"]
+        poly = sb.fast_interpolate(D, V, w, c["root_order"])
+        assert poly.degree() == c["interpolant_degree"]
+        assert sb.Polynomial([F(x) for x in c["interpolant"]]) == poly
+        assert [x.value for x in sb.fast_evaluate(poly, D, w, c["root_order"])] == c["evaluated_back"] == c["values"]
+        assert [x.value for x in sb.fast_evaluate(sb.Polynomial([F(x) for x in c["poly"]]), D, w, c["root_order"])] == c["poly_evaluated"]
+    n = 128
+    w = F.primitive_nth_root(n)
+    for N in (37, 64, 100):
+        values = [F.sample(os.urandom(17)) for _ in range(N)]
+        domain = [F.sample(os.urandom(17)) for _ in range(N)]
+        poly = sb.fast_interpolate(domain, values, w, n)
+        assert sb.fast_evaluate(poly, domain, w, n)[:N] == values
+
+
 def test_reference_test_coset_evaluate_and_batch_inverse(sb):
     F = sb.BaseField.main()
     n = 512
