@@ -3,9 +3,16 @@
 
 namespace bfs {
 
+#ifndef NTT_PREFETCH
+#define NTT_PREFETCH 0
+#endif
+#ifndef NTT_PERSISTENT_GRID
+#define NTT_PERSISTENT_GRID 1024u
+#endif
+
 // Persistent tile kernel: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and issues the (16-byte,
 // paired-lane) global loads of the next tile before computing on the current one.  LDS = tile + inner twiddle table.
-template <int B1, int B2, int B3, bool WIDE>
+template <int B1, int B2, int B3, int PRE /* 0 one tile per workgroup | 1 persistent + 16-byte prefetch | 2 persistent + 8-byte prefetch */>
 __global__ void __launch_bounds__(256, 4) ntt_tile_kernel(const PassArgs a, u32 grid_x, u32 total_tiles, u32 tw_offset) {
     extern __shared__ __attribute__((aligned(16))) u64 smem[];
     typedef TileCfg<B1, B2, B3> Cfg;
@@ -16,19 +23,25 @@ __global__ void __launch_bounds__(256, 4) ntt_tile_kernel(const PassArgs a, u32 
         for (u32 i = threadIdx.x; i < (1u << (B1 + B2)); i += blockDim.x) tw[i] = tab[(u64)i << (a.tb.t_in_log - (B1 + B2))];
         __syncthreads();
     }
-    constexpr bool wide = WIDE;
+    constexpr bool wide = PRE != 0;
     RawTile cur, nxt;
     u32 t = blockIdx.x;
-    if (wide && t < total_tiles) ntt_prefetch<B1, B2, B3>(a, threadIdx.x, t % grid_x, t / grid_x, cur);
+    if (wide && t < total_tiles) {
+        if constexpr (PRE == 1) ntt_prefetch<B1, B2, B3>(a, threadIdx.x, t % grid_x, t / grid_x, cur);
+        else ntt_prefetch_narrow<B1, B2, B3>(a, threadIdx.x, t % grid_x, t / grid_x, cur);
+    }
     for (; t < total_tiles; t += gridDim.x) {
         const u32 tn = t + gridDim.x;
-        if (wide && tn < total_tiles) ntt_prefetch<B1, B2, B3>(a, threadIdx.x, tn % grid_x, tn / grid_x, nxt);
+        if (wide && tn < total_tiles) {
+            if constexpr (PRE == 1) ntt_prefetch<B1, B2, B3>(a, threadIdx.x, tn % grid_x, tn / grid_x, nxt);
+            else ntt_prefetch_narrow<B1, B2, B3>(a, threadIdx.x, tn % grid_x, tn / grid_x, nxt);
+        }
         const u32 bx = t % grid_x, by = t / grid_x;
         // opaque copy of the thread id: keeps the compiler from hoisting every tid-derived address, digit and twiddle
         // out of the tile loop (that costs > 200 VGPRs and spills; recomputing them per tile is a few dozen SALU/VALU ops)
         u32 tid = threadIdx.x;
         asm volatile("" : "+v"(tid));
-        ntt_stage1<B1, B2, B3, WIDE>(a, smem, tw, tid, bx, by, cur);
+        ntt_stage1<B1, B2, B3, PRE>(a, smem, tw, tid, bx, by, cur);
         if constexpr (B2 > 0) {
             __syncthreads();
             ntt_stage2<B1, B2, B3>(a, smem, tid, bx, by);
@@ -38,7 +51,7 @@ __global__ void __launch_bounds__(256, 4) ntt_tile_kernel(const PassArgs a, u32 
             ntt_stage3<B1, B2, B3>(a, smem, tid, bx, by);
         }
         if constexpr (B2 > 0) __syncthreads();   // the next tile's stage 1 overwrites the LDS tile
-        if constexpr (WIDE) cur = nxt;
+        if constexpr (PRE != 0) cur = nxt;
     }
 }
 
@@ -54,11 +67,13 @@ static int launch_tile(const PassArgs& a, u32 grid_x, u32 batch, hipStream_t str
     const u64 total = (u64)grid_x * batch;
     if (total > 0xFFFFFFFFull) { set_error("too many tiles"); return BFS_ERR_BAD_ARG; }
     // persistent grid: enough workgroups to fill the 256 CUs at the residency the 34 KiB LDS tile allows (4 per CU)
-    u32 grid = total < 1024 ? (u32)total : 1024;
-    if (!(B1 == 4 && a.wide_load)) grid = (u32)total;   // without prefetch there is nothing to gain from persistence
     const bool wide = B1 == 4 && a.wide_load && (a.mode == PASS_COLUMN ? a.logC >= 1 : (B2 + B3) >= 1);
-    if (wide) hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, true>), dim3(grid), dim3(threads), lds, stream, a, grid_x, (u32)total, tw_offset);
-    else hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, false>), dim3(grid), dim3(threads), lds, stream, a, grid_x, (u32)total, tw_offset);
+    const int mode = wide ? 1 : ((B1 == 4 && NTT_PREFETCH && total >= 4096) ? 2 : 0);
+    u32 grid = (u32)total;
+    if (mode != 0) grid = total < NTT_PERSISTENT_GRID ? (u32)total : NTT_PERSISTENT_GRID;
+    if (mode == 1) hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, 1>), dim3(grid), dim3(threads), lds, stream, a, grid_x, (u32)total, tw_offset);
+    else if (mode == 2) hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, 2>), dim3(grid), dim3(threads), lds, stream, a, grid_x, (u32)total, tw_offset);
+    else hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, 0>), dim3(grid), dim3(threads), lds, stream, a, grid_x, (u32)total, tw_offset);
     BFS_HIP(hipGetLastError());
     return BFS_OK;
 }

@@ -104,6 +104,7 @@ struct PassArgs {
     u64 post_scale;      // multiplied in at the final store when the final pass has a single stage
     u32 pad_shift;       // LDS padding: phys = lin + (lin >> pad_shift) * pad_amount
     u32 pad_amount;
+    u32 lds_cmajor;      // LDS tile layout: 0 = [row][column], 1 = [column][row] (final pass of a multi-pass plan)
     u32 wide_load;       // 16-byte paired-lane loads allowed (pointer / stride alignment checked on the host)
     u32 wide_store;
     NttTables tb;
@@ -134,6 +135,12 @@ struct alignas(16) U64x2 {
 };
 
 BFS_HD u32 lds_phys(const PassArgs& a, u32 lin) { return lin + (lin >> a.pad_shift) * a.pad_amount; }
+
+// physical LDS word of tile element (row r, column c); S = log2(rows)
+template <int S>
+BFS_HD u32 lds_addr(const PassArgs& a, u32 r, u32 c) {
+    return lds_phys(a, a.lds_cmajor ? ((c << S) + r) : ((r << a.logC) + c));
+}
 
 BFS_HD u32 perm_digit(u32 m, int bits, u32 uinv) { return (bitrev(m, bits) * uinv) & ((1u << bits) - 1); }
 
@@ -298,9 +305,27 @@ BFS_HD void ntt_prefetch(const PassArgs& a, u32 tid, u32 bid_x, u32 bid_y, RawTi
     }
 }
 
+// same for plain 8-byte loads (one element per lane and load): raw.pr[d/2].{x,y} = element d of this thread
+template <int B1, int B2, int B3>
+BFS_HD void ntt_prefetch_narrow(const PassArgs& a, u32 tid, u32 bid_x, u32 bid_y, RawTile& raw) {
+    typedef TileCfg<B1, B2, B3> Cfg;
+    const TileGeom g = tile_geom<Cfg::S>(a, bid_x, bid_y);
+    const u64* in = a.in + g.in_base;
+    const u32 G = tid;
+    u32 o, c;
+    if (a.mode == PASS_COLUMN) { c = G & ((1u << a.logC) - 1); o = G >> a.logC; }
+    else { o = G & ((1u << Cfg::SH1) - 1); c = G >> Cfg::SH1; }
+    BFS_UNROLL
+    for (int d = 0; d < 16; ++d) {
+        u64 idx = in_index<Cfg::S>(a, g, ((u32)d << Cfg::SH1) | o, c);
+        u64 v = (a.pass_index > 0 || idx < a.n_in) ? in[idx] : 0;
+        if (d & 1) raw.pr[d / 2].y = v; else raw.pr[d / 2].x = v;
+    }
+}
+
 // ---- stage 1: global load (+ coset / inter-pass twiddle), first radix, inner twiddle, LDS write (or final store)
 // tw: dense inner-twiddle table for the stage 1 -> 2 exchange (2^(B1+B2) entries, in LDS on the GPU)
-template <int B1, int B2, int B3, bool PRE>
+template <int B1, int B2, int B3, int PRE /* 0 load here, 1 wide prefetched, 2 narrow prefetched */>
 BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, const u64* tw, u32 tid, u32 bid_x, u32 bid_y, const RawTile& pre) {
     typedef TileCfg<B1, B2, B3> Cfg;
     constexpr int Q = 1 << B1, SG = 16 / Q;
@@ -316,7 +341,10 @@ BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, const u64* tw, u32 tid, u32
         u32 o, c;
         if (a.mode == PASS_COLUMN) { c = G & ((1u << a.logC) - 1); o = G >> a.logC; }
         else { o = G & ((1u << Cfg::SH1) - 1); c = G >> Cfg::SH1; }
-        if constexpr (PRE) {
+        if constexpr (PRE == 2) {
+            BFS_UNROLL
+            for (int d = 0; d < 16; ++d) x[d] = (d & 1) ? pre.pr[d / 2].y : pre.pr[d / 2].x;
+        } else if constexpr (PRE == 1) {
             // paired lanes (adjacent columns in a column pass, adjacent rows in the final pass) fetched 16 bytes each:
             // the even lane the first half of the register index d, the odd lane the second half; now they swap
             const u32 par = G & 1;
@@ -374,7 +402,7 @@ BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, const u64* tw, u32 tid, u32
                 u64 v = gl_mul(x[s * Q + m], tw[e]);
 #endif
                 u32 r = (k1 << Cfg::SH1) | o;
-                smem[lds_phys(a, (r << a.logC) + c)] = v;
+                smem[lds_addr<Cfg::S>(a, r, c)] = v;
             }
         }
     }
@@ -398,7 +426,7 @@ BFS_HD void ntt_stage2(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid
             BFS_UNROLL
             for (int d = 0; d < Q; ++d) {
                 u32 r = (f1 << Cfg::SH1) | ((u32)d << Cfg::SH2) | f3;
-                x[s * Q + d] = smem[lds_phys(a, (r << a.logC) + c)];
+                x[s * Q + d] = smem[lds_addr<Cfg::S>(a, r, c)];
             }
 #ifndef BFS_ABL_NO_DIF
             dif<Q>(x + s * Q);
@@ -413,7 +441,7 @@ BFS_HD void ntt_stage2(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid
                     u32 e = (f3 * (f1 + (k2 << B1))) & ((1u << Cfg::S) - 1);
                     u64 v = gl_mul(x[s * Q + m], tab[(u64)e << (a.tb.t_in_log - Cfg::S)]);
                     u32 r = (f1 << Cfg::SH1) | (k2 << Cfg::SH2) | f3;
-                    smem[lds_phys(a, (r << a.logC) + c)] = v;
+                    smem[lds_addr<Cfg::S>(a, r, c)] = v;
                 }
             }
         }
@@ -438,7 +466,7 @@ BFS_HD void ntt_stage3(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid
             BFS_UNROLL
             for (int d = 0; d < Q; ++d) {
                 u32 r = (f1 << Cfg::SH1) | (f2 << Cfg::SH2) | (u32)d;
-                x[s * Q + d] = smem[lds_phys(a, (r << a.logC) + c)];
+                x[s * Q + d] = smem[lds_addr<Cfg::S>(a, r, c)];
             }
             dif<Q>(x + s * Q);
             final_store<B1, B2, B3, B3>(a, g, x, (u32)s, f1 + (f2 << B1), B1 + B2, c, G);

@@ -120,10 +120,18 @@ inline void ntt_build_coset_tables(const NttPlan& p, u64 shift, CosetHostTables&
     fill_powers(t.s_hi, 1ull << hi_bits, gl_pow(shift, 1ull << p.lo_bits), 1);
 }
 
-// default LDS padding for a pass (tuned per configuration in ntt.hip; see DESIGN.md "LDS layout")
-inline void ntt_default_padding(u32 /*S*/, u32 /*logC*/, u32 /*mode*/, u32& pad_shift, u32& pad_amount) {
-    pad_shift = 8;
-    pad_amount = 2;
+// LDS layout and padding per pass, chosen so that both the stage-1 writes and the stage-2 reads of the tile are free of
+// bank conflicts (ds_read_b64: 64 banks x 4 B per 32-lane group; ds_write_b64: 32 banks per 16-lane group).
+//   column pass  [row][col], +16 words every 256: stage-2 lanes (c = tid & 15, f1 = tid >> 4) of one 32-lane group then fall on
+//                disjoint bank halves (first version: +2 words -> 2-way conflicts on every read)
+//   final pass of a multi-pass plan: lanes run along the ROW index when loading (contiguous HBM rows), so the tile is kept
+//                [col][row] with +1 word per column: writes are consecutive, stage-2 reads (lanes along c) step 2 banks per lane
+//                (first version: [row][col] -> 16-way conflicts on every write, 73 % of LDS cycles, profiles/r01)
+//   single-pass plans (one column): +2 words every 256 rows
+inline void ntt_lds_layout(u32 S, u32 logC, u32 mode, u32& cmajor, u32& pad_shift, u32& pad_amount) {
+    if (mode == PASS_FINAL && logC > 0) { cmajor = 1; pad_shift = S; pad_amount = 1; }
+    else if (mode == PASS_COLUMN) { cmajor = 0; pad_shift = 8; pad_amount = 16; }
+    else { cmajor = 0; pad_shift = 8; pad_amount = 2; }
 }
 
 // fill the per-pass kernel arguments (pointers are whatever address space the caller runs in)
@@ -150,7 +158,7 @@ inline PassArgs ntt_pass_args(const NttPlan& p, u32 t, const u64* in, u64* out, 
         u64 stride = (a.mode == PASS_COLUMN) ? ((1ull << (p.log_n - S)) << sh1) : (1ull << sh1);
         a.coset_delta = gl_pow(shift, stride);
     }
-    ntt_default_padding(p.pass_bits[t], a.logC, a.mode, a.pad_shift, a.pad_amount);
+    ntt_lds_layout(p.pass_bits[t], a.logC, a.mode, a.lds_cmajor, a.pad_shift, a.pad_amount);
     // 16-byte paired-lane accesses raise the HBM rate of a pass from 3.2 to 4.4 TB/s but cost ~200 VALU instructions per
     // tile; the kernels are VALU-bound today (74 % VALU busy, profiles/r01), so they are switched on by NTT_WIDE_ACCESS only
     a.wide_load = (NTT_WIDE_ACCESS && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (in_stride & 1) == 0) ? 1 : 0;

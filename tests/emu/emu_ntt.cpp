@@ -22,7 +22,7 @@ static void run_pass(const PassArgs& a, u32 grid_x, u32 batch) {
     for (u32 by = 0; by < batch; ++by)
         for (u32 bx = 0; bx < grid_x; ++bx) {
             RawTile none{};
-            for (u32 t = 0; t < W; ++t) ntt_stage1<B1, B2, B3, false>(a, smem.data(), tw.data(), t, bx, by, none);
+            for (u32 t = 0; t < W; ++t) ntt_stage1<B1, B2, B3, 0>(a, smem.data(), tw.data(), t, bx, by, none);
             if (B2 > 0) for (u32 t = 0; t < W; ++t) ntt_stage2<B1, B2, B3>(a, smem.data(), t, bx, by);
             if (B3 > 0) for (u32 t = 0; t < W; ++t) ntt_stage3<B1, B2, B3>(a, smem.data(), t, bx, by);
         }
