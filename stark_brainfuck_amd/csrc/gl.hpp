@@ -44,10 +44,20 @@ BFS_HD u64 gl_sub(u64 a, u64 b) {
     u32 rhi = dhi - b2;
     return ((u64)rhi << 32) | rlo;
 }
-BFS_HD u64 gl_add(u64 a, u64 b) { return gl_sub(a, GL_P - b); }   // b < p, so p - b is in [1, p]: still exact
+// a + b: s = a + b and u = s + EPS (= s - p mod 2^64) with both carries; a + b >= p  <=>  either addition carried
+BFS_HD u64 gl_add(u64 a, u64 b) {
+    u32 c1, c2, c3, c4;
+    u32 slo = __builtin_addc((u32)a, (u32)b, 0u, &c1);
+    u32 shi = __builtin_addc((u32)(a >> 32), (u32)(b >> 32), c1, &c2);
+    u32 ulo = __builtin_addc(slo, 0xFFFFFFFFu, 0u, &c3);
+    u32 uhi = __builtin_addc(shi, 0u, c3, &c4);
+    const bool over = (c2 | c4) != 0;
+    return over ? (((u64)uhi << 32) | ulo) : (((u64)shi << 32) | slo);
+}
 
-// hi*2^64 + lo  ->  canonical residue
-BFS_HD u64 gl_reduce128(u64 hi, u64 lo) {
+// hi*2^64 + lo  ->  residue; CANON = false leaves the value in [0, 2^64) (fine as an operand of further multiplications)
+template <bool CANON>
+BFS_HD u64 gl_reduce128_t(u64 hi, u64 lo) {
     u32 hh = (u32)(hi >> 32), hl = (u32)hi;
     u32 bl, bh, b2;
     u32 dlo = __builtin_subc((u32)lo, hh, 0u, &bl);    // t0 = lo - hi_hi  (2^96 = -1)
@@ -60,10 +70,37 @@ BFS_HD u64 gl_reduce128(u64 hi, u64 lo) {
     u32 c = r < t0, c2, c3;
     u32 rlo = __builtin_addc((u32)r, 0u - c, 0u, &c2); // wrapped: + EPS (cannot wrap twice)
     u32 rhi = (u32)(r >> 32) + c2;
+    if constexpr (!CANON) return ((u64)rhi << 32) | rlo;
     // canonical form: r >= p  <=>  r + EPS carries out of 64 bits
     u32 ulo = __builtin_addc(rlo, 0xFFFFFFFFu, 0u, &c2);
     u32 uhi = __builtin_addc(rhi, 0u, c2, &c3);
     return c3 ? (((u64)uhi << 32) | ulo) : (((u64)rhi << 32) | rlo);
+}
+BFS_HD u64 gl_reduce128(u64 hi, u64 lo) { return gl_reduce128_t<true>(hi, lo); }
+
+// 64 x 64 -> 128 as four independent 32 x 32 products and a 5-instruction carry tree (no register shuffles)
+BFS_HD void gl_mul128(u64 a, u64 b, u64& hi, u64& lo) {
+    const u32 al = (u32)a, ah = (u32)(a >> 32), bl = (u32)b, bh = (u32)(b >> 32);
+    const u64 A = (u64)al * bl, B = (u64)ah * bh, M1 = (u64)al * bh, M2 = (u64)ah * bl;
+    u32 c, k, k2, c3;
+    u32 mlo = __builtin_addc((u32)M1, (u32)M2, 0u, &c);
+    u32 mhi = __builtin_addc((u32)(M1 >> 32), (u32)(M2 >> 32), c, &k);
+    u32 l1 = __builtin_addc((u32)(A >> 32), mlo, 0u, &k2);
+    u32 h0 = __builtin_addc((u32)B, mhi, k2, &c3);
+    u32 h1 = (u32)(B >> 32) + k + c3;
+    lo = ((u64)l1 << 32) | (u32)A;
+    hi = ((u64)h1 << 32) | h0;
+}
+BFS_HD u64 gl_mul(u64 a, u64 b) {
+    u64 hi, lo;
+    gl_mul128(a, b, hi, lo);
+    return gl_reduce128_t<true>(hi, lo);
+}
+// product left in [0, 2^64): only for values whose next use is another multiplication
+BFS_HD u64 gl_mul_lazy(u64 a, u64 b) {
+    u64 hi, lo;
+    gl_mul128(a, b, hi, lo);
+    return gl_reduce128_t<false>(hi, lo);
 }
 #else
 BFS_HD u64 gl_add(u64 a, u64 b) {
@@ -92,10 +129,13 @@ BFS_HD u64 gl_reduce128(u64 hi, u64 lo) {
 
 BFS_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
 
+#if !defined(__HIP_DEVICE_COMPILE__)
 BFS_HD u64 gl_mul(u64 a, u64 b) {
     u128 z = (u128)a * b;
     return gl_reduce128((u64)(z >> 64), (u64)z);
 }
+BFS_HD u64 gl_mul_lazy(u64 a, u64 b) { return gl_mul(a, b); }
+#endif
 
 BFS_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }
 

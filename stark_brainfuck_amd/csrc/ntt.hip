@@ -3,95 +3,76 @@
 
 namespace bfs {
 
-#ifndef NTT_PREFETCH
-#define NTT_PREFETCH 0
-#endif
-#ifndef NTT_PERSISTENT_GRID
-#define NTT_PERSISTENT_GRID 1024u
-#endif
-
-// Persistent tile kernel: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ... and issues the (16-byte,
-// paired-lane) global loads of the next tile before computing on the current one.  LDS = tile + inner twiddle table.
-template <int B1, int B2, int B3, int PRE /* 0 one tile per workgroup | 1 persistent + 16-byte prefetch | 2 persistent + 8-byte prefetch */>
-__global__ void __launch_bounds__(256, 4) ntt_tile_kernel(const PassArgs a, u32 grid_x, u32 total_tiles, u32 tw_offset) {
+// One workgroup per tile: T/16 threads hold 16 elements each.  LDS = tile (padded) + the stage-1 -> stage-2 twiddles.
+// (A persistent variant with next-tile prefetch and 16-byte paired-lane accesses was measured slower: the kernel is
+//  VALU-issue bound and hardware workgroup turnover already overlaps HBM latency)
+template <int B1, int B2, int B3, int LOGC, int MODE>
+__global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) u64 smem[];
-    typedef TileCfg<B1, B2, B3> Cfg;
-    u64* tw = smem + tw_offset;
+    typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
+    u64* tw = smem + ((Cfg::LDS_WORDS + 1) & ~1);
     if constexpr (Cfg::U >= 2) {
         // dense copy of the stage-1 -> stage-2 twiddles w_M^e, M = 2^(B1+B2) <= 256 (n^-1 folded in when it is the last one)
-        const u64* tab = (Cfg::U == 2 && a.mode == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;
+        const u64* tab = (Cfg::U == 2 && MODE == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;
         for (u32 i = threadIdx.x; i < (1u << (B1 + B2)); i += blockDim.x) tw[i] = tab[(u64)i << (a.tb.t_in_log - (B1 + B2))];
         __syncthreads();
     }
-    constexpr bool wide = PRE != 0;
-    RawTile cur, nxt;
-    u32 t = blockIdx.x;
-    if (wide && t < total_tiles) {
-        if constexpr (PRE == 1) ntt_prefetch<B1, B2, B3>(a, threadIdx.x, t % grid_x, t / grid_x, cur);
-        else ntt_prefetch_narrow<B1, B2, B3>(a, threadIdx.x, t % grid_x, t / grid_x, cur);
+    ntt_stage1<B1, B2, B3, LOGC, MODE>(a, smem, tw, threadIdx.x, blockIdx.x, blockIdx.y);
+    if constexpr (B2 > 0) {
+        __syncthreads();
+        ntt_stage2<B1, B2, B3, LOGC, MODE>(a, smem, threadIdx.x, blockIdx.x, blockIdx.y);
     }
-    for (; t < total_tiles; t += gridDim.x) {
-        const u32 tn = t + gridDim.x;
-        if (wide && tn < total_tiles) {
-            if constexpr (PRE == 1) ntt_prefetch<B1, B2, B3>(a, threadIdx.x, tn % grid_x, tn / grid_x, nxt);
-            else ntt_prefetch_narrow<B1, B2, B3>(a, threadIdx.x, tn % grid_x, tn / grid_x, nxt);
-        }
-        const u32 bx = t % grid_x, by = t / grid_x;
-        // opaque copy of the thread id: keeps the compiler from hoisting every tid-derived address, digit and twiddle
-        // out of the tile loop (that costs > 200 VGPRs and spills; recomputing them per tile is a few dozen SALU/VALU ops)
-        u32 tid = threadIdx.x;
-        asm volatile("" : "+v"(tid));
-        ntt_stage1<B1, B2, B3, PRE>(a, smem, tw, tid, bx, by, cur);
-        if constexpr (B2 > 0) {
-            __syncthreads();
-            ntt_stage2<B1, B2, B3>(a, smem, tid, bx, by);
-        }
-        if constexpr (B3 > 0) {
-            __syncthreads();
-            ntt_stage3<B1, B2, B3>(a, smem, tid, bx, by);
-        }
-        if constexpr (B2 > 0) __syncthreads();   // the next tile's stage 1 overwrites the LDS tile
-        if constexpr (PRE != 0) cur = nxt;
+    if constexpr (B3 > 0) {
+        __syncthreads();
+        ntt_stage3<B1, B2, B3, LOGC, MODE>(a, smem, threadIdx.x, blockIdx.x, blockIdx.y);
     }
 }
 
 __global__ void ntt_small_kernel(const SmallArgs a) { ntt_small_body(a, threadIdx.x, blockIdx.y); }
 
-template <int B1, int B2, int B3>
+template <int B1, int B2, int B3, int LOGC, int MODE>
 static int launch_tile(const PassArgs& a, u32 grid_x, u32 batch, hipStream_t stream) {
-    constexpr u32 S = B1 + B2 + B3;
-    const u32 threads = ((1u << S) << a.logC) >> 4;
-    const u32 tile = (B2 > 0) ? tile_lds_elems(S, a.logC, a.pad_shift, a.pad_amount) : 0;
-    const u32 tw_offset = (tile + 1) & ~1u;
-    const size_t lds = (B2 > 0) ? (tw_offset + (1u << (B1 + B2))) * sizeof(u64) : 0;
-    const u64 total = (u64)grid_x * batch;
-    if (total > 0xFFFFFFFFull) { set_error("too many tiles"); return BFS_ERR_BAD_ARG; }
-    // persistent grid: enough workgroups to fill the 256 CUs at the residency the 34 KiB LDS tile allows (4 per CU)
-    const bool wide = B1 == 4 && a.wide_load && (a.mode == PASS_COLUMN ? a.logC >= 1 : (B2 + B3) >= 1);
-    const int mode = wide ? 1 : ((B1 == 4 && NTT_PREFETCH && total >= 4096) ? 2 : 0);
-    u32 grid = (u32)total;
-    if (mode != 0) grid = total < NTT_PERSISTENT_GRID ? (u32)total : NTT_PERSISTENT_GRID;
-    if (mode == 1) hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, 1>), dim3(grid), dim3(threads), lds, stream, a, grid_x, (u32)total, tw_offset);
-    else if (mode == 2) hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, 2>), dim3(grid), dim3(threads), lds, stream, a, grid_x, (u32)total, tw_offset);
-    else hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, 0>), dim3(grid), dim3(threads), lds, stream, a, grid_x, (u32)total, tw_offset);
+    typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
+    const size_t lds = (B2 > 0) ? (size_t)(((Cfg::LDS_WORDS + 1) & ~1) + Cfg::TW_WORDS) * sizeof(u64) : 0;
+    hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, LOGC, MODE>), dim3(grid_x, batch), dim3(Cfg::W), lds, stream, a);
     BFS_HIP(hipGetLastError());
     return BFS_OK;
 }
 
-static int dispatch_tile(const PassArgs& a, u32 S, u32 grid_x, u32 batch, hipStream_t stream) {
+// multi-pass plans use 4096-element tiles (logC = 12 - S, S = 4..8); single-pass plans one column of 2^S rows (S = 4..12)
+template <int MODE>
+static int dispatch_multi(const PassArgs& a, u32 S, u32 grid_x, u32 batch, hipStream_t stream) {
     switch (S) {
-        case 4: return launch_tile<4, 0, 0>(a, grid_x, batch, stream);
-        case 5: return launch_tile<4, 1, 0>(a, grid_x, batch, stream);
-        case 6: return launch_tile<4, 2, 0>(a, grid_x, batch, stream);
-        case 7: return launch_tile<4, 3, 0>(a, grid_x, batch, stream);
-        case 8: return launch_tile<4, 4, 0>(a, grid_x, batch, stream);
-        case 9: return launch_tile<4, 4, 1>(a, grid_x, batch, stream);
-        case 10: return launch_tile<4, 4, 2>(a, grid_x, batch, stream);
-        case 11: return launch_tile<4, 4, 3>(a, grid_x, batch, stream);
-        case 12: return launch_tile<4, 4, 4>(a, grid_x, batch, stream);
+        case 4: return launch_tile<4, 0, 0, 8, MODE>(a, grid_x, batch, stream);
+        case 5: return launch_tile<4, 1, 0, 7, MODE>(a, grid_x, batch, stream);
+        case 6: return launch_tile<4, 2, 0, 6, MODE>(a, grid_x, batch, stream);
+        case 7: return launch_tile<4, 3, 0, 5, MODE>(a, grid_x, batch, stream);
+        case 8: return launch_tile<4, 4, 0, 4, MODE>(a, grid_x, batch, stream);
     }
-    set_error("internal: no tile kernel for a %u-bit digit", S);
+    set_error("internal: no tile kernel for a %u-bit digit of a multi-pass plan", S);
     return BFS_ERR_BAD_ARG;
+}
+
+static int dispatch_single(const PassArgs& a, u32 S, u32 batch, hipStream_t stream) {
+    switch (S) {
+        case 4: return launch_tile<4, 0, 0, 0, PASS_FINAL>(a, 1, batch, stream);
+        case 5: return launch_tile<4, 1, 0, 0, PASS_FINAL>(a, 1, batch, stream);
+        case 6: return launch_tile<4, 2, 0, 0, PASS_FINAL>(a, 1, batch, stream);
+        case 7: return launch_tile<4, 3, 0, 0, PASS_FINAL>(a, 1, batch, stream);
+        case 8: return launch_tile<4, 4, 0, 0, PASS_FINAL>(a, 1, batch, stream);
+        case 9: return launch_tile<4, 4, 1, 0, PASS_FINAL>(a, 1, batch, stream);
+        case 10: return launch_tile<4, 4, 2, 0, PASS_FINAL>(a, 1, batch, stream);
+        case 11: return launch_tile<4, 4, 3, 0, PASS_FINAL>(a, 1, batch, stream);
+        case 12: return launch_tile<4, 4, 4, 0, PASS_FINAL>(a, 1, batch, stream);
+    }
+    set_error("internal: no tile kernel for a %u-bit single-pass transform", S);
+    return BFS_ERR_BAD_ARG;
+}
+
+static int dispatch_tile(const NttPlan& p, u32 t, const PassArgs& a, u32 grid_x, u32 batch, hipStream_t stream) {
+    if (p.npass == 1) return dispatch_single(a, p.pass_bits[0], batch, stream);
+    if (t + 1 == p.npass) return dispatch_multi<PASS_FINAL>(a, p.pass_bits[t], grid_x, batch, stream);
+    return dispatch_multi<PASS_COLUMN>(a, p.pass_bits[t], grid_x, batch, stream);
 }
 
 enum { TBL_W_LO = 1, TBL_W_HI, TBL_T_IN, TBL_T_IN_LAST, TBL_S_LO, TBL_S_HI };
@@ -164,7 +145,7 @@ int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_str
         PassArgs a = ntt_pass_args(p, t, first ? d_in : ws, last ? d_out : ws, first ? in_stride : n, last ? out_stride : n,
                                    first ? n_in : n, tb, shift != 1, shift, post_scale);
         u32 grid_x = (u32)((n >> p.pass_bits[t]) >> p.logC[t]);
-        BFS_TRY(dispatch_tile(a, p.pass_bits[t], grid_x, batch, stream));
+        BFS_TRY(dispatch_tile(p, t, a, grid_x, batch, stream));
     }
     return BFS_OK;
 }

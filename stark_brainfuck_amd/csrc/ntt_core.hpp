@@ -14,7 +14,12 @@
 // Inside a pass the 2^S-point column transform is again split into <= 3 register stages of radix 2^B <= 16:
 // every thread holds 16 elements in VGPRs, runs a decimation-in-frequency network whose twiddles are powers
 // of two (any primitive 16th root of unity in this field is 2^(12u), u odd), multiplies by the inner twiddle
-// from a 4096-entry table and exchanges through LDS once per stage.
+// and exchanges through LDS once per stage.
+//
+// The kernels are VALU-issue bound (a wave64 integer instruction costs 4 cycles, the tile kernel sits at 97 % VALU
+// utilisation; profiles/r01), so the code spends instructions on arithmetic only: tile shape (LOGC) and pass kind
+// (MODE) are template parameters, every global / LDS access is "per-thread base + wave-uniform or immediate offset",
+// digit permutations are wave-uniform scalars, strides are powers of two applied as shifts.
 //
 // The stage bodies are pure functions of (thread id, block id, LDS pointer) and compile for the host as well,
 // which is how tests/test_emulation.py checks the index arithmetic without a GPU (test infrastructure only:
@@ -33,8 +38,7 @@ constexpr u64 cx_pow2(int k) {
 }
 
 // x * 2^K mod p.  Written as a multiplication by the compile-time constant 2^K mod p: hipcc drops the partial products of
-// the constant's zero limbs (1-2 v_mad_u64_u32 instead of 4), which measured fewer instructions than an explicit
-// shift-and-fold formulation (tools/microbench, DESIGN.md "modular arithmetic").
+// the constant's zero limbs, which measured fewer instructions than an explicit shift-and-fold formulation.
 template <int K>
 BFS_HD u64 mul_pow2(u64 x) {
     if constexpr (K == 0) {
@@ -66,13 +70,16 @@ BFS_HD void dif(u64* x) {
     }
 }
 
-BFS_HD u32 bitrev(u32 v, int bits) {
+constexpr u32 cx_bitrev(u32 v, int bits) {
     u32 r = 0;
-    BFS_UNROLL
-    for (int i = 0; i < 4; ++i)
-        if (i < bits) r |= ((v >> i) & 1u) << (bits - 1 - i);
+    for (int i = 0; i < bits; ++i) r |= ((v >> i) & 1u) << (bits - 1 - i);
     return r;
 }
+
+// output digit held by register m of a radix-2^BITS stage: the network leaves y[bitrev(m)] there, and the true root is
+// (2^(192/Q))^u, so y'[k] = y[u k]  ->  k = bitrev(m) * u^-1 (mod Q).  m is a compile-time constant, uinv is wave-uniform.
+template <int BITS>
+BFS_HD u32 perm_digit(int m, u32 uinv) { return (cx_bitrev((u32)m, BITS) * uinv) & ((1u << BITS) - 1); }
 
 struct NttTables {
     const u64* w_lo;       // w^i,              i < 2^lo_bits
@@ -87,26 +94,27 @@ struct NttTables {
 
 enum { PASS_COLUMN = 0, PASS_FINAL = 1 };
 
+// everything a pass needs, precomputed on the host (ntt_plan.hpp) so that the kernel does no planning arithmetic
 struct PassArgs {
     const u64* in;
     u64* out;
     u64 in_batch_stride, out_batch_stride;
     u64 n_in;            // valid input elements per transform (pass 0 only); the rest reads as zero
+    u32 partial;         // pass 0 with n_in < n: loads are predicated
     u32 log_n;
-    u32 mode;            // PASS_COLUMN | PASS_FINAL
-    u32 logC;            // columns per tile
     u32 pass_index;      // t, 0-based
     u32 npass;
     u32 pass_bits;       // S_v packed one byte per pass (no array: kernel-argument arrays indexed at run time go to scratch)
+    // column pass: element index = h * 2^(S+logL) + row * 2^logL + l ; a tile is all rows x C consecutive l
+    u32 logL;
+    u32 lognl;           // log2(L / C): tiles per h
+    u32 tw_shift;        // K_prev -> exponent of w_n : kstep = (K << tw_shift) mod n
+    // final pass of a multi-pass plan: slot = (((p1 << mid_bits) + mid) << S) + row ; a tile is C consecutive p1 x all rows
+    u32 n1_bits, mid_bits, logch;
     u32 uinv;            // u^-1 mod 16 where w^(n/16) = 2^(12u)
     u32 has_coset;       // pass 0: multiply input j by s^j
     u64 coset_delta;     // s^(stride of the stage-1 register index)
     u64 post_scale;      // multiplied in at the final store when the final pass has a single stage
-    u32 pad_shift;       // LDS padding: phys = lin + (lin >> pad_shift) * pad_amount
-    u32 pad_amount;
-    u32 lds_cmajor;      // LDS tile layout: 0 = [row][column], 1 = [column][row] (final pass of a multi-pass plan)
-    u32 wide_load;       // 16-byte paired-lane loads allowed (pointer / stride alignment checked on the host)
-    u32 wide_store;
     NttTables tb;
 };
 
@@ -116,49 +124,18 @@ BFS_HD u64 tw_pow(const u64* lo, const u64* hi, u32 lo_bits, u64 e) {
     return gl_mul(a, b);
 }
 
-// exchange a 64-bit value with the neighbouring lane (lane ^ 1): two DPP moves, no LDS traffic.
-// Used to turn two 8-byte accesses of adjacent lanes into one 16-byte access per lane (HBM efficiency of the tile
-// passes: 4.4 TB/s with 16 B per lane against 3.2 TB/s with 8 B per lane, tools/microbench/mem.hip).
-BFS_HD u64 lane_swap1(u64 v) {
+// 24-bit x 24-bit multiply (full-rate v_mul_u32_u24; operands here are < 2^12)
+BFS_HD u32 mul24(u32 a, u32 b) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    u32 lo = (u32)v, hi = (u32)(v >> 32);
-    lo = (u32)__builtin_amdgcn_update_dpp((int)lo, (int)lo, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]
-    hi = (u32)__builtin_amdgcn_update_dpp((int)hi, (int)hi, 0xB1, 0xF, 0xF, true);
-    return ((u64)hi << 32) | lo;
+    return __umul24(a, b);
 #else
-    return v;
+    return a * b;
 #endif
 }
 
-struct alignas(16) U64x2 {
-    u64 x, y;
-};
-
-BFS_HD u32 lds_phys(const PassArgs& a, u32 lin) { return lin + (lin >> a.pad_shift) * a.pad_amount; }
-
-// physical LDS word of tile element (row r, column c); S = log2(rows)
-template <int S>
-BFS_HD u32 lds_addr(const PassArgs& a, u32 r, u32 c) {
-    return lds_phys(a, a.lds_cmajor ? ((c << S) + r) : ((r << a.logC) + c));
-}
-
-BFS_HD u32 perm_digit(u32 m, int bits, u32 uinv) { return (bitrev(m, bits) * uinv) & ((1u << bits) - 1); }
-
-// geometry shared by the stages of one tile
-struct TileGeom {
-    u64 in_base, out_base;  // element offsets of this transform (batch)
-    u64 base;               // COLUMN: h * n_t * L
-    u64 L;                  // COLUMN: lower stride
-    u64 c0;                 // COLUMN: first column; FINAL: first p1
-    u64 kstep;              // COLUMN: exponent step of the inter-pass twiddle (w^(kstep * row))
-    u64 mid;                // FINAL: fixed middle slot digits
-    u64 kmid;               // FINAL: their digit-reversed value
-    u32 mid_bits, n1_bits;
-};
-
-// digit-reverse the slot digits p_first..p_last (p_first most significant in h) into K = p_first + n_first*(...)
 BFS_HD u32 pass_bits_of(u32 packed, int v) { return (packed >> (8 * v)) & 0xFFu; }
 
+// digit-reverse the slot digits p_first..p_last (p_first most significant in h) into K = p_first + n_first*(...)
 BFS_HD u64 digit_reverse(u64 h, u32 packed_bits, int first, int last) {
     u64 K = 0;
     bool any = false;
@@ -172,276 +149,198 @@ BFS_HD u64 digit_reverse(u64 h, u32 packed_bits, int first, int last) {
     return K;
 }
 
-template <int S>
-BFS_HD TileGeom tile_geom(const PassArgs& a, u32 bid_x, u32 bid_y) {
-    TileGeom g{};
-    g.in_base = (u64)bid_y * a.in_batch_stride;
-    g.out_base = (u64)bid_y * a.out_batch_stride;
-    const u64 n = 1ull << a.log_n;
-    if (a.mode == PASS_COLUMN) {
-        u32 done = 0;
-        for (u32 v = 0; v <= a.pass_index; ++v) done += pass_bits_of(a.pass_bits, (int)v);
-        g.L = n >> done;
-        u64 nl = g.L >> a.logC;
-        u64 h = bid_x / nl, lch = bid_x % nl;
-        g.c0 = lch << a.logC;
-        g.base = h * (g.L << S);
-        u64 K = a.pass_index ? digit_reverse(h, a.pass_bits, 0, (int)a.pass_index - 1) : 0;
-        g.kstep = (K * (n >> done)) & (n - 1);
-    } else {
-        g.n1_bits = pass_bits_of(a.pass_bits, 0);
-        if (a.npass > 1) {
-            u32 mb = 0;
-            for (u32 v = 1; v + 1 < a.npass; ++v) mb += pass_bits_of(a.pass_bits, (int)v);
-            g.mid_bits = mb;
-            u64 chunks = (1ull << g.n1_bits) >> a.logC;
-            g.c0 = (bid_x % chunks) << a.logC;
-            g.mid = bid_x / chunks;
-            g.kmid = mb ? digit_reverse(g.mid, a.pass_bits, 1, (int)a.npass - 2) : 0;
-        }
-    }
-    return g;
-}
-
-// load address / inter-pass exponent for (row r, column c)
-template <int S>
-BFS_HD u64 in_index(const PassArgs& a, const TileGeom& g, u32 r, u32 c) {
-    if (a.mode == PASS_COLUMN) return g.base + (u64)r * g.L + g.c0 + c;
-    if (a.npass == 1) return r;
-    u64 p1 = g.c0 + c;
-    return (((p1 << g.mid_bits) + g.mid) << S) + r;
-}
-
-template <int S>
-BFS_HD u64 out_index(const PassArgs& a, const TileGeom& g, u32 kpass, u32 c) {
-    if (a.mode == PASS_COLUMN) return g.base + (u64)kpass * g.L + g.c0 + c;
-    if (a.npass == 1) return kpass;
-    u64 K = (g.c0 + c) + (g.kmid << g.n1_bits);
-    return K + ((u64)kpass << (a.log_n - S));
-}
-
-template <int B1, int B2, int B3>
+template <int B1, int B2, int B3, int LOGC, int MODE>
 struct TileCfg {
     static constexpr int S = B1 + B2 + B3;
     static constexpr int SH1 = B2 + B3, SH2 = B3;
     static constexpr int U = (B2 == 0) ? 1 : (B3 == 0 ? 2 : 3);
+    static constexpr int T = (1 << S) << LOGC;           // elements per tile
+    static constexpr int W = T / 16 ? T / 16 : 1;        // threads per tile
+    // LDS layout (bank-conflict analysis: ntt_plan.hpp / DESIGN.md):
+    //   column pass and single-column tiles: [row][col], + 2^PL words every 256
+    //   final pass of a multi-pass plan (lanes run along rows when loading): [col][row], + 1 word per column
+    static constexpr bool CMAJOR = (MODE == PASS_FINAL) && (LOGC > 0);
+    static constexpr int PL = (MODE == PASS_COLUMN) ? 4 : 1;
+    static constexpr int LDS_WORDS = CMAJOR ? (T + (1 << LOGC)) : (T + (((T - 1) >> 8) << PL) + (1 << PL));
+    static constexpr int TW_WORDS = (U >= 2) ? (1 << (B1 + B2)) : 0;   // stage-1 -> stage-2 twiddles kept in LDS
 };
 
-// store the 16 registers of the last stage.  f_lo / f_mid are the already-final lower digits of k_pass.
-template <int B1, int B2, int B3, int BQ>
-BFS_HD void final_store(const PassArgs& a, const TileGeom& g, const u64* x, u32 sub, u32 klow, int kshift, u32 c, u32 G) {
-    typedef TileCfg<B1, B2, B3> Cfg;
-    u64* out = a.out + g.out_base;
+template <typename Cfg, int LOGC>
+BFS_HD u32 lds_addr(u32 r, u32 c) {
+    if constexpr (Cfg::CMAJOR) {
+        return (c << Cfg::S) + c + r;
+    } else {
+        const u32 lin = (r << LOGC) + c;
+        return lin + ((lin >> 8) << Cfg::PL);
+    }
+}
+
+// per-tile scalars
+struct TileGeom {
+    const u64* in;    // transform base (+ batch)
+    u64* out;
+    u64 row0;         // COLUMN: h*2^(S+logL) + c0 ; FINAL multi: ((c0 << mid_bits) + mid) << S ; single: 0
+    u64 kbase;        // COLUMN: exponent step of the inter-pass twiddle ; FINAL: c0 + (kmid << n1_bits)
+};
+
+template <typename Cfg, int LOGC, int MODE>
+BFS_HD TileGeom tile_geom(const PassArgs& a, u32 bid_x, u32 bid_y) {
+    TileGeom g;
+    g.in = a.in + (u64)bid_y * a.in_batch_stride;
+    g.out = a.out + (u64)bid_y * a.out_batch_stride;
+    if constexpr (MODE == PASS_COLUMN) {
+        const u64 h = bid_x >> a.lognl;
+        const u64 c0 = (u64)(bid_x & ((1u << a.lognl) - 1)) << LOGC;
+        g.row0 = (h << (Cfg::S + a.logL)) + c0;
+        const u64 K = a.pass_index ? digit_reverse(h, a.pass_bits, 0, (int)a.pass_index - 1) : 0;
+        g.kbase = (K << a.tw_shift) & ((1ull << a.log_n) - 1);
+    } else if (a.npass > 1) {
+        const u64 c0 = (u64)(bid_x & ((1u << a.logch) - 1)) << LOGC;
+        const u64 mid = bid_x >> a.logch;
+        g.row0 = ((c0 << a.mid_bits) + mid) << Cfg::S;
+        const u64 kmid = a.mid_bits ? digit_reverse(mid, a.pass_bits, 1, (int)a.npass - 2) : 0;
+        g.kbase = c0 + (kmid << a.n1_bits);
+    } else {
+        g.row0 = 0;
+        g.kbase = 0;
+    }
+    return g;
+}
+
+// store the 2^BQ registers of the last stage.  klow = the already-final lower digits of k_pass, c = column
+template <typename Cfg, int LOGC, int MODE, int BQ>
+BFS_HD void final_store(const PassArgs& a, const TileGeom& g, const u64* x, u32 klow, int kshift, u32 c) {
     constexpr int Q = 1 << BQ;
     const bool scale = (Cfg::U == 1) && a.post_scale != 1;
-    u64 v[Q];
-    BFS_UNROLL
-    for (int m = 0; m < Q; ++m) v[m] = scale ? gl_mul(x[sub * Q + m], a.post_scale) : x[sub * Q + m];
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (Q >= 2 && a.wide_store && a.logC >= 1) {
-        // lanes 2i / 2i+1 hold adjacent columns: the even lane stores both columns of outputs m < Q/2, the odd lane
-        // those of m >= Q/2, as one 16-byte store each
-        constexpr int H = Q / 2 ? Q / 2 : 1;
-        const u32 par = G & 1;
-        BFS_UNROLL
-        for (int mm = 0; mm < H; ++mm) {
-            u64 keep = par ? v[H + mm] : v[mm];
-            u64 send = par ? v[mm] : v[H + mm];
-            u64 recv = lane_swap1(send);
-            u32 kd = perm_digit((u32)(par ? H + mm : mm), BQ, a.uinv);
-            u32 kpass = klow + (kd << kshift);
-            U64x2 pr;
-            pr.x = par ? recv : keep;
-            pr.y = par ? keep : recv;
-            *reinterpret_cast<U64x2*>(out + out_index<Cfg::S>(a, g, kpass, c & ~1u)) = pr;
-        }
-        return;
+    u64* tp;          // per-thread base; the per-register offset below is wave-uniform
+    u32 step_log;
+    if constexpr (MODE == PASS_COLUMN) {
+        tp = g.out + g.row0 + ((u64)klow << a.logL) + c;
+        step_log = (u32)kshift + a.logL;
+    } else {
+        tp = g.out + g.kbase + c + ((u64)klow << (a.log_n - Cfg::S));
+        step_log = (u32)kshift + (a.log_n - Cfg::S);
     }
-#endif
     BFS_UNROLL
     for (int m = 0; m < Q; ++m) {
-        u32 kd = perm_digit((u32)m, BQ, a.uinv);
-        u32 kpass = klow + (kd << kshift);
-        out[out_index<Cfg::S>(a, g, kpass, c)] = v[m];
-    }
-}
-
-// raw 16-byte pieces of one tile as fetched by a thread (paired-lane wide loads); lets the kernel issue the loads of
-// the NEXT tile before it starts computing on the current one (software prefetch: HBM latency hides under the VALU work)
-struct RawTile {
-    U64x2 pr[8];
-};
-
-template <int B1, int B2, int B3>
-BFS_HD bool wide_load_possible(const PassArgs& a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return B1 == 4 && a.wide_load && (a.mode == PASS_COLUMN ? a.logC >= 1 : TileCfg<B1, B2, B3>::SH1 >= 1);
-#else
-    return false;
+#ifdef BFS_ABL_NO_MEM
+        if (x[m] != 0x123456789ULL) continue;
 #endif
-}
-
-// issue the global loads of tile (bid_x, bid_y) for this thread; only valid when wide_load_possible()
-template <int B1, int B2, int B3>
-BFS_HD void ntt_prefetch(const PassArgs& a, u32 tid, u32 bid_x, u32 bid_y, RawTile& raw) {
-    typedef TileCfg<B1, B2, B3> Cfg;
-    const TileGeom g = tile_geom<Cfg::S>(a, bid_x, bid_y);
-    const u64* in = a.in + g.in_base;
-    const u32 G = tid;
-    u32 o, c;
-    if (a.mode == PASS_COLUMN) { c = G & ((1u << a.logC) - 1); o = G >> a.logC; }
-    else { o = G & ((1u << Cfg::SH1) - 1); c = G >> Cfg::SH1; }
-    const u32 par = G & 1;
-    const u32 oe = (a.mode == PASS_COLUMN) ? o : (o & ~1u);
-    const u32 ce = (a.mode == PASS_COLUMN) ? (c & ~1u) : c;
-    BFS_UNROLL
-    for (int dd = 0; dd < 8; ++dd) {
-        u32 d = par ? (u32)(8 + dd) : (u32)dd;
-        u64 idx = in_index<Cfg::S>(a, g, (d << Cfg::SH1) | oe, ce);
-        U64x2 pr;
-        if (a.pass_index > 0 || idx + 1 < a.n_in) pr = *reinterpret_cast<const U64x2*>(in + idx);
-        else { pr.x = idx < a.n_in ? in[idx] : 0; pr.y = 0; }
-        raw.pr[dd] = pr;
-    }
-}
-
-// same for plain 8-byte loads (one element per lane and load): raw.pr[d/2].{x,y} = element d of this thread
-template <int B1, int B2, int B3>
-BFS_HD void ntt_prefetch_narrow(const PassArgs& a, u32 tid, u32 bid_x, u32 bid_y, RawTile& raw) {
-    typedef TileCfg<B1, B2, B3> Cfg;
-    const TileGeom g = tile_geom<Cfg::S>(a, bid_x, bid_y);
-    const u64* in = a.in + g.in_base;
-    const u32 G = tid;
-    u32 o, c;
-    if (a.mode == PASS_COLUMN) { c = G & ((1u << a.logC) - 1); o = G >> a.logC; }
-    else { o = G & ((1u << Cfg::SH1) - 1); c = G >> Cfg::SH1; }
-    BFS_UNROLL
-    for (int d = 0; d < 16; ++d) {
-        u64 idx = in_index<Cfg::S>(a, g, ((u32)d << Cfg::SH1) | o, c);
-        u64 v = (a.pass_index > 0 || idx < a.n_in) ? in[idx] : 0;
-        if (d & 1) raw.pr[d / 2].y = v; else raw.pr[d / 2].x = v;
+        const u64 v = scale ? gl_mul(x[m], a.post_scale) : x[m];
+        tp[(u64)perm_digit<BQ>(m, a.uinv) << step_log] = v;
     }
 }
 
 // ---- stage 1: global load (+ coset / inter-pass twiddle), first radix, inner twiddle, LDS write (or final store)
 // tw: dense inner-twiddle table for the stage 1 -> 2 exchange (2^(B1+B2) entries, in LDS on the GPU)
-template <int B1, int B2, int B3, int PRE /* 0 load here, 1 wide prefetched, 2 narrow prefetched */>
-BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, const u64* tw, u32 tid, u32 bid_x, u32 bid_y, const RawTile& pre) {
-    typedef TileCfg<B1, B2, B3> Cfg;
+template <int B1, int B2, int B3, int LOGC, int MODE>
+BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, const u64* tw, u32 tid, u32 bid_x, u32 bid_y) {
+    typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     constexpr int Q = 1 << B1, SG = 16 / Q;
-    const u32 W = ((1u << Cfg::S) << a.logC) >> 4;
-    const TileGeom g = tile_geom<Cfg::S>(a, bid_x, bid_y);
-    const u64* in = a.in + g.in_base;
-    const u64 n = 1ull << a.log_n;
-    const bool twiddle = a.pass_index > 0;
-    u64 x[16];
+    const TileGeom g = tile_geom<Cfg, LOGC, MODE>(a, bid_x, bid_y);
+    const u64 nmask = (1ull << a.log_n) - 1;
     BFS_UNROLL
     for (int s = 0; s < SG; ++s) {
-        u32 G = (u32)s * W + tid;
-        u32 o, c;
-        if (a.mode == PASS_COLUMN) { c = G & ((1u << a.logC) - 1); o = G >> a.logC; }
+        const u32 G = (u32)s * Cfg::W + tid;
+        u32 o, c;      // o: the row bits below this stage's digit, c: column
+        if constexpr (MODE == PASS_COLUMN) { c = G & ((1u << LOGC) - 1); o = G >> LOGC; }
         else { o = G & ((1u << Cfg::SH1) - 1); c = G >> Cfg::SH1; }
-        if constexpr (PRE == 2) {
+        // element d of this thread sits at tp[d << step_log]
+        u32 step_log;
+        u64 idx0;      // index of element d = 0 inside the transform (also the n_in predicate and the coset exponent)
+        if constexpr (MODE == PASS_COLUMN) {
+            idx0 = g.row0 + ((u64)o << a.logL) + c;
+            step_log = Cfg::SH1 + a.logL;
+        } else {
+            idx0 = g.row0 + ((u64)c << (a.mid_bits + Cfg::S)) + o;
+            step_log = Cfg::SH1;
+        }
+        const u64* tp = g.in + idx0;
+        u64 x[Q];
+        if (a.partial) {
             BFS_UNROLL
-            for (int d = 0; d < 16; ++d) x[d] = (d & 1) ? pre.pr[d / 2].y : pre.pr[d / 2].x;
-        } else if constexpr (PRE == 1) {
-            // paired lanes (adjacent columns in a column pass, adjacent rows in the final pass) fetched 16 bytes each:
-            // the even lane the first half of the register index d, the odd lane the second half; now they swap
-            const u32 par = G & 1;
-            BFS_UNROLL
-            for (int dd = 0; dd < 8; ++dd) {
-                U64x2 pr = pre.pr[dd];
-                u64 keep = par ? pr.y : pr.x;
-                u64 recv = lane_swap1(par ? pr.x : pr.y);
-                x[dd] = par ? recv : keep;
-                x[8 + dd] = par ? keep : recv;
-            }
+            for (int d = 0; d < Q; ++d) x[d] = (idx0 + ((u64)d << step_log) < a.n_in) ? tp[(u64)d << step_log] : 0;
         } else {
             BFS_UNROLL
             for (int d = 0; d < Q; ++d) {
-                u32 r = ((u32)d << Cfg::SH1) | o;
-                u64 idx = in_index<Cfg::S>(a, g, r, c);
-                x[s * Q + d] = (a.pass_index > 0 || idx < a.n_in) ? in[idx] : 0;
+#ifdef BFS_ABL_NO_MEM
+                x[d] = (idx0 + d) * 0x9E3779B97F4A7C15ULL >> 1;
+#else
+                x[d] = tp[(u64)d << step_log];
+#endif
             }
         }
-#ifdef BFS_ABL_NO_CHAIN
-        if (false) {
-#else
-        if (twiddle || a.has_coset) {
-#endif
+#ifndef BFS_ABL_NO_CHAIN
+        if (a.pass_index > 0 || a.has_coset) {
+            // factor of row r = (d << SH1) | o is beta^r = gamma * delta^d: a geometric chain per thread
             u64 gam, del;
-            if (twiddle) {
-                u64 ks = (a.mode == PASS_COLUMN) ? g.kstep : ((g.c0 + c) + (g.kmid << g.n1_bits));
-                gam = tw_pow(a.tb.w_lo, a.tb.w_hi, a.tb.lo_bits, ((u64)o * ks) & (n - 1));
-                del = tw_pow(a.tb.w_lo, a.tb.w_hi, a.tb.lo_bits, (ks << Cfg::SH1) & (n - 1));
+            if (a.pass_index > 0) {
+                const u64 ks = (MODE == PASS_COLUMN) ? g.kbase : (g.kbase + c);
+                gam = tw_pow(a.tb.w_lo, a.tb.w_hi, a.tb.lo_bits, ((u64)o * ks) & nmask);
+                del = tw_pow(a.tb.w_lo, a.tb.w_hi, a.tb.lo_bits, (ks << Cfg::SH1) & nmask);
             } else {
-                gam = tw_pow(a.tb.s_lo, a.tb.s_hi, a.tb.lo_bits, in_index<Cfg::S>(a, g, o, c));
+                gam = tw_pow(a.tb.s_lo, a.tb.s_hi, a.tb.lo_bits, idx0);
                 del = a.coset_delta;
             }
             u64 f = gam;
             BFS_UNROLL
             for (int d = 0; d < Q; ++d) {
-                x[s * Q + d] = gl_mul(x[s * Q + d], f);
-                f = gl_mul(f, del);
+                x[d] = gl_mul(x[d], f);
+                if (d + 1 < Q) f = gl_mul_lazy(f, del);   // only ever multiplied again: no canonical form needed
             }
         }
+#endif
 #ifndef BFS_ABL_NO_DIF
-        dif<Q>(x + s * Q);
+        dif<Q>(x);
 #endif
         if constexpr (Cfg::U == 1) {
-            final_store<B1, B2, B3, B1>(a, g, x, (u32)s, 0, 0, c, G);
+            final_store<Cfg, LOGC, MODE, B1>(a, g, x, 0, 0, c);
         } else {
-            u32 i2 = o >> B3;
+            const u32 i2 = o >> B3;
             BFS_UNROLL
             for (int m = 0; m < Q; ++m) {
-                u32 k1 = perm_digit((u32)m, B1, a.uinv);
-                u32 e = (i2 * k1) & ((1u << (B1 + B2)) - 1);
+                const u32 k1 = perm_digit<B1>(m, a.uinv);                      // wave-uniform
+                const u32 e = mul24(i2, k1) & ((1u << (B1 + B2)) - 1);         // exponent of w_M, M = 2^(B1+B2)
 #ifdef BFS_ABL_NO_INNER
-                u64 v = x[s * Q + m] + e;
+                const u64 v = x[m] + e;
 #else
-                u64 v = gl_mul(x[s * Q + m], tw[e]);
+                const u64 v = gl_mul(x[m], tw[e]);
 #endif
-                u32 r = (k1 << Cfg::SH1) | o;
-                smem[lds_addr<Cfg::S>(a, r, c)] = v;
+                smem[lds_addr<Cfg, LOGC>((k1 << Cfg::SH1) | o, c)] = v;
             }
         }
     }
 }
 
 // ---- stage 2: LDS read, second radix, (inner twiddle + LDS write) or final store
-template <int B1, int B2, int B3>
+template <int B1, int B2, int B3, int LOGC, int MODE>
 BFS_HD void ntt_stage2(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid_y) {
-    typedef TileCfg<B1, B2, B3> Cfg;
+    typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     if constexpr (B2 > 0) {
         constexpr int Q = 1 << B2, SG = 16 / Q;
-        const u32 W = ((1u << Cfg::S) << a.logC) >> 4;
-        const TileGeom g = tile_geom<Cfg::S>(a, bid_x, bid_y);
-        u64 x[16];
+        const TileGeom g = tile_geom<Cfg, LOGC, MODE>(a, bid_x, bid_y);
         BFS_UNROLL
-    for (int s = 0; s < SG; ++s) {
-            u32 G = (u32)s * W + tid;
-            u32 c = G & ((1u << a.logC) - 1);
-            u32 rest = G >> a.logC;
-            u32 f1 = rest & ((1u << B1) - 1), f3 = rest >> B1;
+        for (int s = 0; s < SG; ++s) {
+            const u32 G = (u32)s * Cfg::W + tid;
+            const u32 c = G & ((1u << LOGC) - 1);
+            const u32 rest = G >> LOGC;
+            const u32 f1 = rest & ((1u << B1) - 1), f3 = rest >> B1;
+            u64 x[Q];
             BFS_UNROLL
-            for (int d = 0; d < Q; ++d) {
-                u32 r = (f1 << Cfg::SH1) | ((u32)d << Cfg::SH2) | f3;
-                x[s * Q + d] = smem[lds_addr<Cfg::S>(a, r, c)];
-            }
+            for (int d = 0; d < Q; ++d) x[d] = smem[lds_addr<Cfg, LOGC>((f1 << Cfg::SH1) | ((u32)d << Cfg::SH2) | f3, c)];
 #ifndef BFS_ABL_NO_DIF
-            dif<Q>(x + s * Q);
+            dif<Q>(x);
 #endif
             if constexpr (Cfg::U == 2) {
-                final_store<B1, B2, B3, B2>(a, g, x, (u32)s, f1, B1, c, G);
+                final_store<Cfg, LOGC, MODE, B2>(a, g, x, f1, B1, c);
             } else {
-                const u64* tab = (a.mode == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;
+                const u64* tab = (MODE == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;
                 BFS_UNROLL
                 for (int m = 0; m < Q; ++m) {
-                    u32 k2 = perm_digit((u32)m, B2, a.uinv);
-                    u32 e = (f3 * (f1 + (k2 << B1))) & ((1u << Cfg::S) - 1);
-                    u64 v = gl_mul(x[s * Q + m], tab[(u64)e << (a.tb.t_in_log - Cfg::S)]);
-                    u32 r = (f1 << Cfg::SH1) | (k2 << Cfg::SH2) | f3;
-                    smem[lds_addr<Cfg::S>(a, r, c)] = v;
+                    const u32 k2 = perm_digit<B2>(m, a.uinv);
+                    const u32 e = mul24(f3, f1 + (k2 << B1)) & ((1u << Cfg::S) - 1);
+                    const u64 v = gl_mul(x[m], tab[(u64)e << (a.tb.t_in_log - Cfg::S)]);
+                    smem[lds_addr<Cfg, LOGC>((f1 << Cfg::SH1) | (k2 << Cfg::SH2) | f3, c)] = v;
                 }
             }
         }
@@ -449,40 +348,26 @@ BFS_HD void ntt_stage2(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid
 }
 
 // ---- stage 3: LDS read, third radix, final store
-template <int B1, int B2, int B3>
+template <int B1, int B2, int B3, int LOGC, int MODE>
 BFS_HD void ntt_stage3(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid_y) {
-    typedef TileCfg<B1, B2, B3> Cfg;
+    typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     if constexpr (B3 > 0) {
         constexpr int Q = 1 << B3, SG = 16 / Q;
-        const u32 W = ((1u << Cfg::S) << a.logC) >> 4;
-        const TileGeom g = tile_geom<Cfg::S>(a, bid_x, bid_y);
-        u64 x[16];
+        const TileGeom g = tile_geom<Cfg, LOGC, MODE>(a, bid_x, bid_y);
         BFS_UNROLL
-    for (int s = 0; s < SG; ++s) {
-            u32 G = (u32)s * W + tid;
-            u32 c = G & ((1u << a.logC) - 1);
-            u32 rest = G >> a.logC;
-            u32 f1 = rest & ((1u << B1) - 1), f2 = rest >> B1;
+        for (int s = 0; s < SG; ++s) {
+            const u32 G = (u32)s * Cfg::W + tid;
+            const u32 c = G & ((1u << LOGC) - 1);
+            const u32 rest = G >> LOGC;
+            const u32 f1 = rest & ((1u << B1) - 1), f2 = rest >> B1;
+            u64 x[Q];
             BFS_UNROLL
-            for (int d = 0; d < Q; ++d) {
-                u32 r = (f1 << Cfg::SH1) | (f2 << Cfg::SH2) | (u32)d;
-                x[s * Q + d] = smem[lds_addr<Cfg::S>(a, r, c)];
-            }
-            dif<Q>(x + s * Q);
-            final_store<B1, B2, B3, B3>(a, g, x, (u32)s, f1 + (f2 << B1), B1 + B2, c, G);
+            for (int d = 0; d < Q; ++d) x[d] = smem[lds_addr<Cfg, LOGC>((f1 << Cfg::SH1) | (f2 << Cfg::SH2) | (u32)d, c)];
+            dif<Q>(x);
+            final_store<Cfg, LOGC, MODE, B3>(a, g, x, f1 + (f2 << B1), B1 + B2, c);
         }
     }
 }
-
-// elements of LDS a tile needs (including padding)
-inline u32 tile_lds_elems(u32 S, u32 logC, u32 pad_shift, u32 pad_amount) {
-    u32 T = (1u << S) << logC;
-    return T + ((T - 1) >> pad_shift) * pad_amount + pad_amount;
-}
-
-}  // namespace bfs
-
-namespace bfs {
 
 // direct O(n^2) transform for n <= 8 (ntt.py:4-23 evaluated literally); one thread per output element
 struct SmallArgs {

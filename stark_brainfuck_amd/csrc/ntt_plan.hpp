@@ -14,9 +14,7 @@ namespace bfs {
 constexpr u32 NTT_TILE_LOG = 12;      // 4096 elements (32 KiB) per tile in the multi-pass regime
 constexpr u32 NTT_MAX_PASS_BITS = 8;  // digits of a multi-pass plan are <= 2^8 so tiles keep >= 16 columns (128 B segments)
 constexpr u32 NTT_SMALL_LOG = 3;
-#ifndef NTT_WIDE_ACCESS
-#define NTT_WIDE_ACCESS 0
-#endif      // n <= 8 goes through the direct small kernel
+      // n <= 8 goes through the direct small kernel
 
 struct NttPlan {
     u32 log_n = 0;
@@ -120,49 +118,50 @@ inline void ntt_build_coset_tables(const NttPlan& p, u64 shift, CosetHostTables&
     fill_powers(t.s_hi, 1ull << hi_bits, gl_pow(shift, 1ull << p.lo_bits), 1);
 }
 
-// LDS layout and padding per pass, chosen so that both the stage-1 writes and the stage-2 reads of the tile are free of
-// bank conflicts (ds_read_b64: 64 banks x 4 B per 32-lane group; ds_write_b64: 32 banks per 16-lane group).
+// LDS layout per pass (TileCfg in ntt_core.hpp), chosen so that both the stage-1 writes and the stage-2 reads of the tile
+// are free of bank conflicts (ds_read_b64: 64 banks x 4 B per 32-lane group; ds_write_b64: 32 banks per 16-lane group):
 //   column pass  [row][col], +16 words every 256: stage-2 lanes (c = tid & 15, f1 = tid >> 4) of one 32-lane group then fall on
 //                disjoint bank halves (first version: +2 words -> 2-way conflicts on every read)
 //   final pass of a multi-pass plan: lanes run along the ROW index when loading (contiguous HBM rows), so the tile is kept
 //                [col][row] with +1 word per column: writes are consecutive, stage-2 reads (lanes along c) step 2 banks per lane
 //                (first version: [row][col] -> 16-way conflicts on every write, 73 % of LDS cycles, profiles/r01)
 //   single-pass plans (one column): +2 words every 256 rows
-inline void ntt_lds_layout(u32 S, u32 logC, u32 mode, u32& cmajor, u32& pad_shift, u32& pad_amount) {
-    if (mode == PASS_FINAL && logC > 0) { cmajor = 1; pad_shift = S; pad_amount = 1; }
-    else if (mode == PASS_COLUMN) { cmajor = 0; pad_shift = 8; pad_amount = 16; }
-    else { cmajor = 0; pad_shift = 8; pad_amount = 2; }
-}
 
 // fill the per-pass kernel arguments (pointers are whatever address space the caller runs in)
 inline PassArgs ntt_pass_args(const NttPlan& p, u32 t, const u64* in, u64* out, u64 in_stride, u64 out_stride,
                               u64 n_in, const NttTables& tb, bool has_coset, u64 shift, u64 post_scale) {
     PassArgs a{};
+    const bool final_pass = (t + 1 == p.npass);
+    const u32 S = p.pass_bits[t];
     a.in = in; a.out = out;
     a.in_batch_stride = in_stride; a.out_batch_stride = out_stride;
     a.n_in = n_in;
+    a.partial = (t == 0 && n_in < (1ull << p.log_n)) ? 1 : 0;
     a.log_n = p.log_n;
-    a.mode = (t + 1 == p.npass) ? PASS_FINAL : PASS_COLUMN;
-    a.logC = p.logC[t];
     a.pass_index = t;
     a.npass = p.npass;
     a.pass_bits = p.pass_bits[0] | (p.pass_bits[1] << 8) | (p.pass_bits[2] << 16) | (p.pass_bits[3] << 24);
+    u32 done = 0;
+    for (u32 v = 0; v <= t; ++v) done += p.pass_bits[v];
+    if (!final_pass) {
+        a.logL = p.log_n - done;
+        a.lognl = a.logL - p.logC[t];
+        a.tw_shift = p.log_n - done;
+    } else if (p.npass > 1) {
+        a.n1_bits = p.pass_bits[0];
+        for (u32 v = 1; v + 1 < p.npass; ++v) a.mid_bits += p.pass_bits[v];
+        a.logch = a.n1_bits - p.logC[t];
+    }
     a.uinv = p.uinv;
     a.has_coset = (t == 0 && has_coset) ? 1 : 0;
-    a.post_scale = (a.mode == PASS_FINAL) ? post_scale : 1;
+    a.post_scale = final_pass ? post_scale : 1;
     a.tb = tb;
     if (a.has_coset) {
-        u32 S = p.pass_bits[0];
         u32 b1 = S < 4 ? S : 4;
         u32 sh1 = S - b1;
-        u64 stride = (a.mode == PASS_COLUMN) ? ((1ull << (p.log_n - S)) << sh1) : (1ull << sh1);
+        u64 stride = !final_pass ? ((1ull << (p.log_n - S)) << sh1) : (1ull << sh1);
         a.coset_delta = gl_pow(shift, stride);
     }
-    ntt_lds_layout(p.pass_bits[t], a.logC, a.mode, a.lds_cmajor, a.pad_shift, a.pad_amount);
-    // 16-byte paired-lane accesses raise the HBM rate of a pass from 3.2 to 4.4 TB/s but cost ~200 VALU instructions per
-    // tile; the kernels are VALU-bound today (74 % VALU busy, profiles/r01), so they are switched on by NTT_WIDE_ACCESS only
-    a.wide_load = (NTT_WIDE_ACCESS && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && (in_stride & 1) == 0) ? 1 : 0;
-    a.wide_store = (NTT_WIDE_ACCESS && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && (out_stride & 1) == 0) ? 1 : 0;
     return a;
 }
 

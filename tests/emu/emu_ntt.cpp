@@ -10,35 +10,45 @@
 
 using namespace bfs;
 
-template <int B1, int B2, int B3>
+template <int B1, int B2, int B3, int LOGC, int MODE>
 static void run_pass(const PassArgs& a, u32 grid_x, u32 batch) {
-    const u32 S = B1 + B2 + B3;
-    const u32 W = ((1u << S) << a.logC) >> 4;
-    std::vector<u64> smem(tile_lds_elems(S, a.logC, a.pad_shift, a.pad_amount));
+    typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
+    std::vector<u64> smem(Cfg::LDS_WORDS + 2);
     // dense stage-1 -> stage-2 twiddle table, as the kernel builds it in LDS
     std::vector<u64> tw(1u << (B1 + B2));
-    const u64* tab = (B2 > 0 && B3 == 0 && a.mode == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;
+    const u64* tab = (Cfg::U == 2 && MODE == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;
     if (B2 > 0) for (u32 i = 0; i < tw.size(); ++i) tw[i] = tab[(u64)i << (a.tb.t_in_log - (B1 + B2))];
     for (u32 by = 0; by < batch; ++by)
         for (u32 bx = 0; bx < grid_x; ++bx) {
-            RawTile none{};
-            for (u32 t = 0; t < W; ++t) ntt_stage1<B1, B2, B3, 0>(a, smem.data(), tw.data(), t, bx, by, none);
-            if (B2 > 0) for (u32 t = 0; t < W; ++t) ntt_stage2<B1, B2, B3>(a, smem.data(), t, bx, by);
-            if (B3 > 0) for (u32 t = 0; t < W; ++t) ntt_stage3<B1, B2, B3>(a, smem.data(), t, bx, by);
+            for (u32 t = 0; t < (u32)Cfg::W; ++t) ntt_stage1<B1, B2, B3, LOGC, MODE>(a, smem.data(), tw.data(), t, bx, by);
+            if (B2 > 0) for (u32 t = 0; t < (u32)Cfg::W; ++t) ntt_stage2<B1, B2, B3, LOGC, MODE>(a, smem.data(), t, bx, by);
+            if (B3 > 0) for (u32 t = 0; t < (u32)Cfg::W; ++t) ntt_stage3<B1, B2, B3, LOGC, MODE>(a, smem.data(), t, bx, by);
         }
 }
 
-static void dispatch(const PassArgs& a, u32 S, u32 grid_x, u32 batch) {
+template <int MODE>
+static void dispatch_multi(const PassArgs& a, u32 S, u32 grid_x, u32 batch) {
     switch (S) {
-        case 4: run_pass<4, 0, 0>(a, grid_x, batch); break;
-        case 5: run_pass<4, 1, 0>(a, grid_x, batch); break;
-        case 6: run_pass<4, 2, 0>(a, grid_x, batch); break;
-        case 7: run_pass<4, 3, 0>(a, grid_x, batch); break;
-        case 8: run_pass<4, 4, 0>(a, grid_x, batch); break;
-        case 9: run_pass<4, 4, 1>(a, grid_x, batch); break;
-        case 10: run_pass<4, 4, 2>(a, grid_x, batch); break;
-        case 11: run_pass<4, 4, 3>(a, grid_x, batch); break;
-        case 12: run_pass<4, 4, 4>(a, grid_x, batch); break;
+        case 4: run_pass<4, 0, 0, 8, MODE>(a, grid_x, batch); break;
+        case 5: run_pass<4, 1, 0, 7, MODE>(a, grid_x, batch); break;
+        case 6: run_pass<4, 2, 0, 6, MODE>(a, grid_x, batch); break;
+        case 7: run_pass<4, 3, 0, 5, MODE>(a, grid_x, batch); break;
+        case 8: run_pass<4, 4, 0, 4, MODE>(a, grid_x, batch); break;
+        default: abort();
+    }
+}
+
+static void dispatch_single(const PassArgs& a, u32 S, u32 batch) {
+    switch (S) {
+        case 4: run_pass<4, 0, 0, 0, PASS_FINAL>(a, 1, batch); break;
+        case 5: run_pass<4, 1, 0, 0, PASS_FINAL>(a, 1, batch); break;
+        case 6: run_pass<4, 2, 0, 0, PASS_FINAL>(a, 1, batch); break;
+        case 7: run_pass<4, 3, 0, 0, PASS_FINAL>(a, 1, batch); break;
+        case 8: run_pass<4, 4, 0, 0, PASS_FINAL>(a, 1, batch); break;
+        case 9: run_pass<4, 4, 1, 0, PASS_FINAL>(a, 1, batch); break;
+        case 10: run_pass<4, 4, 2, 0, PASS_FINAL>(a, 1, batch); break;
+        case 11: run_pass<4, 4, 3, 0, PASS_FINAL>(a, 1, batch); break;
+        case 12: run_pass<4, 4, 4, 0, PASS_FINAL>(a, 1, batch); break;
         default: abort();
     }
 }
@@ -73,7 +83,9 @@ extern "C" int emu_gl_ntt(const u64* in, u64 n_in, u64 in_stride, u64* out, u64 
         PassArgs a = ntt_pass_args(p, t, src, dst, first ? in_stride : n, last ? out_stride : n, first ? n_in : n, tb,
                                    coset, shift, post_scale);
         u32 grid_x = (u32)((n >> p.pass_bits[t]) >> p.logC[t]);
-        dispatch(a, p.pass_bits[t], grid_x, batch);
+        if (p.npass == 1) dispatch_single(a, p.pass_bits[0], batch);
+        else if (last) dispatch_multi<PASS_FINAL>(a, p.pass_bits[t], grid_x, batch);
+        else dispatch_multi<PASS_COLUMN>(a, p.pass_bits[t], grid_x, batch);
     }
     return 0;
 }
