@@ -10,14 +10,25 @@ template <int B1, int B2, int B3, int LOGC, int MODE>
 __global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) u64 smem[];
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
-    u64* tw = smem + ((Cfg::LDS_WORDS + 1) & ~1);
+    u64* tw = smem + (B2 > 0 ? ((Cfg::LDS_WORDS + 1) & ~1) : 0);
     if constexpr (Cfg::U >= 2) {
         // dense copy of the stage-1 -> stage-2 twiddles w_M^e, M = 2^(B1+B2) <= 256 (n^-1 folded in when it is the last one)
         const u64* tab = (Cfg::U == 2 && MODE == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;
         for (u32 i = threadIdx.x; i < (1u << (B1 + B2)); i += blockDim.x) tw[i] = tab[(u64)i << (a.tb.t_in_log - (B1 + B2))];
         __syncthreads();
     }
-    ntt_stage1<B1, B2, B3, LOGC, MODE>(a, smem, tw, threadIdx.x, blockIdx.x, blockIdx.y);
+    const u64* rowtw = nullptr;
+    if constexpr (MODE == PASS_COLUMN) {
+        if (a.tb.row != nullptr) {
+            // this tile's row of the inter-pass twiddle table -> LDS (one coalesced 2^S-entry read per workgroup)
+            u64* rw = tw + Cfg::TW_WORDS;
+            const u64 K = a.pass_index ? digit_reverse((u64)(blockIdx.x >> a.lognl), a.pass_bits, 0, (int)a.pass_index - 1) : 0;
+            for (u32 i = threadIdx.x; i < (1u << Cfg::S); i += blockDim.x) rw[i] = a.tb.row[(K << Cfg::S) + i];
+            rowtw = rw;
+            __syncthreads();
+        }
+    }
+    ntt_stage1<B1, B2, B3, LOGC, MODE>(a, smem, tw, rowtw, threadIdx.x, blockIdx.x, blockIdx.y);
     if constexpr (B2 > 0) {
         __syncthreads();
         ntt_stage2<B1, B2, B3, LOGC, MODE>(a, smem, threadIdx.x, blockIdx.x, blockIdx.y);
@@ -33,7 +44,8 @@ __global__ void ntt_small_kernel(const SmallArgs a) { ntt_small_body(a, threadId
 template <int B1, int B2, int B3, int LOGC, int MODE>
 static int launch_tile(const PassArgs& a, u32 grid_x, u32 batch, hipStream_t stream) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
-    const size_t lds = (B2 > 0) ? (size_t)(((Cfg::LDS_WORDS + 1) & ~1) + Cfg::TW_WORDS) * sizeof(u64) : 0;
+    const size_t row_words = (MODE == PASS_COLUMN && a.tb.row != nullptr) ? (1u << Cfg::S) : 0;
+    const size_t lds = (size_t)((B2 > 0 ? ((Cfg::LDS_WORDS + 1) & ~1) + Cfg::TW_WORDS : 0) + row_words) * sizeof(u64);
     hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, LOGC, MODE>), dim3(grid_x, batch), dim3(Cfg::W), lds, stream, a);
     BFS_HIP(hipGetLastError());
     return BFS_OK;
@@ -75,7 +87,27 @@ static int dispatch_tile(const NttPlan& p, u32 t, const PassArgs& a, u32 grid_x,
     return dispatch_multi<PASS_COLUMN>(a, p.pass_bits[t], grid_x, batch, stream);
 }
 
-enum { TBL_W_LO = 1, TBL_W_HI, TBL_T_IN, TBL_T_IN_LAST, TBL_S_LO, TBL_S_HI };
+enum { TBL_W_LO = 1, TBL_W_HI, TBL_T_IN, TBL_T_IN_LAST, TBL_S_LO, TBL_S_HI, TBL_ROW };
+
+// row table of column pass t >= 1: row[K * 2^S + r] = w_{N_t}^(K r), N_t = 2^done <= 2^16 (512 KiB, L2 resident)
+static int get_row_table(const NttPlan& p, u32 t, u64 root, const u64** d_row) {
+    *d_row = nullptr;
+    u32 done = 0;
+    for (u32 v = 0; v <= t; ++v) done += p.pass_bits[v];
+    if (t == 0 || t + 1 == p.npass || done > 16) return BFS_OK;
+    const u64 key = ((u64)p.log_n << 8) | TBL_ROW;
+    if (cached_table_lookup(root, key, t, d_row)) return BFS_OK;
+    const u32 S = p.pass_bits[t];
+    const u64 wN = gl_pow(root, 1ull << (p.log_n - done));
+    std::vector<u64> host((size_t)1 << done);
+    u64 wK = 1;                                  // w_N^K
+    for (u64 K = 0; K < (1ull << (done - S)); ++K) {
+        u64 v = 1;
+        for (u64 r = 0; r < (1ull << S); ++r) { host[(K << S) + r] = v; v = gl_mul(v, wK); }
+        wK = gl_mul(wK, wN);
+    }
+    return cached_table(root, key, t, host.data(), host.size(), d_row);
+}
 
 static int get_tables(const NttPlan& p, u64 root, u64 shift, u64 post_scale, NttTables& tb) {
     tb = NttTables{};
@@ -142,6 +174,7 @@ int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_str
     }
     for (u32 t = 0; t < p.npass; ++t) {
         const bool first = t == 0, last = t + 1 == p.npass;
+        BFS_TRY(get_row_table(p, t, root, &tb.row));
         PassArgs a = ntt_pass_args(p, t, first ? d_in : ws, last ? d_out : ws, first ? in_stride : n, last ? out_stride : n,
                                    first ? n_in : n, tb, shift != 1, shift, post_scale);
         u32 grid_x = (u32)((n >> p.pass_bits[t]) >> p.logC[t]);

@@ -90,6 +90,7 @@ struct NttTables {
     const u64* t_in_last;  // Omega^i * post_scale (used for the last inner twiddle of the final pass)
     const u64* s_lo;       // coset shift s: s^i, i < 2^lo_bits (null when no coset)
     const u64* s_hi;       // s^(i * 2^lo_bits)
+    const u64* row;        // column pass t >= 1 with N_t <= 2^16: row[K * 2^S + r] = w_{N_t}^(K r)  (null: use the chain)
 };
 
 enum { PASS_COLUMN = 0, PASS_FINAL = 1 };
@@ -181,6 +182,7 @@ struct TileGeom {
     u64* out;
     u64 row0;         // COLUMN: h*2^(S+logL) + c0 ; FINAL multi: ((c0 << mid_bits) + mid) << S ; single: 0
     u64 kbase;        // COLUMN: exponent step of the inter-pass twiddle ; FINAL: c0 + (kmid << n1_bits)
+    u64 K;            // COLUMN: digit-reversed previous output digits (row of the twiddle table)
 };
 
 template <typename Cfg, int LOGC, int MODE>
@@ -194,6 +196,7 @@ BFS_HD TileGeom tile_geom(const PassArgs& a, u32 bid_x, u32 bid_y) {
         g.row0 = (h << (Cfg::S + a.logL)) + c0;
         const u64 K = a.pass_index ? digit_reverse(h, a.pass_bits, 0, (int)a.pass_index - 1) : 0;
         g.kbase = (K << a.tw_shift) & ((1ull << a.log_n) - 1);
+        g.K = K;
     } else if (a.npass > 1) {
         const u64 c0 = (u64)(bid_x & ((1u << a.logch) - 1)) << LOGC;
         const u64 mid = bid_x >> a.logch;
@@ -204,6 +207,7 @@ BFS_HD TileGeom tile_geom(const PassArgs& a, u32 bid_x, u32 bid_y) {
         g.row0 = 0;
         g.kbase = 0;
     }
+    if constexpr (MODE != PASS_COLUMN) g.K = 0;
     return g;
 }
 
@@ -234,7 +238,7 @@ BFS_HD void final_store(const PassArgs& a, const TileGeom& g, const u64* x, u32 
 // ---- stage 1: global load (+ coset / inter-pass twiddle), first radix, inner twiddle, LDS write (or final store)
 // tw: dense inner-twiddle table for the stage 1 -> 2 exchange (2^(B1+B2) entries, in LDS on the GPU)
 template <int B1, int B2, int B3, int LOGC, int MODE>
-BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, const u64* tw, u32 tid, u32 bid_x, u32 bid_y) {
+BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, const u64* tw, const u64* rowtw, u32 tid, u32 bid_x, u32 bid_y) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     constexpr int Q = 1 << B1, SG = 16 / Q;
     const TileGeom g = tile_geom<Cfg, LOGC, MODE>(a, bid_x, bid_y);
@@ -271,7 +275,11 @@ BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, const u64* tw, u32 tid, u32
             }
         }
 #ifndef BFS_ABL_NO_CHAIN
-        if (a.pass_index > 0 || a.has_coset) {
+        if (MODE == PASS_COLUMN && rowtw != nullptr) {
+            // middle pass: the inter-pass twiddles of this tile are one row of a table (K is the same for the whole tile)
+            BFS_UNROLL
+            for (int d = 0; d < Q; ++d) x[d] = gl_mul(x[d], rowtw[((u32)d << Cfg::SH1) | o]);
+        } else if (a.pass_index > 0 || a.has_coset) {
             // factor of row r = (d << SH1) | o is beta^r = gamma * delta^d: a geometric chain per thread
             u64 gam, del;
             if (a.pass_index > 0) {
