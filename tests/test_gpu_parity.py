@@ -477,3 +477,77 @@ def test_fri_length_assert(sb):
 def test_smoke_entry_point(sb):
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+# ------------------------------------------------------------------------------------------------ plumbing entry points
+def test_c_abi_plumbing_and_elementwise(sb, oracle):
+    """bfs_gl_scale / bfs_gl_mul_pointwise / bfs_gl_batch_inverse / memcpy_d2d / memset / events, straight through the C ABI."""
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.device import DeviceBuffer, synchronize
+    lib = _lib.load()
+    n = 5000                                   # not a power of two on purpose
+    a, b = oracle.felt_array(SEED + 1, 0, n), oracle.felt_array(SEED + 2, 0, n)
+    da, db, dc = DeviceBuffer.from_numpy(a), DeviceBuffer.from_numpy(b), DeviceBuffer(n)
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    _lib.check(lib.bfs_event_create(ctypes.byref(e0))); _lib.check(lib.bfs_event_create(ctypes.byref(e1)))
+    _lib.check(lib.bfs_event_record(e0, 0))
+    _lib.check(lib.bfs_gl_mul_pointwise(da.ptr, db.ptr, dc.ptr, n, 0))
+    _lib.check(lib.bfs_event_record(e1, 0))
+    ms = ctypes.c_float()
+    _lib.check(lib.bfs_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+    assert ms.value >= 0
+    assert (dc.to_numpy() == oracle.hadamard(a, b)).all()
+    _lib.check(lib.bfs_gl_scale(da.ptr, dc.ptr, n, n, 1, 7, 0))
+    assert (dc.to_numpy() == oracle.scale(7, a)).all()
+    a1 = np.where(a == 0, np.uint64(1), a)
+    da1 = DeviceBuffer.from_numpy(a1)
+    _lib.check(lib.bfs_gl_batch_inverse(da1.ptr, dc.ptr, n, 0))
+    assert (dc.to_numpy() == oracle.batch_inverse(a1)).all()
+    a1[17] = 0
+    with pytest.raises(AssertionError, match="batch inverse does not work when input contains a zero"):
+        _lib.check(lib.bfs_gl_batch_inverse(DeviceBuffer.from_numpy(a1).ptr, dc.ptr, n, 0))
+    _lib.check(lib.bfs_memcpy_d2d(dc.ptr, db.ptr, n * 8, 0))
+    assert (dc.to_numpy() == b).all()
+    _lib.check(lib.bfs_memset(dc.ptr, 0, n * 8, 0))
+    synchronize(0)
+    assert not dc.to_numpy().any()
+    cnt = ctypes.c_int()
+    _lib.check(lib.bfs_device_count(ctypes.byref(cnt)))
+    assert cnt.value >= 1
+    lib.bfs_event_destroy(e0); lib.bfs_event_destroy(e1)
+    # HBM-resident arrays through the mirror: nothing is copied to the host
+    F = sb.BaseField.main()
+    arr = sb.BaseArray.from_numpy(oracle.felt_array(SEED, 0, 1 << 12))
+    w = F.primitive_nth_root(1 << 12)
+    out = sb.ntt(w, arr)
+    assert isinstance(out, sb.BaseArray) and (sb.intt(w, out).to_numpy() == arr.to_numpy()).all()
+    inv = sb.batch_inverse(sb.BaseArray.from_numpy(a1 + np.uint64(a1[17] == 0)))
+    assert isinstance(inv, sb.BaseArray)
+
+
+def test_salted_merkle_over_zipped_tuples(sb, oracle, monkeypatch):
+    """leaf = tuple of one extension and several base elements, as BrainfuckStark zips its codewords
+    (brainfuck_stark.py:178-180); preimages come from the native emitter, hashing from the GPU; checked against the oracle."""
+    from stark_brainfuck_amd import salted_merkle
+    ctr = [0]
+
+    def fake_urandom(k):
+        ctr[0] += 1
+        return hashlib.shake_256(b"zip" + ctr[0].to_bytes(8, "little")).digest(k)
+    monkeypatch.setattr(salted_merkle, "urandom", fake_urandom)
+    XF = sb.ExtensionField.main()
+    BF = XF.modulus.coefficients[0].field
+    n, cols = 16, 5
+    leaves, oleaves = [], []
+    for i in range(n):
+        x = [oracle.felt(SEED + 31, 3 * i + k) for k in range(3)]
+        bs = [oracle.felt(SEED + 32 + j, i) for j in range(cols)]
+        leaves.append(tuple([XF.from_limbs(x)] + [sb.BaseFieldElement(v, BF) for v in bs]))
+        oleaves.append(tuple([oracle.make_xfe(x)] + [oracle.make_bfe(v, internal=True) for v in bs]))
+    tree = sb.SaltedMerkle(leaves)
+    salts = [hashlib.shake_256(b"zip" + (i + 1).to_bytes(8, "little")).digest(24) for i in range(n)]
+    ref = oracle.MerkleOracle([oracle.salted_leaf_bytes(l, s) for l, s in zip(oleaves, salts)])
+    assert tree.root() == ref.root()
+    salt, path = tree.open(5)
+    assert salt == salts[5] and path == ref.open(5)
+    assert sb.SaltedMerkle.verify(tree.root(), 5, salt, path, leaves[5])
