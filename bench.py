@@ -10,7 +10,10 @@ timed over exactly K steps between barrier + device synchronisation on both side
 Extra keys on the same JSON line:
     roofline      dominant kernel (the NTT tile kernel) vs the 8 TB/s HBM roofline, from HIP events on the kernel's stream
     cpu_baseline  the CPU oracle (oracle/gl_oracle.c, plain C port of ntt.py, 1 core) on a bounded sample, rank 0, N=1 only
-    fri_prove_ms  Fri.prove on a random degree-2^18 codeword, expansion 4 (config 3), through the C ABI, median of 5
+    fri_prove     Fri.prove on a random degree-2^18 codeword, expansion 4 (config 3), through the C ABI, median of 5;
+                  fri_prove_2p24: the same at N = 2^24 (degree 2^22)
+Before the W warmup steps the device is spun up with untimed steps for --spinup-ms of wall time: after idle the
+first ~10 steps run ~10 % slower while the clocks ramp, and W is chosen by the caller.
 Nothing here reads /root/reference.
 """
 import argparse
@@ -48,6 +51,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=24)
     ap.add_argument("--columns", type=int, default=8, help="columns per GPU")
+    ap.add_argument("--spinup-ms", type=float, default=300.0,
+                    help="untimed steps run before the W warmup steps until this much wall time has passed, so that the "
+                         "device clocks have ramped (the first ~10 steps after idle run ~10 %% slower); 0 disables")
     ap.add_argument("--no-fri", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run round-trip check and root gather (PMC collection runs)")
@@ -94,6 +100,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    spin_t0, spin_steps = time.perf_counter(), 0
+    while args.spinup_ms > 0 and (time.perf_counter() - spin_t0) * 1e3 < args.spinup_ms:
+        step()
+        _lib.check(lib.bfs_stream_synchronize(stream))
+        spin_steps += 1
     for _ in range(args.warmup):
         step()
     ev0, ev1 = ctypes.c_void_p(), ctypes.c_void_p()
@@ -159,6 +170,7 @@ def main():
         "config": {"workload": "forward NTT, 2^%d-point base-field columns, %d columns per GPU resident in HBM (BASELINE config 5 shape)" % (log_n, cols),
                    "log_n": log_n, "columns_per_gpu": cols, "parallelism": "columns sharded %d-way, no data-path collective" % world},
         "algorithmic_GBps": 16.0 * elems / elapsed / 1e9,
+        "clock_spinup": {"ms": args.spinup_ms, "untimed_steps": spin_steps},
     }
     if rank == 0:
         # dominant kernel = ntt_tile_kernel (npass launches per step); algorithmic bytes of one launch =
@@ -178,8 +190,9 @@ def main():
                             "traffic": traffic, "kernel": "ntt_tile_kernel<4,4,0>", "launches_per_step": npass,
                             "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch}
         if not args.no_fri:
-            line["fri_prove"] = bench_fri(lib, _lib, stream)
+            line["fri_prove"] = bench_fri(lib, _lib, stream, 18)
             line["fri_prove_ms"] = line["fri_prove"]["ms"]
+            line["fri_prove_2p24"] = bench_fri(lib, _lib, stream, 22)
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(log_n)
         print(json.dumps(line), flush=True)
@@ -188,10 +201,11 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_fri(lib, _lib, stream):
-    """config 3: Fri.prove on a degree-2^18 extension codeword, expansion 4, 4 colinearity tests, fresh proof stream."""
+def bench_fri(lib, _lib, stream, log_d):
+    """config 3 (log_d = 18) and its 2^24 sibling: Fri.prove on a degree-2^log_d extension codeword, expansion 4,
+    4 colinearity tests, fresh proof stream."""
     from stark_brainfuck_amd.device import DeviceBuffer
-    log_d, expansion, t = 18, 4, 4
+    expansion, t = 4, 4
     d, N = 1 << log_d, (1 << log_d) * expansion
     log_N = N.bit_length() - 1
     omega = lib.bfs_gl_primitive_root(log_N)
