@@ -133,7 +133,8 @@ void bfs_xfe_sample(const uint8_t* bytes, size_t len, uint64_t out[3]);
  * Tree layout = the reference's `nodes` list (merkle.py:26-44): 2*npo2 digests of 64 bytes, npo2 = next power of
  * two >= n, leaf i at index npo2 + i, parent k = BLAKE2b-512(nodes[2k] || nodes[2k+1]), root at index 1.  Index 0
  * and the slots of absent leaves are not written (the reference keeps 32 zero bytes there; the parent of an absent
- * leaf hashes those 32 zero bytes, which these kernels reproduce).  d_nodes must hold 2*npo2*64 bytes.
+ * leaf hashes those 32 zero bytes, which these kernels reproduce).  d_nodes must hold 2*npo2*64 bytes and be 16-byte aligned
+ * (BFS_ERR_BAD_ARG otherwise).
  *   bfs_merkle_build_xfe   Merkle(codeword) over ExtensionFieldElement leaves   merkle.py:8-41 (leaf = blake2b(pickle.dumps(e)))
  *   bfs_merkle_build_bfe   same over BaseFieldElement leaves (stand-alone BaseField instance)
  *   bfs_merkle_build_bytes same over caller-pickled leaves: message i = lengths[i] bytes at d_data + 8*word_offsets[i]

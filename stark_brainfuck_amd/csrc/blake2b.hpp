@@ -22,18 +22,34 @@ constexpr u64 B2_IV0 = 0x6a09e667f3bcc908ULL, B2_IV1 = 0xbb67ae8584caa73bULL, B2
               B2_IV6 = 0x1f83d9abfb41bd6bULL, B2_IV7 = 0x5be0cd19137e2179ULL;
 constexpr u64 B2_PARAM0 = 0x01010040ULL;  // digest_length 64, key_length 0, fanout 1, depth 1
 
-BFS_HD u64 rotr64(u64 x, int r) { return (x >> r) | (x << (64 - r)); }
+// rotate right by a compile-time amount.  On gfx950 a 64-bit rotation is two v_alignbit_b32 (a funnel shift of the
+// two halves); the generic shift/or form compiles to three or four instructions, and the rotations are ~1/3 of G.
+template <int R>
+BFS_HD u64 rotr64(u64 x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    if constexpr (R == 32) {
+        return ((u64)lo << 32) | hi;
+    } else if constexpr (R < 32) {
+        return ((u64)__builtin_amdgcn_alignbit(lo, hi, R) << 32) | __builtin_amdgcn_alignbit(hi, lo, R);
+    } else {
+        return ((u64)__builtin_amdgcn_alignbit(hi, lo, R - 32) << 32) | __builtin_amdgcn_alignbit(lo, hi, R - 32);
+    }
+#else
+    return (x >> R) | (x << (64 - R));
+#endif
+}
 
 #define BFS_B2_G(a, b, c, d, x, y)          \
     do {                                    \
         a = a + b + (x);                    \
-        d = rotr64(d ^ a, 32);              \
+        d = rotr64<32>(d ^ a);              \
         c = c + d;                          \
-        b = rotr64(b ^ c, 24);              \
+        b = rotr64<24>(b ^ c);              \
         a = a + b + (y);                    \
-        d = rotr64(d ^ a, 16);              \
+        d = rotr64<16>(d ^ a);              \
         c = c + d;                          \
-        b = rotr64(b ^ c, 63);              \
+        b = rotr64<63>(b ^ c);              \
     } while (0)
 
 #define BFS_B2_ROUND(s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10, s11, s12, s13, s14, s15) \

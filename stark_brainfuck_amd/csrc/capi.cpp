@@ -73,13 +73,24 @@ int bfs_gl_batch_inverse(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void
     return batch_inverse_launch(d_in, d_out, n, (hipStream_t)stream);
 }
 
+static int check_nodes(const void* d_nodes) {
+    if (((uintptr_t)d_nodes & 15) != 0) {
+        set_error("d_nodes must be 16-byte aligned");
+        return BFS_ERR_BAD_ARG;
+    }
+    return BFS_OK;
+}
+
 int bfs_merkle_build_xfe(const uint64_t* d_limbs, uint64_t limb_stride, uint64_t n, uint8_t* d_nodes, void* stream) {
+    BFS_TRY(check_nodes(d_nodes));
     return merkle_build_xfe_launch(d_limbs, limb_stride, n, (u64*)d_nodes, (hipStream_t)stream);
 }
 int bfs_merkle_build_bfe(const uint64_t* d_values, uint64_t n, uint8_t* d_nodes, void* stream) {
+    BFS_TRY(check_nodes(d_nodes));
     return merkle_build_bfe_launch(d_values, n, (u64*)d_nodes, (hipStream_t)stream);
 }
 int bfs_merkle_build_bytes(const uint8_t* d_data, const uint64_t* d_word_offsets, const uint32_t* d_lengths, uint64_t n, uint8_t* d_nodes, void* stream) {
+    BFS_TRY(check_nodes(d_nodes));
     return merkle_build_bytes_launch((const u64*)d_data, d_word_offsets, d_lengths, n, (u64*)d_nodes, (hipStream_t)stream);
 }
 int bfs_merkle_open(const uint8_t* d_nodes, uint32_t depth, uint64_t index, uint8_t* h_path, void* stream) {

@@ -101,13 +101,30 @@ BFS_HD void merkle_leaf_bfe_body(const u64* values, u64 i, u64* stage, u32 strid
 // parent of two children given as 8-word digests; `present` = how many of the two child slots hold a digest
 // (0, 1 or 2).  An absent leaf slot is the reference's 32 zero bytes (merkle.py:26), so the preimage is
 // 64*present + 32*(2-present) bytes long.  Present children are always a prefix.
+// eight digest words; on the device as four 16-byte accesses (a thread-per-hash kernel reads at a 128-byte lane stride,
+// and halving the number of load instructions took the inner-level kernel from 0.151 to 0.128 ms per 2^21 parents,
+// tools/microbench/merkle_mb.hip).  Node arrays are 16-byte aligned (checked at the C ABI).
+BFS_HD void load_digest(const u64* p, u64* m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef u64 u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2* q = (const u64x2*)p;
+    BFS_UNROLL
+    for (int j = 0; j < 4; ++j) {
+        const u64x2 v = q[j];
+        m[2 * j] = v.x;
+        m[2 * j + 1] = v.y;
+    }
+#else
+    for (int j = 0; j < 8; ++j) m[j] = p[j];
+#endif
+}
+
 BFS_HD void merkle_parent_body(const u64* left, const u64* right, int present, u64* out) {
     u64 m[16];
     BFS_UNROLL
-    for (int j = 0; j < 8; ++j) {
-        m[j] = present >= 1 ? left[j] : 0;
-        m[8 + j] = present >= 2 ? right[j] : 0;
-    }
+    for (int j = 0; j < 16; ++j) m[j] = 0;
+    if (present >= 1) load_digest(left, m);
+    if (present >= 2) load_digest(right, m + 8);
     u64 h[8];
     blake2b_init(h);
     blake2b_compress(h, m, (u64)(64 * present + 32 * (2 - present)), true);
