@@ -37,15 +37,39 @@ constexpr u64 cx_pow2(int k) {
     return r;
 }
 
-// x * 2^K mod p.  Written as a multiplication by the compile-time constant 2^K mod p: hipcc drops the partial products of
-// the constant's zero limbs, which measured fewer instructions than an explicit shift-and-fold formulation.
+// x * 2^K mod p for canonical x, 0 <= K < 96; canonical result.  With K = 32 q + r and (y2:y1:y0) = x << r (96 bits, y2 < 2^r),
+// 2^64 = 2^32 - 1 and 2^96 = -1 (mod p) give
+//   q = 1:  2^32 (y0 + y1) - (y1 + y2)          q = 2:  2^32 y0 - ((y2:y1) + y0)
+// where both operands of the subtraction are canonical by construction (2^32 s mod p = (s_lo : -carry) for a 33-bit s), so
+// the whole product is three funnel shifts, two or three additions and one modular subtraction: 10-12 VALU instructions
+// instead of 20-26 for a multiplication by the constant 2^K mod p.  For q = 0 the constant multiplication (13) is kept:
+// hipcc drops the partial products of the constant's zero limb and the shift-and-fold form is no shorter.
 template <int K>
 BFS_HD u64 mul_pow2(u64 x) {
+    static_assert(K >= 0 && K < 96, "rotation amount");
+    constexpr int q = K / 32, r = K % 32;
     if constexpr (K == 0) {
         return x;
-    } else {
+    } else if constexpr (q == 0) {
         constexpr u64 c = cx_pow2(K);
         return gl_mul(x, c);
+    } else {
+        const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+        u32 y0 = x0, y1 = x1, y2 = 0;
+        if constexpr (r != 0) {
+            y0 = x0 << r;
+            y1 = (u32)(x >> (32 - r));
+            y2 = x1 >> (32 - r);
+        }
+        if constexpr (q == 1) {
+            const u64 s = (u64)y0 + y1;
+            const u64 w = ((u64)(u32)s << 32) | (u32)(0u - (u32)(s >> 32));
+            const u64 u = (u64)y1 + y2;
+            return gl_sub(w, u);
+        } else {
+            const u64 t = (((u64)y2 << 32) | y1) + y0;
+            return gl_sub((u64)y0 << 32, t);
+        }
     }
 }
 
@@ -312,7 +336,9 @@ BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, const u64* tw, const u64* r
 #ifdef BFS_ABL_NO_INNER
                 const u64 v = x[m] + e;
 #else
-                const u64 v = gl_mul(x[m], tw[e]);
+                // register 0 holds output digit 0: its twiddle is w^0, which is 1 unless n^-1 is folded into the table
+                const bool unit = (m == 0) && !(Cfg::U == 2 && MODE == PASS_FINAL);
+                const u64 v = unit ? x[m] : gl_mul(x[m], tw[e]);
 #endif
                 smem[lds_addr<Cfg, LOGC>((k1 << Cfg::SH1) | o, c)] = v;
             }
