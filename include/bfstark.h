@@ -96,7 +96,13 @@ int bfs_gl_batch_inverse(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void
  * with SHAKE256.  Objects are built through handles (opaque, valid for the lifetime of the stream); building the
  * same handle into several containers reproduces Python's shared-object memoisation.
  *   bfs_ps_obj_xfe  : ExtensionFieldElement whose coefficients live in the xfield's own BaseField (extension_field.py:88-98)
- *   bfs_ps_obj_bfe  : BaseFieldElement; internal_field != 0 -> same BaseField instance as the xfield's coefficients
+ *   bfs_ps_obj_bfe  : BaseFieldElement pointing at BaseField instance `field_id`: 1 = the instance inside the xfield's
+ *                     modulus, 0 = a second BaseField.main() instance, 2.. = further instances (the reference creates one
+ *                     per class that calls BaseField.main(): vm.py:70, brainfuck_stark.py:21; pickle writes each out once)
+ *   bfs_ps_obj_xfe_from : ExtensionFieldElement over explicit coefficient objects (handles of bfs_ps_obj_bfe, leading one
+ *                     non-zero): for elements that share BaseFieldElement objects with other elements or whose coefficients
+ *                     point at a foreign BaseField instance -- both happen in the reference (univariate.py:23-27 returns the
+ *                     other operand's polynomial when one summand is zero)
  *   bfs_ps_push                ProofStream.push                ip.py:9-10
  *   bfs_ps_serialize(count)    pickle.dumps(objects[:count])   ip.py:18-19,24-25 (count >= #objects: the whole stream);
  *                              two-call pattern: pass out = NULL to query *length
@@ -107,7 +113,8 @@ void bfs_ps_free(void* ps);
 uint64_t bfs_ps_obj_bytes(void* ps, const uint8_t* data, size_t len);
 uint64_t bfs_ps_obj_int(void* ps, uint64_t value);
 uint64_t bfs_ps_obj_xfe(void* ps, const uint64_t limbs[3]);
-uint64_t bfs_ps_obj_bfe(void* ps, uint64_t value, int internal_field);
+uint64_t bfs_ps_obj_bfe(void* ps, uint64_t value, int field_id);
+uint64_t bfs_ps_obj_xfe_from(void* ps, const uint64_t* coefficient_handles, size_t n);
 uint64_t bfs_ps_obj_list(void* ps, const uint64_t* handles, size_t n);
 uint64_t bfs_ps_obj_tuple(void* ps, const uint64_t* handles, size_t n);
 int bfs_ps_push(void* ps, uint64_t handle);
@@ -168,6 +175,10 @@ void bfs_fri_session_free(void* session);
 int bfs_fri_commit(void* session, void* ps, const uint64_t* d_codeword, uint64_t limb_stride, uint32_t log_n, uint64_t offset,
                    uint64_t omega, uint32_t expansion_factor, void* stream);
 int bfs_fri_query(void* session, void* ps, uint32_t num_colinearity_tests, uint64_t* h_top_level_indices, void* stream);
+/* Tells the session that element `index` of round `round`'s codeword already exists in the transcript as object
+ * `element_handle`: BrainfuckStark.prove pushes leaves of the combination codeword before Fri.prove opens the same
+ * list (brainfuck_stark.py:325-333), and pickle writes a repeated object as a back-reference.  Call before bfs_fri_query. */
+int bfs_fri_session_alias(void* session, void* ps, uint32_t round, uint64_t index, uint64_t element_handle);
 int bfs_fri_prove(void* ps, const uint64_t* d_codeword, uint64_t limb_stride, uint32_t log_n, uint64_t offset, uint64_t omega,
                   uint32_t expansion_factor, uint32_t num_colinearity_tests, uint64_t* h_top_level_indices, void* stream);
 /* wall-clock breakdown (ms) of the last commit/query on the calling thread: rounds, last codeword, Fiat-Shamir + sampling,
@@ -176,6 +187,43 @@ void bfs_fri_last_timing(double out[6]);
 uint32_t bfs_fri_session_rounds(void* session);
 int bfs_fri_session_round(void* session, uint32_t round, const uint64_t** d_codeword, uint64_t* length, uint64_t* limb_stride,
                           const uint8_t** d_nodes, uint8_t h_root[64]);
+
+/* ---- STARK prover kernels around the transforms ------------------------------------------ */
+/*
+ * Codewords over the FRI domain x_i = offset * omega^i, i < n = 2^log_n, are column-major in HBM: base column c at
+ * d_base + c*n, extension column c as three limb planes at d_ext + (3c + limb)*n.
+ *
+ * bfs_poly_randomize  Table.interpolate_columns with one randomizer (table.py:112-136): d_coeffs holds `batch`
+ *     polynomials f0 of h coefficients each (the INTT of a trace column over the omicron subgroup), `stride` >= h+1
+ *     apart.  Each becomes the unique interpolant of degree <= h that also takes the value h_values[b] at `point`
+ *     (omega of the FRI domain): f = f0 + c (X^h - 1), c = (value - f0(point)) / (point^h - 1).  Extension columns are
+ *     passed as three base polynomials with the three limbs of the random value.  Synchronises the stream.
+ * bfs_air_quotients   Table.all_quotients (table.py:148-168, 176-236, 249-281) of table 0..4 = processor,
+ *     instruction, memory, input, output (constraints: processor_table.py:51-327, instruction_table.py:27-165,
+ *     memory_table.py:45-170, io_table.py:32-75; generated into csrc/air_generated.hpp from stark_brainfuck_amd/air.py).
+ *     Writes bfs_air_num_quotients(table) extension codewords (boundary, transition, terminal order) to d_out, 3n words
+ *     each.  h_challenges: 11 x 3 limbs (a b c d e f alpha beta gamma delta eta), h_terminals: 5 x 3 limbs
+ *     (brainfuck_stark.py:103-109), h_params: iota^(height - length) for the input/output tables (io_table.py:58-60), else NULL.
+ *     height = padded table height (0 allowed: the transition quotients are then 0, table.py:181-184),
+ *     unit_distance = n / height (0 when height is 0), omicron_inv = inverse of the subgroup generator.
+ * bfs_difference_quotient   PermutationArgument.quotient (permutation_argument.py:9-18): (lhs - rhs) / (x - 1).
+ * bfs_combination     the non-linear combination codeword (brainfuck_stark.py:236-300):
+ *     out[i] = w0 * randomizer[i] + sum_s (wa_s + wb_s * x_i^shift_s) * source_s[i].  Synchronises the stream.
+ */
+typedef struct bfs_comb_source {
+    const uint64_t* ptr;   /* device: n words (base codeword) or 3n words (extension codeword, limb planes) */
+    uint32_t is_ext, pad;
+    uint64_t shift;        /* max_degree - degree bound of this codeword */
+    uint64_t wa[3], wb[3]; /* weights of the plain and of the shifted term */
+} bfs_comb_source;
+int bfs_poly_randomize(uint64_t* d_coeffs, uint64_t stride, uint64_t h, uint32_t batch, uint64_t point, const uint64_t* h_values, void* stream);
+int bfs_air_num_quotients(int table);
+int bfs_air_quotients(int table, const uint64_t* d_base, const uint64_t* d_ext, uint64_t* d_out, uint32_t log_n, uint64_t unit_distance,
+                      uint64_t height, uint64_t omicron_inv, uint64_t offset, uint64_t omega, const uint64_t* h_challenges,
+                      const uint64_t* h_terminals, const uint64_t* h_params, void* stream);
+int bfs_difference_quotient(const uint64_t* d_lhs, const uint64_t* d_rhs, uint64_t* d_out, uint32_t log_n, uint64_t offset, uint64_t omega, void* stream);
+int bfs_combination(const bfs_comb_source* h_sources, uint32_t count, const uint64_t* d_randomizer, const uint64_t* h_randomizer_weight,
+                    uint64_t* d_out, uint32_t log_n, uint64_t offset, uint64_t omega, void* stream);
 
 #ifdef __cplusplus
 }

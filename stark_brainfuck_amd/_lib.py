@@ -49,6 +49,7 @@ _SIGNATURES = {
     "bfs_ps_obj_int": (u64, [vp, u64]),
     "bfs_ps_obj_xfe": (u64, [vp, ctypes.POINTER(u64)]),
     "bfs_ps_obj_bfe": (u64, [vp, u64, ci]),
+    "bfs_ps_obj_xfe_from": (u64, [vp, ctypes.POINTER(u64), sz]),
     "bfs_ps_obj_list": (u64, [vp, ctypes.POINTER(u64), sz]),
     "bfs_ps_obj_tuple": (u64, [vp, ctypes.POINTER(u64), sz]),
     "bfs_ps_push": (ci, [vp, u64]),
@@ -73,11 +74,22 @@ _SIGNATURES = {
     "bfs_fri_session_free": (None, [vp]),
     "bfs_fri_commit": (ci, [vp, vp, vp, u64, u32, u64, u64, u32, vp]),
     "bfs_fri_query": (ci, [vp, vp, u32, ctypes.POINTER(u64), vp]),
+    "bfs_fri_session_alias": (ci, [vp, vp, u32, u64, u64]),
     "bfs_fri_prove": (ci, [vp, vp, u64, u32, u64, u64, u32, u32, ctypes.POINTER(u64), vp]),
     "bfs_fri_last_timing": (None, [ctypes.POINTER(ctypes.c_double)]),
     "bfs_fri_session_rounds": (u32, [vp]),
     "bfs_fri_session_round": (ci, [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(vp), vp]),
+    "bfs_poly_randomize": (ci, [vp, u64, u64, u32, u64, ctypes.POINTER(u64), vp]),
+    "bfs_air_num_quotients": (ci, [ci]),
+    "bfs_air_quotients": (ci, [ci, vp, vp, vp, u32, u64, u64, u64, u64, u64, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64), vp]),
+    "bfs_difference_quotient": (ci, [vp, vp, vp, u32, u64, u64, vp]),
+    "bfs_combination": (ci, [vp, u32, vp, ctypes.POINTER(u64), vp, u32, u64, u64, vp]),
 }
+
+
+class CombSource(ctypes.Structure):
+    """bfs_comb_source (include/bfstark.h)"""
+    _fields_ = [("ptr", vp), ("is_ext", u32), ("pad", u32), ("shift", u64), ("wa", u64 * 3), ("wb", u64 * 3)]
 
 _lib = None
 
@@ -99,6 +111,13 @@ def load():
         raise BackendUnavailable(
             "libbfstark_hip.so is not built (%s). Run `python -m stark_brainfuck_amd.build`; "
             "there is no CPU fallback for the hot path." % LIB_PATH)
+    try:
+        # torch (used for streams / distributed plumbing) ships its own copy of the HIP runtime.  Load it FIRST so that this
+        # library binds to the runtime already in the process: two HIP runtimes initialised in one process leave the second
+        # one without a device ("no ROCm-capable device is detected").
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)

@@ -1,0 +1,263 @@
+"""STARK prover for the Brainfuck VM -- mirror of the reference's `brainfuck_stark.py`
+(/root/reference/code/brainfuck_stark.py:20-341): same constructor, `prove(...)`, `get_terminals`, `sample_weights`,
+`sample_indices`, and the same transcript, byte for byte.
+
+Where the time goes in the reference, and where it goes here:
+  trace interpolation + low-degree extension (:165-172, 194-195)    batched INTT / randomizer fix / coset NTT in HBM (table.py)
+  commitments to zipped codewords (:178-179, 197-198)               leaves pickled on the host, hashed on the GPU
+  quotient codewords (:204-221, 93 % of the reference's time)       one kernel per table (bfs_air_quotients)
+  non-linear combination of 151 terms (:236-298)                    one kernel (bfs_combination)
+  FRI (:336)                                                        fri.Fri.prove (bfs_fri_commit / bfs_fri_query)
+Scalar steps (padding, running products, Fiat-Shamir sampling, transcript assembly) stay on the host.
+"""
+import ctypes
+from hashlib import blake2b
+from os import urandom          # module-level on purpose: tests patch `brainfuck_stark.urandom` for determinism
+
+import numpy as np
+
+from . import _lib, air
+from .algebra import BaseField, BaseFieldElement
+from .arrays import XArray
+from .device import DeviceBuffer, current_stream, synchronize
+from .evaluation_argument import EvaluationArgument, ProgramEvaluationArgument
+from .extension_field import ExtensionField, ExtensionFieldElement
+from .fri import Fri
+from .instruction_table import InstructionTable
+from .io_table import InputTable, OutputTable
+from .ip import ProofStream
+from .memory_table import MemoryTable
+from .merkle import Merkle
+from .permutation_argument import PermutationArgument
+from .processor_table import ProcessorTable
+from .salted_merkle import SaltedMerkle
+from .table import sample_ext
+from .univariate import Polynomial
+from .vm import VirtualMachine
+
+_u64 = ctypes.c_uint64
+
+
+class BrainfuckStark:
+    field = BaseField.main()
+    xfield = ExtensionField.main()
+
+    def __init__(self, running_time, memory_length, program, input_symbols, output_symbols):
+        self.running_time = running_time
+        self.memory_length = memory_length
+        self.program = program
+        self.input_symbols = input_symbols
+        self.output_symbols = output_symbols
+
+        log_expansion_factor = 2                                     # brainfuck_stark.py:33-34 "for speed"
+        self.expansion_factor = 1 << log_expansion_factor
+        self.security_level = 2                                      # :35-36
+        self.num_colinearity_checks = self.security_level // log_expansion_factor
+        assert self.expansion_factor & (self.expansion_factor - 1) == 0, "expansion factor must be a power of 2"
+        assert self.expansion_factor >= 4, "expansion factor must be 4 or greater"
+        assert self.num_colinearity_checks * log_expansion_factor >= self.security_level, \
+            "number of colinearity checks times log of expansion factor must be at least security level"
+        self.num_randomizers = 1
+
+        order = 1 << 32
+        smooth_generator = BrainfuckStark.field.primitive_nth_root(order)
+        f = self.field
+        self.processor_table = ProcessorTable(f, running_time, self.num_randomizers, smooth_generator, order)
+        self.instruction_table = InstructionTable(f, running_time + len(program), self.num_randomizers, smooth_generator, order)
+        self.memory_table = MemoryTable(f, memory_length, self.num_randomizers, smooth_generator, order)
+        self.input_table = InputTable(f, len(input_symbols), smooth_generator, order)
+        self.output_table = OutputTable(f, len(output_symbols), smooth_generator, order)
+        self.tables = [self.processor_table, self.instruction_table, self.memory_table, self.input_table, self.output_table]
+
+        self.permutation_arguments = [
+            PermutationArgument(self.tables, (0, ProcessorTable.instruction_permutation), (1, InstructionTable.permutation)),
+            PermutationArgument(self.tables, (0, ProcessorTable.memory_permutation), (2, MemoryTable.permutation))]
+        self.evaluation_arguments = [
+            EvaluationArgument(8, 2, [BaseFieldElement(ord(i), f) for i in input_symbols]),
+            EvaluationArgument(9, 3, [BaseFieldElement(ord(o), f) for o in output_symbols]),
+            ProgramEvaluationArgument([0, 1, 2, 10], 4, program)]
+
+        # FRI domain length from the degree of the composed transition constraints (:82-95)
+        self.max_degree = 1
+        ones = [air.X1] * 11
+        for table in self.tables:
+            self.max_degree = max(self.max_degree, table.max_transition_degree(ones))
+        self.max_degree = BrainfuckStark.roundup_npo2(self.max_degree) - 1
+        fri_domain_length = (self.max_degree + 1) * self.expansion_factor
+        generator = BrainfuckStark.field.generator()
+        omega = BrainfuckStark.field.primitive_nth_root(fri_domain_length)
+        self.fri = Fri(generator, omega, fri_domain_length, self.expansion_factor, self.num_colinearity_checks, self.xfield)
+
+    def get_terminals(self):
+        """the five terminals as int triples (:103-109)"""
+        return [self.processor_table.instruction_permutation_terminal, self.processor_table.memory_permutation_terminal,
+                self.processor_table.input_evaluation_terminal, self.processor_table.output_evaluation_terminal,
+                self.instruction_table.evaluation_terminal]
+
+    @staticmethod
+    def _sample_weights(number, randomness):
+        return [sample_ext(blake2b(randomness + bytes(i)).digest()) for i in range(number)]
+
+    def sample_weights(self, number, randomness):
+        """:111-112, as extension-field element objects"""
+        return [self.xfield.from_limbs(w) for w in BrainfuckStark._sample_weights(number, randomness)]
+
+    @staticmethod
+    def sample_indices(number, randomness, bound):
+        """:114-123"""
+        return [int.from_bytes(blake2b(randomness + bytes(i)).digest(), "big") % bound for i in range(number)]
+
+    @staticmethod
+    def roundup_npo2(integer):
+        if integer == 0 or integer == 1:
+            return 1
+        return 1 << (integer - 1).bit_length()
+
+    # ------------------------------------------------------------------------------------------------------------
+    def prove(self, program, processor_matrix, memory_matrix, instruction_matrix, input_matrix, output_matrix, proof_stream=None):
+        assert len(processor_matrix) + len(program) == len(instruction_matrix)
+        lib, stream = _lib.load(), current_stream()
+        xf, n = self.xfield, self.fri.domain.length
+        log_n = n.bit_length() - 1
+        domain = self.fri.domain
+        for table, matrix in zip(self.tables, (processor_matrix, instruction_matrix, memory_matrix, input_matrix, output_matrix)):
+            table.matrix = matrix
+        for table in (self.processor_table, self.memory_table, self.instruction_table, self.input_table, self.output_table):
+            table.pad()                                                                      # :143-148
+        if proof_stream is None:
+            proof_stream = ProofStream()
+
+        # randomizer polynomial and codeword (:162-167)
+        coeffs = np.array([sample_ext(urandom(3 * 9)) for _ in range(self.max_degree + 1)], dtype=np.uint64).T.copy()
+        randomizer_codeword = domain.xevaluate(XArray.from_numpy(coeffs, xf), xf, as_array=True)
+
+        # base codewords of all tables, one commitment to the zipped rows (:169-179)
+        for table in self.tables:
+            table.lde(domain)
+        base_degree_bounds = [t.interpolant_degree() for t in self.tables for _ in range(t.base_width)]
+        synchronize(stream)
+        rand_host = randomizer_codeword.to_numpy()
+        base_host = [t.base_codewords.to_numpy(t.base_width * n).reshape(t.base_width, n) for t in self.tables]
+        base_host = np.concatenate(base_host, axis=0)
+        f2 = BrainfuckStark.field
+        zipped = [tuple([xf.from_limbs([int(rand_host[0, i]), int(rand_host[1, i]), int(rand_host[2, i])])]
+                        + [BaseFieldElement(int(v), f2) for v in base_host[:, i]]) for i in range(n)]
+        base_tree = SaltedMerkle(zipped)
+        proof_stream.push(base_tree.root())
+
+        # challenges, initials, table extension, terminals (:181-192)
+        challenges = BrainfuckStark._sample_weights(11, proof_stream.prover_fiat_shamir())
+        initials = [sample_ext(urandom(3 * 8)) for _ in self.permutation_arguments]
+        for table in self.tables:
+            table.extend(challenges, initials)
+        terminals = self.get_terminals()
+
+        # extension codewords and their commitment (:194-201)
+        for table in self.tables:
+            table.ldex(domain, xf)
+        extension_degree_bounds = [t.interpolant_degree() for t in self.tables for _ in range(t.full_width - t.base_width)]
+        synchronize(stream)
+        ext_host = np.concatenate([t.ext_codewords.to_numpy((t.full_width - t.base_width) * 3 * n).reshape(-1, 3, n) for t in self.tables], axis=0)
+        moduli = [m for t in self.tables for m in t.ext_sharing_moduli(n)]
+        internal = xf.modulus.coefficients[0].field
+        shared = [dict() for _ in moduli]          # per column: i mod modulus -> the coefficient objects of that class
+
+        def ext_element(c, i):
+            limbs = [int(ext_host[c, 0, i]), int(ext_host[c, 1, i]), int(ext_host[c, 2, i])]
+            if moduli[c] is None:
+                return xf.from_limbs(limbs)
+            while limbs and limbs[-1] == 0:
+                limbs.pop()
+            objs = shared[c].setdefault(i % moduli[c], [BaseFieldElement(v, internal) for v in limbs])
+            e = ExtensionFieldElement(Polynomial(objs), xf)
+            e.shares_coefficients = True
+            return e
+        zipped_ext = [tuple(ext_element(c, i) for c in range(ext_host.shape[0])) for i in range(n)]
+        extension_tree = SaltedMerkle(zipped_ext)
+        proof_stream.push(extension_tree.root())
+
+        # quotients (:203-221)
+        quotient_buffers, quotient_degree_bounds = [], []
+        for table in self.tables:
+            quotient_buffers.append((table.all_quotients(domain, None, challenges, terminals), table.num_quotients()))
+            quotient_degree_bounds += table.all_quotient_degree_bounds(challenges, terminals)
+        for pa in self.permutation_arguments:
+            quotient_buffers.append((pa.quotient(domain), 1))
+            quotient_degree_bounds.append(pa.quotient_degree_bound())
+
+        # :223-224.  The input and output evaluations both start from ONE zero object (processor_table.py:340-347) and
+        # stay that object when the program never reads / writes; pickle then writes the second one as a back-reference.
+        # The running evaluations are sums `evaluation * challenge + lift(symbol)`; the first one is `zero + lift(symbol)`,
+        # which returns the lifted symbol's polynomial, and from then on the left operand's coefficients -- BaseFieldElements
+        # of the VM's BaseField instance (vm.py:70), not of the extension field's own -- decide the field of every result
+        # (processor_table.py:390-404, univariate.py:23-35): pickle writes that third BaseField instance out.
+        terminal_objects = [xf.from_limbs(t) for t in terminals]
+        for k, identity in zip((2, 3), self.processor_table.evaluation_terminal_identities):
+            limbs = list(terminals[k])
+            while limbs and limbs[-1] == 0:
+                limbs.pop()
+            if limbs and identity is not None and identity[0] == "object":
+                terminal_objects[k] = ExtensionFieldElement(Polynomial([identity[1]]), xf)
+            elif limbs:
+                base = identity[1] if identity is not None else VirtualMachine.field
+                terminal_objects[k] = ExtensionFieldElement(Polynomial([BaseFieldElement(v, base) for v in limbs]), xf)
+        if not any(terminals[2]) and not any(terminals[3]):
+            terminal_objects[3] = terminal_objects[2]
+        for t in terminal_objects:
+            proof_stream.push(t)
+
+        # weights of the non-linear combination (:226-243)
+        num_base = sum(t.base_width for t in self.tables)
+        num_ext = sum(t.full_width - t.base_width for t in self.tables)
+        num_quot = len(quotient_degree_bounds)
+        weights_seed = proof_stream.prover_fiat_shamir()
+        weights = BrainfuckStark._sample_weights(1 + 2 * (num_base + num_ext + num_quot), weights_seed)
+
+        # sources in the order of the reference's `terms` list (:245-293): base, extension, quotient codewords
+        sources = []
+        for t in self.tables:
+            for c in range(t.base_width):
+                sources.append((t.base_codewords.ptr + 8 * c * n, 0))
+        for t in self.tables:
+            for c in range(t.full_width - t.base_width):
+                sources.append((t.ext_codewords.ptr + 8 * 3 * c * n, 1))
+        for buf, count in quotient_buffers:
+            for q in range(count):
+                sources.append((buf.ptr + 8 * 3 * q * n, 1))
+        bounds = base_degree_bounds + extension_degree_bounds + quotient_degree_bounds
+        assert len(sources) == len(bounds) and 1 + 2 * len(sources) == len(weights)
+        srcs = (_lib.CombSource * len(sources))()
+        for s, ((ptr, is_ext), bound) in enumerate(zip(sources, bounds)):
+            srcs[s].ptr, srcs[s].is_ext, srcs[s].shift = ptr, is_ext, self.max_degree - bound
+            srcs[s].wa = (_u64 * 3)(*weights[1 + 2 * s])
+            srcs[s].wb = (_u64 * 3)(*weights[2 + 2 * s])
+        combination = XArray.empty(n, xf)
+        _lib.check(lib.bfs_combination(srcs, len(sources), randomizer_codeword.ptr, (_u64 * 3)(*weights[0]), combination.ptr,
+                                       log_n, domain.offset.value, domain.omega.value, stream))
+
+        # commitment to the combination codeword, openings (:300-333)
+        combination_tree = Merkle(combination)
+        proof_stream.push(combination_tree.root())
+        indices = BrainfuckStark.sample_indices(self.security_level, proof_stream.prover_fiat_shamir(), n)
+        unit_distances = list(set(table.unit_distance(n) for table in self.tables))
+        for index in indices:
+            for distance in [0] + unit_distances:
+                idx = (index + distance) % n
+                proof_stream.push(base_tree.leafs[idx][0])
+                proof_stream.push(base_tree.open(idx))
+                proof_stream.push(extension_tree.leafs[idx][0])
+                proof_stream.push(extension_tree.open(idx))
+        known = {}
+        for index in indices:
+            leaf = combination_tree.leafs[index]
+            known[index] = leaf
+            proof_stream.push(leaf)
+            proof_stream.push(combination_tree.open(index))
+
+        # low-degree test of the combination codeword (:335-336)
+        self.fri.prove(combination, proof_stream, known_leafs=known)
+        self._last = {"base_tree": base_tree, "extension_tree": extension_tree, "combination_tree": combination_tree,
+                      "challenges": challenges, "terminals": terminals, "indices": indices, "weights_seed": weights_seed,
+                      "quotient_degree_bounds": quotient_degree_bounds, "quotient_buffers": quotient_buffers,
+                      "combination": combination}
+        return proof_stream.serialize()

@@ -1,0 +1,250 @@
+// air.hip -- the STARK-specific kernels around the transforms:
+//   * randomized trace interpolation         Table.interpolate_columns   /root/reference/code/table.py:112-136
+//   * boundary / transition / terminal quotient codewords   table.py:148-168, 176-236, 249-281  (constraints: air_generated.hpp)
+//   * difference quotients of the permutation arguments      permutation_argument.py:9-18
+//   * the non-linear combination codeword                    brainfuck_stark.py:236-300
+// Points of the FRI domain are x_i = offset * omega^i (fri.py:20-21); codewords are column-major: base column c at
+// base[c * n + i], extension column c as three limb planes at ext[(3 c + limb) * n + i].
+#include "air_generated.hpp"
+#include "runtime.hpp"
+
+namespace bfs {
+
+int ntt_power_tables(u64 root, u32 log_n, const u64** lo, const u64** hi, u32* lo_bits);
+
+// ---- randomized interpolation ------------------------------------------------------------------------------------
+// The reference interpolates each trace column over {omicron^i} plus one extra point (omega, random value r) with a
+// generic subproduct-tree routine (ntt.py:82-161).  The interpolant is unique, so it equals
+//     f = f0 + c * (X^h - 1),   f0 = INTT_h(column),   c = (r - f0(omega)) / (omega^h - 1)
+// One workgroup per column: evaluate f0 at `point` (Horner over per-thread chunks), then patch f[0] and f[h].
+__global__ void __launch_bounds__(256) poly_randomize_kernel(u64* coeffs, u64 stride, u64 h, u64 point, u64 inv_den, const u64* r) {
+    __shared__ u64 part[256];
+    u64* f = coeffs + (u64)blockIdx.x * stride;
+    const u32 t = threadIdx.x;
+    const u64 chunk = (h + 255) / 256;
+    const u64 lo = (u64)t * chunk, hi = lo + chunk < h ? lo + chunk : h;
+    u64 acc = 0;
+    if (lo < h) {
+        for (u64 k = hi; k-- > lo;) acc = gl_add(gl_mul(acc, point), f[k]);      // sum_{k in chunk} f_k point^(k - lo)
+        acc = gl_mul(acc, gl_pow(point, lo));
+    }
+    part[t] = acc;
+    __syncthreads();
+    for (u32 s = 128; s > 0; s >>= 1) {
+        if (t < s) part[t] = gl_add(part[t], part[t + s]);
+        __syncthreads();
+    }
+    if (t == 0) {
+        const u64 c = gl_mul(gl_sub(r[blockIdx.x], part[0]), inv_den);
+        f[0] = gl_sub(f[0], c);
+        f[h] = c;
+    }
+}
+
+// ---- quotients -----------------------------------------------------------------------------------------------------
+struct AirArgs {
+    const u64* base;
+    const u64* ext;
+    u64* out;
+    u64 n;
+    u64 unit_distance;
+    u64 height;          // 0: the transition zerofier has no inverse and the reference multiplies by 0 (table.py:181-184)
+    u32 log_height;
+    u64 omicron_inv;
+    u64 offset;
+    const u64* w_lo;
+    const u64* w_hi;
+    u32 lo_bits;
+    Xfe ch[11];
+    Xfe tm[5];
+    Xfe pr[1];
+};
+
+template <int TABLE> struct AirShape;
+template <> struct AirShape<0> { static constexpr int BW = airgen::PROCESSOR_BASE_WIDTH, XW = airgen::PROCESSOR_EXT_WIDTH, NB = airgen::PROCESSOR_NUM_BOUNDARY, NT = airgen::PROCESSOR_NUM_TRANSITION, NZ = airgen::PROCESSOR_NUM_TERMINAL; };
+template <> struct AirShape<1> { static constexpr int BW = airgen::INSTRUCTION_BASE_WIDTH, XW = airgen::INSTRUCTION_EXT_WIDTH, NB = airgen::INSTRUCTION_NUM_BOUNDARY, NT = airgen::INSTRUCTION_NUM_TRANSITION, NZ = airgen::INSTRUCTION_NUM_TERMINAL; };
+template <> struct AirShape<2> { static constexpr int BW = airgen::MEMORY_BASE_WIDTH, XW = airgen::MEMORY_EXT_WIDTH, NB = airgen::MEMORY_NUM_BOUNDARY, NT = airgen::MEMORY_NUM_TRANSITION, NZ = airgen::MEMORY_NUM_TERMINAL; };
+template <> struct AirShape<3> { static constexpr int BW = airgen::INPUT_BASE_WIDTH, XW = airgen::INPUT_EXT_WIDTH, NB = airgen::INPUT_NUM_BOUNDARY, NT = airgen::INPUT_NUM_TRANSITION, NZ = airgen::INPUT_NUM_TERMINAL; };
+template <> struct AirShape<4> { static constexpr int BW = airgen::OUTPUT_BASE_WIDTH, XW = airgen::OUTPUT_EXT_WIDTH, NB = airgen::OUTPUT_NUM_BOUNDARY, NT = airgen::OUTPUT_NUM_TRANSITION, NZ = airgen::OUTPUT_NUM_TERMINAL; };
+
+template <int TABLE>
+__device__ __forceinline__ void air_eval(const u64* bc, const u64* bn, const Xfe* xc, const Xfe* xn, const AirArgs& a, Xfe* out) {
+    if constexpr (TABLE == 0) airgen::air_processor(bc, bn, xc, xn, a.ch, a.tm, a.pr, out);
+    else if constexpr (TABLE == 1) airgen::air_instruction(bc, bn, xc, xn, a.ch, a.tm, a.pr, out);
+    else if constexpr (TABLE == 2) airgen::air_memory(bc, bn, xc, xn, a.ch, a.tm, a.pr, out);
+    else if constexpr (TABLE == 3) airgen::air_input(bc, bn, xc, xn, a.ch, a.tm, a.pr, out);
+    else airgen::air_output(bc, bn, xc, xn, a.ch, a.tm, a.pr, out);
+}
+
+template <int TABLE>
+__global__ void __launch_bounds__(256) air_quotient_kernel(const AirArgs a) {
+    typedef AirShape<TABLE> S;
+    constexpr int NQ = S::NB + S::NT + S::NZ;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (u64)gridDim.x * blockDim.x) {
+        u64 j = i + a.unit_distance;
+        if (j >= a.n) j -= a.n;
+        u64 bc[S::BW], bn[S::BW];
+        Xfe xc[S::XW], xn[S::XW];
+#pragma unroll
+        for (int c = 0; c < S::BW; ++c) { bc[c] = a.base[(u64)c * a.n + i]; bn[c] = a.base[(u64)c * a.n + j]; }
+#pragma unroll
+        for (int c = 0; c < S::XW; ++c)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) { xc[c].c[l] = a.ext[(u64)(3 * c + l) * a.n + i]; xn[c].c[l] = a.ext[(u64)(3 * c + l) * a.n + j]; }
+        Xfe v[NQ];
+        air_eval<TABLE>(bc, bn, xc, xn, a, v);
+        const u64 x = gl_mul(a.offset, tw_pow(a.w_lo, a.w_hi, a.lo_bits, i));
+        const u64 zb = gl_inv(gl_sub(x, 1));                         // boundary: 1 / (x - 1)                     table.py:153-155
+        const u64 xo = gl_sub(x, a.omicron_inv);
+        const u64 zz = gl_inv(xo);                                   // terminal: 1 / (x - omicron^-1)            table.py:253-256
+        u64 zt = 0;                                                  // transition: (x - omicron^-1) / (x^h - 1)   table.py:180-188
+        if (a.height != 0) {
+            u64 xh = x;
+            for (u32 s = 0; s < a.log_height; ++s) xh = gl_sqr(xh);
+            zt = gl_mul(gl_inv(gl_sub(xh, 1)), xo);
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const u64 z = q < S::NB ? zb : (q < S::NB + S::NT ? zt : zz);
+            const Xfe r = xfe_scale(v[q], z);
+#pragma unroll
+            for (int l = 0; l < 3; ++l) a.out[(u64)(3 * q + l) * a.n + i] = r.c[l];
+        }
+    }
+}
+
+// (lhs - rhs) / (x - 1) for two extension codewords (three limb planes of stride n each)
+__global__ void difference_quotient_kernel(const u64* lhs, const u64* rhs, u64* out, u64 n, u64 offset, const u64* w_lo, const u64* w_hi, u32 lo_bits) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 x = gl_mul(offset, tw_pow(w_lo, w_hi, lo_bits, i));
+        const u64 z = gl_inv(gl_sub(x, 1));
+#pragma unroll
+        for (int l = 0; l < 3; ++l) out[(u64)l * n + i] = gl_mul(gl_sub(lhs[(u64)l * n + i], rhs[(u64)l * n + i]), z);
+    }
+}
+
+// ---- non-linear combination -------------------------------------------------------------------------------------
+// sum over sources s of (wa_s + wb_s * x^shift_s) * codeword_s[i], plus w0 * randomizer[i]   (brainfuck_stark.py:236-300)
+struct CombSrc {
+    const u64* ptr;      // base: n values; extension: three planes of n
+    u32 is_ext, pad;
+    u64 shift;
+    Xfe wa, wb;
+};
+
+__global__ void __launch_bounds__(256) combination_kernel(const CombSrc* srcs, u32 count, const u64* randomizer, Xfe w0, u64* out, u64 n,
+                                                          u64 offset, const u64* w_lo, const u64* w_hi, u32 lo_bits) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 x = gl_mul(offset, tw_pow(w_lo, w_hi, lo_bits, i));
+        Xfe acc = xfe_mul(w0, Xfe{{randomizer[i], randomizer[n + i], randomizer[2 * n + i]}});
+        for (u32 s = 0; s < count; ++s) {
+            const CombSrc& src = srcs[s];
+            const Xfe w = xfe_add(src.wa, xfe_scale(src.wb, gl_pow(x, src.shift)));
+            if (src.is_ext) acc = xfe_add(acc, xfe_mul(w, Xfe{{src.ptr[i], src.ptr[n + i], src.ptr[2 * n + i]}}));
+            else acc = xfe_add(acc, xfe_scale(w, src.ptr[i]));
+        }
+        out[i] = acc.c[0];
+        out[n + i] = acc.c[1];
+        out[2 * n + i] = acc.c[2];
+    }
+}
+
+static u32 grid_for(u64 n) {
+    u64 g = (n + 255) / 256;
+    return (u32)(g > 8192 ? 8192 : (g ? g : 1));
+}
+
+static Xfe xfe_from(const u64* p) { return Xfe{{p[0], p[1], p[2]}}; }
+
+}  // namespace bfs
+
+using namespace bfs;
+
+extern "C" {
+
+int bfs_poly_randomize(uint64_t* d_coeffs, uint64_t stride, uint64_t h, uint32_t batch, uint64_t point, const uint64_t* h_values, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (batch == 0) return BFS_OK;
+    if (h == 0 || stride < h + 1) { set_error("bfs_poly_randomize: need h >= 1 and stride >= h + 1"); return BFS_ERR_BAD_ARG; }
+    const u64 den = gl_sub(gl_pow(point, h), 1);
+    if (den == 0) { set_error("bfs_poly_randomize: the extra point lies on the interpolation subgroup"); return BFS_ERR_BAD_ARG; }
+    void* w = nullptr;
+    BFS_TRY(workspace(3, (size_t)batch * sizeof(u64), stream, &w));
+    BFS_HIP(hipMemcpyAsync(w, h_values, (size_t)batch * sizeof(u64), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(poly_randomize_kernel, dim3(batch), dim3(256), 0, stream, d_coeffs, stride, h, point, gl_inv(den), (const u64*)w);
+    BFS_HIP(hipGetLastError());
+    BFS_HIP(hipStreamSynchronize(stream));      // h_values may be reused by the caller
+    return BFS_OK;
+}
+
+int bfs_air_quotients(int table, const uint64_t* d_base, const uint64_t* d_ext, uint64_t* d_out, uint32_t log_n, uint64_t unit_distance,
+                      uint64_t height, uint64_t omicron_inv, uint64_t offset, uint64_t omega, const uint64_t* h_challenges,
+                      const uint64_t* h_terminals, const uint64_t* h_params, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (table < 0 || table > 4) { set_error("bfs_air_quotients: table index %d", table); return BFS_ERR_BAD_ARG; }
+    if (height & (height - 1)) { set_error("bfs_air_quotients: table height must be zero or a power of two"); return BFS_ERR_NOT_POW2; }
+    AirArgs a{};
+    a.base = d_base; a.ext = d_ext; a.out = d_out;
+    a.n = 1ull << log_n;
+    a.unit_distance = unit_distance % a.n;
+    a.height = height;
+    a.log_height = 0;
+    while ((1ull << a.log_height) < height) ++a.log_height;
+    a.omicron_inv = omicron_inv; a.offset = offset;
+    BFS_TRY(ntt_power_tables(omega, log_n, &a.w_lo, &a.w_hi, &a.lo_bits));
+    for (int i = 0; i < 11; ++i) a.ch[i] = xfe_from(h_challenges + 3 * i);
+    for (int i = 0; i < 5; ++i) a.tm[i] = xfe_from(h_terminals + 3 * i);
+    a.pr[0] = h_params ? xfe_from(h_params) : Xfe{{1, 0, 0}};
+    const u32 grid = grid_for(a.n);
+    switch (table) {
+        case 0: hipLaunchKernelGGL(air_quotient_kernel<0>, dim3(grid), dim3(256), 0, stream, a); break;
+        case 1: hipLaunchKernelGGL(air_quotient_kernel<1>, dim3(grid), dim3(256), 0, stream, a); break;
+        case 2: hipLaunchKernelGGL(air_quotient_kernel<2>, dim3(grid), dim3(256), 0, stream, a); break;
+        case 3: hipLaunchKernelGGL(air_quotient_kernel<3>, dim3(grid), dim3(256), 0, stream, a); break;
+        default: hipLaunchKernelGGL(air_quotient_kernel<4>, dim3(grid), dim3(256), 0, stream, a); break;
+    }
+    BFS_HIP(hipGetLastError());
+    return BFS_OK;
+}
+
+int bfs_air_num_quotients(int table) {
+    switch (table) {
+        case 0: return AirShape<0>::NB + AirShape<0>::NT + AirShape<0>::NZ;
+        case 1: return AirShape<1>::NB + AirShape<1>::NT + AirShape<1>::NZ;
+        case 2: return AirShape<2>::NB + AirShape<2>::NT + AirShape<2>::NZ;
+        case 3: return AirShape<3>::NB + AirShape<3>::NT + AirShape<3>::NZ;
+        case 4: return AirShape<4>::NB + AirShape<4>::NT + AirShape<4>::NZ;
+    }
+    return -1;
+}
+
+int bfs_difference_quotient(const uint64_t* d_lhs, const uint64_t* d_rhs, uint64_t* d_out, uint32_t log_n, uint64_t offset, uint64_t omega, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const u64 n = 1ull << log_n;
+    const u64 *lo, *hi;
+    u32 lo_bits;
+    BFS_TRY(ntt_power_tables(omega, log_n, &lo, &hi, &lo_bits));
+    hipLaunchKernelGGL(difference_quotient_kernel, dim3(grid_for(n)), dim3(256), 0, stream, d_lhs, d_rhs, d_out, n, offset, lo, hi, lo_bits);
+    BFS_HIP(hipGetLastError());
+    return BFS_OK;
+}
+
+int bfs_combination(const bfs_comb_source* h_sources, uint32_t count, const uint64_t* d_randomizer, const uint64_t* h_randomizer_weight,
+                    uint64_t* d_out, uint32_t log_n, uint64_t offset, uint64_t omega, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const u64 n = 1ull << log_n;
+    static_assert(sizeof(CombSrc) == sizeof(bfs_comb_source), "layout of bfs_comb_source");
+    void* w = nullptr;
+    BFS_TRY(workspace(3, (size_t)(count ? count : 1) * sizeof(CombSrc), stream, &w));
+    if (count) BFS_HIP(hipMemcpyAsync(w, h_sources, (size_t)count * sizeof(CombSrc), hipMemcpyHostToDevice, stream));
+    const u64 *lo, *hi;
+    u32 lo_bits;
+    BFS_TRY(ntt_power_tables(omega, log_n, &lo, &hi, &lo_bits));
+    hipLaunchKernelGGL(combination_kernel, dim3(grid_for(n)), dim3(256), 0, stream, (const CombSrc*)w, count, d_randomizer,
+                       xfe_from(h_randomizer_weight), d_out, n, offset, lo, hi, lo_bits);
+    BFS_HIP(hipGetLastError());
+    BFS_HIP(hipStreamSynchronize(stream));      // h_sources may be reused by the caller
+    return BFS_OK;
+}
+
+}  // extern "C"

@@ -375,6 +375,13 @@ int bfs_fri_prove(void* ps, const uint64_t* d_codeword, uint64_t limb_stride, ui
     return fri_query(S, *(rp::Transcript*)ps, num_colinearity_tests, h_top_level_indices, (hipStream_t)stream);
 }
 
+int bfs_fri_session_alias(void* session, void* ps, uint32_t round, uint64_t index, uint64_t element_handle) {
+    rp::Ref r = ((rp::Transcript*)ps)->get(element_handle);
+    if (!r) { set_error("bfs_fri_session_alias: unknown object handle"); return BFS_ERR_BAD_ARG; }
+    ((FriSession*)session)->elements[FriSession::Key(round, index)] = r;
+    return BFS_OK;
+}
+
 void bfs_fri_last_timing(double out[6]) { for (int i = 0; i < 6; ++i) out[i] = g_fri_timing[i]; }
 
 uint32_t bfs_fri_session_rounds(void* session) { return (uint32_t)((FriSession*)session)->rounds.size(); }

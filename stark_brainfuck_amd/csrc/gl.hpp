@@ -42,6 +42,11 @@ BFS_HD u64 gl_sub(u64 a, u64 b) {
     u32 t = 0u - bh;                                   // EPS when the subtraction borrowed, else 0
     u32 rlo = __builtin_subc(dlo, t, 0u, &b2);
     u32 rhi = dhi - b2;
+    // hipcc (ROCm 7.2) folds this plain subtraction of a borrow into a following add-with-carry of the consumer and then
+    // reads the MERGED instruction's carry-out, which is wrong: gl_add(gl_sub(a, b), 1) came out as a - b + 1 mod 2^64
+    // (the fold needs a consumer whose own high-word addend is a compile-time zero).  The empty asm makes the value opaque
+    // to that combine; it emits no instruction.  Checked by tools/microbench/prim_check.hip on the device.
+    asm("" : "+v"(rhi));
     return ((u64)rhi << 32) | rlo;
 }
 // a + b: s = a + b and u = s + EPS (= s - p mod 2^64) with both carries; a + b >= p  <=>  either addition carried
@@ -160,6 +165,11 @@ struct Xfe {
 BFS_HD Xfe xfe_add(const Xfe& a, const Xfe& b) { return Xfe{{gl_add(a.c[0], b.c[0]), gl_add(a.c[1], b.c[1]), gl_add(a.c[2], b.c[2])}}; }
 BFS_HD Xfe xfe_sub(const Xfe& a, const Xfe& b) { return Xfe{{gl_sub(a.c[0], b.c[0]), gl_sub(a.c[1], b.c[1]), gl_sub(a.c[2], b.c[2])}}; }
 BFS_HD Xfe xfe_scale(const Xfe& a, u64 s) { return Xfe{{gl_mul(a.c[0], s), gl_mul(a.c[1], s), gl_mul(a.c[2], s)}}; }
+BFS_HD Xfe xfe_neg(const Xfe& a) { return Xfe{{gl_neg(a.c[0]), gl_neg(a.c[1]), gl_neg(a.c[2])}}; }
+BFS_HD Xfe xfe_lift(u64 b) { return Xfe{{b, 0, 0}}; }                                            // extension_field.py:113-116
+BFS_HD Xfe xfe_add_base(const Xfe& a, u64 b) { return Xfe{{gl_add(a.c[0], b), a.c[1], a.c[2]}}; }
+BFS_HD Xfe xfe_sub_base(const Xfe& a, u64 b) { return Xfe{{gl_sub(a.c[0], b), a.c[1], a.c[2]}}; }
+BFS_HD Xfe xfe_base_sub(u64 b, const Xfe& a) { return Xfe{{gl_sub(b, a.c[0]), gl_neg(a.c[1]), gl_neg(a.c[2])}}; }
 
 // schoolbook 3x3 then fold X^3 -> X - 1, X^4 -> X^2 - X:  r0 = d0 - d3, r1 = d1 + d3 - d4, r2 = d2 + d4
 BFS_HD Xfe xfe_mul(const Xfe& a, const Xfe& b) {

@@ -83,10 +83,31 @@ struct World {
     }
 
     // BaseFieldElement(value, field)  algebra.py:15-18
-    Ref bfe(u64 v, bool internal) const {
-        Ref n = mk_instance(c_bfe, {s_value, mk_int(v), s_field, internal ? bf_internal : bf_standalone});
+    Ref bfe(u64 v, bool internal) const { return bfe_in(v, internal ? bf_internal : bf_standalone); }
+    Ref bfe_in(u64 v, const Ref& field) const {
+        Ref n = mk_instance(c_bfe, {s_value, mk_int(v), s_field, field});
         n->role = R_BFE;
         n->limbs[0] = v;
+        return n;
+    }
+
+    // further BaseField.main() instances: the reference creates one per class that asks for it (vm.py:70, brainfuck_stark.py:21)
+    // and elements keep pointing at "their" instance, which pickle writes out separately.  id 0 = bf_standalone,
+    // 1 = bf_internal, >= 2 created on first use.
+    std::vector<Ref> bf_extra;
+    Ref base_field(int id) {
+        if (id == 0) return bf_standalone;
+        if (id == 1) return bf_internal;
+        while ((int)bf_extra.size() <= id - 2) bf_extra.push_back(mk_instance(c_bf, {s_p, mk_int(GL_P)}));
+        return bf_extra[id - 2];
+    }
+
+    // ExtensionFieldElement over explicit coefficient objects (shared BaseFieldElement objects, foreign BaseField instances)
+    Ref xfe_from(const std::vector<Ref>& coeffs) const {
+        Ref poly = mk_instance(c_poly, {s_coefficients, mk_list(coeffs)});
+        Ref n = mk_instance(c_xfe, {s_polynomial, poly, s_field, xfield});
+        n->role = R_XFE;
+        for (size_t i = 0; i < 3; ++i) n->limbs[i] = i < coeffs.size() ? coeffs[i]->limbs[0] : 0;
         return n;
     }
 

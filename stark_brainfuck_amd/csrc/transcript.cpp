@@ -26,7 +26,21 @@ uint64_t bfs_ps_obj_xfe(void* ps, const uint64_t limbs[3]) {
     uint64_t l[3] = {limbs[0] % GL_P, limbs[1] % GL_P, limbs[2] % GL_P};
     return T(ps)->add(T(ps)->world.xfe_compact(l));
 }
-uint64_t bfs_ps_obj_bfe(void* ps, uint64_t value, int internal_field) { return T(ps)->add(T(ps)->world.bfe(value % GL_P, internal_field != 0)); }
+uint64_t bfs_ps_obj_bfe(void* ps, uint64_t value, int field_id) {
+    if (field_id < 0 || field_id > 64) { set_error("BaseField instance id %d out of range", field_id); return 0; }
+    return T(ps)->add(T(ps)->world.bfe_in(value % GL_P, T(ps)->world.base_field(field_id)));
+}
+uint64_t bfs_ps_obj_xfe_from(void* ps, const uint64_t* coefficient_handles, size_t n) {
+    if (n > 3) { set_error("an extension element has at most 3 coefficients"); return 0; }
+    std::vector<Ref> coeffs;
+    for (size_t i = 0; i < n; ++i) {
+        Ref r = T(ps)->get(coefficient_handles[i]);
+        if (!r || r->role != rp::R_BFE) { bad_handle(coefficient_handles[i]); return 0; }
+        coeffs.push_back(r);
+    }
+    if (n && coeffs[n - 1]->limbs[0] == 0) { set_error("leading coefficient of an extension element must be non-zero (extension_field.py:6-9)"); return 0; }
+    return T(ps)->add(T(ps)->world.xfe_from(coeffs));
+}
 
 static uint64_t make_seq(void* ps, rp::Kind kind, const uint64_t* handles, size_t n) {
     std::vector<Ref> items;

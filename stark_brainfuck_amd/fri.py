@@ -131,7 +131,7 @@ class Fri:
             return codeword.array
         return codeword if isinstance(codeword, XArray) else XArray.from_elements(list(codeword))
 
-    def _run_native(self, codeword, proof_stream, with_query):
+    def _run_native(self, codeword, proof_stream, with_query, known_leafs=None):
         lib, stream = _lib.load(), current_stream()
         arr = self._as_xarray(codeword)
         n = len(arr)
@@ -146,6 +146,9 @@ class Fri:
             _lib.check(lib.bfs_fri_commit(session, transcript.handle, arr.ptr, arr.stride, n.bit_length() - 1,
                                           _base_value(self.domain.offset), _base_value(self.domain.omega), self.expansion_factor, stream))
             top = None
+            for index, obj in (known_leafs or {}).items():
+                # element objects of this codeword that are already in the stream keep their identity (pickle memoises by id)
+                _lib.check(lib.bfs_fri_session_alias(session, transcript.handle, 0, index, transcript.to_native(obj)))
             if with_query:
                 out = (_u64 * self.num_colinearity_tests)()
                 _lib.check(lib.bfs_fri_query(session, transcript.handle, self.num_colinearity_tests, out, stream))
@@ -204,10 +207,11 @@ class Fri:
             proof_stream.push(current_tree.open(b_indices[s]))
         return a_indices + b_indices
 
-    def prove(self, codeword, proof_stream):
-        """fri.py:178-199: commit + query in one native call; returns the top-level indices."""
+    def prove(self, codeword, proof_stream, known_leafs=None):
+        """fri.py:178-199: commit + query in one native call; returns the top-level indices.
+        known_leafs: {index: element object} for elements of `codeword` that the caller has already pushed."""
         assert self.domain.length == len(codeword), "initial codeword length does not match length of initial codeword"
-        top, _, session, _ = self._run_native(codeword, proof_stream, with_query=True)
+        top, _, session, _ = self._run_native(codeword, proof_stream, with_query=True, known_leafs=known_leafs)
         _lib.load().bfs_fri_session_free(session)
         return top
 

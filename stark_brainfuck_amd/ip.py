@@ -27,6 +27,7 @@ class NativeTranscript:
         self._by_id = {}     # id(python object) -> native handle
         self._keep = []      # keeps those python objects alive so ids stay unique
         self._by_handle = {}  # native handle -> python object (identity of objects created natively)
+        self._fields = {}    # id(BaseField instance) -> native field id
         self.xfield = None
 
     def __del__(self):
@@ -34,6 +35,17 @@ class NativeTranscript:
             self.lib.bfs_ps_free(self.handle)
         except Exception:
             pass
+
+    def _field_id(self, field):
+        """BaseField instances are distinguished by identity, like pickle does: 1 = the one inside the xfield's modulus,
+        0 = the first other instance met, 2.. = further ones."""
+        if self.xfield is not None and field is self.xfield.modulus.coefficients[0].field:
+            return 1
+        key = id(field)
+        if key not in self._fields:
+            self._fields[key] = 0 if not self._fields else len(self._fields) + 1
+            self._keep.append(field)
+        return self._fields[key]
 
     # ---- python -> native
     def to_native(self, obj):
@@ -46,10 +58,16 @@ class NativeTranscript:
         elif isinstance(obj, ExtensionFieldElement):
             if self.xfield is None:
                 self.xfield = obj.field
-            n = lib.bfs_ps_obj_xfe(h, (_u64 * 3)(*obj.limbs()))
+            coeffs = obj.polynomial.coefficients
+            internal = self.xfield.modulus.coefficients[0].field
+            if all(c.field is internal and id(c) not in self._by_id for c in coeffs) and not getattr(obj, "shares_coefficients", False):
+                n = lib.bfs_ps_obj_xfe(h, (_u64 * 3)(*obj.limbs()))
+            else:
+                # coefficient objects that are shared with another element, or that point at a foreign BaseField instance
+                handles = [self.to_native(c) for c in coeffs]
+                n = lib.bfs_ps_obj_xfe_from(h, (_u64 * len(handles))(*handles), len(handles))
         elif isinstance(obj, BaseFieldElement):
-            internal = self.xfield is not None and obj.field is self.xfield.modulus.coefficients[0].field
-            n = lib.bfs_ps_obj_bfe(h, obj.value, 1 if internal else 0)
+            n = lib.bfs_ps_obj_bfe(h, obj.value, self._field_id(obj.field))
         elif isinstance(obj, bool):
             raise TypeError("bool objects are not supported in the native transcript")
         elif isinstance(obj, int):

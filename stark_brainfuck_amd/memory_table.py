@@ -1,0 +1,48 @@
+"""Memory table -- mirror of the reference's `memory_table.py` (/root/reference/code/memory_table.py): `derive_matrix`
+(:20-38), padding (:40-44) and `extend` (:172-206).  Constraints: air.MemoryAir."""
+from . import air
+from .air import xmul, xsub, xscale
+from .algebra import BaseFieldElement
+from .table import Table, P, _val
+
+
+class MemoryTable(Table):
+    cycle, memory_pointer, memory_value, dummy, permutation = range(5)
+    air = air.TABLE_AIRS[2]
+    table_index = 2
+
+    def __init__(self, field, length, num_randomizers, generator, order):
+        super().__init__(field, 4, 5, length, num_randomizers, generator, order)
+
+    @staticmethod
+    def derive_matrix(processor_matrix):
+        """rows (cycle, memory pointer, memory value, dummy) of every non-padding processor row, sorted by memory pointer
+        (stable), with dummy rows inserted where the cycle count of one address jumps by more than one."""
+        field = processor_matrix[0][0].field if hasattr(processor_matrix[0][0], "field") else None
+        rows = [[_val(r[0]), _val(r[4]), _val(r[5]), 0] for r in processor_matrix if _val(r[2]) != 0]
+        rows.sort(key=lambda r: r[1])
+        i = 0
+        while i < len(rows) - 1:
+            if rows[i][1] == rows[i + 1][1] and rows[i + 1][0] != (rows[i][0] + 1) % P:
+                rows.insert(i + 1, [(rows[i][0] + 1) % P, rows[i][1], rows[i][2], 1])
+            i += 1
+        if field is None:
+            return rows
+        return [[BaseFieldElement(v, field) for v in r] for r in rows]
+
+    def pad(self):
+        rows = self.base_rows()
+        while len(rows) & (len(rows) - 1):
+            rows.append([(rows[-1][0] + 1) % P, rows[-1][1], rows[-1][2], 1])
+        self._append_rows(rows)
+
+    def extend(self, all_challenges, all_initials):
+        a, b, c, d, e, f, alpha, beta, gamma, delta, eta = all_challenges
+        perm = all_initials[1]
+        ext = []
+        for clk, mp, mv, dummy in self.base_rows():
+            ext.append([perm])
+            if dummy == 0:
+                perm = xmul(perm, xsub(xsub(xsub(beta, xscale(d, clk)), xscale(e, mp)), xscale(f, mv)))
+        self.ext_rows = ext
+        self.permutation_terminal = perm

@@ -1,0 +1,28 @@
+"""Permutation argument between two tables -- mirror of the reference's `permutation_argument.py`
+(/root/reference/code/permutation_argument.py:4-34): the difference of two running-product columns must vanish at
+the first row, so (lhs - rhs) / (x - 1) is a polynomial."""
+from . import _lib
+from .device import DeviceBuffer, current_stream
+
+
+class PermutationArgument:
+    def __init__(self, all_tables, lhs, rhs):
+        self.all_tables = all_tables
+        self.lhs = lhs
+        self.rhs = rhs
+
+    def quotient(self, fri_domain):
+        """extension codeword (three limb planes) of the difference quotient, in HBM"""
+        n = fri_domain.length
+        out = DeviceBuffer(3 * n)
+        lt, rt = self.all_tables[self.lhs[0]], self.all_tables[self.rhs[0]]
+        _lib.check(_lib.load().bfs_difference_quotient(lt.ext_codeword_ptr(self.lhs[1]), rt.ext_codeword_ptr(self.rhs[1]), out.ptr,
+                                                       n.bit_length() - 1, fri_domain.offset.value, fri_domain.omega.value, current_stream()))
+        return out
+
+    def evaluate_difference(self, points):
+        from .air import xsub
+        return xsub(points[self.lhs[0]][self.lhs[1]], points[self.rhs[0]][self.rhs[1]])
+
+    def quotient_degree_bound(self):
+        return max(self.all_tables[self.lhs[0]].interpolant_degree(), self.all_tables[self.rhs[0]].interpolant_degree()) - 1

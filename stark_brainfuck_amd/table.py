@@ -1,0 +1,231 @@
+"""Execution-trace tables -- mirror of the reference's `table.py` (/root/reference/code/table.py:8-341) with the heavy
+steps on the GPU:
+
+  interpolate_columns + lde / ldex   (:112-148)  INTT over the omicron subgroup, rank-one randomizer correction
+                                                 (bfs_poly_randomize), coset NTT onto the FRI domain -- per table one
+                                                 batched call over all columns, codewords stay in HBM
+  all_quotients                      (:148-281)  one kernel per table (bfs_air_quotients, constraints from air.py)
+  *_quotient_degree_bounds           (:170-173, 238-247, 300-304)  exact symbolic expansion on the host (air.expand)
+
+Rows live on the host as Python ints (base columns) and int triples (extension columns): padding and the running
+products / evaluations of `extend` are sequential scans over a few thousand rows, as in the reference.
+"""
+import ctypes
+from os import urandom          # module-level on purpose: tests patch `table.urandom` for determinism
+
+import numpy as np
+
+from . import _lib, air
+from .algebra import BaseFieldElement
+from .arrays import raw_ntt
+from .device import DeviceBuffer, current_stream
+
+P = air.P
+_u64 = ctypes.c_uint64
+
+
+def _val(x):
+    return x.value if hasattr(x, "value") else int(x)
+
+
+def sample_base(byte_array):
+    """BaseField.sample (algebra.py:138-142)"""
+    return int.from_bytes(bytes(byte_array), "big") % P
+
+
+def sample_ext(byte_array):
+    """ExtensionField.sample (extension_field.py:100-111): three equal chunks"""
+    chunk = len(byte_array) // 3
+    return tuple(sample_base(byte_array[i * chunk:(i + 1) * chunk]) for i in range(3))
+
+
+class Table:
+    air = None           # the table's constraint set (air.TableAir)
+    table_index = -1     # position in BrainfuckStark.tables = index understood by bfs_air_quotients
+
+    def __init__(self, field, base_width, full_width, length, num_randomizers, generator, order):
+        assert num_randomizers in (0, 1), "one randomizer per column, as in the reference (brainfuck_stark.py:48)"
+        self.field = field
+        self.base_width = base_width
+        self.full_width = full_width
+        self.length = length
+        self.num_randomizers = num_randomizers
+        self.height = Table.roundup_npo2(length)
+        self.omicron = Table.derive_omicron(generator, order, self.height)
+        self.generator = generator
+        self.order = order
+        self.matrix = []
+        self.ext_rows = None         # after extend(): per row, the extension columns as int triples
+        self.base_codewords = None   # DeviceBuffer, base_width * N
+        self.ext_codewords = None    # DeviceBuffer, (full_width - base_width) * 3 * N
+        self._coefficients = None    # host copy of the last interpolants (ext_sharing_moduli)
+
+    @staticmethod
+    def roundup_npo2(integer):
+        if integer == 0 or integer == 1:
+            return integer
+        return 1 << (integer - 1).bit_length()
+
+    @staticmethod
+    def derive_omicron(generator, generator_order, target_order):
+        while generator_order != target_order:
+            generator = generator ^ 2
+            generator_order = generator_order // 2
+        return generator
+
+    def unit_distance(self, omega_order):
+        return 0 if self.height == 0 else omega_order // self.height
+
+    def get_interpolation_domain_length(self):
+        return self.height + self.num_randomizers
+
+    def interpolant_degree(self):
+        return self.get_interpolation_domain_length() - 1
+
+    # ---- rows
+    def base_rows(self):
+        return [[_val(v) for v in row[:self.base_width]] for row in self.matrix]
+
+    def _append_rows(self, rows):
+        """padding: rows beyond the current matrix are appended as new elements; the caller's row objects are kept"""
+        f = self.field
+        self.matrix = list(self.matrix) + [[BaseFieldElement(v, f) for v in row] for row in rows[len(self.matrix):]]
+
+    # ---- interpolation + low-degree extension (table.py:112-148)
+    def _extend_columns(self, domain, columns, randomizers):
+        """columns: uint64 array (ncol, height); randomizers: ncol values at the point omega (or None).
+        Returns the codewords over `domain` as one DeviceBuffer of ncol * N words."""
+        lib, stream = _lib.load(), current_stream()
+        n = domain.length
+        self._n = n
+        log_n = n.bit_length() - 1
+        ncol, h = columns.shape[0], self.height
+        out = DeviceBuffer(ncol * n)
+        self._coefficients = None
+        if ncol == 0:
+            return out
+        if h == 0:
+            _lib.check(lib.bfs_memset(out.ptr, 0, out.nbytes, stream))
+            return out
+        omega, offset = domain.omega.value, domain.offset.value
+        coeffs = DeviceBuffer(ncol * (h + 1))
+        _lib.check(lib.bfs_memset(coeffs.ptr, 0, coeffs.nbytes, stream))
+        d_in = DeviceBuffer.from_numpy(columns.reshape(-1))
+        omicron_inv = pow(self.omicron.value, P - 2, P)
+        raw_ntt(d_in.ptr, h, h, coeffs.ptr, h + 1, h.bit_length() - 1, ncol, omicron_inv, 1, pow(h, P - 2, P), stream)
+        n_in = h
+        self._coefficients = None
+        if randomizers is not None:
+            vals = (_u64 * ncol)(*[int(v) for v in randomizers])
+            _lib.check(lib.bfs_poly_randomize(coeffs.ptr, h + 1, h, ncol, omega, vals, stream))
+            n_in = h + 1
+        assert n_in <= n, "interpolant does not fit the FRI domain"
+        raw_ntt(coeffs.ptr, n_in, h + 1, out.ptr, n, log_n, ncol, omega, offset, 1, stream)
+        self._coefficients = coeffs.to_numpy(ncol * (h + 1)).reshape(ncol, h + 1)     # a few KiB: see ext_sharing_moduli
+        return out
+
+    def ext_sharing_moduli(self, n):
+        """Object identity inside the reference's extension codewords.  Its recursive ntt() adds `evens + w^i * odds`
+        with Polynomial.__add__, which hands back the OTHER operand's coefficient objects when one summand is zero
+        (univariate.py:23-27).  If every non-zero coefficient index of a column's interpolant is a multiple of 2^v, the
+        odd halves of the top v recursion levels are all zero, so codeword elements i and i' with i = i' mod N / 2^v end
+        up holding the very same BaseFieldElement objects -- visible in the proof because pickle memoises by identity
+        (an all-zero trace column plus its randomizer gives c (X^h - 1): 2^v = h, N / 2^v = the table's unit distance).
+        Returns, per extension column, that modulus, 1 for a constant polynomial, or None (no sharing)."""
+        width = self.full_width - self.base_width
+        if self._coefficients is None:
+            return [None] * width
+        out = []
+        for c in range(width):
+            planes = self._coefficients[3 * c:3 * c + 3]
+            support = np.nonzero((planes != 0).any(axis=0))[0]
+            if support.size == 0:
+                out.append(None)
+            elif support.size == 1 and support[0] == 0:
+                out.append(1)
+            else:
+                v = min(int(j & -j).bit_length() - 1 for j in support if j)
+                out.append(n >> v if v else None)
+        return out
+
+    def lde(self, domain):
+        rows = self.base_rows()
+        cols = np.array(rows, dtype=np.uint64).T.copy() if rows else np.zeros((self.base_width, 0), dtype=np.uint64)
+        cols = cols.reshape(self.base_width, self.height)
+        rand = None
+        if self.height != 0 and self.num_randomizers:
+            rand = [sample_base(urandom(3 * 8)) for _ in range(self.base_width)]
+        self.base_codewords = self._extend_columns(domain, cols, rand)
+        return self.base_codewords
+
+    def ldex(self, domain, xfield=None):
+        width = self.full_width - self.base_width
+        cols = np.zeros((width * 3, self.height), dtype=np.uint64)
+        for r, row in enumerate(self.ext_rows):
+            for c, v in enumerate(row):
+                cols[3 * c, r], cols[3 * c + 1, r], cols[3 * c + 2, r] = v
+        rand = None
+        if self.height != 0 and self.num_randomizers:
+            rand = []
+            for _ in range(width):
+                rand.extend(sample_ext(urandom(3 * 8)))
+        self.ext_codewords = self._extend_columns(domain, cols, rand)
+        return self.ext_codewords
+
+    def ext_codeword_ptr(self, column):
+        """device pointer of extension column `column` (full-width numbering): three limb planes of N words"""
+        return self.ext_codewords.ptr + 8 * 3 * (column - self.base_width) * self._n
+
+    # ---- quotients (table.py:148-281)
+    def air_params(self, challenges):
+        return []
+
+    def all_quotients(self, domain, codewords, challenges, terminals):
+        """codewords: ignored (the table's own codewords in HBM are used).  Returns a DeviceBuffer holding
+        num_quotients extension codewords, boundary / transition / terminal order (table.py:274-281)."""
+        lib, stream = _lib.load(), current_stream()
+        n = domain.length
+        nq = lib.bfs_air_num_quotients(self.table_index)
+        out = DeviceBuffer(nq * 3 * n)
+        ch = (_u64 * 33)(*[v for c in challenges for v in c])
+        tm = (_u64 * 15)(*[v for t in terminals for v in t])
+        params = self.air_params(challenges)
+        pr = (_u64 * 3)(*params[0]) if params else None
+        omicron_inv = pow(self.omicron.value, P - 2, P)
+        _lib.check(lib.bfs_air_quotients(self.table_index, self.base_codewords.ptr, self.ext_codewords.ptr, out.ptr,
+                                         n.bit_length() - 1, self.unit_distance(n), self.height, omicron_inv,
+                                         domain.offset.value, domain.omega.value, ch, tm, pr, stream))
+        return out
+
+    def _degree_bounds(self, kind, challenges, terminals):
+        md = self.interpolant_degree()
+        cons = dict(self.air.all())[kind]
+        nvars = 2 * self.full_width if kind == "transition" else self.full_width
+        params = self.air_params(challenges)
+        return [air.symbolic_degree_bound(air.expand(e, nvars, challenges, terminals, params), md) for e in cons]
+
+    def boundary_quotient_degree_bounds(self, challenges):
+        return [b - 1 for b in self._degree_bounds("boundary", challenges, [air.X0] * 5)]
+
+    def transition_quotient_degree_bounds(self, challenges):
+        return [b - self.height + 1 for b in self._degree_bounds("transition", challenges, [air.X0] * 5)]
+
+    def terminal_quotient_degree_bounds(self, challenges, terminals):
+        return [b - 1 for b in self._degree_bounds("terminal", challenges, terminals)]
+
+    def all_quotient_degree_bounds(self, challenges, terminals):
+        return (self.boundary_quotient_degree_bounds(challenges) + self.transition_quotient_degree_bounds(challenges)
+                + self.terminal_quotient_degree_bounds(challenges, terminals))
+
+    def num_quotients(self, challenges=None, terminals=None):
+        return sum(len(c) for _, c in self.air.all())
+
+    def max_transition_degree(self, challenges):
+        """symbolic degree of the composed transition constraints minus the zerofier (brainfuck_stark.py:84-92)"""
+        return max([b - (self.height - 1) for b in self._degree_bounds("transition", challenges, [air.X0] * 5)] or [1])
+
+    # ---- host-side evaluation at one point (the verifier's use, table.py:283-311)
+    def evaluate_constraints(self, kind, point, next_point, challenges, terminals):
+        cons = dict(self.air.all())[kind]
+        params = self.air_params(challenges)
+        return [air.evaluate(e, point, next_point, challenges, terminals, params) for e in cons]

@@ -1,0 +1,136 @@
+"""Brainfuck virtual machine and execution-trace recorder -- host-side mirror of the reference's `vm.py`
+(/root/reference/code/vm.py:69-306): `VirtualMachine.compile / run / simulate / execute`, same return values.
+Scalar control code (a few thousand rows for "Hello World"): it stays on the host, like the reference's.
+Matrices are lists of rows of BaseFieldElement, as in the reference, so they can be handed to either prover.
+"""
+from .algebra import BaseField, BaseFieldElement
+
+P = (1 << 64) - (1 << 32) + 1
+
+
+class VirtualMachine:
+    field = BaseField.main()
+
+    @staticmethod
+    def execute(brainfuck_code):
+        program = VirtualMachine.compile(brainfuck_code)
+        return VirtualMachine.run(program)
+
+    @staticmethod
+    def compile(brainfuck_code):
+        """vm.py:78-105: one word per symbol; `[` and `]` are followed by the jump target (the index just behind the
+        matching bracket's target slot)."""
+        field = VirtualMachine.field
+        words, stack = [], []
+        for symbol in brainfuck_code:
+            words.append(ord(symbol))
+            if symbol == "[":
+                words.append(0)
+                stack.append(len(words) - 1)
+            elif symbol == "]":
+                words.append(stack[-1] + 1)
+                words[stack[-1]] = len(words)
+                stack.pop()
+        return [BaseFieldElement(w, field) for w in words]
+
+    @staticmethod
+    def _words(program):
+        return [w.value if hasattr(w, "value") else int(w) for w in program]
+
+    @staticmethod
+    def run(program, input_data=[]):
+        """vm.py:107-165 -> (running_time, input_data, output_data).  Input symbols that are not supplied cannot be
+        read from a terminal here: running out of input is an error."""
+        prog = VirtualMachine._words(program)
+        ip, mp, memory = 0, 0, {}
+        output_data, input_data, input_counter = [], list(input_data), 0
+        running_time = 1
+        while ip < len(prog):
+            w = prog[ip]
+            if w == ord("["):
+                ip = prog[ip + 1] if memory.get(mp, 0) == 0 else ip + 2
+            elif w == ord("]"):
+                ip = prog[ip + 1] if memory.get(mp, 0) != 0 else ip + 2
+            elif w == ord("<"):
+                ip, mp = ip + 1, (mp - 1) % P
+            elif w == ord(">"):
+                ip, mp = ip + 1, (mp + 1) % P
+            elif w == ord("+"):
+                ip, memory[mp] = ip + 1, (memory.get(mp, 0) + 1) % P
+            elif w == ord("-"):
+                ip, memory[mp] = ip + 1, (memory.get(mp, 0) - 1) % P
+            elif w == ord("."):
+                ip += 1
+                output_data += chr(memory[mp] % 256)
+            elif w == ord(","):
+                ip += 1
+                assert input_counter < len(input_data), "program reads more input symbols than were supplied"
+                memory[mp] = ord(input_data[input_counter])
+                input_counter += 1
+            else:
+                assert False, f"unrecognized instruction at {ip}: {w}"
+            running_time += 1
+        return running_time, input_data, output_data
+
+    @staticmethod
+    def simulate(program, input_data=[]):
+        """vm.py:172-306 -> (processor_matrix, memory_matrix, instruction_matrix, input_matrix, output_matrix)."""
+        from .memory_table import MemoryTable
+        field = VirtualMachine.field
+        prog = VirtualMachine._words(program)
+        n = len(prog)
+        clk = ip = mp = mvi = 0
+        ci = prog[0]
+        ni = prog[1] if n > 1 else 0
+        # Memory cells hold element OBJECTS, and the memory-value register is whatever object sits in the current cell, as
+        # in the reference (vm.py:266-292): the object identity of these entries reaches the proof through the first term of
+        # the input / output running evaluations (processor_table.py:390-404), and pickle memoises by identity.
+        zero = BaseFieldElement(0, field)
+        memory, input_counter = {}, 0
+        mv = BaseFieldElement(0, field)
+        processor, inputs, outputs = [], [], []
+        instruction = [[i, prog[i], prog[i + 1]] for i in range(n - 1)] + [[n - 1, prog[-1], 0]]
+
+        def row():
+            return [BaseFieldElement(clk, field), BaseFieldElement(ip, field), BaseFieldElement(ci, field), BaseFieldElement(ni, field),
+                    BaseFieldElement(mp, field), mv, BaseFieldElement(mvi, field)]
+        while ip < n:
+            processor.append(row())
+            instruction.append([ip, ci, ni])
+            if ci == ord("["):
+                ip = prog[ip + 1] if mv.value == 0 else (ip + 2) % P
+            elif ci == ord("]"):
+                ip = prog[ip + 1] if mv.value != 0 else (ip + 2) % P
+            elif ci == ord("<"):
+                ip, mp = ip + 1, (mp - 1) % P
+            elif ci == ord(">"):
+                ip, mp = ip + 1, (mp + 1) % P
+            elif ci == ord("+"):
+                ip, memory[mp] = ip + 1, BaseFieldElement((memory.get(mp, zero).value + 1) % P, field)
+            elif ci == ord("-"):
+                ip, memory[mp] = ip + 1, BaseFieldElement((memory.get(mp, zero).value - 1) % P, field)
+            elif ci == ord("."):
+                ip += 1
+                outputs.append([memory.get(mp, zero)])
+            elif ci == ord(","):
+                ip += 1
+                assert input_counter < len(input_data), "program reads more input symbols than were supplied"
+                memory[mp] = BaseFieldElement(ord(input_data[input_counter]), field)
+                input_counter += 1
+                inputs.append([memory[mp]])
+            else:
+                assert False, f"unrecognized instruction at {ip}: '{chr(ci)}'"
+            clk += 1
+            ci = prog[ip] if ip < n else 0
+            ni = prog[ip + 1] if ip < n - 1 else 0
+            mv = memory.get(mp, zero)
+            mvi = pow(mv.value, P - 2, P) if mv.value else 0
+        processor.append(row())
+        instruction.append([ip, ci, ni])
+        instruction.sort(key=lambda r: r[0])          # stable, by address (vm.py:302)
+        instruction = [[BaseFieldElement(v, field) for v in r] for r in instruction]
+        return processor, MemoryTable.derive_matrix(processor), instruction, inputs, outputs
+
+    @staticmethod
+    def num_challenges():
+        return 11

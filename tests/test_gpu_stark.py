@@ -1,0 +1,83 @@
+"""BrainfuckStark.prove on the GPU against goldens captured from the reference's own prover:
+tests/golden/stark_<name>.json + stark_<name>_proof.bin, made by tests/golden/gen_stark_golden.py with os.urandom
+replaced by a SHAKE-256 stream.  Every stage is compared -- commitments, challenges, terminals, each quotient codeword,
+degree bounds, the combination codeword, opened indices -- and finally the proof bytes themselves."""
+import glob
+import hashlib
+import json
+import os
+import struct
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLDEN = os.path.join(HERE, "golden")
+NAMES = sorted(os.path.basename(p)[len("stark_"):-len(".json")] for p in glob.glob(os.path.join(GOLDEN, "stark_*.json")))
+
+
+class Stream:
+    """the byte stream the golden generator fed to the reference as os.urandom"""
+
+    def __init__(self, tag):
+        self.tag, self.pos, self.buf = tag, 0, b""
+
+    def __call__(self, n):
+        end = self.pos + n
+        if end > len(self.buf):
+            self.buf = hashlib.shake_256(b"bfs-golden-urandom" + self.tag).digest(max(2 * end, 1 << 16))
+        out = self.buf[self.pos:end]
+        self.pos = end
+        return out
+
+
+def sha_planes(a):
+    """sha256 over elements in order, limbs interleaved (what gen_stark_golden.sha_elems hashes): a is (3, n) or (n,)"""
+    a = np.ascontiguousarray(a.T if a.ndim == 2 else a, dtype="<u8")
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_prove_matches_reference(name, monkeypatch):
+    from stark_brainfuck_amd import brainfuck_stark, salted_merkle, table
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    g = json.load(open(os.path.join(GOLDEN, "stark_%s.json" % name)))
+    stream = Stream(name.encode())
+    for mod in (brainfuck_stark, salted_merkle, table):
+        monkeypatch.setattr(mod, "urandom", stream)
+
+    program = VirtualMachine.compile(g["program"])
+    assert [w.value for w in program] == g["compiled_program"]
+    running_time, input_symbols, output_symbols = VirtualMachine.run(program, input_data=list(g["input"]))
+    assert running_time == g["running_time"] and "".join(output_symbols) == g["output"]
+    pm, mm, im, inm, om = VirtualMachine.simulate(program, input_data=list(input_symbols))
+    stark = BrainfuckStark(running_time, len(mm), program, input_symbols, output_symbols)
+    assert stark.max_degree == g["max_degree"] and stark.fri.domain.length == g["fri_domain_length"]
+    assert [t.height for t in stark.tables] == g["table_heights"]
+
+    proof = stark.prove(program, pm, mm, im, inm, om)
+    last = stark._last
+    n = stark.fri.domain.length
+    assert stream.pos == g["urandom_bytes"], "the prover consumed a different amount of randomness"
+    assert last["base_tree"].root().hex() == g["base_tree"]["root"]
+    assert [list(c) for c in last["challenges"]] == g["quotients"][0]["challenges"]
+    assert [list(t) for t in last["terminals"]] == g["terminals"]
+    assert last["extension_tree"].root().hex() == g["extension_tree"]["root"]
+    bounds, wrong = [], []
+    for (buf, count), q in zip(last["quotient_buffers"], g["quotients"] + g["perm_quotients"]):
+        host = buf.to_numpy(count * 3 * n).reshape(count, 3, n)
+        want = q["sha"] if isinstance(q["sha"], list) else [q["sha"]]
+        wrong += ["%s[%d]" % (q.get("table", "permutation argument"), k) for k in range(count) if sha_planes(host[k]) != want[k]]
+        bounds += q["degree_bounds"] if "degree_bounds" in q else [q["degree_bound"]]
+    assert not wrong, "quotient codewords that differ from the reference's: %s" % wrong
+    assert last["quotient_degree_bounds"] == bounds
+    assert last["weights_seed"].hex() == g["fiat_shamir"][1]["seed"], "transcript differs after the terminals"
+    assert sha_planes(last["combination"].to_numpy()) == g["combination_tree"]["sha"]
+    assert last["combination_tree"].root().hex() == g["combination_tree"]["root"]
+    assert last["indices"] == g["indices"]
+    assert len(proof) == g["proof_len"] and hashlib.sha256(proof).hexdigest() == g["proof_sha256"]
+    path = os.path.join(GOLDEN, "stark_%s_proof.bin" % name)
+    if os.path.exists(path):
+        assert proof == open(path, "rb").read()
