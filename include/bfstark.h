@@ -188,6 +188,11 @@ uint32_t bfs_fri_session_rounds(void* session);
 int bfs_fri_session_round(void* session, uint32_t round, const uint64_t** d_codeword, uint64_t* length, uint64_t* limb_stride,
                           const uint8_t** d_nodes, uint8_t h_root[64]);
 
+/* Device-versus-host comparison of the field primitives and compositions of them on 2^log_count operand pairs (edge values
+ * first): *mismatches must come back 0; the first mismatch is described by bfs_last_error().  A test hook -- it exists
+ * because a compiler fold once broke a composition of two individually correct primitives (csrc/gl.hpp, gl_sub). */
+int bfs_selftest_field(uint32_t log_count, uint64_t* mismatches);
+
 /* ---- STARK prover kernels around the transforms ------------------------------------------ */
 /*
  * Codewords over the FRI domain x_i = offset * omega^i, i < n = 2^log_n, are column-major in HBM: base column c at

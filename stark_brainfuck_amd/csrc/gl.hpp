@@ -45,7 +45,7 @@ BFS_HD u64 gl_sub(u64 a, u64 b) {
     // hipcc (ROCm 7.2) folds this plain subtraction of a borrow into a following add-with-carry of the consumer and then
     // reads the MERGED instruction's carry-out, which is wrong: gl_add(gl_sub(a, b), 1) came out as a - b + 1 mod 2^64
     // (the fold needs a consumer whose own high-word addend is a compile-time zero).  The empty asm makes the value opaque
-    // to that combine; it emits no instruction.  Checked by tools/microbench/prim_check.hip on the device.
+    // to that combine; it emits no instruction.  Checked by csrc/selftest.hip (bfs_selftest_field) on the device.
     asm("" : "+v"(rhi));
     return ((u64)rhi << 32) | rlo;
 }

@@ -480,6 +480,16 @@ def test_smoke_entry_point(sb):
 
 
 # ------------------------------------------------------------------------------------------------ plumbing entry points
+def test_field_primitives_device_vs_host(sb):
+    """every field primitive and a set of compositions (with compile-time constants) must give the same result on the
+    device as the plain 128-bit host arithmetic: guards against compiler folds across the carry chains (gl.hpp, gl_sub)"""
+    from stark_brainfuck_amd import _lib
+    lib = _lib.load()
+    bad = ctypes.c_uint64(1)
+    _lib.check(lib.bfs_selftest_field(18, ctypes.byref(bad)))
+    assert bad.value == 0, lib.bfs_last_error().decode()
+
+
 def test_c_abi_plumbing_and_elementwise(sb, oracle):
     """bfs_gl_scale / bfs_gl_mul_pointwise / bfs_gl_batch_inverse / memcpy_d2d / memset / events, straight through the C ABI."""
     from stark_brainfuck_amd import _lib
