@@ -153,6 +153,21 @@ int bfs_merkle_build_bfe(const uint64_t* d_values, uint64_t n, uint8_t* d_nodes,
 int bfs_merkle_build_bytes(const uint8_t* d_data, const uint64_t* d_word_offsets, const uint32_t* d_lengths, uint64_t n,
                            uint8_t* d_nodes, void* stream);
 int bfs_merkle_open(const uint8_t* d_nodes, uint32_t depth, uint64_t index, uint8_t* h_path, void* stream);
+/*
+ * bfs_merkle_build_rows   SaltedMerkle(list(zip(*codewords)))  (brainfuck_stark.py:178-179, 197-198; salted_merkle.py:22-47):
+ *     leaf i = blake2b(pickle.dumps(tuple of the i-th element of every column) || pickle.dumps(salt_i)).  Columns are
+ *     codewords in HBM: an extension column is three limb planes of n words (elements of the xfield's own BaseField),
+ *     a base column n words whose elements point at BaseField instance `field_id` (as in bfs_ps_obj_bfe).  h_salts: n x 24
+ *     bytes on the host, or NULL for unsalted tuples.  Rows are pickled on `threads` host threads (0 = all cores, at most
+ *     64), hashed on the GPU; synchronises the stream.  n must be a power of two for a SaltedMerkle (salted_merkle.py:22).
+ */
+typedef struct bfs_row_column {
+    const uint64_t* d_values;
+    int32_t is_ext;
+    int32_t field_id;
+} bfs_row_column;
+int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n, const uint8_t* h_salts, uint8_t* d_nodes,
+                          uint32_t threads, void* stream);
 
 /* ---- FRI ---------------------------------------------------------------------------------------------------- */
 /*

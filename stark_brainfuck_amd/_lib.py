@@ -69,6 +69,7 @@ _SIGNATURES = {
     "bfs_merkle_build_bfe": (ci, [vp, u64, vp, vp]),
     "bfs_merkle_build_bytes": (ci, [vp, vp, vp, u64, vp, vp]),
     "bfs_merkle_open": (ci, [vp, u32, u64, vp, vp]),
+    "bfs_merkle_build_rows": (ci, [vp, u32, u64, ctypes.c_char_p, vp, u32, vp]),
     "bfs_xfe_fold": (ci, [vp, u64, vp, u64, u32, ctypes.POINTER(u64), u64, u64, vp]),
     "bfs_fri_session_new": (vp, []),
     "bfs_fri_session_free": (None, [vp]),
@@ -86,6 +87,11 @@ _SIGNATURES = {
     "bfs_difference_quotient": (ci, [vp, vp, vp, u32, u64, u64, vp]),
     "bfs_combination": (ci, [vp, u32, vp, ctypes.POINTER(u64), vp, u32, u64, u64, vp]),
 }
+
+
+class RowColumn(ctypes.Structure):
+    """bfs_row_column (include/bfstark.h)"""
+    _fields_ = [("d_values", vp), ("is_ext", ctypes.c_int32), ("field_id", ctypes.c_int32)]
 
 
 class CombSource(ctypes.Structure):

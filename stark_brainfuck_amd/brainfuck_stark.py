@@ -30,7 +30,7 @@ from .memory_table import MemoryTable
 from .merkle import Merkle
 from .permutation_argument import PermutationArgument
 from .processor_table import ProcessorTable
-from .salted_merkle import SaltedMerkle
+from .salted_merkle import SaltedMerkle, ZippedSaltedMerkle
 from .table import sample_ext
 from .univariate import Polynomial
 from .vm import VirtualMachine
@@ -126,24 +126,41 @@ class BrainfuckStark:
             table.pad()                                                                      # :143-148
         if proof_stream is None:
             proof_stream = ProofStream()
+        import time
+        self.timing = {}
+        mark = [time.perf_counter()]
+
+        def lap(name):
+            synchronize(stream)
+            now = time.perf_counter()
+            self.timing[name] = self.timing.get(name, 0.0) + now - mark[0]
+            mark[0] = now
+        lap("pad")
 
         # randomizer polynomial and codeword (:162-167)
         coeffs = np.array([sample_ext(urandom(3 * 9)) for _ in range(self.max_degree + 1)], dtype=np.uint64).T.copy()
         randomizer_codeword = domain.xevaluate(XArray.from_numpy(coeffs, xf), xf, as_array=True)
 
+        lap("randomizer")
         # base codewords of all tables, one commitment to the zipped rows (:169-179)
         for table in self.tables:
             table.lde(domain)
         base_degree_bounds = [t.interpolant_degree() for t in self.tables for _ in range(t.base_width)]
-        synchronize(stream)
+        lap("base_lde")
         rand_host = randomizer_codeword.to_numpy()
         base_host = [t.base_codewords.to_numpy(t.base_width * n).reshape(t.base_width, n) for t in self.tables]
         base_host = np.concatenate(base_host, axis=0)
         f2 = BrainfuckStark.field
-        zipped = [tuple([xf.from_limbs([int(rand_host[0, i]), int(rand_host[1, i]), int(rand_host[2, i])])]
-                        + [BaseFieldElement(int(v), f2) for v in base_host[:, i]]) for i in range(n)]
-        base_tree = SaltedMerkle(zipped)
+
+        def base_row(i):
+            return tuple([xf.from_limbs([int(rand_host[0, i]), int(rand_host[1, i]), int(rand_host[2, i])])]
+                         + [BaseFieldElement(int(v), f2) for v in base_host[:, i]])
+        base_columns = [(randomizer_codeword.ptr, True, 0)]
+        for t in self.tables:
+            base_columns += [(t.base_codewords.ptr + 8 * c * n, False, 0) for c in range(t.base_width)]
+        base_tree = ZippedSaltedMerkle(base_columns, n, base_row)
         proof_stream.push(base_tree.root())
+        lap("base_tree")
 
         # challenges, initials, table extension, terminals (:181-192)
         challenges = BrainfuckStark._sample_weights(11, proof_stream.prover_fiat_shamir())
@@ -151,12 +168,13 @@ class BrainfuckStark:
         for table in self.tables:
             table.extend(challenges, initials)
         terminals = self.get_terminals()
+        lap("extend")
 
         # extension codewords and their commitment (:194-201)
         for table in self.tables:
             table.ldex(domain, xf)
         extension_degree_bounds = [t.interpolant_degree() for t in self.tables for _ in range(t.full_width - t.base_width)]
-        synchronize(stream)
+        lap("ext_lde")
         ext_host = np.concatenate([t.ext_codewords.to_numpy((t.full_width - t.base_width) * 3 * n).reshape(-1, 3, n) for t in self.tables], axis=0)
         moduli = [m for t in self.tables for m in t.ext_sharing_moduli(n)]
         internal = xf.modulus.coefficients[0].field
@@ -172,9 +190,12 @@ class BrainfuckStark:
             e = ExtensionFieldElement(Polynomial(objs), xf)
             e.shares_coefficients = True
             return e
-        zipped_ext = [tuple(ext_element(c, i) for c in range(ext_host.shape[0])) for i in range(n)]
-        extension_tree = SaltedMerkle(zipped_ext)
+        ext_columns = []
+        for t in self.tables:
+            ext_columns += [(t.ext_codewords.ptr + 8 * 3 * c * n, True, 0) for c in range(t.full_width - t.base_width)]
+        extension_tree = ZippedSaltedMerkle(ext_columns, n, lambda i: tuple(ext_element(c, i) for c in range(ext_host.shape[0])))
         proof_stream.push(extension_tree.root())
+        lap("ext_tree")
 
         # quotients (:203-221)
         quotient_buffers, quotient_degree_bounds = [], []
@@ -185,6 +206,7 @@ class BrainfuckStark:
             quotient_buffers.append((pa.quotient(domain), 1))
             quotient_degree_bounds.append(pa.quotient_degree_bound())
 
+        lap("quotients")
         # :223-224.  The input and output evaluations both start from ONE zero object (processor_table.py:340-347) and
         # stay that object when the program never reads / writes; pickle then writes the second one as a back-reference.
         # The running evaluations are sums `evaluation * challenge + lift(symbol)`; the first one is `zero + lift(symbol)`,
@@ -235,6 +257,7 @@ class BrainfuckStark:
         _lib.check(lib.bfs_combination(srcs, len(sources), randomizer_codeword.ptr, (_u64 * 3)(*weights[0]), combination.ptr,
                                        log_n, domain.offset.value, domain.omega.value, stream))
 
+        lap("combination")
         # commitment to the combination codeword, openings (:300-333)
         combination_tree = Merkle(combination)
         proof_stream.push(combination_tree.root())
@@ -248,16 +271,131 @@ class BrainfuckStark:
                 proof_stream.push(extension_tree.leafs[idx][0])
                 proof_stream.push(extension_tree.open(idx))
         known = {}
+        comb_host = combination.to_numpy()
         for index in indices:
-            leaf = combination_tree.leafs[index]
-            known[index] = leaf
+            if index not in known:                   # the same index twice is the same leaf object twice
+                known[index] = xf.from_limbs([int(comb_host[0, index]), int(comb_host[1, index]), int(comb_host[2, index])])
+            leaf = known[index]
             proof_stream.push(leaf)
             proof_stream.push(combination_tree.open(index))
 
+        lap("openings")
         # low-degree test of the combination codeword (:335-336)
         self.fri.prove(combination, proof_stream, known_leafs=known)
         self._last = {"base_tree": base_tree, "extension_tree": extension_tree, "combination_tree": combination_tree,
                       "challenges": challenges, "terminals": terminals, "indices": indices, "weights_seed": weights_seed,
                       "quotient_degree_bounds": quotient_degree_bounds, "quotient_buffers": quotient_buffers,
                       "combination": combination}
-        return proof_stream.serialize()
+        lap("fri")
+        proof = proof_stream.serialize()
+        lap("serialize")
+        return proof
+
+    # ------------------------------------------------------------------------------------------------------------
+    def verify(self, proof, proof_stream=None):
+        """brainfuck_stark.py:343-579 -- host only, like the reference's verifier: Merkle paths of the opened rows, the
+        non-linear combination recomputed from the opened rows (constraints evaluated through air.evaluate), FRI, and the
+        terminals against the public input, output and program."""
+        from .air import X0, X1, xadd, xinv, xlift, xmul, xscale, xsub
+        P = air.P
+        if proof_stream is None:
+            proof_stream = ProofStream()
+        proof_stream = proof_stream.deserialize(proof)
+        n = self.fri.domain.length
+        offset, omega = self.fri.domain.offset.value, self.fri.domain.omega.value
+
+        def limbs(e):
+            return tuple(e.limbs()) if hasattr(e, "limbs") else (e.value % P, 0, 0)
+
+        base_root = proof_stream.pull()
+        challenges = BrainfuckStark._sample_weights(11, proof_stream.verifier_fiat_shamir())
+        extension_root = proof_stream.pull()
+        terminals = [limbs(proof_stream.pull()) for _ in range(5)]
+
+        base_degree_bounds = [t.interpolant_degree() for t in self.tables for _ in range(t.base_width)]
+        extension_degree_bounds = [t.interpolant_degree() for t in self.tables for _ in range(t.full_width - t.base_width)]
+        num_base = sum(t.base_width for t in self.tables)
+        num_ext = sum(t.full_width - t.base_width for t in self.tables)
+        num_quot = sum(t.num_quotients(challenges, terminals) for t in self.tables)
+        weights = BrainfuckStark._sample_weights(1 + 2 * (num_base + num_ext + num_quot + len(self.permutation_arguments)),
+                                                 proof_stream.verifier_fiat_shamir())
+        combination_root = proof_stream.pull()
+        indices = BrainfuckStark.sample_indices(self.security_level, proof_stream.verifier_fiat_shamir(), n)
+        unit_distances = list(set(table.unit_distance(n) for table in self.tables))
+
+        rows = {}
+        for index in indices:
+            for distance in [0] + unit_distances:
+                idx = (index + distance) % n
+                element = proof_stream.pull()
+                salt, path = proof_stream.pull()
+                assert SaltedMerkle.verify(base_root, idx, salt, path, element), "salted base tree verify must succeed for base codewords"
+                row = [limbs(e) for e in element]
+                element = proof_stream.pull()
+                salt, path = proof_stream.pull()
+                assert SaltedMerkle.verify(extension_root, idx, salt, path, element), \
+                    "salted base tree verify must succeed for extension codewords"
+                rows[idx] = row + [limbs(e) for e in element]
+
+        quotient_bounds = {t: (t.boundary_quotient_degree_bounds(challenges), t.transition_quotient_degree_bounds(challenges),
+                               t.terminal_quotient_degree_bounds(challenges, terminals)) for t in self.tables}
+        for index in indices:
+            x = offset * pow(omega, index, P) % P
+
+            def shifted(value, bound):
+                return xscale(value, pow(x, self.max_degree - bound, P))
+            row = rows[index]
+            terms = [row[0]]
+            for i in range(num_base):
+                terms += [row[1 + i], shifted(row[1 + i], base_degree_bounds[i])]
+            ext_offset = 1 + num_base
+            for i in range(num_ext):
+                terms += [row[ext_offset + i], shifted(row[ext_offset + i], extension_degree_bounds[i])]
+
+            # the rows of every table: base columns, then its extension columns
+            points, next_points = [], []
+            b, e = 1, ext_offset
+            for table in self.tables:
+                xw = table.full_width - table.base_width
+                nrow = rows[(index + table.unit_distance(n)) % n]
+                points.append(row[b:b + table.base_width] + row[e:e + xw])
+                next_points.append(nrow[b:b + table.base_width] + nrow[e:e + xw])
+                b, e = b + table.base_width, e + xw
+
+            boundary_inverse = pow((x - 1) % P, P - 2, P)
+            for table, point, next_point in zip(self.tables, points, next_points):
+                bb, tb, zb = quotient_bounds[table]
+                omicron_inverse = pow(table.omicron.value, P - 2, P)
+                for value, bound in zip(table.evaluate_constraints("boundary", point, None, challenges, terminals), bb):
+                    q = xscale(value, boundary_inverse)
+                    terms += [q, shifted(q, bound)]
+                if table.height == 0:
+                    transition_factor = 0
+                else:
+                    transition_factor = (x - omicron_inverse) * pow((pow(x, table.height, P) - 1) % P, P - 2, P) % P
+                for value, bound in zip(table.evaluate_constraints("transition", point, next_point, challenges, terminals), tb):
+                    q = xscale(value, transition_factor)
+                    terms += [q, shifted(q, bound)]
+                terminal_inverse = pow((x - omicron_inverse) % P, P - 2, P)
+                for value, bound in zip(table.evaluate_constraints("terminal", point, None, challenges, terminals), zb):
+                    q = xscale(value, terminal_inverse)
+                    terms += [q, shifted(q, bound)]
+            for arg in self.permutation_arguments:
+                q = xscale(arg.evaluate_difference(points), boundary_inverse)
+                terms += [q, shifted(q, arg.quotient_degree_bound())]
+            assert len(terms) == len(weights), f"length of terms ({len(terms)}) must be equal to length of weights ({len(weights)})"
+            inner_product = X0
+            for w, t in zip(weights, terms):
+                inner_product = xadd(inner_product, xmul(w, t))
+
+            combination_leaf = proof_stream.pull()
+            combination_path = proof_stream.pull()
+            if not Merkle.verify(combination_root, index, combination_path, combination_leaf):
+                return False
+            if limbs(combination_leaf) != inner_product:
+                return False
+
+        verdict = self.fri.verify(proof_stream, combination_root)
+        for ea in self.evaluation_arguments:
+            verdict = verdict and tuple(ea.select_terminal(terminals)) == tuple(ea.compute_terminal(challenges))
+        return bool(verdict)

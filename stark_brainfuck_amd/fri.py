@@ -138,6 +138,7 @@ class Fri:
         assert n & (n - 1) == 0, "codeword length must be a power of two"
         transcript = NativeTranscript()
         transcript.xfield = self.field
+        transcript.scan(proof_stream.objects)
         for o in proof_stream.objects:
             transcript.push(o)
         before = transcript.num_objects()

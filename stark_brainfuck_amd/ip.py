@@ -28,6 +28,7 @@ class NativeTranscript:
         self._keep = []      # keeps those python objects alive so ids stay unique
         self._by_handle = {}  # native handle -> python object (identity of objects created natively)
         self._fields = {}    # id(BaseField instance) -> native field id
+        self._coefficient_uses = {}   # id(coefficient object) -> number of extension elements holding it (scan())
         self.xfield = None
 
     def __del__(self):
@@ -35,6 +36,27 @@ class NativeTranscript:
             self.lib.bfs_ps_free(self.handle)
         except Exception:
             pass
+
+    def scan(self, objs):
+        """note which BaseFieldElement objects are coefficients of more than one extension element: those elements must be
+        built over explicit coefficient objects so that the second occurrence becomes a back-reference, as in pickle."""
+        seen = {}
+
+        def walk(o):
+            if isinstance(o, ExtensionFieldElement):
+                if id(o) in seen:
+                    return
+                seen[id(o)] = 1
+                for c in o.polynomial.coefficients:
+                    self._coefficient_uses[id(c)] = self._coefficient_uses.get(id(c), 0) + 1
+            elif isinstance(o, (list, tuple)):
+                if id(o) in seen:
+                    return
+                seen[id(o)] = 1
+                for x in o:
+                    walk(x)
+        for o in objs:
+            walk(o)
 
     def _field_id(self, field):
         """BaseField instances are distinguished by identity, like pickle does: 1 = the one inside the xfield's modulus,
@@ -60,7 +82,8 @@ class NativeTranscript:
                 self.xfield = obj.field
             coeffs = obj.polynomial.coefficients
             internal = self.xfield.modulus.coefficients[0].field
-            if all(c.field is internal and id(c) not in self._by_id for c in coeffs) and not getattr(obj, "shares_coefficients", False):
+            plain = all(c.field is internal and id(c) not in self._by_id and self._coefficient_uses.get(id(c), 0) < 2 for c in coeffs)
+            if plain and not getattr(obj, "shares_coefficients", False):
                 n = lib.bfs_ps_obj_xfe(h, (_u64 * 3)(*obj.limbs()))
             else:
                 # coefficient objects that are shared with another element, or that point at a foreign BaseField instance
@@ -180,6 +203,7 @@ class ProofStream:
         t = NativeTranscript()
         objs = self.objects if count is None else self.objects[:count]
         t.xfield = _find_xfield(objs)     # decides which BaseField instance a bare BaseFieldElement refers to
+        t.scan(objs)
         for o in objs:
             t.push(o)
         return t

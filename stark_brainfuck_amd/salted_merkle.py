@@ -6,6 +6,10 @@ import pickle
 from hashlib import blake2b
 from os import urandom          # module-level name on purpose: callers patch `salted_merkle.urandom` for determinism
 
+import ctypes
+
+from . import _lib
+from .device import DeviceBuffer, current_stream
 from .ip import NativeTranscript
 from .merkle import Merkle, leaf_bytes
 
@@ -34,3 +38,41 @@ class SaltedMerkle(Merkle):
             running = blake2b(running + node).digest() if index % 2 == 0 else blake2b(node + running).digest()
             index >>= 1
         return running == root
+
+
+class _LazyLeafs:
+    """`leafs` of a ZippedSaltedMerkle: (row tuple, salt) pairs made on first access and then kept, so that a row opened
+    twice is the same Python object both times (pickle memoises by identity)."""
+
+    def __init__(self, n, make_row, salts):
+        self._n, self._make_row, self._salts, self._cache = n, make_row, salts, {}
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, index):
+        if index not in self._cache:
+            self._cache[index] = (self._make_row(index), self._salts[24 * index:24 * index + 24])
+        return self._cache[index]
+
+
+class ZippedSaltedMerkle(SaltedMerkle):
+    """SaltedMerkle(list(zip(*codewords))) for codewords that live in HBM (brainfuck_stark.py:178-179, 197-198).
+    columns: list of (device pointer, is_extension, base_field_id); make_row(i) builds the tuple of element objects of
+    row i on demand (only opened rows are ever materialised).  Rows are pickled natively on host threads and hashed
+    on the GPU (bfs_merkle_build_rows)."""
+
+    def __init__(self, columns, n, make_row, threads=0):
+        assert n & (n - 1) == 0 and n > 0, f"in SaltedMerkle.__init__, next_power_of_two = {n} =/= 1 << self.depth"
+        salts = urandom(24 * n)                      # the same bytes as n calls of urandom(24) (salted_merkle.py:25)
+        self.num_leafs = n
+        self._npo2, self.depth = n, n.bit_length() - 1
+        self._data = None
+        self._nodes_host = None
+        self._node_cache = {}
+        self._nodes = DeviceBuffer(2 * n * 8)
+        cols = (_lib.RowColumn * len(columns))()
+        for c, (ptr, is_ext, field_id) in zip(cols, columns):
+            c.d_values, c.is_ext, c.field_id = ptr, int(is_ext), field_id
+        _lib.check(_lib.load().bfs_merkle_build_rows(cols, len(columns), n, salts, self._nodes.ptr, threads, current_stream()))
+        self._leafs = _LazyLeafs(n, make_row, salts)

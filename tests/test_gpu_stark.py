@@ -81,3 +81,49 @@ def test_prove_matches_reference(name, monkeypatch):
     path = os.path.join(GOLDEN, "stark_%s_proof.bin" % name)
     if os.path.exists(path):
         assert proof == open(path, "rb").read()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_verify_accepts_reference_proofs_and_rejects_tampering(name):
+    """the verifier mirror (brainfuck_stark.py:343-579) on proofs written by the reference itself"""
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    g = json.load(open(os.path.join(GOLDEN, "stark_%s.json" % name)))
+    program = VirtualMachine.compile(g["program"])
+    running_time, input_symbols, output_symbols = VirtualMachine.run(program, input_data=list(g["input"]))
+    _, mm, _, _, _ = VirtualMachine.simulate(program, input_data=list(input_symbols))
+    proof = open(os.path.join(GOLDEN, "stark_%s_proof.bin" % name), "rb").read()
+    stark = BrainfuckStark(running_time, len(mm), program, input_symbols, output_symbols)
+    assert stark.verify(proof) is True
+    # a claim about a different output must fail (the output evaluation terminal no longer matches, evaluation_argument.py)
+    other = BrainfuckStark(running_time, len(mm), program, input_symbols, list(output_symbols) + ["!"])
+    try:
+        assert other.verify(proof) is False
+    except AssertionError:
+        pass
+    # flipping one bit inside an opened digest breaks an authentication path
+    pos = proof.index(bytes.fromhex(g["combination_tree"]["root"])) + 200
+    bad = bytearray(proof)
+    bad[pos] ^= 1
+    try:
+        assert stark.verify(bytes(bad)) is False
+    except (AssertionError, Exception):
+        pass
+
+
+@pytest.mark.gpu
+def test_prove_then_verify_fresh_randomness():
+    """with real os.urandom there is no golden: the proof must verify, and two proofs of the same claim must differ"""
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    program = VirtualMachine.compile(",>,<[->+<]>.")
+    running_time, input_symbols, output_symbols = VirtualMachine.run(program, input_data=list("!#"))
+    assert "".join(output_symbols) == "D"
+    pm, mm, im, inm, om = VirtualMachine.simulate(program, input_data=list(input_symbols))
+    stark = BrainfuckStark(running_time, len(mm), program, input_symbols, output_symbols)
+    proof_a = stark.prove(program, pm, mm, im, inm, om)
+    proof_b = BrainfuckStark(running_time, len(mm), program, input_symbols, output_symbols).prove(program, pm, mm, im, inm, om)
+    assert proof_a != proof_b
+    assert BrainfuckStark(running_time, len(mm), program, input_symbols, output_symbols).verify(proof_a) is True
+    assert BrainfuckStark(running_time, len(mm), program, input_symbols, output_symbols).verify(proof_b) is True

@@ -1,0 +1,168 @@
+"""Host-side logic of the STARK prover mirror against the goldens captured from the reference (tests/golden/stark_*.json,
+made by tests/golden/gen_stark_golden.py): VM traces, FRI domain sizing, symbolic degree bounds, generated constraint code,
+and the wire format (the reference's own proofs, read into this package's classes and written back, byte for byte).
+No GPU: the native transcript code is host C++."""
+import glob
+import hashlib
+import io
+import json
+import os
+import random
+import struct
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+GOLDEN = os.path.join(HERE, "golden")
+NAMES = sorted(os.path.basename(p)[len("stark_"):-len(".json")] for p in glob.glob(os.path.join(GOLDEN, "stark_*.json")))
+
+
+def golden(name):
+    return json.load(open(os.path.join(GOLDEN, "stark_%s.json" % name)))
+
+
+def sha_rows(matrix):
+    h = hashlib.sha256()
+    for row in matrix:
+        for e in row:
+            h.update(struct.pack("<Q", e.value))
+    return h.hexdigest()
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_vm_traces_and_domain_sizing(name):
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    g = golden(name)
+    program = VirtualMachine.compile(g["program"])
+    assert [w.value for w in program] == g["compiled_program"]
+    running_time, inputs, outputs = VirtualMachine.run(program, input_data=list(g["input"]))
+    assert running_time == g["running_time"] and "".join(outputs) == g["output"]
+    matrices = VirtualMachine.simulate(program, input_data=list(inputs))
+    for matrix, key in zip(matrices, ("processor", "memory", "instruction", "input", "output")):
+        assert [len(matrix), len(matrix[0]) if matrix else g["matrix_shapes"][key][1]] == g["matrix_shapes"][key]
+        assert sha_rows(matrix) == g["matrix_sha"][key], key
+    stark = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs)
+    assert stark.max_degree == g["max_degree"]
+    assert stark.fri.domain.length == g["fri_domain_length"]
+    assert [t.height for t in stark.tables] == g["table_heights"]
+    assert [t.unit_distance(stark.fri.domain.length) for t in stark.tables] == g["unit_distances"]
+    assert stark.num_colinearity_checks == g["num_colinearity_checks"] and stark.expansion_factor == g["expansion_factor"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_quotient_degree_bounds(name):
+    """exact symbolic expansion (air.expand) gives the reference's MPolynomial.symbolic_degree_bound for every quotient"""
+    from stark_brainfuck_amd import air
+    g = golden(name)
+    randomizers = [1, 1, 1, 0, 0]
+    for ti, (ta, q) in enumerate(zip(air.TABLE_AIRS, g["quotients"])):
+        challenges = [tuple(c) for c in q["challenges"]]
+        terminals = [tuple(t) for t in q["terminals"]]
+        height, length = g["table_heights"][ti], g["table_lengths"][ti]
+        md = height + randomizers[ti] - 1
+        params = [air.xpow(challenges[ta.challenge_index], height - length)] if ta.num_params else []
+        got = []
+        for kind, constraints in ta.all():
+            nvars = 2 * ta.full_width if kind == "transition" else ta.full_width
+            for e in constraints:
+                bound = air.symbolic_degree_bound(air.expand(e, nvars, challenges, terminals, params), md)
+                got.append(bound - height + 1 if kind == "transition" else bound - 1)
+        assert got == q["degree_bounds"], ta.name
+
+
+def test_generated_constraint_code_matches_the_expression_graphs(tmp_path):
+    """csrc/air_generated.hpp (what the quotient kernels run), compiled for the host, against air.evaluate at random
+    points; also checks that the committed header is what tools/gen_air.py produces from air.py today."""
+    from stark_brainfuck_amd import air
+    header = os.path.join(ROOT, "stark_brainfuck_amd", "csrc", "air_generated.hpp")
+    before = open(header).read()
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_air.py")], check=True, capture_output=True)
+    assert open(header).read() == before, "air_generated.hpp is stale: run tools/gen_air.py"
+    src = tmp_path / "chk.cpp"
+    src.write_text(r'''
+#include "%s"
+#include <cstdio>
+using namespace bfs;
+int main() {
+    u64 bc[16], bn[16]; Xfe xc[8], xn[8], ch[11], tm[5], pr[1]; unsigned long long v;
+    auto rd = [&]() { if (scanf("%%llu", &v) != 1) return (u64)0; return (u64)v; };
+    int table = (int)rd();
+    for (int i = 0; i < 16; ++i) bc[i] = rd();
+    for (int i = 0; i < 16; ++i) bn[i] = rd();
+    for (int i = 0; i < 8; ++i) for (int l = 0; l < 3; ++l) xc[i].c[l] = rd();
+    for (int i = 0; i < 8; ++i) for (int l = 0; l < 3; ++l) xn[i].c[l] = rd();
+    for (int i = 0; i < 11; ++i) for (int l = 0; l < 3; ++l) ch[i].c[l] = rd();
+    for (int i = 0; i < 5; ++i) for (int l = 0; l < 3; ++l) tm[i].c[l] = rd();
+    for (int l = 0; l < 3; ++l) pr[0].c[l] = rd();
+    Xfe out[32]; int n = 0;
+    if (table == 0) { airgen::air_processor(bc, bn, xc, xn, ch, tm, pr, out); n = 21; }
+    if (table == 1) { airgen::air_instruction(bc, bn, xc, xn, ch, tm, pr, out); n = 10; }
+    if (table == 2) { airgen::air_memory(bc, bn, xc, xn, ch, tm, pr, out); n = 11; }
+    if (table == 3) { airgen::air_input(bc, bn, xc, xn, ch, tm, pr, out); n = 3; }
+    if (table == 4) { airgen::air_output(bc, bn, xc, xn, ch, tm, pr, out); n = 3; }
+    for (int i = 0; i < n; ++i) printf("%%llu %%llu %%llu\n", (unsigned long long)out[i].c[0], (unsigned long long)out[i].c[1], (unsigned long long)out[i].c[2]);
+}
+''' % header)
+    exe = tmp_path / "chk"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-o", str(exe), str(src)], check=True)
+    rng = random.Random(11)
+    P = air.P
+
+    def rx():
+        return tuple(rng.randrange(P) for _ in range(3))
+    for ti, ta in enumerate(air.TABLE_AIRS):
+        for trial in range(4):
+            bc = [rng.randrange(P) for _ in range(16)]
+            bn = [rng.randrange(P) for _ in range(16)]
+            if trial < 2:
+                bc[2] = ord(",.+-<>[]"[rng.randrange(8)])       # a real instruction in the current-instruction column
+            xc, xn = [rx() for _ in range(8)], [rx() for _ in range(8)]
+            ch, tm, pr = [rx() for _ in range(11)], [rx() for _ in range(5)], [rx()]
+            flat = [ti] + bc + bn + [v for x in xc + xn + ch + tm + pr for v in x]
+            out = subprocess.run([str(exe)], input=" ".join(map(str, flat)), capture_output=True, text=True, check=True).stdout.split()
+            got = [tuple(int(out[3 * i + l]) for l in range(3)) for i in range(len(out) // 3)]
+            bw = ta.base_width
+            cur = [air.xlift(v) for v in bc[:bw]] + xc[:ta.full_width - bw]
+            nxt = [air.xlift(v) for v in bn[:bw]] + xn[:ta.full_width - bw]
+            want = [air.evaluate(e, cur, nxt, ch, tm, pr) for _, cons in ta.all() for e in cons]
+            assert got == want, ta.name
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_reference_proofs_round_trip_byte_for_byte(name):
+    """a proof written by the reference, read into this package's classes (identity of shared objects preserved by the
+    unpickler) and serialised by the native transcript code, must come back identical: covers foreign BaseField
+    instances, coefficient objects shared between elements, repeated rows, multi-object memoisation"""
+    from stark_brainfuck_amd.ip import ProofStream
+    path = os.path.join(GOLDEN, "stark_%s_proof.bin" % name)
+    if not os.path.exists(path):
+        pytest.skip("proof fixture not committed for this golden")
+    proof = open(path, "rb").read()
+    stream = ProofStream().deserialize(proof)
+    assert len(stream.objects) == golden(name)["num_objects"]
+    assert stream.serialize() == proof
+    # the verifier's view after k objects is the prefix pickle: hash equal to the golden Fiat-Shamir seeds
+    g = golden(name)
+    stream.read_index = 1
+    assert stream.verifier_fiat_shamir().hex() == g["fiat_shamir"][0]["seed"]
+    stream.read_index = 7
+    assert stream.verifier_fiat_shamir().hex() == g["fiat_shamir"][1]["seed"]
+
+
+def test_running_evaluation_identity_rules():
+    """processor_table._evaluation_step: which objects the reference's running evaluations are made of"""
+    from stark_brainfuck_amd.algebra import BaseField, BaseFieldElement
+    from stark_brainfuck_amd.processor_table import _evaluation_step
+    f = BaseField.main()
+    gamma = (5, 6, 7)
+    a, b = BaseFieldElement(97, f), BaseFieldElement(98, f)
+    state, ident = _evaluation_step((0, 0, 0), None, gamma, a)
+    assert state == (97, 0, 0) and ident == ("object", a)            # zero + lift(a) IS a's polynomial
+    state, ident = _evaluation_step(state, ident, gamma, b)
+    assert ident == ("fresh", f) and state[1:] != (0, 0)             # afterwards new elements of a's field instance
+    state, ident = _evaluation_step((0, 0, 0), None, gamma, BaseFieldElement(0, f))
+    assert state == (0, 0, 0) and ident is None                      # lifting zero leaves no coefficient at all

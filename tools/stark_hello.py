@@ -1,0 +1,22 @@
+"""BrainfuckStark.prove on the "Hello World!" program (BASELINE.json config 4: FRI domain 2^17, 26 columns), timed."""
+import os, sys, time, hashlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+from stark_brainfuck_amd.vm import VirtualMachine
+from stark_brainfuck_amd.device import synchronize
+code = sys.argv[1] if len(sys.argv) > 1 else "++++++++[>++++[>++>+++>+++>+<<<<-]>+>+>->>+[<]<-]>>.>---.+++++++..+++.>>.<-.<.+++.------.--------.>>+.>++."
+t0 = time.perf_counter()
+program = VirtualMachine.compile(code)
+running_time, inp, out = VirtualMachine.run(program)
+pm, mm, im, inm, om = VirtualMachine.simulate(program, input_data=inp)
+t1 = time.perf_counter()
+stark = BrainfuckStark(running_time, len(mm), program, inp, out)
+t2 = time.perf_counter()
+print("running time %d, memory rows %d, FRI domain 2^%d, setup %.3f s (vm %.3f s)" % (running_time, len(mm), stark.fri.domain.length.bit_length() - 1, t2 - t1, t1 - t0), flush=True)
+for rep in range(3):
+    t = time.perf_counter()
+    proof = stark.prove(program, pm, mm, im, inm, om)
+    synchronize()
+    print("prove: %.3f s, proof %d bytes, sha256 %s" % (time.perf_counter() - t, len(proof), hashlib.sha256(proof).hexdigest()[:16]), flush=True)
+    if hasattr(stark, "timing"):
+        print("   ", {k: round(v, 4) for k, v in stark.timing.items()})
