@@ -55,6 +55,7 @@ def main():
                     help="untimed steps run before the W warmup steps until this much wall time has passed, so that the "
                          "device clocks have ramped (the first ~10 steps after idle run ~10 %% slower); 0 disables")
     ap.add_argument("--no-fri", action="store_true")
+    ap.add_argument("--no-stark", action="store_true", help="skip BrainfuckStark.prove on Hello World (config 4)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run round-trip check and root gather (PMC collection runs)")
     args = ap.parse_args()
@@ -193,6 +194,8 @@ def main():
             line["fri_prove"] = bench_fri(lib, _lib, stream, 18)
             line["fri_prove_ms"] = line["fri_prove"]["ms"]
             line["fri_prove_2p24"] = bench_fri(lib, _lib, stream, 22)
+        if not args.no_stark and not args.no_fri:
+            line["stark_prove"] = bench_stark()
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(log_n)
         print(json.dumps(line), flush=True)
@@ -232,6 +235,30 @@ def bench_fri(lib, _lib, stream, log_d):
             "top_level_indices": idx, "breakdown_ms": {k: round(v, 4) for k, v in zip(("rounds", "last_codeword", "fiat_shamir_sampling", "plan_openings", "gather", "build_objects"), tm)},
             "algorithmic_GBps": 376.0 * N / (ms * 1e-3) / 1e9,
             "note": "bfs_fri_prove through the C ABI, codeword resident in HBM, includes host Fiat-Shamir round trips and D2H of openings"}
+
+
+def bench_stark():
+    """config 4: BrainfuckStark.prove on the "Hello World!" program (FRI domain 2^17, 16 base + 10 extension columns, 52
+    quotients), through the Python mirror of the reference's call surface; the proof is checked with verify()."""
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    code = "++++++++[>++++[>++>+++>+++>+<<<<-]>+>+>->>+[<]<-]>>.>---.+++++++..+++.>>.<-.<.+++.------.--------.>>+.>++."
+    program = VirtualMachine.compile(code)
+    running_time, inputs, outputs = VirtualMachine.run(program)
+    matrices = VirtualMachine.simulate(program, input_data=inputs)
+    times, timing, proof = [], None, None
+    for rep in range(4):
+        stark = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs)
+        t0 = time.perf_counter()
+        proof = stark.prove(program, *matrices)
+        times.append(time.perf_counter() - t0)
+        timing = stark.timing
+    ok = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs).verify(proof)
+    return {"ms": statistics.median(times[1:]) * 1e3, "program": "Hello World!", "running_time": running_time,
+            "fri_domain_length": stark.fri.domain.length, "proof_bytes": len(proof), "verified": bool(ok),
+            "breakdown_ms": {k: round(v * 1e3, 2) for k, v in timing.items()},
+            "reference": "not runnable: > 12 h extrapolated from 361 s at N = 1024 (BASELINE.md); 757 s measured at N = 2048 (tests/golden/stark_loop.json)",
+            "note": "wall clock of prove() incl. host steps (padding, running products, row pickling for the zipped commitments, Fiat-Shamir)"}
 
 
 def cpu_baseline(log_n):
