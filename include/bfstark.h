@@ -135,6 +135,17 @@ int bfs_ps_obj_get_limbs(void* ps, uint64_t handle, uint64_t limbs[3]);
 uint64_t bfs_gl_sample(const uint8_t* bytes, size_t len);
 void bfs_xfe_sample(const uint8_t* bytes, size_t len, uint64_t out[3]);
 
+/* Scattered reads from HBM in one round trip: request r delivers `nwords` words d_base[0], d_base[stride], d_base[2*stride], ...;
+ * results are packed into h_out in request order.  One small kernel writes into pinned host memory (no copy commands); used for
+ * the handful of codeword rows and tree nodes a proof reveals (fri.py:141-176, brainfuck_stark.py:315-333).  `out_offset` is
+ * ignored on input.  Synchronises the stream. */
+typedef struct bfs_gather_request {
+    const uint64_t* d_base;
+    uint32_t nwords, stride;
+    uint64_t out_offset;
+} bfs_gather_request;
+int bfs_gather(const bfs_gather_request* requests, uint32_t count, uint64_t* h_out, void* stream);
+
 /* ---- Merkle trees ------------------------------------------------------------------------------------------- */
 /*
  * Tree layout = the reference's `nodes` list (merkle.py:26-44): 2*npo2 digests of 64 bytes, npo2 = next power of
@@ -156,10 +167,11 @@ int bfs_merkle_open(const uint8_t* d_nodes, uint32_t depth, uint64_t index, uint
 /*
  * bfs_merkle_build_rows   SaltedMerkle(list(zip(*codewords)))  (brainfuck_stark.py:178-179, 197-198; salted_merkle.py:22-47):
  *     leaf i = blake2b(pickle.dumps(tuple of the i-th element of every column) || pickle.dumps(salt_i)).  Columns are
- *     codewords in HBM: an extension column is three limb planes of n words (elements of the xfield's own BaseField),
- *     a base column n words whose elements point at BaseField instance `field_id` (as in bfs_ps_obj_bfe).  h_salts: n x 24
- *     bytes on the host, or NULL for unsalted tuples.  Rows are pickled on `threads` host threads (0 = all cores, at most
- *     64), hashed on the GPU; synchronises the stream.  n must be a power of two for a SaltedMerkle (salted_merkle.py:22).
+ *     codewords in HBM (at most 32, at most 16 of them extension columns): an extension column is three limb planes of n
+ *     words (elements of the xfield's own BaseField), a base column n words whose elements point at BaseField instance
+ *     `field_id` (as in bfs_ps_obj_bfe).  h_salts: n x 24 bytes on the host, or NULL for unsalted tuples.  The pickle of every
+ *     row is synthesised on the GPU and streamed into BLAKE2b (csrc/rows.hip); synchronises the stream.  n must be a power
+ *     of two for a SaltedMerkle (salted_merkle.py:22).
  */
 typedef struct bfs_row_column {
     const uint64_t* d_values;
@@ -167,7 +179,7 @@ typedef struct bfs_row_column {
     int32_t field_id;
 } bfs_row_column;
 int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n, const uint8_t* h_salts, uint8_t* d_nodes,
-                          uint32_t threads, void* stream);
+                          void* stream);
 
 /* ---- FRI ---------------------------------------------------------------------------------------------------- */
 /*

@@ -65,11 +65,12 @@ _SIGNATURES = {
     "bfs_ps_obj_get_limbs": (ci, [vp, u64, ctypes.POINTER(u64)]),
     "bfs_gl_sample": (u64, [ctypes.c_char_p, sz]),
     "bfs_xfe_sample": (None, [ctypes.c_char_p, sz, ctypes.POINTER(u64)]),
+    "bfs_gather": (ci, [vp, u32, vp, vp]),
     "bfs_merkle_build_xfe": (ci, [vp, u64, u64, vp, vp]),
     "bfs_merkle_build_bfe": (ci, [vp, u64, vp, vp]),
     "bfs_merkle_build_bytes": (ci, [vp, vp, vp, u64, vp, vp]),
     "bfs_merkle_open": (ci, [vp, u32, u64, vp, vp]),
-    "bfs_merkle_build_rows": (ci, [vp, u32, u64, ctypes.c_char_p, vp, u32, vp]),
+    "bfs_merkle_build_rows": (ci, [vp, u32, u64, ctypes.c_char_p, vp, vp]),
     "bfs_xfe_fold": (ci, [vp, u64, vp, u64, u32, ctypes.POINTER(u64), u64, u64, vp]),
     "bfs_fri_session_new": (vp, []),
     "bfs_fri_session_free": (None, [vp]),
@@ -87,6 +88,11 @@ _SIGNATURES = {
     "bfs_difference_quotient": (ci, [vp, vp, vp, u32, u64, u64, vp]),
     "bfs_combination": (ci, [vp, u32, vp, ctypes.POINTER(u64), vp, u32, u64, u64, vp]),
 }
+
+
+class GatherRequest(ctypes.Structure):
+    """bfs_gather_request (include/bfstark.h)"""
+    _fields_ = [("d_base", vp), ("nwords", u32), ("stride", u32), ("out_offset", u64)]
 
 
 class RowColumn(ctypes.Structure):

@@ -19,7 +19,7 @@ import numpy as np
 from . import _lib, air
 from .algebra import BaseField, BaseFieldElement
 from .arrays import XArray
-from .device import DeviceBuffer, current_stream, synchronize
+from .device import DeviceBuffer, current_stream, gather, synchronize
 from .evaluation_argument import EvaluationArgument, ProgramEvaluationArgument
 from .extension_field import ExtensionField, ExtensionFieldElement
 from .fri import Fri
@@ -31,7 +31,7 @@ from .merkle import Merkle
 from .permutation_argument import PermutationArgument
 from .processor_table import ProcessorTable
 from .salted_merkle import SaltedMerkle, ZippedSaltedMerkle
-from .table import sample_ext
+from .table import sample_ext, sample_ext_many
 from .univariate import Polynomial
 from .vm import VirtualMachine
 
@@ -138,7 +138,8 @@ class BrainfuckStark:
         lap("pad")
 
         # randomizer polynomial and codeword (:162-167)
-        coeffs = np.array([sample_ext(urandom(3 * 9)) for _ in range(self.max_degree + 1)], dtype=np.uint64).T.copy()
+        count = self.max_degree + 1
+        coeffs = sample_ext_many(urandom(3 * 9 * count), count, 9)       # the same bytes as `count` calls of urandom(27)
         randomizer_codeword = domain.xevaluate(XArray.from_numpy(coeffs, xf), xf, as_array=True)
 
         lap("randomizer")
@@ -147,14 +148,12 @@ class BrainfuckStark:
             table.lde(domain)
         base_degree_bounds = [t.interpolant_degree() for t in self.tables for _ in range(t.base_width)]
         lap("base_lde")
-        rand_host = randomizer_codeword.to_numpy()
-        base_host = [t.base_codewords.to_numpy(t.base_width * n).reshape(t.base_width, n) for t in self.tables]
-        base_host = np.concatenate(base_host, axis=0)
         f2 = BrainfuckStark.field
 
-        def base_row(i):
-            return tuple([xf.from_limbs([int(rand_host[0, i]), int(rand_host[1, i]), int(rand_host[2, i])])]
-                         + [BaseFieldElement(int(v), f2) for v in base_host[:, i]])
+        def base_row(i):         # only opened rows are ever read back: one gather per row
+            words = gather([(randomizer_codeword.ptr + 8 * i, 3, randomizer_codeword.stride)]
+                           + [(t.base_codewords.ptr + 8 * i, t.base_width, n) for t in self.tables])
+            return tuple([xf.from_limbs([int(v) for v in words[:3]])] + [BaseFieldElement(int(v), f2) for v in words[3:]])
         base_columns = [(randomizer_codeword.ptr, True, 0)]
         for t in self.tables:
             base_columns += [(t.base_codewords.ptr + 8 * c * n, False, 0) for c in range(t.base_width)]
@@ -175,25 +174,30 @@ class BrainfuckStark:
             table.ldex(domain, xf)
         extension_degree_bounds = [t.interpolant_degree() for t in self.tables for _ in range(t.full_width - t.base_width)]
         lap("ext_lde")
-        ext_host = np.concatenate([t.ext_codewords.to_numpy((t.full_width - t.base_width) * 3 * n).reshape(-1, 3, n) for t in self.tables], axis=0)
+        num_ext_columns = sum(t.full_width - t.base_width for t in self.tables)
         moduli = [m for t in self.tables for m in t.ext_sharing_moduli(n)]
         internal = xf.modulus.coefficients[0].field
         shared = [dict() for _ in moduli]          # per column: i mod modulus -> the coefficient objects of that class
 
-        def ext_element(c, i):
-            limbs = [int(ext_host[c, 0, i]), int(ext_host[c, 1, i]), int(ext_host[c, 2, i])]
-            if moduli[c] is None:
-                return xf.from_limbs(limbs)
-            while limbs and limbs[-1] == 0:
-                limbs.pop()
-            objs = shared[c].setdefault(i % moduli[c], [BaseFieldElement(v, internal) for v in limbs])
-            e = ExtensionFieldElement(Polynomial(objs), xf)
-            e.shares_coefficients = True
-            return e
+        def ext_row(i):
+            words = gather([(t.ext_codewords.ptr + 8 * i, 3 * (t.full_width - t.base_width), n) for t in self.tables])
+            row = []
+            for c in range(num_ext_columns):
+                limbs = [int(v) for v in words[3 * c:3 * c + 3]]
+                if moduli[c] is None:
+                    row.append(xf.from_limbs(limbs))
+                    continue
+                while limbs and limbs[-1] == 0:
+                    limbs.pop()
+                objs = shared[c].setdefault(i % moduli[c], [BaseFieldElement(v, internal) for v in limbs])
+                e = ExtensionFieldElement(Polynomial(objs), xf)
+                e.shares_coefficients = True
+                row.append(e)
+            return tuple(row)
         ext_columns = []
         for t in self.tables:
             ext_columns += [(t.ext_codewords.ptr + 8 * 3 * c * n, True, 0) for c in range(t.full_width - t.base_width)]
-        extension_tree = ZippedSaltedMerkle(ext_columns, n, lambda i: tuple(ext_element(c, i) for c in range(ext_host.shape[0])))
+        extension_tree = ZippedSaltedMerkle(ext_columns, n, ext_row)
         proof_stream.push(extension_tree.root())
         lap("ext_tree")
 
@@ -271,10 +275,9 @@ class BrainfuckStark:
                 proof_stream.push(extension_tree.leafs[idx][0])
                 proof_stream.push(extension_tree.open(idx))
         known = {}
-        comb_host = combination.to_numpy()
         for index in indices:
             if index not in known:                   # the same index twice is the same leaf object twice
-                known[index] = xf.from_limbs([int(comb_host[0, index]), int(comb_host[1, index]), int(comb_host[2, index])])
+                known[index] = xf.from_limbs([int(v) for v in gather([(combination.ptr + 8 * index, 3, combination.stride)])])
             leaf = known[index]
             proof_stream.push(leaf)
             proof_stream.push(combination_tree.open(index))

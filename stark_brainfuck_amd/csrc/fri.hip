@@ -375,6 +375,26 @@ int bfs_fri_prove(void* ps, const uint64_t* d_codeword, uint64_t limb_stride, ui
     return fri_query(S, *(rp::Transcript*)ps, num_colinearity_tests, h_top_level_indices, (hipStream_t)stream);
 }
 
+int bfs_gather(const bfs_gather_request* requests, uint32_t count, uint64_t* h_out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (count == 0) return BFS_OK;
+    static_assert(sizeof(bfs_gather_request) == sizeof(GatherReq), "layout of bfs_gather_request");
+    u64 nwords = 0;
+    std::vector<GatherReq> reqs(count);
+    for (uint32_t i = 0; i < count; ++i) {
+        reqs[i] = GatherReq{requests[i].d_base, requests[i].nwords, requests[i].stride, nwords};
+        nwords += requests[i].nwords;
+    }
+    BFS_TRY(g_req_area.ensure(reqs.size() * sizeof(GatherReq)));
+    BFS_TRY(g_res_area.ensure(nwords * sizeof(u64)));
+    memcpy(g_req_area.host, reqs.data(), reqs.size() * sizeof(GatherReq));
+    hipLaunchKernelGGL(gather_requests_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, (const GatherReq*)g_req_area.dev, count, (u64*)g_res_area.dev);
+    BFS_HIP(hipGetLastError());
+    BFS_HIP(hipStreamSynchronize(stream));
+    memcpy(h_out, g_res_area.host, nwords * sizeof(u64));
+    return BFS_OK;
+}
+
 int bfs_fri_session_alias(void* session, void* ps, uint32_t round, uint64_t index, uint64_t element_handle) {
     rp::Ref r = ((rp::Transcript*)ps)->get(element_handle);
     if (!r) { set_error("bfs_fri_session_alias: unknown object handle"); return BFS_ERR_BAD_ARG; }

@@ -138,6 +138,7 @@ class Pickler {
     std::string dumps(const Ref& root) {
         out_.clear();
         memo_.clear();
+        int_marks.clear();
         frame_start_ = NPOS;
         framing_ = false;
         const unsigned char proto[2] = {0x80, 4};
@@ -232,7 +233,20 @@ class Pickler {
         else { unsigned char b[5] = {0x6a}; memcpy(b + 1, &idx, 4); write(b, 5); }
     }
 
+   public:
+    // (offset, length, value) of every integer opcode written by the last dumps(): used to cut a pickle into a template
+    // around its variable-length integers (rows.hip)
+    struct IntMark { size_t offset, length; u64 value; };
+    std::vector<IntMark> int_marks;
+    bool record_ints = false;
+
+   private:
     void save_long(u64 v) {
+        const size_t mark_at = out_.size() + ((framing_ && frame_start_ == NPOS) ? FRAME_HEADER : 0);
+        save_long_raw(v);
+        if (record_ints) int_marks.push_back(IntMark{mark_at, out_.size() - mark_at, v});
+    }
+    void save_long_raw(u64 v) {
         unsigned char b[12];
         if (v < (1ull << 31)) {
             uint32_t x = (uint32_t)v;

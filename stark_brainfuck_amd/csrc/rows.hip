@@ -1,0 +1,326 @@
+// rows.hip -- commitment to "zipped" codewords: leaf i is the TUPLE of the i-th elements of several codewords plus a salt,
+// the reference's SaltedMerkle(list(zip(*codewords)))  (/root/reference/code/brainfuck_stark.py:178-179,197-198 with
+// salted_merkle.py:22-47): leaf preimage = pickle.dumps(tuple) || pickle.dumps(salt), 0.8-1.3 KB per row.
+//
+// The bytes of a row's pickle are a fixed skeleton with the integers of the row spliced in, and the skeleton depends only on
+// how many coefficients each extension element of the row stores (0..3, trailing zeros are dropped: extension_field.py:6-9):
+// the memo indices that later back-references use shift with that count.  So:
+//   1. a kernel computes every row's PATTERN (2 bits per extension column);
+//   2. the host builds one TEMPLATE per pattern that actually occurs (normally one or two) by running the generic pickle
+//      emitter (refpickle.hpp) on a row of sentinel values and cutting the result around the integer opcodes;
+//   3. the leaf kernel expands the template of each row -- constant segments from a small pool, integers encoded on the fly
+//      (BININT1/2, BININT, LONG1 as CPython's save_long), frame length patched in -- and feeds the bytes straight into BLAKE2b:
+//      one 128-byte block buffer per lane in LDS, compressed whenever it fills.  The preimage never exists in memory.
+#include <algorithm>
+#include <map>
+#include <vector>
+
+#include "blake2b.hpp"
+#include "leaf_encode.hpp"
+#include "refpickle.hpp"
+#include "runtime.hpp"
+
+namespace bfs {
+
+int merkle_inner_launch(u64* d_nodes, u32 depth, u64 n_leaves, hipStream_t stream, u64* root_out, u64 seq);
+
+constexpr int ROW_MAX_COLS = 32;
+enum { SEG_CONST = 0, SEG_INT = 1, SEG_FRAMELEN = 2, SEG_SALT = 3 };
+
+struct RowSeg {
+    u32 kind;
+    u32 a;      // CONST: word offset into the pool (segments start on a 64-bit word); INT: column
+    u32 b;      // CONST: length in bytes; INT: limb
+    u32 pad;
+};
+struct RowTemplate {
+    u32 code, first_seg, num_segs, tuple_const_bytes, salt_bytes, pad[3];
+};
+struct RowArgs {
+    const u64* const* columns;   // device array of column pointers
+    const u32* is_ext;           // device array
+    u32 ncols;
+    u64 n;
+    const u64* salts;            // n x 3 words, or null
+    const RowTemplate* templates;
+    u32 num_templates;
+    const RowSeg* segs;
+    const u64* pool;
+    u64* digests;                // n x 8 words
+    u32* codes;                  // pattern kernel output
+    u32* error;
+};
+
+__device__ __forceinline__ u32 row_pattern(const RowArgs& a, u64 i) {
+    u32 code = 0, shift = 0;
+    for (u32 c = 0; c < a.ncols; ++c) {
+        if (!a.is_ext[c]) continue;
+        const u64* p = a.columns[c];
+        const u32 k = p[2 * a.n + i] ? 3u : (p[a.n + i] ? 2u : (p[i] ? 1u : 0u));
+        code |= k << shift;
+        shift += 2;
+    }
+    return code;
+}
+
+__global__ void row_pattern_kernel(const RowArgs a) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.n) a.codes[i] = row_pattern(a, i);
+}
+
+__global__ void __launch_bounds__(64) row_leaves_kernel(const RowArgs a) {
+    __shared__ u64 blk[16 * 64];
+    const u32 lane = threadIdx.x;
+    const u64 i = (u64)blockIdx.x * 64 + lane;
+    if (i >= a.n) return;
+    const u32 code = row_pattern(a, i);
+    const RowTemplate* tp = nullptr;
+    for (u32 t = 0; t < a.num_templates; ++t)
+        if (a.templates[t].code == code) tp = a.templates + t;
+    if (tp == nullptr) { atomicOr(a.error, 1u); return; }
+    // pass 1: length of the tuple pickle = constant bytes + the integer opcodes of this row
+    u32 int_bytes = 0;
+    for (u32 s = 0; s < tp->num_segs; ++s) {
+        const RowSeg sg = a.segs[tp->first_seg + s];
+        if (sg.kind == SEG_INT) int_bytes += pickle_int_len(a.columns[sg.a][(u64)sg.b * a.n + i]);
+    }
+    const u32 tuple_len = tp->tuple_const_bytes + int_bytes;
+    const u32 total = tuple_len + tp->salt_bytes;
+    // pass 2: expand the template into the block buffer, compressing as it fills
+    u64 h[8];
+    blake2b_init(h);
+    u64 acc = 0;            // funnel: pending bytes (< 8)
+    u32 fill = 0, wpos = 0;
+    u64 absorbed = 0;
+    u32 s = 0, w = 0;       // current segment, word within it
+    while (s < tp->num_segs) {
+        const RowSeg sg = a.segs[tp->first_seg + s];
+        u64 data = 0;
+        u32 nb = 0;
+        if (sg.kind == SEG_CONST) {
+            data = a.pool[sg.a + w];
+            const u32 left = sg.b - 8 * w;
+            nb = left < 8 ? left : 8;
+            if (nb < 8) data &= (1ull << (8 * nb)) - 1;
+            if (8 * (w + 1) >= sg.b) { ++s; w = 0; } else ++w;
+        } else if (sg.kind == SEG_INT) {
+            const u64 v = a.columns[sg.a][(u64)sg.b * a.n + i];
+            u64 lo, hi = 0;
+            u32 len;
+            if (v < (1ull << 8)) { lo = 0x4b | (v << 8); len = 2; }
+            else if (v < (1ull << 16)) { lo = 0x4d | (v << 8); len = 3; }
+            else if (v < (1ull << 31)) { lo = 0x4a | (v << 8); len = 5; }
+            else {
+                const u32 nn = (64 - (u32)__builtin_clzll(v)) / 8 + 1;
+                lo = 0x8a | ((u64)nn << 8) | (v << 16);
+                hi = v >> 48;
+                len = 2 + nn;
+            }
+            if (w == 0) { data = lo; nb = len < 8 ? len : 8; if (len > 8) w = 1; else { ++s; } }
+            else { data = hi; nb = len - 8; ++s; w = 0; }
+        } else if (sg.kind == SEG_FRAMELEN) {
+            data = (u64)tuple_len - 11;
+            nb = 8;
+            ++s;
+        } else {
+            data = a.salts[3 * i + w];
+            nb = 8;
+            if (w == 2) { ++s; w = 0; } else ++w;
+        }
+        // funnel the nb bytes into 64-bit words of the block buffer
+        acc |= data << (8 * fill);
+        const u32 nf = fill + nb;
+        if (nf >= 8) {
+            if (wpos == 16) {       // the buffer is full and more data follows: not the last block
+                u64 m[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) m[j] = blk[j * 64 + lane];
+                absorbed += 128;
+                blake2b_compress(h, m, absorbed, false);
+                wpos = 0;
+            }
+            blk[wpos * 64 + lane] = acc;
+            ++wpos;
+            acc = fill ? (data >> (8 * (8 - fill))) : 0;
+            fill = nf - 8;
+        } else {
+            fill = nf;
+        }
+    }
+    // last block: pending bytes, zero padding, total length as the counter
+    if (fill) {
+        if (wpos == 16) {
+            u64 m[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) m[j] = blk[j * 64 + lane];
+            absorbed += 128;
+            blake2b_compress(h, m, absorbed, false);
+            wpos = 0;
+        }
+        blk[wpos * 64 + lane] = acc;
+        ++wpos;
+    }
+    {
+        u64 m[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) m[j] = (u32)j < wpos ? blk[j * 64 + lane] : 0;
+        blake2b_compress(h, m, (u64)total, true);
+    }
+    u64* out = a.digests + i * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = h[j];
+}
+
+// ---- host: one template per pattern -------------------------------------------------------------------------------
+struct HostTemplates {
+    std::vector<RowTemplate> templates;
+    std::vector<RowSeg> segs;
+    std::vector<u64> pool;
+};
+
+static void add_const(HostTemplates& ht, const std::string& bytes, size_t from, size_t to) {
+    if (to <= from) return;
+    RowSeg sg{SEG_CONST, (u32)ht.pool.size(), (u32)(to - from), 0};
+    const size_t words = (to - from + 7) / 8;
+    const size_t base = ht.pool.size();
+    ht.pool.resize(base + words, 0);
+    memcpy(&ht.pool[base], bytes.data() + from, to - from);
+    ht.segs.push_back(sg);
+}
+
+// sentinel for (column, limb): above 2^63 so that it is written as a 11-byte LONG1, never equal to a constant of the skeleton
+static u64 sentinel(u32 column, u32 limb) { return 0xE000000000000000ULL | ((u64)column << 8) | limb | 0x5A5A0000ULL; }
+
+static int build_template(const bfs_row_column* cols, u32 ncols, u32 code, bool salted, HostTemplates& ht) {
+    rp::World world;
+    rp::Pickler pickler(&world);
+    pickler.record_ints = true;
+    std::vector<rp::Ref> items(ncols);
+    std::map<u64, std::pair<u32, u32>> slot_of;
+    u32 shift = 0;
+    for (u32 c = 0; c < ncols; ++c) {
+        if (cols[c].is_ext) {
+            const u32 k = (code >> shift) & 3u;
+            shift += 2;
+            u64 l[3] = {0, 0, 0};
+            for (u32 j = 0; j < k; ++j) { l[j] = sentinel(c, j); slot_of[l[j]] = {c, j}; }
+            items[c] = world.xfe_compact(l);
+        } else {
+            const u64 v = sentinel(c, 0);
+            slot_of[v] = {c, 0};
+            items[c] = world.bfe_in(v, world.base_field(cols[c].field_id));
+        }
+    }
+    const std::string s = pickler.dumps(rp::mk_tuple(items));
+    if (s.size() < 11 || (unsigned char)s[2] != 0x95) { set_error("row pickle without a frame"); return BFS_ERR_BAD_ARG; }
+    RowTemplate t{};
+    t.code = code;
+    t.first_seg = (u32)ht.segs.size();
+    size_t pos = 0;
+    u32 const_bytes = 0;
+    auto flush = [&](size_t to) { add_const(ht, s, pos, to); const_bytes += (u32)(to - pos); pos = to; };
+    flush(3);                                          // PROTO 4, FRAME opcode
+    ht.segs.push_back(RowSeg{SEG_FRAMELEN, 0, 0, 0});
+    pos = 11;
+    const_bytes += 8;
+    for (const auto& m : pickler.int_marks) {
+        auto it = slot_of.find(m.value);
+        if (it == slot_of.end()) continue;             // a constant of the skeleton (the modulus, p)
+        flush(m.offset);
+        ht.segs.push_back(RowSeg{SEG_INT, it->second.first, it->second.second, 0});
+        pos = m.offset + m.length;
+    }
+    flush(s.size());
+    t.tuple_const_bytes = const_bytes;
+    if (salted) {
+        unsigned char salt[24];
+        for (int j = 0; j < 24; ++j) salt[j] = (unsigned char)(0xA0 + j);
+        const std::string ss = pickler.dumps(rp::mk_bytes(salt, 24));
+        const size_t at = ss.find(std::string((const char*)salt, 24));
+        if (at == std::string::npos) { set_error("salt pickle layout"); return BFS_ERR_BAD_ARG; }
+        add_const(ht, ss, 0, at);
+        ht.segs.push_back(RowSeg{SEG_SALT, 0, 0, 0});
+        add_const(ht, ss, at + 24, ss.size());
+        t.salt_bytes = (u32)ss.size();
+    }
+    t.num_segs = (u32)ht.segs.size() - t.first_seg;
+    ht.templates.push_back(t);
+    return BFS_OK;
+}
+
+}  // namespace bfs
+
+using namespace bfs;
+
+extern "C" int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n, const uint8_t* h_salts, uint8_t* d_nodes,
+                                     void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n == 0) return BFS_OK;
+    if (((uintptr_t)d_nodes & 15) != 0) { set_error("d_nodes must be 16-byte aligned"); return BFS_ERR_BAD_ARG; }
+    if (ncols == 0 || ncols > ROW_MAX_COLS) { set_error("bfs_merkle_build_rows: 1..%d columns", ROW_MAX_COLS); return BFS_ERR_BAD_ARG; }
+    u32 next = 0;
+    for (u32 c = 0; c < ncols; ++c) next += columns[c].is_ext ? 1 : 0;
+    if (next > 16) { set_error("bfs_merkle_build_rows: at most 16 extension columns"); return BFS_ERR_BAD_ARG; }
+    u32 depth = 0;
+    while ((1ull << depth) < n) ++depth;
+    const u64 npo2 = 1ull << depth;
+
+    // device-side description of the columns, scratch for patterns / salts / flags
+    std::vector<const u64*> h_cols(ncols);
+    std::vector<u32> h_ext(ncols);
+    for (u32 c = 0; c < ncols; ++c) { h_cols[c] = columns[c].d_values; h_ext[c] = columns[c].is_ext ? 1u : 0u; }
+    const size_t salt_words = h_salts ? (size_t)3 * n : 0;
+    const size_t fixed_bytes = ncols * sizeof(u64*) + ncols * sizeof(u32) + 64 + n * sizeof(u32) + salt_words * sizeof(u64) + 64;
+    void* w = nullptr;
+    BFS_TRY(workspace(5, fixed_bytes, stream, &w));
+    char* base = (char*)w;
+    const u64** d_cols = (const u64**)base;                     base += ((ncols * sizeof(u64*) + 15) & ~(size_t)15);
+    u32* d_ext = (u32*)base;                                    base += ((ncols * sizeof(u32) + 15) & ~(size_t)15);
+    u32* d_err = (u32*)base;                                    base += 16;
+    u64* d_salts = (u64*)base;                                  base += salt_words * sizeof(u64);
+    u32* d_codes = (u32*)base;
+    BFS_HIP(hipMemcpyAsync(d_cols, h_cols.data(), ncols * sizeof(u64*), hipMemcpyHostToDevice, stream));
+    BFS_HIP(hipMemcpyAsync(d_ext, h_ext.data(), ncols * sizeof(u32), hipMemcpyHostToDevice, stream));
+    BFS_HIP(hipMemsetAsync(d_err, 0, 16, stream));
+    if (h_salts) BFS_HIP(hipMemcpyAsync(d_salts, h_salts, salt_words * sizeof(u64), hipMemcpyHostToDevice, stream));
+
+    RowArgs a{};
+    a.columns = d_cols; a.is_ext = d_ext; a.ncols = ncols; a.n = n;
+    a.salts = h_salts ? d_salts : nullptr;
+    a.digests = (u64*)d_nodes + npo2 * 8;
+    a.codes = d_codes; a.error = d_err;
+
+    // 1. patterns present in this batch of rows
+    hipLaunchKernelGGL(row_pattern_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, stream, a);
+    BFS_HIP(hipGetLastError());
+    std::vector<u32> codes(n);
+    BFS_HIP(hipMemcpyAsync(codes.data(), d_codes, n * sizeof(u32), hipMemcpyDeviceToHost, stream));
+    BFS_HIP(hipStreamSynchronize(stream));
+    std::sort(codes.begin(), codes.end());
+    codes.erase(std::unique(codes.begin(), codes.end()), codes.end());
+
+    // 2. one template per pattern
+    HostTemplates ht;
+    for (u32 code : codes) BFS_TRY(build_template(columns, ncols, code, h_salts != nullptr, ht));
+    const size_t tbytes = ht.templates.size() * sizeof(RowTemplate), sbytes = ht.segs.size() * sizeof(RowSeg), pbytes = ht.pool.size() * sizeof(u64);
+    void* tw = nullptr;
+    BFS_TRY(workspace(6, tbytes + sbytes + pbytes + 64, stream, &tw));
+    char* tb = (char*)tw;
+    BFS_HIP(hipMemcpyAsync(tb, ht.templates.data(), tbytes, hipMemcpyHostToDevice, stream));
+    BFS_HIP(hipMemcpyAsync(tb + tbytes, ht.segs.data(), sbytes, hipMemcpyHostToDevice, stream));
+    BFS_HIP(hipMemcpyAsync(tb + tbytes + sbytes, ht.pool.data(), pbytes, hipMemcpyHostToDevice, stream));
+    a.templates = (const RowTemplate*)tb;
+    a.num_templates = (u32)ht.templates.size();
+    a.segs = (const RowSeg*)(tb + tbytes);
+    a.pool = (const u64*)(tb + tbytes + sbytes);
+
+    // 3. leaf digests, then the tree
+    hipLaunchKernelGGL(row_leaves_kernel, dim3((u32)((n + 63) / 64)), dim3(64), 0, stream, a);
+    BFS_HIP(hipGetLastError());
+    BFS_TRY(merkle_inner_launch((u64*)d_nodes, depth, n, stream, nullptr, 0));
+    u32 err = 0;
+    BFS_HIP(hipMemcpyAsync(&err, d_err, sizeof(u32), hipMemcpyDeviceToHost, stream));
+    BFS_HIP(hipStreamSynchronize(stream));
+    if (err) { set_error("bfs_merkle_build_rows: a row pattern without a template (internal)"); return BFS_ERR_BAD_ARG; }
+    return BFS_OK;
+}

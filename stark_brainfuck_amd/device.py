@@ -73,3 +73,18 @@ def device_ptr(x):
 
 def synchronize(stream=None):
     _lib.check(_lib.load().bfs_stream_synchronize(stream if stream is not None else current_stream()))
+
+
+def gather(requests, stream=None):
+    """scattered reads from HBM in one round trip (bfs_gather): requests = [(device address, nwords, stride in words), ...];
+    returns a numpy uint64 array with the words of all requests, in order."""
+    lib = _lib.load()
+    reqs = (_lib.GatherRequest * len(requests))()
+    total = 0
+    for r, (ptr, nwords, stride) in zip(reqs, requests):
+        r.d_base, r.nwords, r.stride = ptr, nwords, stride
+        total += nwords
+    out = np.empty(total, dtype=np.uint64)
+    if requests:
+        _lib.check(lib.bfs_gather(reqs, len(requests), out.ctypes.data, stream if stream is not None else current_stream()))
+    return out

@@ -14,7 +14,7 @@ class InstructionTable(Table):
         super().__init__(field, 3, 5, length, num_randomizers, generator, order)
 
     def pad(self):
-        rows = self.base_rows()
+        rows = [list(r) for r in self.base_rows()]
         while len(rows) & (len(rows) - 1):
             rows.append([rows[-1][0], 0, 0])
         self._append_rows(rows)

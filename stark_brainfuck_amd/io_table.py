@@ -12,7 +12,7 @@ class IOTable(Table):
         super().__init__(field, 1, 2, length, 0, generator, order)
 
     def pad(self):
-        rows = self.base_rows()
+        rows = [list(r) for r in self.base_rows()]
         self.length = len(rows)
         while len(rows) & (len(rows) - 1):
             rows.append([0])

@@ -31,7 +31,7 @@ class MemoryTable(Table):
         return [[BaseFieldElement(v, field) for v in r] for r in rows]
 
     def pad(self):
-        rows = self.base_rows()
+        rows = [list(r) for r in self.base_rows()]
         while len(rows) & (len(rows) - 1):
             rows.append([(rows[-1][0] + 1) % P, rows[-1][1], rows[-1][2], 1])
         self._append_rows(rows)

@@ -16,7 +16,7 @@ class ProcessorTable(Table):
         super().__init__(field, 7, 11, length, num_randomizers, generator, order)
 
     def pad(self):
-        rows = self.base_rows()
+        rows = [list(r) for r in self.base_rows()]
         while len(rows) & (len(rows) - 1):
             last = rows[-1]
             rows.append([(last[0] + 1) % P, last[1], 0, 0, last[4], last[5], last[6]])

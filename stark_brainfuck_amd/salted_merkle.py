@@ -59,10 +59,10 @@ class _LazyLeafs:
 class ZippedSaltedMerkle(SaltedMerkle):
     """SaltedMerkle(list(zip(*codewords))) for codewords that live in HBM (brainfuck_stark.py:178-179, 197-198).
     columns: list of (device pointer, is_extension, base_field_id); make_row(i) builds the tuple of element objects of
-    row i on demand (only opened rows are ever materialised).  Rows are pickled natively on host threads and hashed
-    on the GPU (bfs_merkle_build_rows)."""
+    row i on demand (only opened rows are ever materialised).  The pickle of every row is synthesised and hashed on the
+    GPU (bfs_merkle_build_rows, csrc/rows.hip)."""
 
-    def __init__(self, columns, n, make_row, threads=0):
+    def __init__(self, columns, n, make_row):
         assert n & (n - 1) == 0 and n > 0, f"in SaltedMerkle.__init__, next_power_of_two = {n} =/= 1 << self.depth"
         salts = urandom(24 * n)                      # the same bytes as n calls of urandom(24) (salted_merkle.py:25)
         self.num_leafs = n
@@ -74,5 +74,5 @@ class ZippedSaltedMerkle(SaltedMerkle):
         cols = (_lib.RowColumn * len(columns))()
         for c, (ptr, is_ext, field_id) in zip(cols, columns):
             c.d_values, c.is_ext, c.field_id = ptr, int(is_ext), field_id
-        _lib.check(_lib.load().bfs_merkle_build_rows(cols, len(columns), n, salts, self._nodes.ptr, threads, current_stream()))
+        _lib.check(_lib.load().bfs_merkle_build_rows(cols, len(columns), n, salts, self._nodes.ptr, current_stream()))
         self._leafs = _LazyLeafs(n, make_row, salts)

@@ -33,6 +33,28 @@ def sample_base(byte_array):
     return int.from_bytes(bytes(byte_array), "big") % P
 
 
+def sample_ext_many(data, count, chunk):
+    """`count` extension elements from count * 3 * chunk bytes (chunk <= 15): ExtensionField.sample applied to consecutive
+    3*chunk-byte strings, vectorised.  Returns a uint64 array of shape (3, count) (limb planes)."""
+    raw = np.frombuffer(data, dtype=np.uint8).reshape(count * 3, chunk)
+    out = np.zeros(count * 3, dtype=np.uint64)
+    p = np.uint64(P)
+    eps = np.uint64(0xFFFFFFFF)
+    with np.errstate(over="ignore"):
+        for b in range(chunk):                      # Horner over the big-endian bytes: acc = acc * 256 + byte  (mod p)
+            # acc * 256 = (acc << 8) with the 8 bits shifted out worth hi * 2^64 = hi * (2^32 - 1) (mod p)
+            hi = out >> np.uint64(56)
+            lo = out << np.uint64(8)
+            lo = np.where(lo >= p, lo - p, lo)
+            t = lo + hi * eps                       # lo < p, hi * eps < 2^40: at most one wrap
+            t = np.where(t < lo, t + eps, t)
+            t = np.where(t >= p, t - p, t)
+            t2 = t + raw[:, b].astype(np.uint64)
+            t2 = np.where(t2 < t, t2 + eps, t2)
+            out = np.where(t2 >= p, t2 - p, t2)
+    return out.reshape(count, 3).T.copy()
+
+
 def sample_ext(byte_array):
     """ExtensionField.sample (extension_field.py:100-111): three equal chunks"""
     chunk = len(byte_array) // 3
@@ -84,12 +106,18 @@ class Table:
 
     # ---- rows
     def base_rows(self):
-        return [[_val(v) for v in row[:self.base_width]] for row in self.matrix]
+        """the base columns as Python ints, converted once per matrix object / length"""
+        key = (id(self.matrix), len(self.matrix))
+        if getattr(self, "_rows_key", None) != key:
+            self._rows = [[_val(v) for v in row[:self.base_width]] for row in self.matrix]
+            self._rows_key = key
+        return self._rows
 
     def _append_rows(self, rows):
         """padding: rows beyond the current matrix are appended as new elements; the caller's row objects are kept"""
         f = self.field
         self.matrix = list(self.matrix) + [[BaseFieldElement(v, f) for v in row] for row in rows[len(self.matrix):]]
+        self._rows, self._rows_key = [list(r) for r in rows], (id(self.matrix), len(self.matrix))
 
     # ---- interpolation + low-degree extension (table.py:112-148)
     def _extend_columns(self, domain, columns, randomizers):
