@@ -561,3 +561,66 @@ def test_salted_merkle_over_zipped_tuples(sb, oracle, monkeypatch):
     salt, path = tree.open(5)
     assert salt == salts[5] and path == ref.open(5)
     assert sb.SaltedMerkle.verify(tree.root(), 5, salt, path, leaves[5])
+
+
+def test_zipped_rows_commitment_on_device_vs_oracle(sb, oracle, monkeypatch):
+    """bfs_merkle_build_rows (csrc/rows.hip): every row's pickle is synthesised on the GPU from a per-pattern template.
+    Rows here mix all coefficient counts (0..3 stored coefficients per extension element, so memo indices shift from row
+    to row) and all integer opcode widths (BININT1 / BININT2 / BININT / LONG1 of 5..9 bytes); the oracle pickles every
+    row with CPython on look-alike classes, exactly like brainfuck_stark.py:178-179 + salted_merkle.py:32-35."""
+    from stark_brainfuck_amd import salted_merkle
+    from stark_brainfuck_amd.device import DeviceBuffer
+    from stark_brainfuck_amd.salted_merkle import ZippedSaltedMerkle
+    P = (1 << 64) - (1 << 32) + 1
+    n = 1 << 9
+    rng = np.random.default_rng(0xB0B)
+    edges = [0, 1, 255, 256, 65535, 65536, (1 << 31) - 1, 1 << 31, (1 << 32) - 1, 1 << 39, (1 << 47) - 1, 1 << 47, (1 << 55), (1 << 63) - 1, 1 << 63, P - 1]
+
+    def column(kind):
+        vals = rng.integers(0, P, n, dtype=np.uint64)
+        pick = rng.integers(0, 4, n)
+        vals = np.where(pick == 0, np.array([edges[i % len(edges)] for i in range(n)], dtype=np.uint64), vals)
+        if kind == "zero":
+            vals[:] = 0
+        elif kind == "sparse":
+            vals[rng.integers(0, 2, n) == 0] = 0
+        return vals
+    # 3 extension columns (limb planes with different zero patterns -> k = 0..3) and 5 base columns
+    ext = [np.stack([column("any"), column("sparse"), column("sparse")]), np.stack([column("sparse"), column("zero"), column("zero")]),
+           np.stack([column("sparse"), column("sparse"), column("zero")])]
+    base = [column("any") for _ in range(5)]
+    order = ["x0", "b0", "b1", "x1", "b2", "x2", "b3", "b4"]          # extension and base columns interleaved
+    bufs, cols = [], []
+    for name in order:
+        data = ext[int(name[1])] if name[0] == "x" else base[int(name[1])]
+        buf = DeviceBuffer.from_numpy(np.ascontiguousarray(data).reshape(-1))
+        bufs.append(buf)
+        cols.append((buf.ptr, name[0] == "x", 0))
+    salts = rng.integers(0, 256, 24 * n, dtype=np.uint8).tobytes()
+    monkeypatch.setattr(salted_merkle, "urandom", lambda count: salts[:count])
+    tree = ZippedSaltedMerkle(cols, n, lambda i: None)
+
+    def orow(i):
+        items = []
+        for name in order:
+            if name[0] == "x":
+                e = ext[int(name[1])]
+                items.append(oracle.make_xfe([int(e[0, i]), int(e[1, i]), int(e[2, i])]))
+            else:
+                items.append(oracle.make_bfe(int(base[int(name[1])][i])))
+        return tuple(items)
+    ref = oracle.MerkleOracle([oracle.salted_leaf_bytes(orow(i), salts[24 * i:24 * i + 24]) for i in range(n)])
+    patterns = {tuple(len(oracle.xtrim([int(e[0, i]), int(e[1, i]), int(e[2, i])])) for e in ext) for i in range(n)}
+    assert len(patterns) >= 8, "the test data should exercise many coefficient-count patterns"
+    assert tree.root() == ref.root()
+    assert tree.open(5)[1] == ref.open(5)
+    # unsalted rows go through the same kernel (no second pickle)
+    from stark_brainfuck_amd import _lib
+    lib = _lib.load()
+    nodes = DeviceBuffer(2 * n * 8)
+    rc = (_lib.RowColumn * len(cols))()
+    for r, (ptr, is_ext, fid) in zip(rc, cols):
+        r.d_values, r.is_ext, r.field_id = ptr, int(is_ext), fid
+    _lib.check(lib.bfs_merkle_build_rows(rc, len(cols), n, None, nodes.ptr, 0))
+    ref2 = oracle.MerkleOracle([oracle.dumps(orow(i)) for i in range(n)])
+    assert nodes.to_numpy(8, offset=8).tobytes() == ref2.root()
