@@ -5,6 +5,9 @@
 //   * the non-linear combination codeword                    brainfuck_stark.py:236-300
 // Points of the FRI domain are x_i = offset * omega^i (fri.py:20-21); codewords are column-major: base column c at
 // base[c * n + i], extension column c as three limb planes at ext[(3 c + limb) * n + i].
+#include <algorithm>
+#include <vector>
+
 #include "air_generated.hpp"
 #include "runtime.hpp"
 
@@ -94,15 +97,21 @@ __global__ void __launch_bounds__(256) air_quotient_kernel(const AirArgs a) {
         Xfe v[NQ];
         air_eval<TABLE>(bc, bn, xc, xn, a, v);
         const u64 x = gl_mul(a.offset, tw_pow(a.w_lo, a.w_hi, a.lo_bits, i));
-        const u64 zb = gl_inv(gl_sub(x, 1));                         // boundary: 1 / (x - 1)                     table.py:153-155
-        const u64 xo = gl_sub(x, a.omicron_inv);
-        const u64 zz = gl_inv(xo);                                   // terminal: 1 / (x - omicron^-1)            table.py:253-256
-        u64 zt = 0;                                                  // transition: (x - omicron^-1) / (x^h - 1)   table.py:180-188
+        // zerofier inverses with ONE field inversion (Montgomery's trick over a = x - 1, b = x - omicron^-1, c = x^h - 1):
+        //   boundary 1 / a (table.py:153-155), terminal 1 / b (:253-256), transition b / c (:180-188; 0 for an empty table)
+        const u64 za = gl_sub(x, 1), xo = gl_sub(x, a.omicron_inv);
+        u64 zc = 1;
         if (a.height != 0) {
             u64 xh = x;
             for (u32 s = 0; s < a.log_height; ++s) xh = gl_sqr(xh);
-            zt = gl_mul(gl_inv(gl_sub(xh, 1)), xo);
+            zc = gl_sub(xh, 1);
         }
+        const u64 ab = gl_mul(za, xo);
+        const u64 iabc = gl_inv(gl_mul(ab, zc));
+        const u64 iab = gl_mul(iabc, zc);
+        const u64 zb = gl_mul(iab, xo);
+        const u64 zz = gl_mul(iab, za);
+        const u64 zt = a.height != 0 ? gl_mul(xo, gl_mul(iabc, ab)) : 0;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const u64 z = q < S::NB ? zb : (q < S::NB + S::NT ? zt : zz);
@@ -137,9 +146,14 @@ __global__ void __launch_bounds__(256) combination_kernel(const CombSrc* srcs, u
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
         const u64 x = gl_mul(offset, tw_pow(w_lo, w_hi, lo_bits, i));
         Xfe acc = xfe_mul(w0, Xfe{{randomizer[i], randomizer[n + i], randomizer[2 * n + i]}});
+        u64 shift = ~0ull, xs = 0;
         for (u32 s = 0; s < count; ++s) {
             const CombSrc& src = srcs[s];
-            const Xfe w = xfe_add(src.wa, xfe_scale(src.wb, gl_pow(x, src.shift)));
+            if (src.shift != shift) {          // sources arrive grouped by shift (host side): one power per distinct shift
+                shift = src.shift;
+                xs = gl_pow(x, shift);
+            }
+            const Xfe w = xfe_add(src.wa, xfe_scale(src.wb, xs));
             if (src.is_ext) acc = xfe_add(acc, xfe_mul(w, Xfe{{src.ptr[i], src.ptr[n + i], src.ptr[2 * n + i]}}));
             else acc = xfe_add(acc, xfe_scale(w, src.ptr[i]));
         }
@@ -236,7 +250,11 @@ int bfs_combination(const bfs_comb_source* h_sources, uint32_t count, const uint
     static_assert(sizeof(CombSrc) == sizeof(bfs_comb_source), "layout of bfs_comb_source");
     void* w = nullptr;
     BFS_TRY(workspace(3, (size_t)(count ? count : 1) * sizeof(CombSrc), stream, &w));
-    if (count) BFS_HIP(hipMemcpyAsync(w, h_sources, (size_t)count * sizeof(CombSrc), hipMemcpyHostToDevice, stream));
+    // the sum does not depend on the order of its terms: group the sources by shift so the kernel raises x to each distinct
+    // shift once per point (11 distinct values among the 75 sources of a Brainfuck proof)
+    std::vector<CombSrc> sorted((const CombSrc*)h_sources, (const CombSrc*)h_sources + count);
+    std::stable_sort(sorted.begin(), sorted.end(), [](const CombSrc& l, const CombSrc& r) { return l.shift < r.shift; });
+    if (count) BFS_HIP(hipMemcpyAsync(w, sorted.data(), (size_t)count * sizeof(CombSrc), hipMemcpyHostToDevice, stream));
     const u64 *lo, *hi;
     u32 lo_bits;
     BFS_TRY(ntt_power_tables(omega, log_n, &lo, &hi, &lo_bits));

@@ -152,7 +152,16 @@ int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_str
     const u64 n = 1ull << log_n;
     if (n_in > n) { set_error("more coefficients (%llu) than the evaluation order (%llu)", (unsigned long long)n_in, (unsigned long long)n); return BFS_ERR_TOO_MANY_COEFFS; }
     if (batch == 0) return BFS_OK;
-    if (batch > 65535) { set_error("batch %u exceeds 65535", batch); return BFS_ERR_BAD_ARG; }
+    if (batch > 65535) {
+        // grid.y carries the batch index and is limited to 65535: larger batches go in slices (transforms are independent)
+        for (u32 done = 0; done < batch;) {
+            const u32 part = batch - done < 65535 ? batch - done : 65535;
+            BFS_TRY(ntt_launch(d_in + (u64)done * in_stride, n_in, in_stride, d_out + (u64)done * out_stride, out_stride, log_n, part, root,
+                               shift, post_scale, stream));
+            done += part;
+        }
+        return BFS_OK;
+    }
     int rc = ntt_check_root(root, log_n);
     if (rc == BFS_ERR_NOT_ROOT) { set_error("primitive root must be nth root of unity, where n is %llu", (unsigned long long)n); return rc; }
     if (rc == BFS_ERR_NOT_PRIMITIVE) { set_error("primitive root %llu is not primitive nth root of unity, where n is %llu", (unsigned long long)root, (unsigned long long)n); return rc; }

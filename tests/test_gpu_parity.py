@@ -624,3 +624,18 @@ def test_zipped_rows_commitment_on_device_vs_oracle(sb, oracle, monkeypatch):
     _lib.check(lib.bfs_merkle_build_rows(rc, len(cols), n, None, nodes.ptr, 0))
     ref2 = oracle.MerkleOracle([oracle.dumps(orow(i)) for i in range(n)])
     assert nodes.to_numpy(8, offset=8).tobytes() == ref2.root()
+
+
+def test_ntt_batch_larger_than_grid_limit(sb, oracle):
+    """more than 65535 independent transforms in one call (the batch index lives in grid.y): sliced internally"""
+    logn, batch = 5, 70001
+    n = 1 << logn
+    rng = np.random.default_rng(5)
+    v = rng.integers(0, (1 << 64) - (1 << 32) + 1, n * batch, dtype=np.uint64)
+    w = oracle.primitive_nth_root(n)
+    out = raw_ntt(sb, v, logn, w, batch=batch).reshape(batch, n)
+    for b in (0, 1, 65534, 65535, 65536, batch - 1):
+        assert (out[b] == oracle.ntt(w, v[b * n:(b + 1) * n])).all(), b
+    lo = raw_ntt(sb, v[:n * 40000], logn, w, batch=40000).reshape(40000, n)
+    hi = raw_ntt(sb, v[n * 40000:], logn, w, batch=batch - 40000).reshape(batch - 40000, n)
+    assert (out[:40000] == lo).all() and (out[40000:] == hi).all()
