@@ -136,11 +136,15 @@ class Fri:
         arr = self._as_xarray(codeword)
         n = len(arr)
         assert n & (n - 1) == 0, "codeword length must be a power of two"
-        transcript = NativeTranscript()
-        transcript.xfield = self.field
-        transcript.scan(proof_stream.objects)
-        for o in proof_stream.objects:
-            transcript.push(o)
+        transcript = proof_stream._native() if hasattr(proof_stream, "_native") else None
+        if transcript is None or (transcript.xfield is not None and transcript.xfield is not self.field):
+            transcript = NativeTranscript()
+            transcript.xfield = self.field
+            transcript.scan(proof_stream.objects)
+            for o in proof_stream.objects:
+                transcript.push(o)
+        elif transcript.xfield is None:
+            transcript.xfield = self.field
         before = transcript.num_objects()
         session = lib.bfs_fri_session_new()
         try:
@@ -154,8 +158,12 @@ class Fri:
                 out = (_u64 * self.num_colinearity_tests)()
                 _lib.check(lib.bfs_fri_query(session, transcript.handle, self.num_colinearity_tests, out, stream))
                 top = [int(x) for x in out]
-            for i in range(before, transcript.num_objects()):
-                proof_stream.push(transcript.to_python(lib.bfs_ps_object_at(transcript.handle, i), self.field))
+            fresh = [transcript.to_python(lib.bfs_ps_object_at(transcript.handle, i), self.field) for i in range(before, transcript.num_objects())]
+            if hasattr(proof_stream, "_adopt"):
+                proof_stream._adopt(transcript, fresh)
+            else:
+                for o in fresh:
+                    proof_stream.push(o)
             rounds = []
             for r in range(lib.bfs_fri_session_rounds(session)):
                 cw, nodes = ctypes.c_void_p(), ctypes.c_void_p()
@@ -166,6 +174,8 @@ class Fri:
             return top, rounds, session, arr
         except Exception:
             lib.bfs_fri_session_free(session)
+            if getattr(proof_stream, "_cached", None) is transcript:
+                proof_stream._cached = None          # native code may have appended objects the Python list does not have
             raise
 
     def commit(self, codeword, proof_stream, round_index=0):

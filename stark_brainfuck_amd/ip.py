@@ -29,6 +29,7 @@ class NativeTranscript:
         self._by_handle = {}  # native handle -> python object (identity of objects created natively)
         self._fields = {}    # id(BaseField instance) -> native field id
         self._coefficient_uses = {}   # id(coefficient object) -> number of extension elements holding it (scan())
+        self._compact_coefficients = set()   # ids of coefficient objects of elements written in compact form
         self.xfield = None
 
     def __del__(self):
@@ -85,6 +86,7 @@ class NativeTranscript:
             plain = all(c.field is internal and id(c) not in self._by_id and self._coefficient_uses.get(id(c), 0) < 2 for c in coeffs)
             if plain and not getattr(obj, "shares_coefficients", False):
                 n = lib.bfs_ps_obj_xfe(h, (_u64 * 3)(*obj.limbs()))
+                self._compact_coefficients.update(id(c) for c in coeffs)
             else:
                 # coefficient objects that are shared with another element, or that point at a foreign BaseField instance
                 handles = [self.to_native(c) for c in coeffs]
@@ -200,13 +202,51 @@ class ProofStream:
         return obj
 
     def _native(self, count=None):
+        """native transcript holding objects[:count] (all when count is None).  The full-stream transcript is kept and
+        extended as objects are appended (a proof asks for Fiat-Shamir randomness several times, each time over everything
+        pushed so far); it is rebuilt from scratch whenever an earlier choice could have been wrong: the list was edited
+        in place, an extension field shows up after bare base elements, or a coefficient object turns out to be shared
+        with an element that was already written in compact form."""
+        if count is not None and count != len(self.objects):
+            return self._build(self.objects[:count])
+        t = getattr(self, "_cached", None)
+        objs = self.objects
+        if t is not None:
+            k = len(self._cached_ids)
+            stale = k > len(objs) or any(id(o) != i for o, i in zip(objs, self._cached_ids))
+            if not stale and k < len(objs):
+                new = objs[k:]
+                if t.xfield is None and _find_xfield(new) is not None:
+                    stale = True
+                else:
+                    before = dict(t._coefficient_uses)
+                    t.scan(new)
+                    stale = any(uses >= 2 and before.get(c, 0) == 1 and c in t._compact_coefficients
+                                for c, uses in t._coefficient_uses.items())
+                    if not stale:
+                        for o in new:
+                            t.push(o)
+                        self._cached_ids += [id(o) for o in new]
+            if not stale:
+                return t
+        t = self._build(objs)
+        self._cached, self._cached_ids = t, [id(o) for o in objs]
+        return t
+
+    @staticmethod
+    def _build(objs):
         t = NativeTranscript()
-        objs = self.objects if count is None else self.objects[:count]
         t.xfield = _find_xfield(objs)     # decides which BaseField instance a bare BaseFieldElement refers to
         t.scan(objs)
         for o in objs:
             t.push(o)
         return t
+
+    def _adopt(self, transcript, new_objects):
+        """objects appended by native code (Fri.prove) to the cached transcript: keep list and cache in step"""
+        self.objects += new_objects
+        if getattr(self, "_cached", None) is transcript:
+            self._cached_ids += [id(o) for o in new_objects]
 
     def serialize(self):
         return self._native().serialize()
