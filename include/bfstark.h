@@ -169,7 +169,7 @@ int bfs_merkle_open(const uint8_t* d_nodes, uint32_t depth, uint64_t index, uint
  *     leaf i = blake2b(pickle.dumps(tuple of the i-th element of every column) || pickle.dumps(salt_i)).  Columns are
  *     codewords in HBM (at most 32, at most 16 of them extension columns): an extension column is three limb planes of n
  *     words (elements of the xfield's own BaseField), a base column n words whose elements point at BaseField instance
- *     `field_id` (as in bfs_ps_obj_bfe).  h_salts: n x 24 bytes on the host, or NULL for unsalted tuples.  The pickle of every
+ *     `field_id` (as in bfs_ps_obj_bfe).  salts: n x 24 bytes, on the host or (salts_on_device != 0) in HBM; NULL for unsalted tuples.  The pickle of every
  *     row is synthesised on the GPU and streamed into BLAKE2b (csrc/rows.hip); synchronises the stream.  n must be a power
  *     of two for a SaltedMerkle (salted_merkle.py:22).
  */
@@ -178,8 +178,11 @@ typedef struct bfs_row_column {
     int32_t is_ext;
     int32_t field_id;
 } bfs_row_column;
-int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n, const uint8_t* h_salts, uint8_t* d_nodes,
-                          void* stream);
+int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n, const uint8_t* salts, int salts_on_device,
+                          uint8_t* d_nodes, void* stream);
+/* nwords (a multiple of 8) pseudo-random words in HBM: 64-byte block j = BLAKE2b-512(seed || j).  For salts that never visit
+ * the host (the reference draws os.urandom(24) per leaf, salted_merkle.py:25; the caller seeds this from os.urandom(32)). */
+int bfs_random_fill(const uint8_t seed[32], uint64_t* d_out, uint64_t nwords, void* stream);
 
 /* ---- FRI ---------------------------------------------------------------------------------------------------- */
 /*

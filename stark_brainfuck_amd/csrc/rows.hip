@@ -171,6 +171,20 @@ __global__ void __launch_bounds__(64) row_leaves_kernel(const RowArgs a) {
     for (int j = 0; j < 8; ++j) out[j] = h[j];
 }
 
+// Salts can also be made on the device: 64-byte block j of the stream is BLAKE2b-512(seed || j), seed = 32 bytes of os.urandom.
+// (The reference draws urandom(24) per leaf, salted_merkle.py:25; any cryptographic stream serves.  Tests that need the
+// reference's exact bytes pass host salts instead.)
+__global__ void random_fill_kernel(u64 s0, u64 s1, u64 s2, u64 s3, u64* out, u64 nblocks) {
+    const u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nblocks) return;
+    u64 m[16] = {s0, s1, s2, s3, j, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    u64 h[8];
+    blake2b_init(h);
+    blake2b_compress(h, m, 40, true);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out[8 * j + k] = h[k];
+}
+
 // ---- host: one template per pattern -------------------------------------------------------------------------------
 struct HostTemplates {
     std::vector<RowTemplate> templates;
@@ -252,9 +266,23 @@ static int build_template(const bfs_row_column* cols, u32 ncols, u32 code, bool 
 
 using namespace bfs;
 
-extern "C" int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n, const uint8_t* h_salts, uint8_t* d_nodes,
-                                     void* stream_) {
+extern "C" int bfs_random_fill(const uint8_t seed[32], uint64_t* d_out, uint64_t nwords, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (nwords % 8) { set_error("bfs_random_fill: the word count must be a multiple of 8"); return BFS_ERR_BAD_ARG; }
+    if (nwords == 0) return BFS_OK;
+    u64 s[4];
+    memcpy(s, seed, 32);
+    const u64 nblocks = nwords / 8;
+    hipLaunchKernelGGL(random_fill_kernel, dim3((u32)((nblocks + 255) / 256)), dim3(256), 0, stream, s[0], s[1], s[2], s[3], d_out, nblocks);
+    BFS_HIP(hipGetLastError());
+    return BFS_OK;
+}
+
+extern "C" int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n, const uint8_t* salts, int salts_on_device,
+                                     uint8_t* d_nodes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const uint8_t* h_salts = salts_on_device ? nullptr : salts;
+    const bool salted = salts != nullptr;
     if (n == 0) return BFS_OK;
     if (((uintptr_t)d_nodes & 15) != 0) { set_error("d_nodes must be 16-byte aligned"); return BFS_ERR_BAD_ARG; }
     if (ncols == 0 || ncols > ROW_MAX_COLS) { set_error("bfs_merkle_build_rows: 1..%d columns", ROW_MAX_COLS); return BFS_ERR_BAD_ARG; }
@@ -269,7 +297,7 @@ extern "C" int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t nco
     std::vector<const u64*> h_cols(ncols);
     std::vector<u32> h_ext(ncols);
     for (u32 c = 0; c < ncols; ++c) { h_cols[c] = columns[c].d_values; h_ext[c] = columns[c].is_ext ? 1u : 0u; }
-    const size_t salt_words = h_salts ? (size_t)3 * n : 0;
+    const size_t salt_words = h_salts ? (size_t)3 * n : 0;      // staging only for host salts
     const size_t fixed_bytes = ncols * sizeof(u64*) + ncols * sizeof(u32) + 64 + n * sizeof(u32) + salt_words * sizeof(u64) + 64;
     void* w = nullptr;
     BFS_TRY(workspace(5, fixed_bytes, stream, &w));
@@ -286,7 +314,7 @@ extern "C" int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t nco
 
     RowArgs a{};
     a.columns = d_cols; a.is_ext = d_ext; a.ncols = ncols; a.n = n;
-    a.salts = h_salts ? d_salts : nullptr;
+    a.salts = h_salts ? d_salts : (salted ? (const u64*)salts : nullptr);
     a.digests = (u64*)d_nodes + npo2 * 8;
     a.codes = d_codes; a.error = d_err;
 
@@ -301,7 +329,7 @@ extern "C" int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t nco
 
     // 2. one template per pattern
     HostTemplates ht;
-    for (u32 code : codes) BFS_TRY(build_template(columns, ncols, code, h_salts != nullptr, ht));
+    for (u32 code : codes) BFS_TRY(build_template(columns, ncols, code, salted, ht));
     const size_t tbytes = ht.templates.size() * sizeof(RowTemplate), sbytes = ht.segs.size() * sizeof(RowSeg), pbytes = ht.pool.size() * sizeof(u64);
     void* tw = nullptr;
     BFS_TRY(workspace(6, tbytes + sbytes + pbytes + 64, stream, &tw));

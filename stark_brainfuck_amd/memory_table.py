@@ -21,11 +21,17 @@ class MemoryTable(Table):
         field = processor_matrix[0][0].field if hasattr(processor_matrix[0][0], "field") else None
         rows = [[_val(r[0]), _val(r[4]), _val(r[5]), 0] for r in processor_matrix if _val(r[2]) != 0]
         rows.sort(key=lambda r: r[1])
-        i = 0
-        while i < len(rows) - 1:
-            if rows[i][1] == rows[i + 1][1] and rows[i + 1][0] != (rows[i][0] + 1) % P:
-                rows.insert(i + 1, [(rows[i][0] + 1) % P, rows[i][1], rows[i][2], 1])
-            i += 1
+        # the reference inserts one dummy row at a time with list.insert (quadratic); same result in one pass: between two
+        # rows of the same address whose cycle counts are not consecutive, dummy rows count the cycles up and keep the value
+        out = []
+        for k, row in enumerate(rows):
+            out.append(row)
+            if k + 1 < len(rows) and rows[k + 1][1] == row[1]:
+                clk, target = row[0], rows[k + 1][0]
+                while (clk + 1) % P != target:
+                    clk = (clk + 1) % P
+                    out.append([clk, row[1], row[2], 1])
+        rows = out
         if field is None:
             return rows
         return [[BaseFieldElement(v, field) for v in r] for r in rows]

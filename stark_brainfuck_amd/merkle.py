@@ -133,14 +133,17 @@ class Merkle:
         if self._nodes_host is not None:
             nodes = self._nodes_host
             return [nodes[k ^ 1] for k in _walk((1 << self.depth) | index)]
-        buf = ctypes.create_string_buffer(64 * self.depth)
-        _lib.check(_lib.load().bfs_merkle_open(self._nodes.ptr, self.depth, index, buf, current_stream()))
+        siblings = [k ^ 1 for k in _walk((1 << self.depth) | index)]
+        missing = [sib for sib in siblings if sib not in self._node_cache and sib < self._npo2 + self.num_leafs]
+        if missing:              # all digests of the path in one round trip (bfs_gather)
+            from .device import gather
+            raw = gather([(self._nodes.ptr + 64 * sib, 8, 1) for sib in missing]).tobytes()
+            for j, sib in enumerate(missing):
+                self._node_cache[sib] = raw[64 * j:64 * j + 64]
         path = []
-        for lvl, k in enumerate(_walk((1 << self.depth) | index)):
-            sib = k ^ 1
+        for sib in siblings:
             if sib not in self._node_cache:
-                absent = sib >= self._npo2 + self.num_leafs       # the reference keeps 32 zero bytes there (merkle.py:26)
-                self._node_cache[sib] = bytes(32) if absent else buf.raw[64 * lvl:64 * lvl + 64]
+                self._node_cache[sib] = bytes(32)                 # absent leaf slot: the reference keeps 32 zero bytes there (merkle.py:26)
             path.append(self._node_cache[sib])
         return path
 

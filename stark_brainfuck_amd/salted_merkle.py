@@ -44,15 +44,15 @@ class _LazyLeafs:
     """`leafs` of a ZippedSaltedMerkle: (row tuple, salt) pairs made on first access and then kept, so that a row opened
     twice is the same Python object both times (pickle memoises by identity)."""
 
-    def __init__(self, n, make_row, salts):
-        self._n, self._make_row, self._salts, self._cache = n, make_row, salts, {}
+    def __init__(self, n, make_row, salt_of):
+        self._n, self._make_row, self._salt_of, self._cache = n, make_row, salt_of, {}
 
     def __len__(self):
         return self._n
 
     def __getitem__(self, index):
         if index not in self._cache:
-            self._cache[index] = (self._make_row(index), self._salts[24 * index:24 * index + 24])
+            self._cache[index] = (self._make_row(index), self._salt_of(index))
         return self._cache[index]
 
 
@@ -60,11 +60,16 @@ class ZippedSaltedMerkle(SaltedMerkle):
     """SaltedMerkle(list(zip(*codewords))) for codewords that live in HBM (brainfuck_stark.py:178-179, 197-198).
     columns: list of (device pointer, is_extension, base_field_id); make_row(i) builds the tuple of element objects of
     row i on demand (only opened rows are ever materialised).  The pickle of every row is synthesised and hashed on the
-    GPU (bfs_merkle_build_rows, csrc/rows.hip)."""
+    GPU (bfs_merkle_build_rows, csrc/rows.hip).
+
+    Salts: when `salted_merkle.urandom` is the operating system's (the normal case) they are expanded on the GPU from 32
+    bytes of it and never visit the host (bfs_random_fill); when a test has replaced `urandom` to reproduce the reference's
+    byte stream they are drawn from it, 24 bytes per leaf in leaf order (salted_merkle.py:25)."""
 
     def __init__(self, columns, n, make_row):
+        import os
         assert n & (n - 1) == 0 and n > 0, f"in SaltedMerkle.__init__, next_power_of_two = {n} =/= 1 << self.depth"
-        salts = urandom(24 * n)                      # the same bytes as n calls of urandom(24) (salted_merkle.py:25)
+        lib, stream = _lib.load(), current_stream()
         self.num_leafs = n
         self._npo2, self.depth = n, n.bit_length() - 1
         self._data = None
@@ -74,5 +79,20 @@ class ZippedSaltedMerkle(SaltedMerkle):
         cols = (_lib.RowColumn * len(columns))()
         for c, (ptr, is_ext, field_id) in zip(cols, columns):
             c.d_values, c.is_ext, c.field_id = ptr, int(is_ext), field_id
-        _lib.check(_lib.load().bfs_merkle_build_rows(cols, len(columns), n, salts, self._nodes.ptr, current_stream()))
-        self._leafs = _LazyLeafs(n, make_row, salts)
+        if urandom is os.urandom:
+            words = (3 * n + 7) // 8 * 8
+            self._salts = DeviceBuffer(words)
+            _lib.check(lib.bfs_random_fill(urandom(32), self._salts.ptr, words, stream))
+            _lib.check(lib.bfs_merkle_build_rows(cols, len(columns), n, self._salts.ptr, 1, self._nodes.ptr, stream))
+
+            def salt_of(i):
+                from .device import gather
+                return gather([(self._salts.ptr + 24 * i, 3, 1)]).tobytes()
+        else:
+            salts = urandom(24 * n)                      # the same bytes as n calls of urandom(24)
+            keep = ctypes.create_string_buffer(salts, len(salts))
+            _lib.check(lib.bfs_merkle_build_rows(cols, len(columns), n, ctypes.cast(keep, ctypes.c_void_p), 0, self._nodes.ptr, stream))
+
+            def salt_of(i):
+                return salts[24 * i:24 * i + 24]
+        self._leafs = _LazyLeafs(n, make_row, salt_of)

@@ -37,21 +37,33 @@ def sample_ext_many(data, count, chunk):
     """`count` extension elements from count * 3 * chunk bytes (chunk <= 15): ExtensionField.sample applied to consecutive
     3*chunk-byte strings, vectorised.  Returns a uint64 array of shape (3, count) (limb planes)."""
     raw = np.frombuffer(data, dtype=np.uint8).reshape(count * 3, chunk)
-    out = np.zeros(count * 3, dtype=np.uint64)
     p = np.uint64(P)
     eps = np.uint64(0xFFFFFFFF)
     with np.errstate(over="ignore"):
-        for b in range(chunk):                      # Horner over the big-endian bytes: acc = acc * 256 + byte  (mod p)
-            # acc * 256 = (acc << 8) with the 8 bits shifted out worth hi * 2^64 = hi * (2^32 - 1) (mod p)
-            hi = out >> np.uint64(56)
-            lo = out << np.uint64(8)
-            lo = np.where(lo >= p, lo - p, lo)
-            t = lo + hi * eps                       # lo < p, hi * eps < 2^40: at most one wrap
-            t = np.where(t < lo, t + eps, t)
-            t = np.where(t >= p, t - p, t)
-            t2 = t + raw[:, b].astype(np.uint64)
-            t2 = np.where(t2 < t, t2 + eps, t2)
-            out = np.where(t2 >= p, t2 - p, t2)
+        if chunk <= 8:
+            padded = np.zeros((count * 3, 8), dtype=np.uint8)
+            padded[:, 8 - chunk:] = raw
+            out = padded.view(">u8").reshape(-1).astype(np.uint64)
+            out = np.where(out >= p, out - p, out)
+        elif chunk == 9:
+            # value = top * 2^64 + low, 2^64 = 2^32 - 1 (mod p): one multiply-add instead of a Horner loop over the bytes
+            low = np.ascontiguousarray(raw[:, 1:]).view(">u8").reshape(-1).astype(np.uint64)
+            low = np.where(low >= p, low - p, low)
+            out = low + raw[:, 0].astype(np.uint64) * eps            # < p + 2^40: wraps at most once
+            out = np.where(out < low, out + eps, out)
+            out = np.where(out >= p, out - p, out)
+        else:
+            out = np.zeros(count * 3, dtype=np.uint64)
+            for b in range(chunk):                      # Horner over the big-endian bytes: acc = acc * 256 + byte  (mod p)
+                hi = out >> np.uint64(56)               # the 8 bits shifted out are worth hi * 2^64 = hi * (2^32 - 1)
+                lo = out << np.uint64(8)
+                lo = np.where(lo >= p, lo - p, lo)
+                t = lo + hi * eps                       # lo < p, hi * eps < 2^40: at most one wrap
+                t = np.where(t < lo, t + eps, t)
+                t = np.where(t >= p, t - p, t)
+                t2 = t + raw[:, b].astype(np.uint64)
+                t2 = np.where(t2 < t, t2 + eps, t2)
+                out = np.where(t2 >= p, t2 - p, t2)
     return out.reshape(count, 3).T.copy()
 
 
@@ -59,6 +71,30 @@ def sample_ext(byte_array):
     """ExtensionField.sample (extension_field.py:100-111): three equal chunks"""
     chunk = len(byte_array) // 3
     return tuple(sample_base(byte_array[i * chunk:(i + 1) * chunk]) for i in range(3))
+
+
+class _PaddedMatrix:
+    """the caller's matrix followed by padding rows that are materialised on demand"""
+
+    def __init__(self, original, rows, field):
+        self._original, self._rows, self._field, self._made = list(original), rows, field, {}
+
+    def __len__(self):
+        return len(self._rows)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if i < len(self._original):
+            return self._original[i]
+        if i not in self._made:
+            self._made[i] = [BaseFieldElement(v, self._field) for v in self._rows[i]]
+        return self._made[i]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
 
 
 class Table:
@@ -114,10 +150,10 @@ class Table:
         return self._rows
 
     def _append_rows(self, rows):
-        """padding: rows beyond the current matrix are appended as new elements; the caller's row objects are kept"""
-        f = self.field
-        self.matrix = list(self.matrix) + [[BaseFieldElement(v, f) for v in row] for row in rows[len(self.matrix):]]
-        self._rows, self._rows_key = [list(r) for r in rows], (id(self.matrix), len(self.matrix))
+        """padding: the caller's rows (and their element objects) are kept, the padding rows exist as integers and turn
+        into element objects only if somebody looks at them (`matrix` stays a sequence of rows, as in the reference)"""
+        self.matrix = _PaddedMatrix(self.matrix, rows, self.field)
+        self._rows, self._rows_key = rows, (id(self.matrix), len(self.matrix))
 
     # ---- interpolation + low-degree extension (table.py:112-148)
     def _extend_columns(self, domain, columns, randomizers):
@@ -188,10 +224,10 @@ class Table:
 
     def ldex(self, domain, xfield=None):
         width = self.full_width - self.base_width
-        cols = np.zeros((width * 3, self.height), dtype=np.uint64)
-        for r, row in enumerate(self.ext_rows):
-            for c, v in enumerate(row):
-                cols[3 * c, r], cols[3 * c + 1, r], cols[3 * c + 2, r] = v
+        if self.height:
+            cols = np.array(self.ext_rows, dtype=np.uint64).reshape(self.height, width * 3).T.copy()     # (column, limb) planes
+        else:
+            cols = np.zeros((width * 3, 0), dtype=np.uint64)
         rand = None
         if self.height != 0 and self.num_randomizers:
             rand = []

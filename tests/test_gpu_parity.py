@@ -621,9 +621,24 @@ def test_zipped_rows_commitment_on_device_vs_oracle(sb, oracle, monkeypatch):
     rc = (_lib.RowColumn * len(cols))()
     for r, (ptr, is_ext, fid) in zip(rc, cols):
         r.d_values, r.is_ext, r.field_id = ptr, int(is_ext), fid
-    _lib.check(lib.bfs_merkle_build_rows(rc, len(cols), n, None, nodes.ptr, 0))
+    _lib.check(lib.bfs_merkle_build_rows(rc, len(cols), n, None, 0, nodes.ptr, 0))
     ref2 = oracle.MerkleOracle([oracle.dumps(orow(i)) for i in range(n)])
     assert nodes.to_numpy(8, offset=8).tobytes() == ref2.root()
+    # salts expanded on the device (bfs_random_fill): the tree must be the tree of exactly those salts
+    monkeypatch.undo()
+    tree3 = ZippedSaltedMerkle(cols, n, lambda i: None)
+    dsalts = tree3._salts.to_numpy(3 * n).tobytes()
+    assert len(set(dsalts[24 * i:24 * i + 24] for i in range(n))) == n
+    ref3 = oracle.MerkleOracle([oracle.salted_leaf_bytes(orow(i), dsalts[24 * i:24 * i + 24]) for i in range(n)])
+    assert tree3.root() == ref3.root()
+    assert tree3.leafs[7][1] == dsalts[24 * 7:24 * 8]
+    import hashlib
+    seed = bytes(range(32))
+    buf = DeviceBuffer(16)
+    _lib.check(lib.bfs_random_fill(seed, buf.ptr, 16, 0))
+    got = buf.to_numpy(16).tobytes()
+    assert got[:64] == hashlib.blake2b(seed + (0).to_bytes(8, "little")).digest()
+    assert got[64:] == hashlib.blake2b(seed + (1).to_bytes(8, "little")).digest()
 
 
 def test_ntt_batch_larger_than_grid_limit(sb, oracle):
