@@ -1,0 +1,38 @@
+// hostscan.cpp -- the sequential column extensions of the tables (running products and running evaluations over a few
+// thousand trace rows), host code like the reference's loops but without a Python interpreter in the loop:
+//   ProcessorTable.extend   /root/reference/code/processor_table.py:329-427
+//   InstructionTable.extend instruction_table.py:167-231
+//   MemoryTable.extend      memory_table.py:172-206
+//   IOTable.extend_iotable  io_table.py:77-110
+// One primitive covers all of them: over rows i = 0..n-1 with base-field columns x1, x2, x3 and a row mask,
+//   kind 0 (running product):     state <- state * (c0 - c1 x1[i] - c2 x2[i] - c3 x3[i])      on masked rows
+//   kind 1 (running evaluation):  state <- state * c0 + c1 x1[i] + c2 x2[i] + c3 x3[i]        on masked rows
+// and the state is recorded for every row either before or after the row's update.
+#include <string.h>
+
+#include "../../include/bfstark.h"
+#include "gl.hpp"
+#include "runtime.hpp"
+
+using namespace bfs;
+
+extern "C" int bfs_xfe_scan(int kind, const uint64_t* x1, const uint64_t* x2, const uint64_t* x3, const uint8_t* mask, uint64_t n,
+                            const uint64_t constants[12], const uint64_t initial[3], int record_before, uint64_t* out, uint64_t terminal[3]) {
+    if (kind != 0 && kind != 1) { set_error("bfs_xfe_scan: kind must be 0 (product) or 1 (evaluation)"); return BFS_ERR_BAD_ARG; }
+    Xfe c[4];
+    for (int j = 0; j < 4; ++j) c[j] = Xfe{{constants[3 * j] % GL_P, constants[3 * j + 1] % GL_P, constants[3 * j + 2] % GL_P}};
+    Xfe state{{initial[0] % GL_P, initial[1] % GL_P, initial[2] % GL_P}};
+    for (uint64_t i = 0; i < n; ++i) {
+        if (record_before) { out[3 * i] = state.c[0]; out[3 * i + 1] = state.c[1]; out[3 * i + 2] = state.c[2]; }
+        if (!mask || mask[i]) {
+            Xfe lin{{0, 0, 0}};
+            if (x1) lin = xfe_add(lin, xfe_scale(c[1], x1[i]));
+            if (x2) lin = xfe_add(lin, xfe_scale(c[2], x2[i]));
+            if (x3) lin = xfe_add(lin, xfe_scale(c[3], x3[i]));
+            state = kind == 0 ? xfe_mul(state, xfe_sub(c[0], lin)) : xfe_add(xfe_mul(state, c[0]), lin);
+        }
+        if (!record_before) { out[3 * i] = state.c[0]; out[3 * i + 1] = state.c[1]; out[3 * i + 2] = state.c[2]; }
+    }
+    terminal[0] = state.c[0]; terminal[1] = state.c[1]; terminal[2] = state.c[2];
+    return BFS_OK;
+}

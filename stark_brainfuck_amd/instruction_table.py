@@ -1,7 +1,9 @@
 """Instruction table -- mirror of the reference's `instruction_table.py` (/root/reference/code/instruction_table.py):
 padding (:19-25) and `extend` (:167-231).  Constraints: air.InstructionAir."""
+import numpy as np
+
 from . import air
-from .air import xadd, xmul, xsub, xscale, xlift, X0, X1, xneg
+from .air import X0
 from .table import Table
 
 
@@ -20,19 +22,15 @@ class InstructionTable(Table):
         self._append_rows(rows)
 
     def extend(self, all_challenges, all_initials):
+        """instruction_table.py:167-231"""
         a, b, c, d, e, f, alpha, beta, gamma, delta, eta = all_challenges
-        perm = all_initials[0]
-        ev = X0
-        prev_addr = None
-        rows, ext = self.base_rows(), []
-        for i, (addr, ci, ni) in enumerate(rows):
-            # the running product absorbs a row when it is not padding and repeats the previous row's address (:197-205)
-            if ci != 0 and i > 0 and addr == rows[i - 1][0]:
-                perm = xmul(perm, xsub(xsub(xsub(alpha, xscale(a, addr)), xscale(b, ci)), xscale(c, ni)))
-            if prev_addr is None or addr != prev_addr:
-                ev = xadd(xadd(xadd(xmul(eta, ev), xscale(a, addr)), xscale(b, ci)), xscale(c, ni))
-            ext.append([perm, ev])
-            prev_addr = addr
-        self.ext_rows = ext
-        self.permutation_terminal = perm
-        self.evaluation_terminal = ev
+        m = self.base_array()
+        addr, ci, ni = m[0], m[1], m[2]
+        same = np.concatenate([[False], addr[1:] == addr[:-1]]) if len(addr) else np.zeros(0, dtype=bool)
+        # the running product absorbs a row when it is not padding and repeats the previous row's address (:197-205);
+        # the running evaluation absorbs the first row of every address (:209-214); both are recorded AFTER the row's update
+        perm, t_perm = self.scan(0, [addr, ci, ni], (ci != 0) & same, [alpha, a, b, c], all_initials[0], False)
+        ev, t_ev = self.scan(1, [addr, ci, ni], ~same, [eta, a, b, c], X0, False)
+        self.ext_columns = [perm, ev]
+        self.permutation_terminal = t_perm
+        self.evaluation_terminal = t_ev

@@ -1,7 +1,7 @@
 """Input / output tables -- mirror of the reference's `io_table.py` (/root/reference/code/io_table.py): padding that
 redefines length and height (:17-21) and the running evaluation (:77-110).  Constraints: air.IOAir."""
 from . import air
-from .air import xadd, xmul, xlift, xpow, X0
+from .air import xpow, X0
 from .table import Table
 
 
@@ -23,16 +23,13 @@ class IOTable(Table):
         return [xpow(tuple(challenges[self.challenge_index]), self.height - self.length)]
 
     def extend(self, all_challenges, all_initials):
+        """io_table.py:77-110: evaluation = evaluation * iota + symbol on every row; the terminal is the value after the last
+        real (unpadded) row"""
         iota = all_challenges[self.challenge_index]
-        running = terminal = X0
-        ext = []
-        for i, (v,) in enumerate(self.base_rows()):
-            running = xadd(xmul(running, iota), xlift(v))
-            ext.append([running])
-            if i == self.length - 1:
-                terminal = running
-        self.ext_rows = ext
-        self.evaluation_terminal = terminal
+        m = self.base_array()
+        ev, _ = self.scan(1, [m[0]], None, [iota, (1, 0, 0)], X0, False)
+        self.ext_columns = [ev]
+        self.evaluation_terminal = tuple(int(v) for v in ev[self.length - 1]) if self.length else X0
 
 
 class InputTable(IOTable):

@@ -1,7 +1,6 @@
 """Memory table -- mirror of the reference's `memory_table.py` (/root/reference/code/memory_table.py): `derive_matrix`
 (:20-38), padding (:40-44) and `extend` (:172-206).  Constraints: air.MemoryAir."""
 from . import air
-from .air import xmul, xsub, xscale
 from .algebra import BaseFieldElement
 from .table import Table, P, _val
 
@@ -43,12 +42,9 @@ class MemoryTable(Table):
         self._append_rows(rows)
 
     def extend(self, all_challenges, all_initials):
+        """memory_table.py:172-206"""
         a, b, c, d, e, f, alpha, beta, gamma, delta, eta = all_challenges
-        perm = all_initials[1]
-        ext = []
-        for clk, mp, mv, dummy in self.base_rows():
-            ext.append([perm])
-            if dummy == 0:
-                perm = xmul(perm, xsub(xsub(xsub(beta, xscale(d, clk)), xscale(e, mp)), xscale(f, mv)))
-        self.ext_rows = ext
-        self.permutation_terminal = perm
+        m = self.base_array()
+        perm, t_perm = self.scan(0, [m[0], m[1], m[2]], m[3] == 0, [beta, d, e, f], all_initials[1], True)
+        self.ext_columns = [perm]
+        self.permutation_terminal = t_perm

@@ -1,8 +1,10 @@
 """Processor table -- mirror of the reference's `processor_table.py` (/root/reference/code/processor_table.py):
 column names, padding (:24-35) and the running products / evaluations of `extend` (:329-427).  The constraints
 themselves live in air.ProcessorAir."""
+import numpy as np
+
 from . import air
-from .air import xadd, xmul, xsub, xlift, X0
+from .air import xadd, xmul, xlift, X0
 from .table import Table, P
 
 
@@ -23,27 +25,33 @@ class ProcessorTable(Table):
         self._append_rows(rows)
 
     def extend(self, all_challenges, all_initials):
+        """the four extension columns as running products / evaluations (processor_table.py:329-427), one native scan each"""
         a, b, c, d, e, f, alpha, beta, gamma, delta, eta = all_challenges
-        ipp, mpp = all_initials
-        iev = oev = X0
-        iev_id = oev_id = None
-        rows, ext = self.base_rows(), []
-        for i, row in enumerate(rows):
-            clk, ip, ci, ni, mp, mv, _ = row
-            ext.append([ipp, mpp, iev, oev])
-            if ci != 0:
-                ipp = xmul(ipp, xsub(xsub(xsub(alpha, air.xscale(a, ip)), air.xscale(b, ci)), air.xscale(c, ni)))
-                mpp = xmul(mpp, xsub(xsub(xsub(beta, air.xscale(d, clk)), air.xscale(e, mp)), air.xscale(f, mv)))
-            if ci == ord(","):      # the input symbol shows up in the NEXT row's memory value
-                iev, iev_id = _evaluation_step(iev, iev_id, gamma, self.matrix[i + 1][5])
-            if ci == ord("."):
-                oev, oev_id = _evaluation_step(oev, oev_id, delta, self.matrix[i][5])
-        self.ext_rows = ext
-        self.instruction_permutation_terminal = ipp
-        self.memory_permutation_terminal = mpp
-        self.input_evaluation_terminal = iev
-        self.output_evaluation_terminal = oev
-        self.evaluation_terminal_identities = (iev_id, oev_id)
+        m = self.base_array()
+        clk, ip, ci, ni, mp, mv = m[0], m[1], m[2], m[3], m[4], m[5]
+        active = ci != 0                                                   # padding rows leave the products alone
+        ipp, t_ipp = self.scan(0, [ip, ci, ni], active, [alpha, a, b, c], all_initials[0], True)
+        mpp, t_mpp = self.scan(0, [clk, mp, mv], active, [beta, d, e, f], all_initials[1], True)
+        one = (1, 0, 0)
+        reads, writes = ci == ord(","), ci == ord(".")
+        mv_next = np.concatenate([mv[1:], mv[:1]]) if len(mv) else mv       # an input symbol shows up in the NEXT row's memory value
+        iev, t_iev = self.scan(1, [mv_next], reads, [gamma, one], X0, True)
+        oev, t_oev = self.scan(1, [mv], writes, [delta, one], X0, True)
+        self.ext_columns = [ipp, mpp, iev, oev]
+        self.instruction_permutation_terminal = t_ipp
+        self.memory_permutation_terminal = t_mpp
+        self.input_evaluation_terminal = t_iev
+        self.output_evaluation_terminal = t_oev
+        self.evaluation_terminal_identities = (self._identity(iev, t_iev, gamma, np.nonzero(reads)[0] + 1),
+                                               self._identity(oev, t_oev, delta, np.nonzero(writes)[0]))
+
+    def _identity(self, states, terminal, challenge, symbol_rows):
+        """what the reference's OBJECT of this terminal is made of, replaying _evaluation_step over the update rows"""
+        state, identity = X0, None
+        for r in symbol_rows:
+            state, identity = _evaluation_step(state, identity, challenge, self.matrix[int(r)][5])
+        assert tuple(state) == tuple(terminal)
+        return identity
 
 
 def _evaluation_step(state, identity, challenge, symbol):

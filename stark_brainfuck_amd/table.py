@@ -113,7 +113,7 @@ class Table:
         self.generator = generator
         self.order = order
         self.matrix = []
-        self.ext_rows = None         # after extend(): per row, the extension columns as int triples
+        self.ext_columns = None      # after extend(): per extension column a uint64 array (rows, 3)
         self.base_codewords = None   # DeviceBuffer, base_width * N
         self.ext_codewords = None    # DeviceBuffer, (full_width - base_width) * 3 * N
         self._coefficients = None    # host copy of the last interpolants (ext_sharing_moduli)
@@ -148,6 +148,30 @@ class Table:
             self._rows = [[_val(v) for v in row[:self.base_width]] for row in self.matrix]
             self._rows_key = key
         return self._rows
+
+    def base_array(self):
+        """base columns as a uint64 array of shape (base_width, rows), cached with base_rows()"""
+        rows = self.base_rows()
+        if getattr(self, "_array_key", None) != self._rows_key:
+            self._array = (np.array(rows, dtype=np.uint64).T.copy() if rows else np.zeros((self.base_width, 0), dtype=np.uint64))
+            self._array = self._array.reshape(self.base_width, len(rows))
+            self._array_key = self._rows_key
+        return self._array
+
+    @staticmethod
+    def scan(kind, columns, mask, constants, initial, record_before):
+        """bfs_xfe_scan: running product (kind 0) or running evaluation (kind 1) over the rows.  columns: up to three uint64
+        arrays (None = absent); mask: bool array or None.  Returns (states as uint64 array (rows, 3), terminal triple)."""
+        n = next((len(c) for c in columns if c is not None), 0 if mask is None else len(mask))
+        cols = [np.ascontiguousarray(c, dtype=np.uint64) if c is not None else None for c in columns] + [None] * (3 - len(columns))
+        m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
+        out = np.empty((n, 3), dtype=np.uint64)
+        flat = [v for c in constants for v in c] + [0] * (12 - 3 * len(constants))
+        terminal = (_u64 * 3)()
+        _lib.check(_lib.load().bfs_xfe_scan(kind, *[c.ctypes.data if c is not None else None for c in cols[:3]],
+                                            m.ctypes.data if m is not None else None, n, (_u64 * 12)(*flat), (_u64 * 3)(*initial),
+                                            1 if record_before else 0, out.ctypes.data, terminal))
+        return out, (int(terminal[0]), int(terminal[1]), int(terminal[2]))
 
     def _append_rows(self, rows):
         """padding: the caller's rows (and their element objects) are kept, the padding rows exist as integers and turn
@@ -213,9 +237,7 @@ class Table:
         return out
 
     def lde(self, domain):
-        rows = self.base_rows()
-        cols = np.array(rows, dtype=np.uint64).T.copy() if rows else np.zeros((self.base_width, 0), dtype=np.uint64)
-        cols = cols.reshape(self.base_width, self.height)
+        cols = self.base_array().reshape(self.base_width, self.height)
         rand = None
         if self.height != 0 and self.num_randomizers:
             rand = [sample_base(urandom(3 * 8)) for _ in range(self.base_width)]
@@ -224,8 +246,8 @@ class Table:
 
     def ldex(self, domain, xfield=None):
         width = self.full_width - self.base_width
-        if self.height:
-            cols = np.array(self.ext_rows, dtype=np.uint64).reshape(self.height, width * 3).T.copy()     # (column, limb) planes
+        if self.height:      # ext_columns: one (rows, 3) array per extension column -> (column, limb) planes
+            cols = np.concatenate([np.ascontiguousarray(c.T) for c in self.ext_columns], axis=0)
         else:
             cols = np.zeros((width * 3, 0), dtype=np.uint64)
         rand = None
