@@ -151,8 +151,13 @@ class BrainfuckStark:
 
         # randomizer polynomial and codeword (:162-167)
         count = self.max_degree + 1
-        coeffs = sample_ext_many(urandom(3 * 9 * count), count, 9)       # the same bytes as `count` calls of urandom(27)
-        randomizer_codeword = domain.xevaluate(XArray.from_numpy(coeffs, xf), xf, as_array=True)
+        import os
+        if urandom is os.urandom:        # production: coefficients expanded on the GPU from 32 bytes of the system's randomness
+            randomizer_polynomial = XArray.empty(count, xf)
+            _lib.check(lib.bfs_xfe_sample_fill(urandom(32), randomizer_polynomial.ptr, count, count, stream))
+        else:                            # a test replaced urandom: the reference's byte stream, `count` draws of 27 bytes
+            randomizer_polynomial = XArray.from_numpy(sample_ext_many(urandom(3 * 9 * count), count, 9), xf)
+        randomizer_codeword = domain.xevaluate(randomizer_polynomial, xf, as_array=True)
 
         lap("randomizer")
         # base codewords of all tables, one commitment to the zipped rows (:169-179)

@@ -185,6 +185,21 @@ __global__ void random_fill_kernel(u64 s0, u64 s1, u64 s2, u64 s3, u64* out, u64
     for (int k = 0; k < 8; ++k) out[8 * j + k] = h[k];
 }
 
+// ExtensionField.sample (extension_field.py:100-111) of 27 pseudo-random bytes, on the device: limb j of element i is the
+// big-endian integer of the first 9 bytes of BLAKE2b-512(seed || 3 i + j), reduced mod p (2^64 = 2^32 - 1).
+__global__ void xfe_sample_kernel(u64 s0, u64 s1, u64 s2, u64 s3, u64* out, u64 count, u64 stride) {
+    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 3 * count) return;
+    u64 m[16] = {s0, s1, s2, s3, t, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    u64 h[8];
+    blake2b_init(h);
+    blake2b_compress(h, m, 40, true);
+    const u64 top = h[0] & 0xFF;                                  // first byte = most significant
+    const u64 low = __builtin_bswap64((h[0] >> 8) | (h[1] << 56));   // bytes 1..8 as a big-endian integer
+    const u64 v = gl_add(gl_mul(top, GL_EPS), low >= GL_P ? low - GL_P : low);
+    out[(t % 3) * stride + t / 3] = v;
+}
+
 // ---- host: one template per pattern -------------------------------------------------------------------------------
 struct HostTemplates {
     std::vector<RowTemplate> templates;
@@ -278,6 +293,16 @@ extern "C" int bfs_random_fill(const uint8_t seed[32], uint64_t* d_out, uint64_t
     return BFS_OK;
 }
 
+extern "C" int bfs_xfe_sample_fill(const uint8_t seed[32], uint64_t* d_out, uint64_t count, uint64_t limb_stride, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (count == 0) return BFS_OK;
+    u64 s[4];
+    memcpy(s, seed, 32);
+    hipLaunchKernelGGL(xfe_sample_kernel, dim3((u32)((3 * count + 255) / 256)), dim3(256), 0, stream, s[0], s[1], s[2], s[3], d_out, count, limb_stride);
+    BFS_HIP(hipGetLastError());
+    return BFS_OK;
+}
+
 extern "C" int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n, const uint8_t* salts, int salts_on_device,
                                      uint8_t* d_nodes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -324,8 +349,17 @@ extern "C" int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t nco
     std::vector<u32> codes(n);
     BFS_HIP(hipMemcpyAsync(codes.data(), d_codes, n * sizeof(u32), hipMemcpyDeviceToHost, stream));
     BFS_HIP(hipStreamSynchronize(stream));
-    std::sort(codes.begin(), codes.end());
-    codes.erase(std::unique(codes.begin(), codes.end()), codes.end());
+    {   // distinct patterns: neighbouring rows almost always share theirs, so compare with the previous row first
+        std::vector<u32> distinct;
+        u32 last = ~codes[0];
+        for (u32 code : codes) {
+            if (code == last) continue;
+            last = code;
+            if (std::find(distinct.begin(), distinct.end(), code) == distinct.end()) distinct.push_back(code);
+        }
+        std::sort(distinct.begin(), distinct.end());
+        codes.swap(distinct);
+    }
 
     // 2. one template per pattern
     HostTemplates ht;

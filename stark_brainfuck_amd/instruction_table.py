@@ -16,10 +16,10 @@ class InstructionTable(Table):
         super().__init__(field, 3, 5, length, num_randomizers, generator, order)
 
     def pad(self):
-        rows = [list(r) for r in self.base_rows()]
-        while len(rows) & (len(rows) - 1):
-            rows.append([rows[-1][0], 0, 0])
-        self._append_rows(rows)
+        m = self.base_array()
+        pad = np.zeros((3, self._padding_length(m.shape[1])), dtype=np.uint64)
+        pad[0] = m[0, -1] if m.shape[1] else 0                         # the last address repeats (instruction_table.py:19-25)
+        self._pad_to(pad)
 
     def extend(self, all_challenges, all_initials):
         """instruction_table.py:167-231"""

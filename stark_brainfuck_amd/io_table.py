@@ -1,5 +1,7 @@
 """Input / output tables -- mirror of the reference's `io_table.py` (/root/reference/code/io_table.py): padding that
 redefines length and height (:17-21) and the running evaluation (:77-110).  Constraints: air.IOAir."""
+import numpy as np
+
 from . import air
 from .air import xpow, X0
 from .table import Table
@@ -12,12 +14,10 @@ class IOTable(Table):
         super().__init__(field, 1, 2, length, 0, generator, order)
 
     def pad(self):
-        rows = [list(r) for r in self.base_rows()]
-        self.length = len(rows)
-        while len(rows) & (len(rows) - 1):
-            rows.append([0])
-        self._append_rows(rows)
-        self.height = len(rows)
+        m = self.base_array()
+        self.length = m.shape[1]
+        self._pad_to(np.zeros((1, self._padding_length(self.length)), dtype=np.uint64))
+        self.height = len(self.matrix)
 
     def air_params(self, challenges):
         return [xpow(tuple(challenges[self.challenge_index]), self.height - self.length)]

@@ -1,5 +1,7 @@
 """Memory table -- mirror of the reference's `memory_table.py` (/root/reference/code/memory_table.py): `derive_matrix`
 (:20-38), padding (:40-44) and `extend` (:172-206).  Constraints: air.MemoryAir."""
+import numpy as np
+
 from . import air
 from .algebra import BaseFieldElement
 from .table import Table, P, _val
@@ -18,7 +20,11 @@ class MemoryTable(Table):
         """rows (cycle, memory pointer, memory value, dummy) of every non-padding processor row, sorted by memory pointer
         (stable), with dummy rows inserted where the cycle count of one address jumps by more than one."""
         field = processor_matrix[0][0].field if hasattr(processor_matrix[0][0], "field") else None
-        rows = [[_val(r[0]), _val(r[4]), _val(r[5]), 0] for r in processor_matrix if _val(r[2]) != 0]
+        values = getattr(processor_matrix, "values", None)
+        if values is not None:
+            rows = [[r[0], r[4], r[5], 0] for r in values.tolist() if r[2] != 0]
+        else:
+            rows = [[_val(r[0]), _val(r[4]), _val(r[5]), 0] for r in processor_matrix if _val(r[2]) != 0]
         rows.sort(key=lambda r: r[1])
         # the reference inserts one dummy row at a time with list.insert (quadratic); same result in one pass: between two
         # rows of the same address whose cycle counts are not consecutive, dummy rows count the cycles up and keep the value
@@ -33,13 +39,18 @@ class MemoryTable(Table):
         rows = out
         if field is None:
             return rows
-        return [[BaseFieldElement(v, field) for v in r] for r in rows]
+        from .vm import _matrix
+        return _matrix(rows, 4, field)
 
     def pad(self):
-        rows = [list(r) for r in self.base_rows()]
-        while len(rows) & (len(rows) - 1):
-            rows.append([(rows[-1][0] + 1) % P, rows[-1][1], rows[-1][2], 1])
-        self._append_rows(rows)
+        m = self.base_array()
+        k = self._padding_length(m.shape[1])
+        pad = np.zeros((4, k), dtype=np.uint64)
+        if k:
+            last = [int(v) for v in m[:, -1]]
+            pad[0] = [(last[0] + 1 + j) % P for j in range(k)]        # dummy rows: cycle counts up, pointer and value stay (:40-44)
+            pad[1], pad[2], pad[3] = last[1], last[2], 1
+        self._pad_to(pad)
 
     def extend(self, all_challenges, all_initials):
         """memory_table.py:172-206"""

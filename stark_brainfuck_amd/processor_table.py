@@ -18,11 +18,14 @@ class ProcessorTable(Table):
         super().__init__(field, 7, 11, length, num_randomizers, generator, order)
 
     def pad(self):
-        rows = [list(r) for r in self.base_rows()]
-        while len(rows) & (len(rows) - 1):
-            last = rows[-1]
-            rows.append([(last[0] + 1) % P, last[1], 0, 0, last[4], last[5], last[6]])
-        self._append_rows(rows)
+        m = self.base_array()
+        k = self._padding_length(m.shape[1])
+        last = [int(v) for v in m[:, -1]]
+        pad = np.zeros((7, k), dtype=np.uint64)
+        pad[0] = [(last[0] + 1 + j) % P for j in range(k)]            # the cycle count keeps counting (processor_table.py:24-35)
+        for col in (1, 4, 5, 6):                                       # instruction pointer, memory pointer / value / inverse stay
+            pad[col] = last[col]
+        self._pad_to(pad)
 
     def extend(self, all_challenges, all_initials):
         """the four extension columns as running products / evaluations (processor_table.py:329-427), one native scan each"""

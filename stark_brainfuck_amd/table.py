@@ -74,23 +74,25 @@ def sample_ext(byte_array):
 
 
 class _PaddedMatrix:
-    """the caller's matrix followed by padding rows that are materialised on demand"""
+    """the caller's matrix followed by padding rows; padding rows exist as integers and turn into element objects only if
+    somebody looks at them (`matrix` stays a sequence of rows, as in the reference; the caller's row objects are kept)"""
 
-    def __init__(self, original, rows, field):
-        self._original, self._rows, self._field, self._made = list(original), rows, field, {}
+    def __init__(self, original, array, field):
+        self._original, self._array, self._field, self._made = original, array, field, {}
+        self._count = len(original)
 
     def __len__(self):
-        return len(self._rows)
+        return self._array.shape[1]
 
     def __getitem__(self, i):
         if isinstance(i, slice):
             return [self[j] for j in range(*i.indices(len(self)))]
         if i < 0:
             i += len(self)
-        if i < len(self._original):
+        if i < self._count:
             return self._original[i]
         if i not in self._made:
-            self._made[i] = [BaseFieldElement(v, self._field) for v in self._rows[i]]
+            self._made[i] = [BaseFieldElement(int(v), self._field) for v in self._array[:, i]]
         return self._made[i]
 
     def __iter__(self):
@@ -141,22 +143,34 @@ class Table:
         return self.get_interpolation_domain_length() - 1
 
     # ---- rows
-    def base_rows(self):
-        """the base columns as Python ints, converted once per matrix object / length"""
-        key = (id(self.matrix), len(self.matrix))
-        if getattr(self, "_rows_key", None) != key:
-            self._rows = [[_val(v) for v in row[:self.base_width]] for row in self.matrix]
-            self._rows_key = key
-        return self._rows
-
     def base_array(self):
-        """base columns as a uint64 array of shape (base_width, rows), cached with base_rows()"""
-        rows = self.base_rows()
-        if getattr(self, "_array_key", None) != self._rows_key:
-            self._array = (np.array(rows, dtype=np.uint64).T.copy() if rows else np.zeros((self.base_width, 0), dtype=np.uint64))
-            self._array = self._array.reshape(self.base_width, len(rows))
-            self._array_key = self._rows_key
+        """base columns as a uint64 array of shape (base_width, rows).  Converted once per matrix: from the `values` array a
+        TraceMatrix of this package's VM carries, or element by element for plain lists of rows (the reference's format)."""
+        key = (id(self.matrix), len(self.matrix))
+        if getattr(self, "_array_key", None) != key:
+            values = getattr(self.matrix, "values", None)
+            if values is not None:
+                arr = np.ascontiguousarray(values[:, :self.base_width].T, dtype=np.uint64)
+            elif len(self.matrix):
+                arr = np.array([[_val(v) for v in row[:self.base_width]] for row in self.matrix], dtype=np.uint64).T.copy()
+            else:
+                arr = np.zeros((self.base_width, 0), dtype=np.uint64)
+            self._array, self._array_key = arr.reshape(self.base_width, len(self.matrix)), key
         return self._array
+
+    def base_rows(self):
+        return self.base_array().T.tolist()
+
+    def _pad_to(self, padding):
+        """append `padding` (uint64 array, base_width x k) to the matrix"""
+        arr = np.concatenate([self.base_array(), padding.astype(np.uint64)], axis=1) if padding.shape[1] else self.base_array()
+        self.matrix = _PaddedMatrix(self.matrix, arr, self.field)
+        self._array, self._array_key = arr, (id(self.matrix), len(self.matrix))
+
+    @staticmethod
+    def _padding_length(rows):
+        """rows to add so that the count becomes a power of two (0 and powers of two stay: `while len & (len - 1)`)"""
+        return 0 if rows & (rows - 1) == 0 else (1 << rows.bit_length()) - rows
 
     @staticmethod
     def scan(kind, columns, mask, constants, initial, record_before):
@@ -172,12 +186,6 @@ class Table:
                                             m.ctypes.data if m is not None else None, n, (_u64 * 12)(*flat), (_u64 * 3)(*initial),
                                             1 if record_before else 0, out.ctypes.data, terminal))
         return out, (int(terminal[0]), int(terminal[1]), int(terminal[2]))
-
-    def _append_rows(self, rows):
-        """padding: the caller's rows (and their element objects) are kept, the padding rows exist as integers and turn
-        into element objects only if somebody looks at them (`matrix` stays a sequence of rows, as in the reference)"""
-        self.matrix = _PaddedMatrix(self.matrix, rows, self.field)
-        self._rows, self._rows_key = rows, (id(self.matrix), len(self.matrix))
 
     # ---- interpolation + low-degree extension (table.py:112-148)
     def _extend_columns(self, domain, columns, randomizers):
@@ -288,7 +296,8 @@ class Table:
         cons = dict(self.air.all())[kind]
         nvars = 2 * self.full_width if kind == "transition" else self.full_width
         params = self.air_params(challenges)
-        return [air.symbolic_degree_bound(air.expand(e, nvars, challenges, terminals, params), md) for e in cons]
+        memo = {}            # sub-expressions (deselectors, instruction zerofier, row differences) are shared between constraints
+        return [air.symbolic_degree_bound(air.expand(e, nvars, challenges, terminals, params, memo), md) for e in cons]
 
     def boundary_quotient_degree_bounds(self, challenges):
         return [b - 1 for b in self._degree_bounds("boundary", challenges, [air.X0] * 5)]

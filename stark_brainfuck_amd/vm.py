@@ -8,6 +8,19 @@ from .algebra import BaseField, BaseFieldElement
 P = (1 << 64) - (1 << 32) + 1
 
 
+class TraceMatrix(list):
+    """a matrix in the reference's format (list of rows of BaseFieldElement) that also carries the same values as a uint64
+    array (`values`, rows x columns), so that the tables need not unbox hundreds of thousands of elements again"""
+    values = None
+
+
+def _matrix(rows, width, field, objects=None):
+    import numpy as np
+    m = TraceMatrix(objects if objects is not None else [[BaseFieldElement(v, field) for v in r] for r in rows])
+    m.values = np.array(rows, dtype=np.uint64).reshape(len(rows), width)
+    return m
+
+
 class VirtualMachine:
     field = BaseField.main()
 
@@ -91,7 +104,10 @@ class VirtualMachine:
         processor, inputs, outputs = [], [], []
         instruction = [[i, prog[i], prog[i + 1]] for i in range(n - 1)] + [[n - 1, prog[-1], 0]]
 
+        processor_values = []
+
         def row():
+            processor_values.append([clk, ip, ci, ni, mp, mv.value, mvi])
             return [BaseFieldElement(clk, field), BaseFieldElement(ip, field), BaseFieldElement(ci, field), BaseFieldElement(ni, field),
                     BaseFieldElement(mp, field), mv, BaseFieldElement(mvi, field)]
         while ip < n:
@@ -128,8 +144,10 @@ class VirtualMachine:
         processor.append(row())
         instruction.append([ip, ci, ni])
         instruction.sort(key=lambda r: r[0])          # stable, by address (vm.py:302)
-        instruction = [[BaseFieldElement(v, field) for v in r] for r in instruction]
-        return processor, MemoryTable.derive_matrix(processor), instruction, inputs, outputs
+        processor = _matrix(processor_values, 7, field, processor)
+        memory = MemoryTable.derive_matrix(processor)
+        return (processor, memory, _matrix(instruction, 3, field),
+                _matrix([[r[0].value] for r in inputs], 1, field, inputs), _matrix([[r[0].value] for r in outputs], 1, field, outputs))
 
     @staticmethod
     def num_challenges():

@@ -654,3 +654,20 @@ def test_ntt_batch_larger_than_grid_limit(sb, oracle):
     lo = raw_ntt(sb, v[:n * 40000], logn, w, batch=40000).reshape(40000, n)
     hi = raw_ntt(sb, v[n * 40000:], logn, w, batch=batch - 40000).reshape(batch - 40000, n)
     assert (out[:40000] == lo).all() and (out[40000:] == hi).all()
+
+
+def test_device_side_sampling_of_the_randomizer_polynomial(sb):
+    """bfs_xfe_sample_fill: ExtensionField.sample of 27 pseudo-random bytes per element, bytes = BLAKE2b(seed || counter)"""
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.device import DeviceBuffer
+    lib = _lib.load()
+    P = (1 << 64) - (1 << 32) + 1
+    seed, count = bytes(range(100, 132)), 1000
+    buf = DeviceBuffer(3 * count)
+    _lib.check(lib.bfs_xfe_sample_fill(seed, buf.ptr, count, count, 0))
+    got = buf.to_numpy(3 * count).reshape(3, count)
+    for i in (0, 1, 2, 499, 999):
+        for j in range(3):
+            digest = hashlib.blake2b(seed + (3 * i + j).to_bytes(8, "little")).digest()
+            assert int(got[j, i]) == int.from_bytes(digest[:9], "big") % P
+    assert (got < np.uint64(P)).all() and len(set(got.reshape(-1).tolist())) == 3 * count
