@@ -14,12 +14,10 @@ import ctypes
 from hashlib import blake2b
 from os import urandom          # module-level on purpose: tests patch `brainfuck_stark.urandom` for determinism
 
-import numpy as np
-
 from . import _lib, air
 from .algebra import BaseField, BaseFieldElement
 from .arrays import XArray
-from .device import DeviceBuffer, current_stream, gather, synchronize
+from .device import current_stream, gather, synchronize
 from .evaluation_argument import EvaluationArgument, ProgramEvaluationArgument
 from .extension_field import ExtensionField, ExtensionFieldElement
 from .fri import Fri
@@ -316,7 +314,7 @@ class BrainfuckStark:
         """brainfuck_stark.py:343-579 -- host only, like the reference's verifier: Merkle paths of the opened rows, the
         non-linear combination recomputed from the opened rows (constraints evaluated through air.evaluate), FRI, and the
         terminals against the public input, output and program."""
-        from .air import X0, X1, xadd, xinv, xlift, xmul, xscale, xsub
+        from .air import X0, xadd, xmul, xscale
         P = air.P
         if proof_stream is None:
             proof_stream = ProofStream()

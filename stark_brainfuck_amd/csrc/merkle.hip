@@ -13,7 +13,11 @@ namespace bfs {
 constexpr int LEAF_THREADS = 64;  // one wavefront per workgroup: the staging area is 52 words x 64 lanes = 26 KiB
 
 __global__ void __launch_bounds__(LEAF_THREADS) merkle_leaves_xfe_kernel(const u64* limbs, u64 limb_stride, u64 n, u64* leaf_digests, const u64* midstates) {
+#ifdef BFS_LEAF_LDS_PAD
+    __shared__ u64 stage[(XFE_TAIL_MAX_WORDS + BFS_LEAF_LDS_PAD) * LEAF_THREADS];
+#else
     __shared__ u64 stage[XFE_TAIL_MAX_WORDS * LEAF_THREADS];
+#endif
     const u64 i = (u64)blockIdx.x * LEAF_THREADS + threadIdx.x;
     if (i >= n) return;
     u64 d[8];

@@ -1,7 +1,7 @@
 """Evaluation arguments -- mirror of the reference's `evaluation_argument.py`
 (/root/reference/code/evaluation_argument.py:1-53): what the verifier recomputes from public data (input and output
 symbols, the program) and compares with the terminals.  Values are int triples (air.x*)."""
-from .air import X0, X1, xadd, xmul, xneg, xlift, xscale
+from .air import X0, xadd, xmul, xlift, xscale
 
 
 def _v(x):

@@ -3,7 +3,6 @@
 import numpy as np
 
 from . import air
-from .algebra import BaseFieldElement
 from .table import Table, P, _val
 
 

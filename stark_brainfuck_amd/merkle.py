@@ -6,7 +6,6 @@ Leaf hashing and all inner levels run in HIP kernels (csrc/merkle.hip).  When th
 XArray / BaseArray in HBM) the pickle preimage of every leaf is synthesised on the GPU from the limbs; arbitrary
 picklable leaves are pickled on the host, exactly like the reference does, and hashed on the GPU in one batch.
 """
-import ctypes
 import pickle
 from hashlib import blake2b
 

@@ -188,7 +188,7 @@ class Table:
         return out, (int(terminal[0]), int(terminal[1]), int(terminal[2]))
 
     # ---- interpolation + low-degree extension (table.py:112-148)
-    def _extend_columns(self, domain, columns, randomizers):
+    def _extend_columns(self, domain, columns, randomizers, keep_coefficients=False):
         """columns: uint64 array (ncol, height); randomizers: ncol values at the point omega (or None).
         Returns the codewords over `domain` as one DeviceBuffer of ncol * N words."""
         lib, stream = _lib.load(), current_stream()
@@ -217,7 +217,8 @@ class Table:
             n_in = h + 1
         assert n_in <= n, "interpolant does not fit the FRI domain"
         raw_ntt(coeffs.ptr, n_in, h + 1, out.ptr, n, log_n, ncol, omega, offset, 1, stream)
-        self._coefficients = coeffs.to_numpy(ncol * (h + 1)).reshape(ncol, h + 1)     # a few KiB: see ext_sharing_moduli
+        if keep_coefficients:
+            self._coefficients = coeffs.to_numpy(ncol * (h + 1)).reshape(ncol, h + 1)     # see ext_sharing_moduli
         return out
 
     def ext_sharing_moduli(self, n):
@@ -263,7 +264,7 @@ class Table:
             rand = []
             for _ in range(width):
                 rand.extend(sample_ext(urandom(3 * 8)))
-        self.ext_codewords = self._extend_columns(domain, cols, rand)
+        self.ext_codewords = self._extend_columns(domain, cols, rand, keep_coefficients=True)
         return self.ext_codewords
 
     def ext_codeword_ptr(self, column):
