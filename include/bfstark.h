@@ -265,6 +265,11 @@ typedef struct bfs_comb_source {
     uint64_t shift;        /* max_degree - degree bound of this codeword */
     uint64_t wa[3], wb[3]; /* weights of the plain and of the shifted term */
 } bfs_comb_source;
+/* Support summary of `batch` polynomials of `len` coefficients (`stride` apart): h_masks[b] has bit 63 set when the constant
+ * coefficient is non-zero, and its low bits are the OR over the non-zero indices j > 0 of (j & -j) -- the lowest set bit gives the
+ * power of two dividing every non-zero index, which decides which codeword elements share coefficient objects in the reference
+ * (univariate.py:23-27 inside the recursive ntt).  Synchronises the stream. */
+int bfs_poly_support(const uint64_t* d_coeffs, uint64_t stride, uint64_t len, uint32_t batch, uint64_t* h_masks, void* stream);
 int bfs_poly_randomize(uint64_t* d_coeffs, uint64_t stride, uint64_t h, uint32_t batch, uint64_t point, const uint64_t* h_values, void* stream);
 int bfs_air_num_quotients(int table);
 int bfs_air_quotients(int table, const uint64_t* d_base, const uint64_t* d_ext, uint64_t* d_out, uint32_t log_n, uint64_t unit_distance,

@@ -44,6 +44,24 @@ __global__ void __launch_bounds__(256) poly_randomize_kernel(u64* coeffs, u64 st
     }
 }
 
+// Which coefficient indices of a polynomial are non-zero, condensed to what the prover needs (table.ext_sharing_moduli): bit 63 =
+// the constant coefficient is non-zero; the low bits = OR over the non-zero indices j > 0 of (j & -j), so the lowest set bit is 2^v
+// with v the 2-adic valuation common to all of them.  One workgroup per polynomial.
+__global__ void __launch_bounds__(256) coefficient_support_kernel(const u64* coeffs, u64 stride, u64 len, u64* out) {
+    __shared__ u64 part[256];
+    const u64* f = coeffs + (u64)blockIdx.x * stride;
+    u64 acc = 0;
+    for (u64 j = threadIdx.x; j < len; j += 256)
+        if (f[j] != 0) acc |= j ? (j & (0 - j)) : (1ull << 63);
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (u32 s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) part[threadIdx.x] |= part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = part[0];
+}
+
 // ---- quotients -----------------------------------------------------------------------------------------------------
 struct AirArgs {
     const u64* base;
@@ -188,6 +206,18 @@ int bfs_poly_randomize(uint64_t* d_coeffs, uint64_t stride, uint64_t h, uint32_t
     hipLaunchKernelGGL(poly_randomize_kernel, dim3(batch), dim3(256), 0, stream, d_coeffs, stride, h, point, gl_inv(den), (const u64*)w);
     BFS_HIP(hipGetLastError());
     BFS_HIP(hipStreamSynchronize(stream));      // h_values may be reused by the caller
+    return BFS_OK;
+}
+
+int bfs_poly_support(const uint64_t* d_coeffs, uint64_t stride, uint64_t len, uint32_t batch, uint64_t* h_masks, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (batch == 0) return BFS_OK;
+    void* w = nullptr;
+    BFS_TRY(workspace(3, (size_t)batch * sizeof(u64), stream, &w));
+    hipLaunchKernelGGL(coefficient_support_kernel, dim3(batch), dim3(256), 0, stream, d_coeffs, stride, len, (u64*)w);
+    BFS_HIP(hipGetLastError());
+    BFS_HIP(hipMemcpyAsync(h_masks, w, (size_t)batch * sizeof(u64), hipMemcpyDeviceToHost, stream));
+    BFS_HIP(hipStreamSynchronize(stream));
     return BFS_OK;
 }
 

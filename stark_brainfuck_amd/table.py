@@ -217,8 +217,10 @@ class Table:
             n_in = h + 1
         assert n_in <= n, "interpolant does not fit the FRI domain"
         raw_ntt(coeffs.ptr, n_in, h + 1, out.ptr, n, log_n, ncol, omega, offset, 1, stream)
-        if keep_coefficients:
-            self._coefficients = coeffs.to_numpy(ncol * (h + 1)).reshape(ncol, h + 1)     # see ext_sharing_moduli
+        if keep_coefficients:      # see ext_sharing_moduli: only a per-polynomial summary of the support comes back
+            masks = (_u64 * ncol)()
+            _lib.check(lib.bfs_poly_support(coeffs.ptr, h + 1, n_in, ncol, masks, stream))
+            self._coefficients = [int(v) for v in masks]
         return out
 
     def ext_sharing_moduli(self, n):
@@ -234,14 +236,14 @@ class Table:
             return [None] * width
         out = []
         for c in range(width):
-            planes = self._coefficients[3 * c:3 * c + 3]
-            support = np.nonzero((planes != 0).any(axis=0))[0]
-            if support.size == 0:
-                out.append(None)
-            elif support.size == 1 and support[0] == 0:
-                out.append(1)
+            mask = self._coefficients[3 * c] | self._coefficients[3 * c + 1] | self._coefficients[3 * c + 2]   # any limb non-zero
+            low = mask & ((1 << 63) - 1)
+            if mask == 0:
+                out.append(None)                     # the zero polynomial: elements without coefficients
+            elif low == 0:
+                out.append(1)                        # a constant: every element holds the same coefficient objects
             else:
-                v = min(int(j & -j).bit_length() - 1 for j in support if j)
+                v = (low & -low).bit_length() - 1
                 out.append(n >> v if v else None)
         return out
 
