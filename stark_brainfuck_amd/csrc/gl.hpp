@@ -60,28 +60,54 @@ BFS_HD u64 gl_add(u64 a, u64 b) {
     return over ? (((u64)uhi << 32) | ulo) : (((u64)shi << 32) | slo);
 }
 
-// hi*2^64 + lo  ->  residue; CANON = false leaves the value in [0, 2^64) (fine as an operand of further multiplications)
+// a VGPR holding 0 that the optimiser cannot see through: `x - 0 - borrow` written with it compiles to one v_subb_co_u32,
+// while a literal 0 makes hipcc materialise the borrow with v_cndmask first (one more instruction per carry step)
+BFS_HD u32 gl_opaque_zero() {
+    u32 z;
+    asm("v_mov_b32 %0, 0" : "=v"(z));
+    return z;
+}
+
+// hi*2^64 + lo  ->  residue; CANON = false leaves the value in [0, 2^64) (fine as an operand of further multiplications).
+// 13 VALU instructions (17 as plain C): the multiply-add  hi_lo * (2^32 - 1) + t0  is ONE v_mad_u64_u32 whose carry-out is used
+// directly -- C has no way to ask for that carry, and the compiler's version is mad + 64-bit add + 64-bit compare.
 template <bool CANON>
 BFS_HD u64 gl_reduce128_t(u64 hi, u64 lo) {
+    const u32 z = gl_opaque_zero();
     u32 hh = (u32)(hi >> 32), hl = (u32)hi;
-    u32 bl, bh, b2;
+    u32 bl, bh, b2, b3;
     u32 dlo = __builtin_subc((u32)lo, hh, 0u, &bl);    // t0 = lo - hi_hi  (2^96 = -1)
-    u32 dhi = __builtin_subc((u32)(lo >> 32), 0u, bl, &bh);
+    u32 dhi = __builtin_subc((u32)(lo >> 32), z, bl, &bh);
     u32 t = 0u - bh;
     u32 t0lo = __builtin_subc(dlo, t, 0u, &b2);
-    u32 t0hi = dhi - b2;
+    u32 t0hi = __builtin_subc(dhi, z, b2, &b3);
     u64 t0 = ((u64)t0hi << 32) | t0lo;
-    u64 r = (u64)hl * 0xFFFFFFFFu + t0;                // + hi_lo * (2^32 - 1)  (2^64 = 2^32 - 1): one v_mad_u64_u32
-    u32 c = r < t0, c2, c3;
-    u32 rlo = __builtin_addc((u32)r, 0u - c, 0u, &c2); // wrapped: + EPS (cannot wrap twice)
-    u32 rhi = (u32)(r >> 32) + c2;
+    u64 r;                                             // + hi_lo * (2^32 - 1)  (2^64 = 2^32 - 1)
+    u32 m;                                             // 0xFFFFFFFF when that addition wrapped: + EPS (cannot wrap twice)
+    asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\ts_nop 1\n\tv_cndmask_b32 %1, 0, -1, vcc" : "=&v"(r), "=v"(m) : "v"(hl), "v"(t0) : "vcc");
+    u32 c2, c3;
+    u32 rlo = __builtin_addc((u32)r, m, 0u, &c2);
+    u32 rhi = __builtin_addc((u32)(r >> 32), z, c2, &c3);
     if constexpr (!CANON) return ((u64)rhi << 32) | rlo;
     // canonical form: r >= p  <=>  r + EPS carries out of 64 bits
     u32 ulo = __builtin_addc(rlo, 0xFFFFFFFFu, 0u, &c2);
-    u32 uhi = __builtin_addc(rhi, 0u, c2, &c3);
+    u32 uhi = __builtin_addc(rhi, z, c2, &c3);
     return c3 ? (((u64)uhi << 32) | ulo) : (((u64)rhi << 32) | rlo);
 }
 BFS_HD u64 gl_reduce128(u64 hi, u64 lo) { return gl_reduce128_t<true>(hi, lo); }
+
+// lo + top * 2^64 for a 32-bit top  ->  canonical residue (x << r for r < 32 is such a 96-bit value): the tail of gl_reduce128_t
+BFS_HD u64 gl_reduce96(u32 top, u64 lo) {
+    const u32 z = gl_opaque_zero();
+    u64 r;
+    u32 m, c2, c3;
+    asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\ts_nop 1\n\tv_cndmask_b32 %1, 0, -1, vcc" : "=&v"(r), "=v"(m) : "v"(top), "v"(lo) : "vcc");
+    u32 rlo = __builtin_addc((u32)r, m, 0u, &c2);
+    u32 rhi = __builtin_addc((u32)(r >> 32), z, c2, &c3);
+    u32 ulo = __builtin_addc(rlo, 0xFFFFFFFFu, 0u, &c2);
+    u32 uhi = __builtin_addc(rhi, z, c2, &c3);
+    return c3 ? (((u64)uhi << 32) | ulo) : (((u64)rhi << 32) | rlo);
+}
 
 // 64 x 64 -> 128 as four independent 32 x 32 products and a 5-instruction carry tree (no register shuffles)
 BFS_HD void gl_mul128(u64 a, u64 b, u64& hi, u64& lo) {
@@ -130,6 +156,10 @@ BFS_HD u64 gl_reduce128(u64 hi, u64 lo) {
     if (r < t1) r += GL_EPS;               // carry -> +2^64 = +EPS ; cannot carry twice
     return r >= GL_P ? r - GL_P : r;
 }
+#endif
+
+#if !defined(__HIP_DEVICE_COMPILE__)
+BFS_HD u64 gl_reduce96(u32 top, u64 lo) { return gl_reduce128((u64)top, lo); }
 #endif
 
 BFS_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }

@@ -42,8 +42,8 @@ constexpr u64 cx_pow2(int k) {
 //   q = 1:  2^32 (y0 + y1) - (y1 + y2)          q = 2:  2^32 y0 - ((y2:y1) + y0)
 // where both operands of the subtraction are canonical by construction (2^32 s mod p = (s_lo : -carry) for a 33-bit s), so
 // the whole product is three funnel shifts, two or three additions and one modular subtraction: 10-12 VALU instructions
-// instead of 20-26 for a multiplication by the constant 2^K mod p.  For q = 0 the constant multiplication (13) is kept:
-// hipcc drops the partial products of the constant's zero limb and the shift-and-fold form is no shorter.
+// instead of 20-26 for a multiplication by the constant 2^K mod p.  For q = 0 the 96-bit value x << r is folded with one
+// multiply-add by 2^32 - 1 (gl_reduce96): 11 instructions.
 template <int K>
 BFS_HD u64 mul_pow2(u64 x) {
     static_assert(K >= 0 && K < 96, "rotation amount");
@@ -51,8 +51,7 @@ BFS_HD u64 mul_pow2(u64 x) {
     if constexpr (K == 0) {
         return x;
     } else if constexpr (q == 0) {
-        constexpr u64 c = cx_pow2(K);
-        return gl_mul(x, c);
+        return gl_reduce96((u32)(x >> (64 - r)), x << r);          // (y2 : y1:y0) = x << r,  2^64 = 2^32 - 1
     } else {
         const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
         u32 y0 = x0, y1 = x1, y2 = 0;
