@@ -5,7 +5,7 @@ namespace bfs {
 
 // One workgroup per tile: T/16 threads hold 16 elements each.  LDS = tile (padded) + the stage-1 -> stage-2 twiddles.
 // (A persistent variant with next-tile prefetch and 16-byte paired-lane accesses was measured slower: the kernel is
-//  VALU-issue bound and hardware workgroup turnover already overlaps HBM latency)
+//  VALU-issue bound at the time and hardware workgroup turnover already overlaps HBM latency)
 template <int B1, int B2, int B3, int LOGC, int MODE>
 __global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) u64 smem[];

@@ -16,10 +16,11 @@
 // of two (any primitive 16th root of unity in this field is 2^(12u), u odd), multiplies by the inner twiddle
 // and exchanges through LDS once per stage.
 //
-// The kernels are VALU-issue bound (a wave64 integer instruction costs 4 cycles, the tile kernel sits at 97 % VALU
-// utilisation; profiles/r01), so the code spends instructions on arithmetic only: tile shape (LOGC) and pass kind
-// (MODE) are template parameters, every global / LDS access is "per-thread base + wave-uniform or immediate offset",
-// digit permutations are wave-uniform scalars, strides are powers of two applied as shifts.
+// A wave64 integer instruction costs 4 cycles and the tile kernels issue ~2000 of them per 16 elements, which is about what one
+// pass' HBM time is worth: the first two passes of a 2^24 transform are memory-bound, the last one VALU-bound.
+// So the code spends instructions on arithmetic only: tile shape (LOGC) and pass kind (MODE) are template parameters, every
+// global / LDS access is "per-thread base + wave-uniform or immediate offset", digit permutations are wave-uniform scalars,
+// strides are powers of two applied as shifts, power-of-two twiddles are shifts and folds.
 //
 // The stage bodies are pure functions of (thread id, block id, LDS pointer) and compile for the host as well,
 // which is how tests/test_emulation.py checks the index arithmetic without a GPU (test infrastructure only:
