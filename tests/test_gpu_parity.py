@@ -671,3 +671,35 @@ def test_device_side_sampling_of_the_randomizer_polynomial(sb):
             digest = hashlib.blake2b(seed + (3 * i + j).to_bytes(8, "little")).digest()
             assert int(got[j, i]) == int.from_bytes(digest[:9], "big") % P
     assert (got < np.uint64(P)).all() and len(set(got.reshape(-1).tolist())) == 3 * count
+
+
+@pytest.mark.parametrize("n,n_ext,n_base", [(1, 1, 0), (2, 0, 3), (3, 2, 2), (65, 16, 16), (1000, 2, 2)])
+def test_zipped_rows_edge_shapes(sb, oracle, n, n_ext, n_base):
+    """row emitter on tiny, ragged (absent leaf slots) and wide inputs; 32 columns make the row pickle longer than 2.5 KB,
+    with memo back-references beyond index 255 (LONG_BINGET)"""
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.device import DeviceBuffer
+    lib = _lib.load()
+    P = (1 << 64) - (1 << 32) + 1
+    rng = np.random.default_rng(n * 100 + n_ext)
+    ext = [rng.integers(0, P, (3, n), dtype=np.uint64) for _ in range(n_ext)]
+    for e in ext:
+        e[2, ::2] = 0
+        e[1, ::4] = 0
+        e[0, ::8] = 0
+    base = [rng.integers(0, 300, n, dtype=np.uint64) for _ in range(n_base)]
+    bufs = [DeviceBuffer.from_numpy(np.ascontiguousarray(e).reshape(-1)) for e in ext] + [DeviceBuffer.from_numpy(b) for b in base]
+    rc = (_lib.RowColumn * len(bufs))()
+    for k, b in enumerate(bufs):
+        rc[k].d_values, rc[k].is_ext, rc[k].field_id = b.ptr, int(k < n_ext), 0
+    npo2 = 1
+    while npo2 < n:
+        npo2 <<= 1
+    nodes = DeviceBuffer(2 * npo2 * 8)
+    salts = rng.integers(0, 256, 24 * n, dtype=np.uint8).tobytes()
+    keep = ctypes.create_string_buffer(salts, len(salts))
+    _lib.check(lib.bfs_merkle_build_rows(rc, len(bufs), n, ctypes.cast(keep, ctypes.c_void_p), 0, nodes.ptr, 0))
+    rows = [tuple([oracle.make_xfe([int(e[0, i]), int(e[1, i]), int(e[2, i])]) for e in ext] + [oracle.make_bfe(int(b[i])) for b in base])
+            for i in range(n)]
+    ref = oracle.MerkleOracle([oracle.salted_leaf_bytes(r, salts[24 * i:24 * i + 24]) for i, r in enumerate(rows)])
+    assert nodes.to_numpy(8, offset=8).tobytes() == ref.root()
