@@ -14,7 +14,8 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbfstark_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
-         "-ffp-contract=off"]
+         "-ffp-contract=off",
+         "-Xarch_host", "-mbmi", "-Xarch_host", "-mbmi2"]      # host side: andn / rorx for Keccak (keccak.hpp), any x86-64-v3 CPU
 
 
 def sources():

@@ -151,8 +151,57 @@ class Pickler {
         return out_;
     }
 
+    // ---- incremental pickling of a growing list (the proof stream): pickle.dumps(objects) for objects[:k] is a prefix-stable
+    // byte string -- memo indices are handed out in order, so the encoding of the first k objects never changes -- followed by
+    // APPENDS STOP and the frame length patched in.  Valid from two objects on (a one-element list has no MARK, _pickle.c
+    // batch_list_exact).  stream_begin / stream_item build the open form, stream_bytes returns the closed pickle of what has
+    // been added so far and leaves the open form intact.
+    void stream_begin() {
+        out_.clear();
+        memo_.clear();
+        int_marks.clear();
+        frame_start_ = NPOS;
+        framing_ = false;
+        const unsigned char proto[2] = {0x80, 4};
+        write(proto, 2);
+        framing_ = true;
+        op(0x5d);                      // EMPTY_LIST
+        memo_put(&stream_list_);
+        stream_items_ = 0;
+        stream_batch_ = 0;
+    }
+    void stream_item(const Ref& item) {
+        if (stream_batch_ == 0) op(0x28);                      // MARK opens a batch
+        save(item.get());
+        ++stream_items_;
+        if (++stream_batch_ == BATCH) { op(0x65); stream_batch_ = 0; }   // APPENDS closes it after 1000 items
+    }
+    size_t stream_items() const { return stream_items_; }
+    std::string stream_bytes() {
+        const size_t size = out_.size(), frame = frame_start_;
+        std::string saved_header;
+        if (frame != NPOS) saved_header = out_.substr(frame, FRAME_HEADER);
+        if (stream_batch_ != 0) op(0x65);                      // APPENDS of the open batch
+        op(0x2e);                                              // STOP
+        // after the two writes a frame is open in any case; remember where, in case it was opened by them
+        const size_t frame_now = frame_start_;
+        commit_frame();
+        std::string result = out_;
+        if (frame == NPOS) {                                   // the closing opcodes opened a frame of their own: drop all of it
+            out_.resize(size);
+        } else {
+            (void)frame_now;
+            out_.resize(size);
+            out_.replace(frame, FRAME_HEADER, saved_header);   // reopen the frame the items live in
+        }
+        frame_start_ = frame;
+        return result;
+    }
+
    private:
     const World* world_;
+    Node stream_list_;
+    size_t stream_items_ = 0, stream_batch_ = 0;
     static constexpr size_t NPOS = (size_t)-1;
     static constexpr size_t FRAME_HEADER = 9, FRAME_MIN = 4, FRAME_TARGET = 64 * 1024, BATCH = 1000;
     std::string out_;
@@ -371,7 +420,17 @@ struct Transcript {
     uint64_t add(const Ref& r) { arena.push_back(r); return arena.size(); }
     Ref get(uint64_t h) const { return (h >= 1 && h <= arena.size()) ? arena[h - 1] : Ref(); }
 
+    // the whole stream is pickled incrementally (a proof asks for Fiat-Shamir randomness after almost every push, each time
+    // over everything pushed so far); prefixes (the verifier's view) and streams of fewer than two objects take the plain route
+    mutable Pickler stream{&world};
+    mutable bool streaming = false;
+
     std::string serialize(size_t count) const {
+        if (count >= objects.size() && objects.size() >= 2) {
+            if (!streaming) { stream.stream_begin(); streaming = true; }
+            for (size_t i = stream.stream_items(); i < objects.size(); ++i) stream.stream_item(objects[i]);
+            return stream.stream_bytes();
+        }
         Ref lst = mk(K_LIST);
         lst->items.assign(objects.begin(), objects.begin() + (count < objects.size() ? count : objects.size()));
         Pickler p(&world);
