@@ -278,24 +278,27 @@ TABLE_AIRS = [ProcessorAir(), InstructionAir(), MemoryAir(), IOAir("input", GAMM
 # interpretation 1: exact expansion (dictionary exponent vector -> extension coefficient)
 
 
+_EXP_BITS = 6          # bits per variable in a packed exponent vector (degrees stay below 64: the largest constraint has 11)
+
+
 def expand(e, nvars, challenges, terminals, params=(), _memo=None):
-    """multivariate expansion of expression e as {exponent tuple of length nvars: (c0, c1, c2)}; variable (c, next) has
-    index c + next * (nvars // 2).  Zero coefficients are dropped."""
+    """multivariate expansion of expression e as {packed exponent vector: (c0, c1, c2)}: the exponent of variable i sits in
+    bits [6 i, 6 i + 6) of the key, so multiplying monomials is adding keys; variable (c, next) has index c + next * (nvars // 2).
+    Zero coefficients are dropped.  (`unpack_exponents` turns a key back into the reference's exponent tuple.)"""
     memo = {} if _memo is None else _memo
     key = id(e)
     if key in memo:
         return memo[key]
     op = e.op
-    zero_exp = (0,) * nvars
     if op == "v":
         col, nxt = e.val
         idx = col + (nvars // 2 if nxt else 0)
-        r = {tuple(1 if i == idx else 0 for i in range(nvars)): X1}
+        r = {1 << (_EXP_BITS * idx): X1}
     elif op == "k":
-        r = {zero_exp: xlift(e.val)} if e.val % P else {}
+        r = {0: xlift(e.val)} if e.val % P else {}
     elif op in "ctp":
         v = {"c": challenges, "t": terminals, "p": params}[op][e.val]
-        r = {zero_exp: tuple(v)} if any(v) else {}
+        r = {0: tuple(v)} if any(v) else {}
     elif op == "n":
         r = {k: xneg(v) for k, v in expand(e.a, nvars, challenges, terminals, params, memo).items()}
     else:
@@ -311,10 +314,11 @@ def expand(e, nvars, challenges, terminals, params=(), _memo=None):
                     r.pop(k, None)
         else:
             r = {}
+            get = r.get
             for k0, v0 in x.items():
                 for k1, v1 in y.items():
-                    k = tuple(i + j for i, j in zip(k0, k1))
-                    w = xadd(r.get(k, X0), xmul(v0, v1))
+                    k = k0 + k1
+                    w = xadd(get(k, X0), xmul(v0, v1))
                     if any(w):
                         r[k] = w
                     else:
@@ -323,12 +327,21 @@ def expand(e, nvars, challenges, terminals, params=(), _memo=None):
     return r
 
 
+def unpack_exponents(key, nvars):
+    return tuple((key >> (_EXP_BITS * i)) & ((1 << _EXP_BITS) - 1) for i in range(nvars))
+
+
 def symbolic_degree_bound(expansion, max_degree):
     """multivariate.py:144-170 with a uniform bound on every argument: max over the non-zero monomials of
     (total degree * max_degree); -1 for the zero polynomial."""
     bound = -1
-    for exps in expansion:
-        bound = max(bound, sum(exps) * max_degree)
+    mask = (1 << _EXP_BITS) - 1
+    for key in expansion:
+        total = 0
+        while key:
+            total += key & mask
+            key >>= _EXP_BITS
+        bound = max(bound, total * max_degree)
     return bound
 
 
