@@ -113,16 +113,15 @@ class BrainfuckStark:
 
     # ------------------------------------------------------------------------------------------------------------
     def prove(self, program, processor_matrix, memory_matrix, instruction_matrix, input_matrix, output_matrix, proof_stream=None):
-        # the host steps allocate millions of small tuples while the trace matrices keep hundreds of thousands of element objects
-        # alive: every generational collection would walk all of them (measured: 3x on the running-product loops)
+        # The trace matrices keep ~10^5 element objects alive; every full garbage collection during (or right after) the proof
+        # would walk all of them (measured: 20 ms pauses on a 17 ms proof).  gc.freeze() parks everything that exists now in a
+        # permanent generation for the duration of the call; objects made by the proof itself are collected as usual.
         import gc
-        was_enabled = gc.isenabled()
-        gc.disable()
+        gc.freeze()
         try:
             return self._prove(program, processor_matrix, memory_matrix, instruction_matrix, input_matrix, output_matrix, proof_stream)
         finally:
-            if was_enabled:
-                gc.enable()
+            gc.unfreeze()
 
     def _prove(self, program, processor_matrix, memory_matrix, instruction_matrix, input_matrix, output_matrix, proof_stream=None):
         assert len(processor_matrix) + len(program) == len(instruction_matrix)
