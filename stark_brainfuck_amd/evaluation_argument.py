@@ -1,45 +1,47 @@
-"""Evaluation arguments -- mirror of the reference's `evaluation_argument.py`
-(/root/reference/code/evaluation_argument.py:1-53): what the verifier recomputes from public data (input and output
-symbols, the program) and compares with the terminals.  Values are int triples (air.x*)."""
-from .air import X0, xadd, xmul, xlift, xscale
+"""Evaluation arguments: what the verifier recomputes from public data -- the input and output symbols, the program -- and
+compares with the terminals the prover sent.  Host-side mirror of /root/reference/code/evaluation_argument.py:1-53;
+values are int triples (air.x*).
+
+Both arguments are Horner evaluations in a challenge: of the symbol string in iota (input: gamma, output: delta), and of the
+compressed program rows a*address + b*instruction + c*next_instruction in eta (the instruction table's evaluation column)."""
+from functools import reduce
+
+from .air import X0, xadd, xlift, xmul, xscale
 
 
-def _v(x):
+def _value(x):
     return x.value if hasattr(x, "value") else int(x)
 
 
-class EvaluationArgument:
+def _horner(terms, point):
+    return reduce(lambda acc, term: xadd(xmul(acc, point), term), terms, X0)
+
+
+class _TerminalCheck:
+    terminal_index = None
+
+    def select_terminal(self, terminals):
+        return terminals[self.terminal_index]
+
+
+class EvaluationArgument(_TerminalCheck):
     def __init__(self, challenge_index, terminal_index, symbols):
-        self.challenge_index = challenge_index
-        self.terminal_index = terminal_index
-        self.symbols = symbols
+        self.challenge_index, self.terminal_index, self.symbols = challenge_index, terminal_index, symbols
 
     def compute_terminal(self, challenges):
-        iota = challenges[self.challenge_index]
-        acc = X0
-        for s in self.symbols:
-            acc = xadd(xmul(iota, acc), xlift(_v(s)))
-        return acc
-
-    def select_terminal(self, terminals):
-        return terminals[self.terminal_index]
+        return _horner([xlift(_value(s)) for s in self.symbols], challenges[self.challenge_index])
 
 
-class ProgramEvaluationArgument:
+class ProgramEvaluationArgument(_TerminalCheck):
     def __init__(self, challenge_indices, terminal_index, program):
-        self.challenge_indices = challenge_indices
-        self.terminal_index = terminal_index
-        self.program = program
+        self.challenge_indices, self.terminal_index, self.program = challenge_indices, terminal_index, program
 
     def compute_terminal(self, challenges):
-        a, b, c, eta = [challenges[i] for i in range(len(challenges)) if i in self.challenge_indices]
-        words = [_v(p) for p in self.program] + [0]
-        running = X0
-        for i in range(len(words) - 1):          # every address occurs once: the "address changed" test is always true
-            running = xadd(xadd(xadd(xmul(running, eta), xscale(a, i)), xscale(b, words[i])), xscale(c, words[i + 1]))
-        index = len(words) - 1
-        running = xadd(xadd(xmul(running, eta), xscale(a, index)), xscale(b, words[index]))
-        return running
-
-    def select_terminal(self, terminals):
-        return terminals[self.terminal_index]
+        a, b, c, eta = (challenges[i] for i in sorted(self.challenge_indices))
+        words = [_value(w) for w in self.program]
+        following = words[1:] + [0]
+        rows = [xadd(xadd(xscale(a, address), xscale(b, word)), xscale(c, nxt))
+                for address, (word, nxt) in enumerate(zip(words, following))]
+        # the reference appends one more row for the address just behind the program: instruction 0, next instruction 0
+        rows.append(xscale(a, len(words)))
+        return _horner(rows, eta)

@@ -166,3 +166,17 @@ def test_running_evaluation_identity_rules():
     assert ident == ("fresh", f) and state[1:] != (0, 0)             # afterwards new elements of a's field instance
     state, ident = _evaluation_step((0, 0, 0), None, gamma, BaseFieldElement(0, f))
     assert state == (0, 0, 0) and ident is None                      # lifting zero leaves no coefficient at all
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_evaluation_arguments_reproduce_the_terminals(name):
+    """what the verifier recomputes from public data (evaluation_argument.py) equals the terminals the reference's prover sent"""
+    from stark_brainfuck_amd.evaluation_argument import EvaluationArgument, ProgramEvaluationArgument
+    from stark_brainfuck_amd.vm import VirtualMachine
+    g = golden(name)
+    program = VirtualMachine.compile(g["program"])
+    _, inputs, outputs = VirtualMachine.run(program, input_data=list(g["input"]))
+    challenges = [tuple(c) for c in g["quotients"][0]["challenges"]]
+    assert list(ProgramEvaluationArgument([0, 1, 2, 10], 4, program).compute_terminal(challenges)) == g["terminals"][4]
+    assert list(EvaluationArgument(8, 2, [ord(s) for s in inputs]).compute_terminal(challenges)) == g["terminals"][2]
+    assert list(EvaluationArgument(9, 3, [ord(s) for s in outputs]).compute_terminal(challenges)) == g["terminals"][3]
