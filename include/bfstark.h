@@ -254,7 +254,8 @@ int bfs_selftest_field(uint32_t log_count, uint64_t* mismatches);
  *     memory_table.py:172-206, io_table.py:77-110.  Over rows i < n with base-field columns x1, x2, x3 (NULL = absent) and an
  *     optional row mask (NULL = every row), constants c0..c3 (4 x 3 limbs):
  *       kind 0: state <- state * (c0 - c1 x1[i] - c2 x2[i] - c3 x3[i])      kind 1: state <- state * c0 + c1 x1[i] + c2 x2[i] + c3 x3[i]
- *     on masked rows; out[3 i .. 3 i + 2] = the state before (record_before != 0) or after row i's update; terminal = final state.
+ *     on masked rows; out[i], out[n + i], out[2n + i] = limbs of the state before (record_before != 0) or after row i's update;
+ *     terminal = final state.
  */
 int bfs_xfe_scan(int kind, const uint64_t* x1, const uint64_t* x2, const uint64_t* x3, const uint8_t* mask, uint64_t n,
                  const uint64_t constants[12], const uint64_t initial[3], int record_before, uint64_t* out, uint64_t terminal[3]);

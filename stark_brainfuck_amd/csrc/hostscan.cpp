@@ -7,7 +7,8 @@
 // One primitive covers all of them: over rows i = 0..n-1 with base-field columns x1, x2, x3 and a row mask,
 //   kind 0 (running product):     state <- state * (c0 - c1 x1[i] - c2 x2[i] - c3 x3[i])      on masked rows
 //   kind 1 (running evaluation):  state <- state * c0 + c1 x1[i] + c2 x2[i] + c3 x3[i]        on masked rows
-// and the state is recorded for every row either before or after the row's update.
+// and the state is recorded for every row either before or after the row's update, as three limb planes of n words (the layout
+// the low-degree extension uploads).
 #include <string.h>
 
 #include "../../include/bfstark.h"
@@ -23,7 +24,7 @@ extern "C" int bfs_xfe_scan(int kind, const uint64_t* x1, const uint64_t* x2, co
     for (int j = 0; j < 4; ++j) c[j] = Xfe{{constants[3 * j] % GL_P, constants[3 * j + 1] % GL_P, constants[3 * j + 2] % GL_P}};
     Xfe state{{initial[0] % GL_P, initial[1] % GL_P, initial[2] % GL_P}};
     for (uint64_t i = 0; i < n; ++i) {
-        if (record_before) { out[3 * i] = state.c[0]; out[3 * i + 1] = state.c[1]; out[3 * i + 2] = state.c[2]; }
+        if (record_before) { out[i] = state.c[0]; out[n + i] = state.c[1]; out[2 * n + i] = state.c[2]; }
         if (!mask || mask[i]) {
             Xfe lin{{0, 0, 0}};
             if (x1) lin = xfe_add(lin, xfe_scale(c[1], x1[i]));
@@ -31,7 +32,7 @@ extern "C" int bfs_xfe_scan(int kind, const uint64_t* x1, const uint64_t* x2, co
             if (x3) lin = xfe_add(lin, xfe_scale(c[3], x3[i]));
             state = kind == 0 ? xfe_mul(state, xfe_sub(c[0], lin)) : xfe_add(xfe_mul(state, c[0]), lin);
         }
-        if (!record_before) { out[3 * i] = state.c[0]; out[3 * i + 1] = state.c[1]; out[3 * i + 2] = state.c[2]; }
+        if (!record_before) { out[i] = state.c[0]; out[n + i] = state.c[1]; out[2 * n + i] = state.c[2]; }
     }
     terminal[0] = state.c[0]; terminal[1] = state.c[1]; terminal[2] = state.c[2];
     return BFS_OK;

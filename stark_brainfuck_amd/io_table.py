@@ -29,7 +29,7 @@ class IOTable(Table):
         m = self.base_array()
         ev, _ = self.scan(1, [m[0]], None, [iota, (1, 0, 0)], X0, False)
         self.ext_columns = [ev]
-        self.evaluation_terminal = tuple(int(v) for v in ev[self.length - 1]) if self.length else X0
+        self.evaluation_terminal = tuple(int(v) for v in ev[:, self.length - 1]) if self.length else X0
 
 
 class InputTable(IOTable):

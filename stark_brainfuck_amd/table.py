@@ -115,7 +115,7 @@ class Table:
         self.generator = generator
         self.order = order
         self.matrix = []
-        self.ext_columns = None      # after extend(): per extension column a uint64 array (rows, 3)
+        self.ext_columns = None      # after extend(): per extension column a uint64 array (3, rows) of limb planes
         self.base_codewords = None   # DeviceBuffer, base_width * N
         self.ext_codewords = None    # DeviceBuffer, (full_width - base_width) * 3 * N
         self._coefficients = None    # host copy of the last interpolants (ext_sharing_moduli)
@@ -179,7 +179,7 @@ class Table:
         n = next((len(c) for c in columns if c is not None), 0 if mask is None else len(mask))
         cols = [np.ascontiguousarray(c, dtype=np.uint64) if c is not None else None for c in columns] + [None] * (3 - len(columns))
         m = np.ascontiguousarray(mask, dtype=np.uint8) if mask is not None else None
-        out = np.empty((n, 3), dtype=np.uint64)
+        out = np.empty((3, n), dtype=np.uint64)
         flat = [v for c in constants for v in c] + [0] * (12 - 3 * len(constants))
         terminal = (_u64 * 3)()
         _lib.check(_lib.load().bfs_xfe_scan(kind, *[c.ctypes.data if c is not None else None for c in cols[:3]],
@@ -257,8 +257,8 @@ class Table:
 
     def ldex(self, domain, xfield=None):
         width = self.full_width - self.base_width
-        if self.height:      # ext_columns: one (rows, 3) array per extension column -> (column, limb) planes
-            cols = np.concatenate([np.ascontiguousarray(c.T) for c in self.ext_columns], axis=0)
+        if self.height:      # ext_columns: one (3, rows) array per extension column -> (column, limb) planes
+            cols = np.concatenate(self.ext_columns, axis=0)
         else:
             cols = np.zeros((width * 3, 0), dtype=np.uint64)
         rand = None
