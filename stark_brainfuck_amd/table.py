@@ -322,6 +322,32 @@ class Table:
         """symbolic degree of the composed transition constraints minus the zerofier (brainfuck_stark.py:84-92)"""
         return max([b - (self.height - 1) for b in self._degree_bounds("transition", challenges, [air.X0] * 5)] or [1])
 
+    # ---- the constraints as the reference presents them: lists of MPolynomial (table.py:145-146, 173-174, 248-249)
+    def _constraints_ext(self, kind, challenges, terminals=None):
+        from .extension_field import ExtensionField
+        from .multivariate import MPolynomial
+        xfield = challenges[0].field if hasattr(challenges[0], "field") else ExtensionField.main()
+
+        def triple(v):
+            return tuple(v.limbs()) if hasattr(v, "limbs") else tuple(v)
+        ch = [triple(c) for c in challenges]
+        tm = [triple(t) for t in terminals] if terminals is not None else [air.X0] * 5
+        nvars = 2 * self.full_width if kind == "transition" else self.full_width
+        memo, out = {}, []
+        for e in dict(self.air.all())[kind]:
+            expansion = air.expand(e, nvars, ch, tm, self.air_params(ch), memo)
+            out.append(MPolynomial({air.unpack_exponents(k, nvars): xfield.from_limbs(list(v)) for k, v in expansion.items()}))
+        return out
+
+    def boundary_constraints_ext(self, challenges):
+        return self._constraints_ext("boundary", challenges)
+
+    def transition_constraints_ext(self, challenges):
+        return self._constraints_ext("transition", challenges)
+
+    def terminal_constraints_ext(self, challenges, terminals):
+        return self._constraints_ext("terminal", challenges, terminals)
+
     # ---- host-side evaluation at one point (the verifier's use, table.py:283-311)
     def evaluate_constraints(self, kind, point, next_point, challenges, terminals):
         cons = dict(self.air.all())[kind]

@@ -180,3 +180,41 @@ def test_evaluation_arguments_reproduce_the_terminals(name):
     assert list(ProgramEvaluationArgument([0, 1, 2, 10], 4, program).compute_terminal(challenges)) == g["terminals"][4]
     assert list(EvaluationArgument(8, 2, [ord(s) for s in inputs]).compute_terminal(challenges)) == g["terminals"][2]
     assert list(EvaluationArgument(9, 3, [ord(s) for s in outputs]).compute_terminal(challenges)) == g["terminals"][3]
+
+
+def test_constraints_as_mpolynomials():
+    """Table.*_constraints_ext give the reference's view of the AIR (lists of MPolynomial): evaluating them at a point must
+    agree with the expression graphs, and their symbolic degree bounds with the golden ones"""
+    import random
+    from stark_brainfuck_amd import air
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.multivariate import MPolynomial
+    from stark_brainfuck_amd.vm import VirtualMachine
+    g = golden("io")
+    program = VirtualMachine.compile(g["program"])
+    running_time, inputs, outputs = VirtualMachine.run(program, input_data=list(g["input"]))
+    matrices = VirtualMachine.simulate(program, input_data=list(inputs))
+    stark = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs)
+    xf = stark.xfield
+    rng = random.Random(3)
+    for table, q in zip(stark.tables, g["quotients"]):
+        challenges = [xf.from_limbs(c) for c in q["challenges"]]
+        terminals = [xf.from_limbs(t) for t in q["terminals"]]
+        md = [table.interpolant_degree()]
+        polys = {"boundary": table.boundary_constraints_ext(challenges), "transition": table.transition_constraints_ext(challenges),
+                 "terminal": table.terminal_constraints_ext(challenges, terminals)}
+        bounds = ([p.symbolic_degree_bound(md * table.full_width) - 1 for p in polys["boundary"]]
+                  + [p.symbolic_degree_bound(md * 2 * table.full_width) - table.height + 1 for p in polys["transition"]]
+                  + [p.symbolic_degree_bound(md * table.full_width) - 1 for p in polys["terminal"]])
+        assert bounds == q["degree_bounds"], type(table).__name__
+        cur = [tuple(rng.randrange(air.P) for _ in range(3)) for _ in range(table.full_width)]
+        nxt = [tuple(rng.randrange(air.P) for _ in range(3)) for _ in range(table.full_width)]
+        ch, tm = [tuple(c) for c in q["challenges"]], [tuple(t) for t in q["terminals"]]
+        for kind, ps in polys.items():
+            point = [xf.from_limbs(v) for v in (cur + nxt if kind == "transition" else cur)]
+            want = table.evaluate_constraints(kind, cur, nxt, ch, tm)
+            for p, w in zip(ps, want):
+                value = p.evaluate(point) if p.dictionary else xf.zero()
+                assert tuple(value.limbs()) == tuple(w)
+    x, y = MPolynomial.variables(2, xf)
+    assert ((x + y) ^ 2).dictionary.keys() == {(2, 0), (1, 1), (0, 2)} and (x - x).is_zero()
