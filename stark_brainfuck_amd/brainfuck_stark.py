@@ -40,16 +40,17 @@ class BrainfuckStark:
     field = BaseField.main()
     xfield = ExtensionField.main()
 
-    def __init__(self, running_time, memory_length, program, input_symbols, output_symbols):
+    def __init__(self, running_time, memory_length, program, input_symbols, output_symbols, log_expansion_factor=2, security_level=2):
+        """the reference fixes log_expansion_factor = 2 and security_level = 2 "for speed" (brainfuck_stark.py:31-36, with 4 and 160
+        commented as the real values); they are parameters here, the defaults reproduce the reference"""
         self.running_time = running_time
         self.memory_length = memory_length
         self.program = program
         self.input_symbols = input_symbols
         self.output_symbols = output_symbols
 
-        log_expansion_factor = 2                                     # brainfuck_stark.py:33-34 "for speed"
         self.expansion_factor = 1 << log_expansion_factor
-        self.security_level = 2                                      # :35-36
+        self.security_level = security_level
         self.num_colinearity_checks = self.security_level // log_expansion_factor
         assert self.expansion_factor & (self.expansion_factor - 1) == 0, "expansion factor must be a power of 2"
         assert self.expansion_factor >= 4, "expansion factor must be 4 or greater"

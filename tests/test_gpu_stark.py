@@ -127,3 +127,24 @@ def test_prove_then_verify_fresh_randomness():
     assert proof_a != proof_b
     assert BrainfuckStark(running_time, len(mm), program, input_symbols, output_symbols).verify(proof_a) is True
     assert BrainfuckStark(running_time, len(mm), program, input_symbols, output_symbols).verify(proof_b) is True
+
+
+@pytest.mark.gpu
+def test_prove_and_verify_with_other_protocol_parameters():
+    """expansion factor 16 with 32 colinearity checks and 128 opened indices (the reference hard-codes 4 / 1 / 2 "for speed",
+    brainfuck_stark.py:31-36; FRI caps the number of checks at the length of the last codeword, fri.py:69-70)"""
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    program = VirtualMachine.compile("++>+++<[->+<]>.")
+    running_time, inputs, outputs = VirtualMachine.run(program)
+    matrices = VirtualMachine.simulate(program, input_data=inputs)
+    args = (running_time, len(matrices[1]), program, inputs, outputs)
+    stark = BrainfuckStark(*args, log_expansion_factor=4, security_level=128)
+    assert stark.expansion_factor == 16 and stark.num_colinearity_checks == 32
+    proof = stark.prove(program, *matrices)
+    assert BrainfuckStark(*args, log_expansion_factor=4, security_level=128).verify(proof) is True
+    try:
+        accepted = BrainfuckStark(*args).verify(proof)          # the default parameters describe a different protocol
+    except Exception:
+        accepted = False
+    assert accepted is False
