@@ -218,3 +218,47 @@ def test_constraints_as_mpolynomials():
                 assert tuple(value.limbs()) == tuple(w)
     x, y = MPolynomial.variables(2, xf)
     assert ((x + y) ^ 2).dictionary.keys() == {(2, 0), (1, 1), (0, 2)} and (x - x).is_zero()
+
+
+@pytest.mark.parametrize("code,inp", [("++>+++<[->[->+>+<<]>>[-<<+>>]<<<]>>.", ""), (",>,<[->+<]>.", "!#"), (",.,.", "ab"), ("+", "")])
+def test_extended_tables_satisfy_the_air(code, inp):
+    """the restatement of Table.test / Table.xtest (/root/reference/code/table.py:48-110, used by test_vm.py:26-110): on the
+    padded and extended trace every boundary constraint vanishes on the first row, every transition constraint on every pair
+    of consecutive rows, every terminal constraint on the last row -- ties VM, padding, the native scans and air.py together"""
+    import numpy as np
+    from stark_brainfuck_amd import air
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    program = VirtualMachine.compile(code)
+    running_time, inputs, outputs = VirtualMachine.run(program, input_data=list(inp))
+    matrices = VirtualMachine.simulate(program, input_data=list(inputs))
+    stark = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs)
+    rng = np.random.default_rng(1)
+    challenges = [tuple(int(v) for v in rng.integers(1, air.P, 3, dtype=np.uint64)) for _ in range(11)]
+    initials = [tuple(int(v) for v in rng.integers(1, air.P, 3, dtype=np.uint64)) for _ in range(2)]
+    for table, matrix in zip(stark.tables, (matrices[0], matrices[2], matrices[1], matrices[3], matrices[4])):
+        table.matrix = matrix
+        table.pad()
+        table.extend(challenges, initials)
+    terminals = stark.get_terminals()
+    # the permutation arguments: processor and instruction / memory tables reach the same terminal (running products over
+    # the same multiset), which is what lets the difference quotients be polynomials
+    assert stark.processor_table.instruction_permutation_terminal == stark.instruction_table.permutation_terminal
+    assert stark.processor_table.memory_permutation_terminal == stark.memory_table.permutation_terminal
+    for table in stark.tables:
+        base = table.base_array()
+        height = base.shape[1]
+        if height == 0:
+            continue
+        rows = []
+        for r in range(height):
+            row = [air.xlift(int(base[c, r])) for c in range(table.base_width)]
+            row += [tuple(int(v) for v in col[:, r]) for col in table.ext_columns]
+            rows.append(row)
+        for value in table.evaluate_constraints("boundary", rows[0], None, challenges, terminals):
+            assert value == air.X0, type(table).__name__
+        for r in range(height - 1):
+            for k, value in enumerate(table.evaluate_constraints("transition", rows[r], rows[r + 1], challenges, terminals)):
+                assert value == air.X0, (type(table).__name__, r, k)
+        for value in table.evaluate_constraints("terminal", rows[-1], None, challenges, terminals):
+            assert value == air.X0, type(table).__name__
