@@ -111,12 +111,12 @@ def test_vm_hello_world():
 
 
 def test_vm_states():
-    """/root/reference/code/test_vm.py:18-23: a program whose loop is skipped; five tables come back, the processor
-    table has one row per cycle plus the final state"""
+    """/root/reference/code/test_vm.py:18-23: a program whose loop is skipped; five tables come back, one processor
+    row per cycle"""
     program = VirtualMachine.compile(">>[++-]<")
     running_time, _, _ = VirtualMachine.run(program)
     processor, memory, instruction, inp, out = VirtualMachine.simulate(program)      # vm.py:306
-    assert len(processor) == running_time and len(memory) == running_time
+    assert len(processor) == running_time and len(memory) == running_time - 1    # the final row (instruction 0) is left out, no dummy rows needed here (memory_table.py:21-38)
     assert len(instruction) == running_time + len(program)
     assert len(inp) == 0 and len(out) == 0
 
