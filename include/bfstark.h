@@ -43,8 +43,21 @@ int bfs_version(void);
 const char* bfs_last_error(void);
 int bfs_device_count(int* count);
 int bfs_set_device(int device);
+/* HBM comes from a pool inside the library (size-class free lists over hipMalloc: the driver calls cost 50-500 us and
+ * hipFree synchronises the device).  bfs_malloc / bfs_free keep hipMalloc / hipFree semantics (bfs_free waits for the
+ * device).  The *_async pair is stream-ordered like hipMallocAsync / hipFreeAsync: the block goes back to the pool at
+ * once, work already queued on `stream` may still use it, and a later request on the same stream gets it without
+ * waiting (a request on another stream synchronises `stream` first).  bfs_pool_trim returns the cached blocks to the
+ * driver; BFS_POOL=0 in the environment disables caching.  bfs_host_alloc hands out pinned host memory from a pool of
+ * the same kind (staging buffers for bfs_memcpy_h2d: pageable sources copy at ~1 GB/s, pinned ones at link speed). */
 int bfs_malloc(void** d_ptr, size_t bytes);
 int bfs_free(void* d_ptr);
+int bfs_malloc_async(void** d_ptr, size_t bytes, void* stream);
+int bfs_free_async(void* d_ptr, void* stream);
+int bfs_pool_trim(void);
+int bfs_pool_stats(size_t* live_bytes, size_t* cached_bytes);
+int bfs_host_alloc(void** h_ptr, size_t bytes);
+int bfs_host_free(void* h_ptr);
 int bfs_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes, void* stream);
 int bfs_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
 int bfs_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream);

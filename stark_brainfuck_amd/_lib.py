@@ -26,6 +26,12 @@ _SIGNATURES = {
     "bfs_set_device": (ci, [ci]),
     "bfs_malloc": (ci, [ctypes.POINTER(vp), sz]),
     "bfs_free": (ci, [vp]),
+    "bfs_malloc_async": (ci, [ctypes.POINTER(vp), sz, vp]),
+    "bfs_free_async": (ci, [vp, vp]),
+    "bfs_pool_trim": (ci, []),
+    "bfs_pool_stats": (ci, [ctypes.POINTER(sz), ctypes.POINTER(sz)]),
+    "bfs_host_alloc": (ci, [ctypes.POINTER(vp), sz]),
+    "bfs_host_free": (ci, [vp]),
     "bfs_memcpy_h2d": (ci, [vp, vp, sz, vp]),
     "bfs_memcpy_d2h": (ci, [vp, vp, sz, vp]),
     "bfs_memcpy_d2d": (ci, [vp, vp, sz, vp]),

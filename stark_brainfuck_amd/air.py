@@ -331,18 +331,23 @@ def unpack_exponents(key, nvars):
     return tuple((key >> (_EXP_BITS * i)) & ((1 << _EXP_BITS) - 1) for i in range(nvars))
 
 
-def symbolic_degree_bound(expansion, max_degree):
-    """multivariate.py:144-170 with a uniform bound on every argument: max over the non-zero monomials of
-    (total degree * max_degree); -1 for the zero polynomial."""
-    bound = -1
+def total_degrees(expansion):
+    """the distinct total degrees of the (non-zero) monomials of an expansion, as a sorted tuple"""
     mask = (1 << _EXP_BITS) - 1
+    out = set()
     for key in expansion:
         total = 0
         while key:
             total += key & mask
             key >>= _EXP_BITS
-        bound = max(bound, total * max_degree)
-    return bound
+        out.add(total)
+    return tuple(sorted(out))
+
+
+def symbolic_degree_bound(expansion, max_degree):
+    """multivariate.py:144-170 with a uniform bound on every argument: max over the non-zero monomials of
+    (total degree * max_degree); -1 for the zero polynomial."""
+    return max([-1] + [t * max_degree for t in total_degrees(expansion)])
 
 
 # ---------------------------------------------------------------------------------------------------------------

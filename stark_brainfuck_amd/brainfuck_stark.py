@@ -113,6 +113,22 @@ class BrainfuckStark:
         return 1 << (integer - 1).bit_length()
 
     # ------------------------------------------------------------------------------------------------------------
+    keep_intermediates = False      # True: prove() leaves trees, quotient codewords and the combination codeword in `_last` (tests)
+
+    @staticmethod
+    def _release(*holders):
+        """hand device memory back to the pool now instead of when the garbage collector gets to it (the blocks are
+        stream-ordered: kernels already queued keep reading them, the next proof on this stream reuses them)"""
+        for h in holders:
+            for name in ("buf", "_nodes", "_salts", "base_codewords", "ext_codewords"):
+                b = getattr(h, name, None)
+                if hasattr(b, "free"):
+                    b.free()
+                    if name.endswith("codewords"):
+                        setattr(h, name, None)
+            if hasattr(h, "free"):
+                h.free()
+
     def prove(self, program, processor_matrix, memory_matrix, instruction_matrix, input_matrix, output_matrix, proof_stream=None):
         # The trace matrices keep ~10^5 element objects alive; every full garbage collection during (or right after) the proof
         # would walk all of them (measured: 20 ms pauses on a 17 ms proof).  gc.freeze() parks everything that exists now in a
@@ -276,6 +292,9 @@ class BrainfuckStark:
         _lib.check(lib.bfs_combination(srcs, len(sources), randomizer_codeword.ptr, (_u64 * 3)(*weights[0]), combination.ptr,
                                        log_n, domain.offset.value, domain.omega.value, stream))
 
+        if not self.keep_intermediates:
+            BrainfuckStark._release(randomizer_polynomial, *[buf for buf, _ in quotient_buffers])
+            quotient_buffers = []
         lap("combination")
         # commitment to the combination codeword, openings (:300-333)
         combination_tree = Merkle(combination)
@@ -297,13 +316,19 @@ class BrainfuckStark:
             proof_stream.push(leaf)
             proof_stream.push(combination_tree.open(index))
 
+        if not self.keep_intermediates:
+            BrainfuckStark._release(base_tree, extension_tree, combination_tree, randomizer_codeword, *self.tables)
+            base_tree = extension_tree = combination_tree = None
         lap("openings")
         # low-degree test of the combination codeword (:335-336)
         self.fri.prove(combination, proof_stream, known_leafs=known)
-        self._last = {"base_tree": base_tree, "extension_tree": extension_tree, "combination_tree": combination_tree,
-                      "challenges": challenges, "terminals": terminals, "indices": indices, "weights_seed": weights_seed,
-                      "quotient_degree_bounds": quotient_degree_bounds, "quotient_buffers": quotient_buffers,
-                      "combination": combination}
+        self._last = {"challenges": challenges, "terminals": terminals, "indices": indices, "weights_seed": weights_seed,
+                      "quotient_degree_bounds": quotient_degree_bounds}
+        if self.keep_intermediates:
+            self._last.update({"base_tree": base_tree, "extension_tree": extension_tree, "combination_tree": combination_tree,
+                               "quotient_buffers": quotient_buffers, "combination": combination})
+        else:
+            BrainfuckStark._release(combination)
         lap("fri")
         proof = proof_stream.serialize()
         lap("serialize")

@@ -3,6 +3,8 @@
 
 #include "runtime.hpp"
 
+#include <cstring>
+
 namespace bfs {
 int mul_pointwise_launch(const u64* a, const u64* b, u64* out, u64 n, hipStream_t stream);
 int batch_inverse_launch(const u64* in, u64* out, u64 n, hipStream_t stream);
@@ -21,18 +23,20 @@ const char* bfs_last_error(void) { return last_error(); }
 
 int bfs_device_count(int* count) { BFS_HIP(hipGetDeviceCount(count)); return BFS_OK; }
 int bfs_set_device(int device) { BFS_HIP(hipSetDevice(device)); return BFS_OK; }
-int bfs_malloc(void** d_ptr, size_t bytes) { BFS_HIP(hipMalloc(d_ptr, bytes)); return BFS_OK; }
-int bfs_free(void* d_ptr) { BFS_HIP(hipFree(d_ptr)); return BFS_OK; }
-int bfs_memcpy_h2d(void* d, const void* h, size_t bytes, void* stream) {
-    BFS_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
-    BFS_HIP(hipStreamSynchronize((hipStream_t)stream));
-    return BFS_OK;
+int bfs_malloc(void** d_ptr, size_t bytes) { return device_alloc(bytes, NO_STREAM, d_ptr); }
+int bfs_free(void* d_ptr) {
+    if (!d_ptr) return BFS_OK;
+    BFS_HIP(hipDeviceSynchronize());             // the semantics of hipFree: nothing in flight touches the block afterwards
+    return device_release(d_ptr, NO_STREAM);
 }
-int bfs_memcpy_d2h(void* h, const void* d, size_t bytes, void* stream) {
-    BFS_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
-    BFS_HIP(hipStreamSynchronize((hipStream_t)stream));
-    return BFS_OK;
-}
+int bfs_malloc_async(void** d_ptr, size_t bytes, void* stream) { return device_alloc(bytes, (hipStream_t)stream, d_ptr); }
+int bfs_free_async(void* d_ptr, void* stream) { return device_release(d_ptr, (hipStream_t)stream); }
+int bfs_pool_trim(void) { return device_pool_trim(); }
+int bfs_pool_stats(size_t* live_bytes, size_t* cached_bytes) { device_pool_stats(live_bytes, cached_bytes); return BFS_OK; }
+int bfs_host_alloc(void** h_ptr, size_t bytes) { return host_alloc(bytes, h_ptr); }
+int bfs_host_free(void* h_ptr) { return host_release(h_ptr); }
+int bfs_memcpy_h2d(void* d, const void* h, size_t bytes, void* stream) { return copy_h2d(d, h, bytes, (hipStream_t)stream); }
+int bfs_memcpy_d2h(void* h, const void* d, size_t bytes, void* stream) { return copy_d2h(h, d, bytes, (hipStream_t)stream); }
 int bfs_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
     BFS_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return BFS_OK;

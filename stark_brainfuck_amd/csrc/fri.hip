@@ -88,12 +88,12 @@ struct RootMailbox {
     u64 seq = 0;
     int init() {
         if (host) return BFS_OK;
-        BFS_HIP(hipHostMalloc((void**)&host, 16 * sizeof(u64), hipHostMallocMapped | hipHostMallocCoherent));
+        BFS_TRY(host_alloc(16 * sizeof(u64), (void**)&host));       // pooled: hipHostFree per session stalls later dispatches
         memset(host, 0, 16 * sizeof(u64));
         BFS_HIP(hipHostGetDevicePointer((void**)&dev, host, 0));
         return BFS_OK;
     }
-    ~RootMailbox() { if (host) (void)hipHostFree(host); }
+    ~RootMailbox() { if (host) (void)host_release(host); }
 };
 
 struct FriSession {
@@ -112,7 +112,8 @@ struct FriSession {
     struct KeyHash { size_t operator()(const Key& k) const { return (size_t)(k.v * 0x9E3779B97F4A7C15ULL >> 16); } };
     std::unordered_map<Key, rp::Ref, KeyHash> elements, nodes;
     std::vector<uint64_t> last_handles;
-    ~FriSession() { if (block) (void)hipFree(block); }
+    hipStream_t block_stream = nullptr;
+    ~FriSession() { if (block) (void)device_release(block, block_stream); }
 };
 
 static u32 fri_num_rounds(u64 length, u32 expansion) {  // fri.py:54-60
@@ -142,7 +143,9 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
         BFS_TRY(workspace(4, words * sizeof(u64), stream, &w));   // bfs_fri_prove: nothing outlives the call
         p = (u64*)w;
     } else {
-        BFS_HIP(hipMalloc(&S.block, words * sizeof(u64)));
+        if (S.block) { (void)device_release(S.block, S.block_stream); S.block = nullptr; }
+        BFS_TRY(device_alloc(words * sizeof(u64), stream, &S.block));
+        S.block_stream = stream;
         p = (u64*)S.block;
     }
     BFS_TRY(S.mailbox.init());

@@ -47,8 +47,8 @@ struct RowArgs {
     const RowSeg* segs;
     const u64* pool;
     u64* digests;                // n x 8 words
-    u32* codes;                  // pattern kernel output
-    u32* error;
+    u64* pattern_set;            // pattern kernel output: open-addressing set of the codes present (PATTERN_SLOTS entries, ~0 = empty)
+    u32* error;                  // [0]: a row without a template, [1]: the pattern set overflowed
 };
 
 __device__ __forceinline__ u32 row_pattern(const RowArgs& a, u64 i) {
@@ -63,9 +63,22 @@ __device__ __forceinline__ u32 row_pattern(const RowArgs& a, u64 i) {
     return code;
 }
 
+// Which patterns occur?  Neighbouring rows almost always share theirs, so a lane only goes to the set when its code differs
+// from the lane below, and the set is probed with a plain load before any atomic (after the first few waves every probe hits).
+constexpr u32 PATTERN_SLOTS = 1024;
 __global__ void row_pattern_kernel(const RowArgs a) {
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < a.n) a.codes[i] = row_pattern(a, i);
+    const bool valid = i < a.n;
+    const u32 code = valid ? row_pattern(a, i) : 0u;
+    const u32 below = __shfl_up(code, 1);
+    if (!valid || ((threadIdx.x & 63) != 0 && below == code)) return;
+    u32 slot = (code * 2654435761u) >> 22;                      // 10 bits
+    for (u32 tries = 0; tries < PATTERN_SLOTS; ++tries, slot = (slot + 1) & (PATTERN_SLOTS - 1)) {
+        u64 seen = __atomic_load_n(a.pattern_set + slot, __ATOMIC_RELAXED);
+        if (seen == ~0ull) seen = atomicCAS((unsigned long long*)(a.pattern_set + slot), ~0ull, (unsigned long long)code);
+        if (seen == ~0ull || seen == code) return;
+    }
+    atomicOr(a.error + 1, 1u);
 }
 
 __global__ void __launch_bounds__(64) row_leaves_kernel(const RowArgs a) {
@@ -323,43 +336,40 @@ extern "C" int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t nco
     std::vector<u32> h_ext(ncols);
     for (u32 c = 0; c < ncols; ++c) { h_cols[c] = columns[c].d_values; h_ext[c] = columns[c].is_ext ? 1u : 0u; }
     const size_t salt_words = h_salts ? (size_t)3 * n : 0;      // staging only for host salts
-    const size_t fixed_bytes = ncols * sizeof(u64*) + ncols * sizeof(u32) + 64 + n * sizeof(u32) + salt_words * sizeof(u64) + 64;
+    const size_t set_bytes = PATTERN_SLOTS * sizeof(u64);
+    const size_t fixed_bytes = ncols * sizeof(u64*) + ncols * sizeof(u32) + 64 + set_bytes + salt_words * sizeof(u64) + 64;
     void* w = nullptr;
     BFS_TRY(workspace(5, fixed_bytes, stream, &w));
     char* base = (char*)w;
     const u64** d_cols = (const u64**)base;                     base += ((ncols * sizeof(u64*) + 15) & ~(size_t)15);
     u32* d_ext = (u32*)base;                                    base += ((ncols * sizeof(u32) + 15) & ~(size_t)15);
     u32* d_err = (u32*)base;                                    base += 16;
-    u64* d_salts = (u64*)base;                                  base += salt_words * sizeof(u64);
-    u32* d_codes = (u32*)base;
+    u64* d_set = (u64*)base;                                    base += set_bytes;
+    u64* d_salts = (u64*)base;
     BFS_HIP(hipMemcpyAsync(d_cols, h_cols.data(), ncols * sizeof(u64*), hipMemcpyHostToDevice, stream));
     BFS_HIP(hipMemcpyAsync(d_ext, h_ext.data(), ncols * sizeof(u32), hipMemcpyHostToDevice, stream));
     BFS_HIP(hipMemsetAsync(d_err, 0, 16, stream));
-    if (h_salts) BFS_HIP(hipMemcpyAsync(d_salts, h_salts, salt_words * sizeof(u64), hipMemcpyHostToDevice, stream));
+    BFS_HIP(hipMemsetAsync(d_set, 0xFF, set_bytes, stream));
+    if (h_salts) BFS_TRY(copy_h2d(d_salts, h_salts, salt_words * sizeof(u64), stream));   // test mode: the reference's byte stream
 
     RowArgs a{};
     a.columns = d_cols; a.is_ext = d_ext; a.ncols = ncols; a.n = n;
     a.salts = h_salts ? d_salts : (salted ? (const u64*)salts : nullptr);
     a.digests = (u64*)d_nodes + npo2 * 8;
-    a.codes = d_codes; a.error = d_err;
+    a.pattern_set = d_set; a.error = d_err;
 
-    // 1. patterns present in this batch of rows
+    // 1. patterns present in this batch of rows: only the (small) set comes back -- a pageable n-word copy would be pinned
+    // and unpinned by the runtime, and the unmapping stalls the next dispatches for ~25 ms (profiles/r01/README.md)
     hipLaunchKernelGGL(row_pattern_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, stream, a);
     BFS_HIP(hipGetLastError());
-    std::vector<u32> codes(n);
-    BFS_HIP(hipMemcpyAsync(codes.data(), d_codes, n * sizeof(u32), hipMemcpyDeviceToHost, stream));
+    std::vector<u64> set(PATTERN_SLOTS + 2);
+    BFS_HIP(hipMemcpyAsync(set.data(), d_err, 16 + set_bytes, hipMemcpyDeviceToHost, stream));   // error words sit right before the set
     BFS_HIP(hipStreamSynchronize(stream));
-    {   // distinct patterns: neighbouring rows almost always share theirs, so compare with the previous row first
-        std::vector<u32> distinct;
-        u32 last = ~codes[0];
-        for (u32 code : codes) {
-            if (code == last) continue;
-            last = code;
-            if (std::find(distinct.begin(), distinct.end(), code) == distinct.end()) distinct.push_back(code);
-        }
-        std::sort(distinct.begin(), distinct.end());
-        codes.swap(distinct);
-    }
+    if (((const u32*)set.data())[1]) { set_error("bfs_merkle_build_rows: more than %u distinct row patterns", PATTERN_SLOTS); return BFS_ERR_BAD_ARG; }
+    std::vector<u32> codes;
+    for (u32 k = 0; k < PATTERN_SLOTS; ++k)
+        if (set[2 + k] != ~0ull) codes.push_back((u32)set[2 + k]);
+    std::sort(codes.begin(), codes.end());
 
     // 2. one template per pattern
     HostTemplates ht;

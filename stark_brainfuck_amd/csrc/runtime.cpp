@@ -3,9 +3,13 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <unordered_map>
+#include <vector>
 
 namespace bfs {
 
@@ -29,6 +33,204 @@ std::mutex g_mu;
 std::map<std::tuple<int, hipStream_t, int>, Scratch> g_scratch;
 std::map<std::tuple<int, uint64_t, uint64_t, uint64_t>, const u64*> g_tables;
 }  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// memory pools (runtime.hpp)
+namespace {
+size_t size_class(size_t bytes) {
+    if (bytes <= 256) return 256;
+    size_t p = 256;
+    while (p < bytes) p <<= 1;                   // smallest power of two >= bytes
+    if (p <= (1u << 20)) return p;
+    const size_t step = p >> 4;                  // eight classes per octave: (p/2, p] in steps of p/16
+    return (bytes + step - 1) / step * step;
+}
+
+struct Block {
+    void* ptr;
+    hipStream_t released_on;
+};
+
+struct Pool {
+    bool pinned = false;
+    std::mutex mu;
+    std::map<std::pair<int, size_t>, std::vector<Block>> free_lists;     // (device, class) -> blocks
+    std::unordered_map<void*, std::pair<int, size_t>> live;              // ptr -> (device, class)
+    size_t live_bytes = 0, cached_bytes = 0;
+
+    hipError_t raw_alloc(void** p, size_t bytes) {
+        return pinned ? hipHostMalloc(p, bytes, hipHostMallocMapped | hipHostMallocCoherent) : hipMalloc(p, bytes);
+    }
+    void raw_free(void* p) { (void)(pinned ? hipHostFree(p) : hipFree(p)); }
+
+    void trim_locked() {
+        for (auto& kv : free_lists)
+            for (Block& b : kv.second) raw_free(b.ptr);
+        free_lists.clear();
+        cached_bytes = 0;
+    }
+
+    int alloc(size_t bytes, hipStream_t stream, void** out) {
+        int dev = 0;
+        if (!pinned) BFS_HIP(hipGetDevice(&dev));
+        const size_t cls = size_class(bytes);
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = free_lists.find(std::make_pair(dev, cls));
+        if (it != free_lists.end() && !it->second.empty()) {
+            // prefer a block whose release needs no waiting
+            std::vector<Block>& v = it->second;
+            size_t pick = v.size() - 1;
+            for (size_t i = v.size(); i-- > 0;)
+                if (v[i].released_on == NO_STREAM || v[i].released_on == stream) { pick = i; break; }
+            Block b = v[pick];
+            v.erase(v.begin() + (long)pick);
+            if (b.released_on != NO_STREAM && b.released_on != stream)
+                if (hipStreamSynchronize(b.released_on) != hipSuccess) BFS_HIP(hipDeviceSynchronize());
+            cached_bytes -= cls;
+            live_bytes += cls;
+            live[b.ptr] = std::make_pair(dev, cls);
+            *out = b.ptr;
+            return BFS_OK;
+        }
+        void* p = nullptr;
+        hipError_t e = raw_alloc(&p, cls);
+        if (e != hipSuccess) {                   // out of memory: give the cache back to the driver and try once more
+            (void)hipGetLastError();
+            (void)hipDeviceSynchronize();
+            trim_locked();
+            e = raw_alloc(&p, cls);
+        }
+        if (e != hipSuccess) {
+            set_error("%s of %zu bytes failed: %s", pinned ? "hipHostMalloc" : "hipMalloc", cls, hipGetErrorString(e));
+            return BFS_ERR_HIP;
+        }
+        live_bytes += cls;
+        live[p] = std::make_pair(dev, cls);
+        *out = p;
+        return BFS_OK;
+    }
+
+    int release(void* p, hipStream_t stream) {
+        if (!p) return BFS_OK;
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = live.find(p);
+        if (it == live.end()) {
+            set_error("release of a pointer this library did not allocate");
+            return BFS_ERR_BAD_ARG;
+        }
+        const std::pair<int, size_t> key = it->second;
+        live.erase(it);
+        live_bytes -= key.second;
+        static const bool keep = [] { const char* v = getenv("BFS_POOL"); return !(v && v[0] == '0'); }();
+        if (!keep) {                             // BFS_POOL=0: straight to the driver (debugging aid)
+            raw_free(p);
+            return BFS_OK;
+        }
+        free_lists[key].push_back(Block{p, stream});
+        cached_bytes += key.second;
+        return BFS_OK;
+    }
+};
+
+Pool g_device_pool, g_host_pool;
+struct PoolInit { PoolInit() { g_host_pool.pinned = true; } } g_pool_init;
+}  // namespace
+
+int device_alloc(size_t bytes, hipStream_t stream, void** out) { return g_device_pool.alloc(bytes, stream, out); }
+int device_release(void* ptr, hipStream_t stream) { return g_device_pool.release(ptr, stream); }
+int device_pool_trim() {
+    BFS_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lock(g_device_pool.mu);
+    g_device_pool.trim_locked();
+    return BFS_OK;
+}
+void device_pool_stats(size_t* live_bytes, size_t* cached_bytes) {
+    std::lock_guard<std::mutex> lock(g_device_pool.mu);
+    if (live_bytes) *live_bytes = g_device_pool.live_bytes;
+    if (cached_bytes) *cached_bytes = g_device_pool.cached_bytes;
+}
+int host_alloc(size_t bytes, void** out) { return g_host_pool.alloc(bytes, NO_STREAM, out); }
+int host_release(void* ptr) { return g_host_pool.release(ptr, NO_STREAM); }
+
+namespace {
+bool is_pageable(const void* h) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, h) != hipSuccess) {
+        (void)hipGetLastError();
+        return true;
+    }
+    return attr.type == hipMemoryTypeUnregistered;
+}
+
+int copy_staged(void* dst, const void* src, size_t bytes, bool to_device, hipStream_t stream) {
+    constexpr size_t CHUNK = 8u << 20;
+    void* bounce[2] = {nullptr, nullptr};
+    hipEvent_t done[2] = {nullptr, nullptr};
+    int rc = BFS_OK;
+    auto fail = [&](hipError_t e, const char* what) {
+        set_error("%s failed: %s", what, hipGetErrorString(e));
+        rc = BFS_ERR_HIP;
+    };
+    for (int i = 0; i < 2 && rc == BFS_OK; ++i) {
+        rc = host_alloc(CHUNK, &bounce[i]);
+        if (rc != BFS_OK) break;
+        hipError_t e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+        if (e != hipSuccess) fail(e, "hipEventCreate");
+    }
+    const size_t chunks = (bytes + CHUNK - 1) / CHUNK;
+    auto span = [&](size_t k) { return bytes - k * CHUNK < CHUNK ? bytes - k * CHUNK : CHUNK; };
+    if (to_device) {
+        for (size_t k = 0; rc == BFS_OK && k < chunks; ++k) {
+            const int b = (int)(k & 1);
+            hipError_t e = k >= 2 ? hipEventSynchronize(done[b]) : hipSuccess;       // the DMA out of this buffer two chunks ago
+            if (e != hipSuccess) { fail(e, "hipEventSynchronize"); break; }
+            memcpy(bounce[b], (const char*)src + k * CHUNK, span(k));
+            e = hipMemcpyAsync((char*)dst + k * CHUNK, bounce[b], span(k), hipMemcpyHostToDevice, stream);
+            if (e == hipSuccess) e = hipEventRecord(done[b], stream);
+            if (e != hipSuccess) fail(e, "hipMemcpyAsync");
+        }
+    } else {
+        // chunk k lands in bounce[k & 1] while the host drains chunk k - 1
+        for (size_t k = 0; rc == BFS_OK && k <= chunks; ++k) {
+            if (k < chunks) {
+                const int b = (int)(k & 1);
+                hipError_t e = hipMemcpyAsync(bounce[b], (const char*)src + k * CHUNK, span(k), hipMemcpyDeviceToHost, stream);
+                if (e == hipSuccess) e = hipEventRecord(done[b], stream);
+                if (e != hipSuccess) { fail(e, "hipMemcpyAsync"); break; }
+            }
+            if (k >= 1) {
+                const int b = (int)((k - 1) & 1);
+                hipError_t e = hipEventSynchronize(done[b]);
+                if (e != hipSuccess) { fail(e, "hipEventSynchronize"); break; }
+                memcpy((char*)dst + (k - 1) * CHUNK, bounce[b], span(k - 1));
+            }
+        }
+    }
+    hipError_t e = hipStreamSynchronize(stream);
+    if (e != hipSuccess && rc == BFS_OK) fail(e, "hipStreamSynchronize");
+    for (int i = 0; i < 2; ++i) {
+        if (done[i]) (void)hipEventDestroy(done[i]);
+        if (bounce[i]) (void)host_release(bounce[i]);
+    }
+    return rc;
+}
+}  // namespace
+
+int copy_h2d(void* d, const void* h, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return BFS_OK;
+    if (bytes >= (256u << 10) && is_pageable(h)) return copy_staged(d, h, bytes, true, stream);
+    BFS_HIP(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, stream));
+    BFS_HIP(hipStreamSynchronize(stream));
+    return BFS_OK;
+}
+
+int copy_d2h(void* h, const void* d, size_t bytes, hipStream_t stream) {
+    if (bytes == 0) return BFS_OK;
+    if (bytes >= (256u << 10) && is_pageable(h)) return copy_staged(h, d, bytes, false, stream);
+    BFS_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, stream));
+    BFS_HIP(hipStreamSynchronize(stream));
+    return BFS_OK;
+}
 
 int workspace(int slot, size_t bytes, hipStream_t stream, void** out) {
     int dev = 0;

@@ -30,6 +30,26 @@ const char* last_error();
 // grow-only scratch buffer keyed by (device, stream, slot); contents are only valid within one API call
 int workspace(int slot, size_t bytes, hipStream_t stream, void** out);
 
+// Pooled HBM and pinned-host memory.  hipMalloc / hipFree cost 50-500 us and hipFree synchronises the device, which at
+// 288 GB of HBM is the wrong trade: freed blocks go back to a size-class free list (8 classes per octave above 1 MiB,
+// powers of two below) and are handed out again without touching the driver.  Reuse is STREAM-ORDERED, like
+// hipMallocAsync: a block released on stream S may be handed to work on S immediately (earlier work on S still reading
+// it is ahead in the queue); a request from another stream -- or from the stream-less bfs_malloc -- synchronises S first.
+// `NO_STREAM` as the release stream means "the device was idle when the block came back".
+static const hipStream_t NO_STREAM = (hipStream_t)(uintptr_t)-1;
+int device_alloc(size_t bytes, hipStream_t stream, void** out);
+int device_release(void* ptr, hipStream_t stream);
+int device_pool_trim();                                     // hipFree every cached block (synchronises the device)
+void device_pool_stats(size_t* live_bytes, size_t* cached_bytes);
+int host_alloc(size_t bytes, void** out);                   // pinned, pooled the same way (no stream semantics: callers copy synchronously)
+int host_release(void* ptr);
+
+// Blocking copies between host and HBM.  Large pageable host buffers are bounced through two pinned 8 MiB buffers from
+// the host pool (the memcpy of chunk k+1 overlaps the DMA of chunk k) instead of letting the runtime pin the user pages:
+// that path measured ~1 GB/s, and the unpinning afterwards stalls later kernel dispatches for ~25 ms.
+int copy_h2d(void* d, const void* h, size_t bytes, hipStream_t stream);
+int copy_d2h(void* h, const void* d, size_t bytes, hipStream_t stream);
+
 // upload a host table once and keep it for the lifetime of the process (keyed by caller-chosen 128-bit key)
 int cached_table(uint64_t key_a, uint64_t key_b, uint64_t key_c, const u64* host, size_t count, const u64** d_out);
 bool cached_table_lookup(uint64_t key_a, uint64_t key_b, uint64_t key_c, const u64** d_out);

@@ -1,6 +1,7 @@
 """Device-memory plumbing for the array API: raw HIP buffers owned through the C ABI, plus adapters for
 torch tensors (torch is only used for memory/streams/distributed, never for arithmetic)."""
 import ctypes
+import weakref
 
 import numpy as np
 
@@ -19,13 +20,15 @@ def current_stream():
 
 
 class DeviceBuffer:
-    """`count` uint64 words in HBM (hipMalloc through bfs_malloc)."""
+    """`count` uint64 words in HBM, from the library's pool (bfs_malloc_async / bfs_free_async: stream-ordered on the
+    stream that is current when the buffer is made, which is also where this package enqueues all its work)."""
 
     def __init__(self, count):
         self.count = int(count)
         self.nbytes = self.count * 8
+        self._stream = current_stream()
         p = ctypes.c_void_p()
-        _lib.check(_lib.load().bfs_malloc(ctypes.byref(p), max(self.nbytes, 8)))
+        _lib.check(_lib.load().bfs_malloc_async(ctypes.byref(p), max(self.nbytes, 8), self._stream))
         self.ptr = p.value
 
     @classmethod
@@ -46,7 +49,10 @@ class DeviceBuffer:
 
     def free(self):
         if self.ptr:
-            _lib.load().bfs_free(self.ptr)
+            stream = current_stream()
+            if stream != self._stream:           # used under another stream since: hand the block back only when both are idle
+                synchronize(stream)
+            _lib.load().bfs_free_async(self.ptr, self._stream)
             self.ptr = None
 
     def __del__(self):
@@ -54,6 +60,31 @@ class DeviceBuffer:
             self.free()
         except Exception:
             pass
+
+
+def pinned_empty(shape):
+    """uninitialised uint64 numpy array in pinned host memory from the library's pool (bfs_host_alloc); the memory goes
+    back to the pool when the array and every view of it are gone.  H2D copies from it run at link speed."""
+    shape = (int(shape),) if np.isscalar(shape) else tuple(int(d) for d in shape)
+    count = int(np.prod(shape, dtype=np.int64)) if shape else 1
+    lib = _lib.load()
+    p = ctypes.c_void_p()
+    _lib.check(lib.bfs_host_alloc(ctypes.byref(p), max(count * 8, 8)))
+    raw = (ctypes.c_uint64 * max(count, 1)).from_address(p.value)
+    weakref.finalize(raw, lib.bfs_host_free, p.value)
+    return np.ctypeslib.as_array(raw)[:count].reshape(shape)
+
+
+def pool_stats():
+    """(bytes handed out, bytes cached) of the library's HBM pool"""
+    live, cached = ctypes.c_size_t(), ctypes.c_size_t()
+    _lib.check(_lib.load().bfs_pool_stats(ctypes.byref(live), ctypes.byref(cached)))
+    return live.value, cached.value
+
+
+def pool_trim():
+    """give the cached HBM blocks back to the driver"""
+    _lib.check(_lib.load().bfs_pool_trim())
 
 
 def device_ptr(x):

@@ -294,13 +294,33 @@ class Table:
                                          domain.offset.value, domain.omega.value, ch, tm, pr, stream))
         return out
 
-    def _degree_bounds(self, kind, challenges, terminals):
-        md = self.interpolant_degree()
-        cons = dict(self.air.all())[kind]
+    _generic_totals = {}      # (table, kind, which challenges / terminals / parameters are zero) -> total degrees per constraint
+
+    def _constraint_total_degrees(self, kind, challenges, terminals, params):
+        """per constraint, the set of total degrees of the monomials that survive the exact expansion (air.expand)"""
         nvars = 2 * self.full_width if kind == "transition" else self.full_width
-        params = self.air_params(challenges)
         memo = {}            # sub-expressions (deselectors, instruction zerofier, row differences) are shared between constraints
-        return [air.symbolic_degree_bound(air.expand(e, nvars, challenges, terminals, params, memo), md) for e in cons]
+        return [air.total_degrees(air.expand(e, nvars, challenges, terminals, params, memo)) for e in dict(self.air.all())[kind]]
+
+    def _degree_bounds(self, kind, challenges, terminals):
+        """symbolic degree bounds of the constraints composed with the interpolants (multivariate.py:144-170).  Which
+        monomials survive depends on the numeric challenges only through cancellations; for values that look sampled (pairwise
+        distinct, zero or with more than 32 significant bits) the surviving set is the generic one except with probability
+        ~2^-160, so it is computed once per zero pattern and reused.  Crafted values (the constructor's all-ones challenges,
+        brainfuck_stark.py:84-92, or small test values) always take the exact expansion."""
+        md = self.interpolant_degree()
+        params = self.air_params(challenges)
+        values = [tuple(v) for v in list(challenges) + list(terminals) + list(params)]
+        nonzero = [v for v in values if any(v)]
+        generic = len(set(nonzero)) == len(nonzero) and all(v[0] >> 32 or v[1] or v[2] for v in nonzero)
+        if generic:
+            key = (type(self).__name__, self.table_index, kind, tuple(any(v) for v in values))
+            totals = Table._generic_totals.get(key)
+            if totals is None:
+                totals = Table._generic_totals[key] = self._constraint_total_degrees(kind, challenges, terminals, params)
+        else:
+            totals = self._constraint_total_degrees(kind, challenges, terminals, params)
+        return [max([-1] + [t * md for t in ts]) for ts in totals]
 
     def boundary_quotient_degree_bounds(self, challenges):
         return [b - 1 for b in self._degree_bounds("boundary", challenges, [air.X0] * 5)]

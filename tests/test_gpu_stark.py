@@ -57,6 +57,7 @@ def test_prove_matches_reference(name, monkeypatch):
     assert stark.max_degree == g["max_degree"] and stark.fri.domain.length == g["fri_domain_length"]
     assert [t.height for t in stark.tables] == g["table_heights"]
 
+    stark.keep_intermediates = True
     proof = stark.prove(program, pm, mm, im, inm, om)
     last = stark._last
     n = stark.fri.domain.length

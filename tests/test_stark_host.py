@@ -262,3 +262,34 @@ def test_extended_tables_satisfy_the_air(code, inp):
                 assert value == air.X0, (type(table).__name__, r, k)
         for value in table.evaluate_constraints("terminal", rows[-1], None, challenges, terminals):
             assert value == air.X0, type(table).__name__
+
+
+def test_generic_degree_bound_cache_agrees_with_the_exact_expansion():
+    """Table._degree_bounds reuses the surviving-monomial pattern for sampled-looking challenges; the result must equal the
+    exact expansion with those very values, for zero and non-zero terminals, and crafted small values must bypass the cache"""
+    import numpy as np
+    from stark_brainfuck_amd import air
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.table import Table
+    from stark_brainfuck_amd.vm import VirtualMachine
+    program = VirtualMachine.compile(",+.")
+    running_time, inputs, outputs = VirtualMachine.run(program, input_data=["a"])
+    matrices = VirtualMachine.simulate(program, input_data=list(inputs))
+    stark = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs)
+    rng = np.random.default_rng(7)
+    sample = lambda k: [tuple(int(v) for v in rng.integers(1 << 40, air.P, 3, dtype=np.uint64)) for _ in range(k)]
+    for trial in range(3):
+        challenges = sample(11)
+        terminals = sample(5)
+        if trial == 1:
+            terminals[2] = terminals[3] = air.X0          # a program without input / output
+        for table in stark.tables:
+            for kind in ("boundary", "transition", "terminal"):
+                exact = [max([-1] + [t * table.interpolant_degree() for t in ts])
+                         for ts in table._constraint_total_degrees(kind, challenges, terminals, table.air_params(challenges))]
+                assert table._degree_bounds(kind, challenges, terminals) == exact, (type(table).__name__, kind)
+    cached = len(Table._generic_totals)
+    small = [(i + 2, 0, 0) for i in range(11)]
+    for table in stark.tables:
+        table._degree_bounds("transition", small, [air.X0] * 5)
+    assert len(Table._generic_totals) == cached             # crafted values: exact path, nothing new cached
