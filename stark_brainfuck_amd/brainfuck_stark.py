@@ -29,7 +29,7 @@ from .merkle import Merkle
 from .permutation_argument import PermutationArgument
 from .processor_table import ProcessorTable
 from .salted_merkle import SaltedMerkle, ZippedSaltedMerkle
-from .table import sample_ext, sample_ext_many
+from .table import extend_all, sample_ext, sample_ext_many
 from .univariate import Polynomial
 from .vm import VirtualMachine
 
@@ -195,8 +195,7 @@ class BrainfuckStark:
         # challenges, initials, table extension, terminals (:181-192)
         challenges = BrainfuckStark._sample_weights(11, proof_stream.prover_fiat_shamir())
         initials = [sample_ext(urandom(3 * 8)) for _ in self.permutation_arguments]
-        for table in self.tables:
-            table.extend(challenges, initials)
+        extend_all(self.tables, challenges, initials)
         terminals = self.get_terminals()
         lap("extend")
 

@@ -29,8 +29,9 @@ class InstructionTable(Table):
         same = np.concatenate([[False], addr[1:] == addr[:-1]]) if len(addr) else np.zeros(0, dtype=bool)
         # the running product absorbs a row when it is not padding and repeats the previous row's address (:197-205);
         # the running evaluation absorbs the first row of every address (:209-214); both are recorded AFTER the row's update
-        perm, t_perm = self.scan(0, [addr, ci, ni], (ci != 0) & same, [alpha, a, b, c], all_initials[0], False)
-        ev, t_ev = self.scan(1, [addr, ci, ni], ~same, [eta, a, b, c], X0, False)
+        f_perm = self.scan_async(0, [addr, ci, ni], (ci != 0) & same, [alpha, a, b, c], all_initials[0], False)
+        f_ev = self.scan_async(1, [addr, ci, ni], ~same, [eta, a, b, c], X0, False)
+        (perm, t_perm), (ev, t_ev) = f_perm.result(), f_ev.result()
         self.ext_columns = [perm, ev]
         self.permutation_terminal = t_perm
         self.evaluation_terminal = t_ev

@@ -47,7 +47,7 @@ class MemoryTable(Table):
         pad = np.zeros((4, k), dtype=np.uint64)
         if k:
             last = [int(v) for v in m[:, -1]]
-            pad[0] = [(last[0] + 1 + j) % P for j in range(k)]        # dummy rows: cycle counts up, pointer and value stay (:40-44)
+            pad[0] = self._counting(last[0], k)                         # dummy rows: cycle counts up, pointer and value stay (:40-44)
             pad[1], pad[2], pad[3] = last[1], last[2], 1
         self._pad_to(pad)
 

@@ -22,7 +22,7 @@ class ProcessorTable(Table):
         k = self._padding_length(m.shape[1])
         last = [int(v) for v in m[:, -1]]
         pad = np.zeros((7, k), dtype=np.uint64)
-        pad[0] = [(last[0] + 1 + j) % P for j in range(k)]            # the cycle count keeps counting (processor_table.py:24-35)
+        pad[0] = self._counting(last[0], k)                            # the cycle count keeps counting (processor_table.py:24-35)
         for col in (1, 4, 5, 6):                                       # instruction pointer, memory pointer / value / inverse stay
             pad[col] = last[col]
         self._pad_to(pad)
@@ -33,13 +33,14 @@ class ProcessorTable(Table):
         m = self.base_array()
         clk, ip, ci, ni, mp, mv = m[0], m[1], m[2], m[3], m[4], m[5]
         active = ci != 0                                                   # padding rows leave the products alone
-        ipp, t_ipp = self.scan(0, [ip, ci, ni], active, [alpha, a, b, c], all_initials[0], True)
-        mpp, t_mpp = self.scan(0, [clk, mp, mv], active, [beta, d, e, f], all_initials[1], True)
+        f_ipp = self.scan_async(0, [ip, ci, ni], active, [alpha, a, b, c], all_initials[0], True)
+        f_mpp = self.scan_async(0, [clk, mp, mv], active, [beta, d, e, f], all_initials[1], True)
         one = (1, 0, 0)
         reads, writes = ci == ord(","), ci == ord(".")
         mv_next = np.concatenate([mv[1:], mv[:1]]) if len(mv) else mv       # an input symbol shows up in the NEXT row's memory value
-        iev, t_iev = self.scan(1, [mv_next], reads, [gamma, one], X0, True)
-        oev, t_oev = self.scan(1, [mv], writes, [delta, one], X0, True)
+        f_iev = self.scan_async(1, [mv_next], reads, [gamma, one], X0, True)
+        f_oev = self.scan_async(1, [mv], writes, [delta, one], X0, True)
+        (ipp, t_ipp), (mpp, t_mpp), (iev, t_iev), (oev, t_oev) = f_ipp.result(), f_mpp.result(), f_iev.result(), f_oev.result()
         self.ext_columns = [ipp, mpp, iev, oev]
         self.instruction_permutation_terminal = t_ipp
         self.memory_permutation_terminal = t_mpp

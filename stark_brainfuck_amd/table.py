@@ -73,6 +73,42 @@ def sample_ext(byte_array):
     return tuple(sample_base(byte_array[i * chunk:(i + 1) * chunk]) for i in range(3))
 
 
+_POOLS = {}
+_THREAD_ROWS = 1 << 14
+
+
+def _scan_pool():
+    if "scan" not in _POOLS:
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        _POOLS["scan"] = ThreadPoolExecutor(max_workers=max(2, min(9, os.cpu_count() or 2)), thread_name_prefix="bfs-scan")
+    return _POOLS["scan"]
+
+
+def extend_all(tables, challenges, initials):
+    """Table.extend of every table, concurrently (brainfuck_stark.py:186-187 runs them one after the other; they are independent)"""
+    if max(t.height for t in tables) < _THREAD_ROWS:
+        for t in tables:
+            t.extend(challenges, initials)
+        return
+    if "tables" not in _POOLS:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOLS["tables"] = ThreadPoolExecutor(max_workers=5, thread_name_prefix="bfs-extend")
+    for future in [_POOLS["tables"].submit(t.extend, challenges, initials) for t in tables]:
+        future.result()
+
+
+def staging_empty(shape):
+    """uint64 array for data on its way to HBM: pinned memory from the library's pool when there is a GPU, plain numpy otherwise"""
+    if _POOLS.get("pinned", True):
+        try:
+            from .device import pinned_empty
+            return pinned_empty(shape)
+        except Exception:
+            _POOLS["pinned"] = False
+    return np.empty(shape, dtype=np.uint64)
+
+
 class _PaddedMatrix:
     """the caller's matrix followed by padding rows; padding rows exist as integers and turn into element objects only if
     somebody looks at them (`matrix` stays a sequence of rows, as in the reference; the caller's row objects are kept)"""
@@ -163,9 +199,19 @@ class Table:
 
     def _pad_to(self, padding):
         """append `padding` (uint64 array, base_width x k) to the matrix"""
-        arr = np.concatenate([self.base_array(), padding.astype(np.uint64)], axis=1) if padding.shape[1] else self.base_array()
+        base = self.base_array()
+        arr = staging_empty((base.shape[0], base.shape[1] + padding.shape[1]))      # goes to HBM as it is (Table.lde)
+        arr[:, :base.shape[1]] = base
+        arr[:, base.shape[1]:] = padding
         self.matrix = _PaddedMatrix(self.matrix, arr, self.field)
         self._array, self._array_key = arr, (id(self.matrix), len(self.matrix))
+
+    @staticmethod
+    def _counting(last, k):
+        """last + 1, last + 2, ..., last + k modulo p as a uint64 array"""
+        if last + k < P:
+            return np.arange(last + 1, last + k + 1, dtype=np.uint64) if k else np.zeros(0, dtype=np.uint64)
+        return np.array([(last + 1 + j) % P for j in range(k)], dtype=np.uint64)
 
     @staticmethod
     def _padding_length(rows):
@@ -186,6 +232,18 @@ class Table:
                                             m.ctypes.data if m is not None else None, n, (_u64 * 12)(*flat), (_u64 * 3)(*initial),
                                             1 if record_before else 0, out.ctypes.data, terminal))
         return out, (int(terminal[0]), int(terminal[1]), int(terminal[2]))
+
+    @staticmethod
+    def scan_async(*args):
+        """Table.scan on a worker thread (the native scan releases the GIL; the nine scans of a proof are independent) -> Future"""
+        columns, mask = args[1], args[2]
+        rows = next((len(c) for c in columns if c is not None), 0 if mask is None else len(mask))
+        if rows < _THREAD_ROWS:                  # short traces: waking a worker costs more than the scan
+            from concurrent.futures import Future
+            done = Future()
+            done.set_result(Table.scan(*args))
+            return done
+        return _scan_pool().submit(Table.scan, *args)
 
     # ---- interpolation + low-degree extension (table.py:112-148)
     def _extend_columns(self, domain, columns, randomizers, keep_coefficients=False):
@@ -258,7 +316,8 @@ class Table:
     def ldex(self, domain, xfield=None):
         width = self.full_width - self.base_width
         if self.height:      # ext_columns: one (3, rows) array per extension column -> (column, limb) planes
-            cols = np.concatenate(self.ext_columns, axis=0)
+            cols = staging_empty((3 * width, self.height))
+            np.concatenate(self.ext_columns, axis=0, out=cols)
         else:
             cols = np.zeros((width * 3, 0), dtype=np.uint64)
         rand = None
