@@ -272,6 +272,16 @@ int bfs_selftest_field(uint32_t log_count, uint64_t* mismatches);
  */
 int bfs_xfe_scan(int kind, const uint64_t* x1, const uint64_t* x2, const uint64_t* x3, const uint8_t* mask, uint64_t n,
                  const uint64_t constants[12], const uint64_t initial[3], int record_before, uint64_t* out, uint64_t terminal[3]);
+/*
+ * bfs_xfe_scan_device: the same primitive as a prefix scan on the GPU (csrc/scan.hip): the row updates are affine maps of the
+ *     running value and compose associatively.  d_x1..d_x3 / d_mask are device pointers (n words / n bytes, NULL = absent),
+ *     d_x1 is read `shift1` rows ahead (cyclically), the three limb planes of the result go to d_out, d_out + out_stride,
+ *     d_out + 2 out_stride.  The final state is written to d_terminal (device, three words) and / or terminal (host; this
+ *     synchronises the stream); either may be NULL.
+ */
+int bfs_xfe_scan_device(int kind, const uint64_t* d_x1, const uint64_t* d_x2, const uint64_t* d_x3, uint64_t shift1,
+                        const uint8_t* d_mask, uint64_t n, const uint64_t constants[12], const uint64_t initial[3],
+                        int record_before, uint64_t* d_out, uint64_t out_stride, uint64_t* d_terminal, uint64_t* terminal, void* stream);
 
 typedef struct bfs_comb_source {
     const uint64_t* ptr;   /* device: n words (base codeword) or 3n words (extension codeword, limb planes) */

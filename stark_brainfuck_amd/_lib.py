@@ -91,6 +91,7 @@ _SIGNATURES = {
     "bfs_fri_session_round": (ci, [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(vp), vp]),
     "bfs_selftest_field": (ci, [u32, ctypes.POINTER(u64)]),
     "bfs_xfe_scan": (ci, [ci, vp, vp, vp, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(u64), ci, vp, ctypes.POINTER(u64)]),
+    "bfs_xfe_scan_device": (ci, [ci, vp, vp, vp, u64, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(u64), ci, vp, u64, vp, ctypes.POINTER(u64), vp]),
     "bfs_poly_support": (ci, [vp, u64, u64, u32, ctypes.POINTER(u64), vp]),
     "bfs_poly_randomize": (ci, [vp, u64, u64, u32, u64, ctypes.POINTER(u64), vp]),
     "bfs_air_num_quotients": (ci, [ci]),

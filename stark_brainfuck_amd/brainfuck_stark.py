@@ -29,7 +29,7 @@ from .merkle import Merkle
 from .permutation_argument import PermutationArgument
 from .processor_table import ProcessorTable
 from .salted_merkle import SaltedMerkle, ZippedSaltedMerkle
-from .table import extend_all, sample_ext, sample_ext_many
+from .table import sample_ext, sample_ext_many
 from .univariate import Polynomial
 from .vm import VirtualMachine
 
@@ -120,11 +120,11 @@ class BrainfuckStark:
         """hand device memory back to the pool now instead of when the garbage collector gets to it (the blocks are
         stream-ordered: kernels already queued keep reading them, the next proof on this stream reuses them)"""
         for h in holders:
-            for name in ("buf", "_nodes", "_salts", "base_codewords", "ext_codewords"):
+            for name in ("buf", "_nodes", "_salts", "base_codewords", "ext_codewords", "_base_device", "_ext_device"):
                 b = getattr(h, name, None)
                 if hasattr(b, "free"):
                     b.free()
-                    if name.endswith("codewords"):
+                    if name.endswith("codewords") or name.endswith("_device"):
                         setattr(h, name, None)
             if hasattr(h, "free"):
                 h.free()
@@ -195,7 +195,8 @@ class BrainfuckStark:
         # challenges, initials, table extension, terminals (:181-192)
         challenges = BrainfuckStark._sample_weights(11, proof_stream.prover_fiat_shamir())
         initials = [sample_ext(urandom(3 * 8)) for _ in self.permutation_arguments]
-        extend_all(self.tables, challenges, initials)
+        for table in self.tables:
+            table.extend_device(challenges, initials)       # prefix scans on the trace columns lde() left in HBM
         terminals = self.get_terminals()
         lap("extend")
 

@@ -1,0 +1,194 @@
+// scan.hip -- the column extensions of the tables on the GPU: running products and running evaluations
+//   ProcessorTable.extend   /root/reference/code/processor_table.py:329-427
+//   InstructionTable.extend instruction_table.py:167-231
+//   MemoryTable.extend      memory_table.py:172-206
+//   IOTable.extend_iotable  io_table.py:77-110
+// The reference walks the rows one after the other.  Each row is an affine map of the running value,
+//   kind 0 (running product):     s -> s * (c0 - c1 x1[i] - c2 x2[i] - c3 x3[i])         (masked rows; identity otherwise)
+//   kind 1 (running evaluation):  s -> s * c0 + (c1 x1[i] + c2 x2[i] + c3 x3[i])
+// and maps compose associatively, so the column is a prefix scan: per-block aggregates (scan_reduce_kernel), one workgroup
+// scanning the <= 256 block aggregates (scan_spine_kernel), then every thread replays its rows from its own starting value
+// (scan_apply_kernel).  Same semantics as the host primitive bfs_xfe_scan (hostscan.cpp), which the tests compare it with;
+// the trace columns are already in HBM for the low-degree extension, and the extension columns never visit the host.
+#include <string.h>
+
+#include "../../include/bfstark.h"
+#include "gl.hpp"
+#include "runtime.hpp"
+
+namespace bfs {
+
+struct ScanArgs {
+    const u64 *x1, *x2, *x3;      // device columns (null = absent)
+    const unsigned char* mask;    // device bytes (null = every row)
+    u64 n;
+    u64 shift1;                   // x1 is read at (i + shift1) mod n: "the next row's memory value" of the input evaluation
+    u64 items;                    // consecutive rows per thread
+    Xfe c[4];
+    Xfe initial;
+    int record_before;
+    u64* out;                     // three limb planes
+    u64 out_stride;
+    Xfe* block_m;                 // per block: aggregate map x -> x * m + c ...
+    Xfe* block_c;
+    Xfe* block_state;             // ... and, after the spine, the running value the block starts from; [gridDim.x] = terminal
+    u64* terminal;                // optional device copy of the terminal (three words)
+};
+
+struct Affine {
+    Xfe m, c;
+};
+
+template <int KIND>
+__device__ __forceinline__ Affine row_map(const ScanArgs& a, u64 i) {
+    Affine r{Xfe{{1, 0, 0}}, Xfe{{0, 0, 0}}};
+    if (a.mask && !a.mask[i]) return r;
+    Xfe lin{{0, 0, 0}};
+    if (a.x1) {
+        u64 j = i + a.shift1;
+        if (j >= a.n) j -= a.n;
+        lin = xfe_add(lin, xfe_scale(a.c[1], a.x1[j]));
+    }
+    if (a.x2) lin = xfe_add(lin, xfe_scale(a.c[2], a.x2[i]));
+    if (a.x3) lin = xfe_add(lin, xfe_scale(a.c[3], a.x3[i]));
+    if (KIND == 0) r.m = xfe_sub(a.c[0], lin);
+    else { r.m = a.c[0]; r.c = lin; }
+    return r;
+}
+
+// first `f`, then `g`
+template <int KIND>
+__device__ __forceinline__ Affine compose(const Affine& f, const Affine& g) {
+    Affine r;
+    r.m = xfe_mul(f.m, g.m);
+    if (KIND == 0) r.c = Xfe{{0, 0, 0}};
+    else r.c = xfe_add(xfe_mul(f.c, g.m), g.c);
+    return r;
+}
+
+template <int KIND>
+__device__ __forceinline__ Xfe apply(const Affine& f, const Xfe& s) {
+    Xfe r = xfe_mul(s, f.m);
+    return KIND == 0 ? r : xfe_add(r, f.c);
+}
+
+template <int KIND>
+__device__ __forceinline__ Affine thread_aggregate(const ScanArgs& a, u64 first) {
+    Affine agg{Xfe{{1, 0, 0}}, Xfe{{0, 0, 0}}};
+    const u64 last = first + a.items < a.n ? first + a.items : a.n;
+    for (u64 i = first; i < last; ++i) agg = compose<KIND>(agg, row_map<KIND>(a, i));
+    return agg;
+}
+
+// inclusive scan of 256 maps in LDS (Hillis-Steele: map t becomes the composition of maps 0..t)
+template <int KIND>
+__device__ __forceinline__ Affine block_inclusive_scan(Affine mine, Affine* lds) {
+    const u32 t = threadIdx.x;
+    lds[t] = mine;
+    __syncthreads();
+    for (u32 d = 1; d < 256; d <<= 1) {
+        Affine left;
+        const bool has = t >= d;
+        if (has) left = lds[t - d];
+        __syncthreads();
+        if (has) {
+            mine = compose<KIND>(left, mine);
+            lds[t] = mine;
+        }
+        __syncthreads();
+    }
+    return mine;
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256) scan_reduce_kernel(const ScanArgs a) {
+    __shared__ Affine lds[256];
+    const u64 first = ((u64)blockIdx.x * 256 + threadIdx.x) * a.items;
+    const Affine total = block_inclusive_scan<KIND>(thread_aggregate<KIND>(a, first), lds);
+    if (threadIdx.x == 255) { a.block_m[blockIdx.x] = total.m; a.block_c[blockIdx.x] = total.c; }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256) scan_spine_kernel(const ScanArgs a, u32 blocks) {
+    __shared__ Affine lds[256];
+    const u32 t = threadIdx.x;
+    Affine mine{Xfe{{1, 0, 0}}, Xfe{{0, 0, 0}}};
+    if (t < blocks) { mine.m = a.block_m[t]; mine.c = a.block_c[t]; }
+    const Affine incl = block_inclusive_scan<KIND>(mine, lds);
+    // block t + 1 starts from the value after blocks 0..t; slot `blocks` is the terminal
+    if (t < blocks) {
+        const Xfe after = apply<KIND>(incl, a.initial);
+        a.block_state[t + 1] = after;
+        if (t + 1 == blocks && a.terminal) { a.terminal[0] = after.c[0]; a.terminal[1] = after.c[1]; a.terminal[2] = after.c[2]; }
+    }
+    if (t == 0) a.block_state[0] = a.initial;
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(256) scan_apply_kernel(const ScanArgs a) {
+    __shared__ Affine lds[256];
+    const u32 t = threadIdx.x;
+    const u64 first = ((u64)blockIdx.x * 256 + t) * a.items;
+    const Affine incl = block_inclusive_scan<KIND>(thread_aggregate<KIND>(a, first), lds);
+    __syncthreads();
+    lds[t] = incl;
+    __syncthreads();
+    Xfe state = a.block_state[blockIdx.x];
+    if (t > 0) state = apply<KIND>(lds[t - 1], state);
+    const u64 last = first + a.items < a.n ? first + a.items : a.n;
+    for (u64 i = first; i < last; ++i) {
+        if (a.record_before) { a.out[i] = state.c[0]; a.out[a.out_stride + i] = state.c[1]; a.out[2 * a.out_stride + i] = state.c[2]; }
+        state = apply<KIND>(row_map<KIND>(a, i), state);
+        if (!a.record_before) { a.out[i] = state.c[0]; a.out[a.out_stride + i] = state.c[1]; a.out[2 * a.out_stride + i] = state.c[2]; }
+    }
+}
+
+template <int KIND>
+static int scan_launch(ScanArgs& a, u32 blocks, hipStream_t stream) {
+    hipLaunchKernelGGL(scan_reduce_kernel<KIND>, dim3(blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(scan_spine_kernel<KIND>, dim3(1), dim3(256), 0, stream, a, blocks);
+    hipLaunchKernelGGL(scan_apply_kernel<KIND>, dim3(blocks), dim3(256), 0, stream, a);
+    BFS_HIP(hipGetLastError());
+    return BFS_OK;
+}
+
+}  // namespace bfs
+
+using namespace bfs;
+
+extern "C" int bfs_xfe_scan_device(int kind, const uint64_t* d_x1, const uint64_t* d_x2, const uint64_t* d_x3, uint64_t shift1,
+                                   const uint8_t* d_mask, uint64_t n, const uint64_t constants[12], const uint64_t initial[3],
+                                   int record_before, uint64_t* d_out, uint64_t out_stride, uint64_t* d_terminal, uint64_t* terminal,
+                                   void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (kind != 0 && kind != 1) { set_error("bfs_xfe_scan_device: kind must be 0 (product) or 1 (evaluation)"); return BFS_ERR_BAD_ARG; }
+    if (n == 0) {
+        u64 t[3] = {initial[0] % GL_P, initial[1] % GL_P, initial[2] % GL_P};
+        if (terminal) memcpy(terminal, t, sizeof t);
+        if (d_terminal) {
+            BFS_HIP(hipMemcpyAsync(d_terminal, t, sizeof t, hipMemcpyHostToDevice, stream));
+            BFS_HIP(hipStreamSynchronize(stream));
+        }
+        return BFS_OK;
+    }
+    if (out_stride < n) { set_error("bfs_xfe_scan_device: out_stride < n"); return BFS_ERR_BAD_ARG; }
+    ScanArgs a{};
+    a.x1 = d_x1; a.x2 = d_x2; a.x3 = d_x3; a.mask = d_mask; a.n = n; a.shift1 = d_x1 ? shift1 % n : 0;
+    for (int j = 0; j < 4; ++j) a.c[j] = Xfe{{constants[3 * j] % GL_P, constants[3 * j + 1] % GL_P, constants[3 * j + 2] % GL_P}};
+    a.initial = Xfe{{initial[0] % GL_P, initial[1] % GL_P, initial[2] % GL_P}};
+    a.record_before = record_before;
+    a.out = d_out; a.out_stride = out_stride; a.terminal = d_terminal;
+    u64 blocks = (n + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    a.items = (n + blocks * 256 - 1) / (blocks * 256);
+    blocks = (n + a.items * 256 - 1) / (a.items * 256);          // no empty blocks at the end
+    void* w = nullptr;
+    BFS_TRY(workspace(7, (3 * 256 + 8) * sizeof(Xfe), stream, &w));       // reused by the next scan on this stream: stream order keeps it safe
+    a.block_m = (Xfe*)w; a.block_c = a.block_m + 256; a.block_state = a.block_c + 256;
+    BFS_TRY(kind == 0 ? scan_launch<0>(a, (u32)blocks, stream) : scan_launch<1>(a, (u32)blocks, stream));
+    if (terminal) {
+        BFS_HIP(hipMemcpyAsync(terminal, a.block_state + blocks, sizeof(Xfe), hipMemcpyDeviceToHost, stream));
+        BFS_HIP(hipStreamSynchronize(stream));
+    }
+    return BFS_OK;
+}

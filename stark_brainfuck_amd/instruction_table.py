@@ -21,17 +21,16 @@ class InstructionTable(Table):
         pad[0] = m[0, -1] if m.shape[1] else 0                         # the last address repeats (instruction_table.py:19-25)
         self._pad_to(pad)
 
-    def extend(self, all_challenges, all_initials):
+    def _scans(self, all_challenges, all_initials):
         """instruction_table.py:167-231"""
         a, b, c, d, e, f, alpha, beta, gamma, delta, eta = all_challenges
         m = self.base_array()
-        addr, ci, ni = m[0], m[1], m[2]
+        addr, ci = m[0], m[1]
         same = np.concatenate([[False], addr[1:] == addr[:-1]]) if len(addr) else np.zeros(0, dtype=bool)
         # the running product absorbs a row when it is not padding and repeats the previous row's address (:197-205);
         # the running evaluation absorbs the first row of every address (:209-214); both are recorded AFTER the row's update
-        f_perm = self.scan_async(0, [addr, ci, ni], (ci != 0) & same, [alpha, a, b, c], all_initials[0], False)
-        f_ev = self.scan_async(1, [addr, ci, ni], ~same, [eta, a, b, c], X0, False)
-        (perm, t_perm), (ev, t_ev) = f_perm.result(), f_ev.result()
-        self.ext_columns = [perm, ev]
-        self.permutation_terminal = t_perm
-        self.evaluation_terminal = t_ev
+        return [dict(kind=0, cols=[0, 1, 2], mask=(ci != 0) & same, constants=[alpha, a, b, c], initial=all_initials[0], before=False),
+                dict(kind=1, cols=[0, 1, 2], mask=~same, constants=[eta, a, b, c], initial=X0, before=False)]
+
+    def _after_extend(self, terminals, all_challenges, read):
+        self.permutation_terminal, self.evaluation_terminal = terminals

@@ -22,14 +22,13 @@ class IOTable(Table):
     def air_params(self, challenges):
         return [xpow(tuple(challenges[self.challenge_index]), self.height - self.length)]
 
-    def extend(self, all_challenges, all_initials):
-        """io_table.py:77-110: evaluation = evaluation * iota + symbol on every row; the terminal is the value after the last
-        real (unpadded) row"""
-        iota = all_challenges[self.challenge_index]
-        m = self.base_array()
-        ev, _ = self.scan(1, [m[0]], None, [iota, (1, 0, 0)], X0, False)
-        self.ext_columns = [ev]
-        self.evaluation_terminal = tuple(int(v) for v in ev[:, self.length - 1]) if self.length else X0
+    def _scans(self, all_challenges, all_initials):
+        """io_table.py:77-110: evaluation = evaluation * iota + symbol on every row"""
+        return [dict(kind=1, cols=[0], mask=None, constants=[all_challenges[self.challenge_index], (1, 0, 0)], initial=X0, before=False)]
+
+    def _after_extend(self, terminals, all_challenges, read):
+        # the terminal is the value after the last real (unpadded) row
+        self.evaluation_terminal = read(0, self.length - 1) if self.length else X0
 
 
 class InputTable(IOTable):

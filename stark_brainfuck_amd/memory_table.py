@@ -51,10 +51,10 @@ class MemoryTable(Table):
             pad[1], pad[2], pad[3] = last[1], last[2], 1
         self._pad_to(pad)
 
-    def extend(self, all_challenges, all_initials):
+    def _scans(self, all_challenges, all_initials):
         """memory_table.py:172-206"""
         a, b, c, d, e, f, alpha, beta, gamma, delta, eta = all_challenges
-        m = self.base_array()
-        perm, t_perm = self.scan(0, [m[0], m[1], m[2]], m[3] == 0, [beta, d, e, f], all_initials[1], True)
-        self.ext_columns = [perm]
-        self.permutation_terminal = t_perm
+        return [dict(kind=0, cols=[0, 1, 2], mask=self.base_array()[3] == 0, constants=[beta, d, e, f], initial=all_initials[1], before=True)]
+
+    def _after_extend(self, terminals, all_challenges, read):
+        self.permutation_terminal = terminals[0]

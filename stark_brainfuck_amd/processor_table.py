@@ -27,27 +27,28 @@ class ProcessorTable(Table):
             pad[col] = last[col]
         self._pad_to(pad)
 
-    def extend(self, all_challenges, all_initials):
-        """the four extension columns as running products / evaluations (processor_table.py:329-427), one native scan each"""
+    def _scans(self, all_challenges, all_initials):
+        """the four extension columns as running products / evaluations (processor_table.py:329-427)"""
         a, b, c, d, e, f, alpha, beta, gamma, delta, eta = all_challenges
-        m = self.base_array()
-        clk, ip, ci, ni, mp, mv = m[0], m[1], m[2], m[3], m[4], m[5]
+        ci = self.base_array()[2]
         active = ci != 0                                                   # padding rows leave the products alone
-        f_ipp = self.scan_async(0, [ip, ci, ni], active, [alpha, a, b, c], all_initials[0], True)
-        f_mpp = self.scan_async(0, [clk, mp, mv], active, [beta, d, e, f], all_initials[1], True)
+        self._reads, self._writes = ci == ord(","), ci == ord(".")
         one = (1, 0, 0)
-        reads, writes = ci == ord(","), ci == ord(".")
-        mv_next = np.concatenate([mv[1:], mv[:1]]) if len(mv) else mv       # an input symbol shows up in the NEXT row's memory value
-        f_iev = self.scan_async(1, [mv_next], reads, [gamma, one], X0, True)
-        f_oev = self.scan_async(1, [mv], writes, [delta, one], X0, True)
-        (ipp, t_ipp), (mpp, t_mpp), (iev, t_iev), (oev, t_oev) = f_ipp.result(), f_mpp.result(), f_iev.result(), f_oev.result()
-        self.ext_columns = [ipp, mpp, iev, oev]
+        return [dict(kind=0, cols=[1, 2, 3], mask=active, constants=[alpha, a, b, c], initial=all_initials[0], before=True),
+                dict(kind=0, cols=[0, 4, 5], mask=active, constants=[beta, d, e, f], initial=all_initials[1], before=True),
+                # an input symbol shows up in the NEXT row's memory value
+                dict(kind=1, cols=[5], shift1=1, mask=self._reads, constants=[gamma, one], initial=X0, before=True),
+                dict(kind=1, cols=[5], mask=self._writes, constants=[delta, one], initial=X0, before=True)]
+
+    def _after_extend(self, terminals, all_challenges, read):
+        gamma, delta = all_challenges[8], all_challenges[9]
+        t_ipp, t_mpp, t_iev, t_oev = terminals
         self.instruction_permutation_terminal = t_ipp
         self.memory_permutation_terminal = t_mpp
         self.input_evaluation_terminal = t_iev
         self.output_evaluation_terminal = t_oev
-        self.evaluation_terminal_identities = (self._identity(iev, t_iev, gamma, np.nonzero(reads)[0] + 1),
-                                               self._identity(oev, t_oev, delta, np.nonzero(writes)[0]))
+        self.evaluation_terminal_identities = (self._identity(None, t_iev, gamma, np.nonzero(self._reads)[0] + 1),
+                                               self._identity(None, t_oev, delta, np.nonzero(self._writes)[0]))
 
     def _identity(self, states, terminal, challenge, symbol_rows):
         """what the reference's OBJECT of this terminal is made of, replaying _evaluation_step over the update rows"""

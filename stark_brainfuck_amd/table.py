@@ -86,7 +86,7 @@ def _scan_pool():
 
 
 def extend_all(tables, challenges, initials):
-    """Table.extend of every table, concurrently (brainfuck_stark.py:186-187 runs them one after the other; they are independent)"""
+    """Table.extend (the host scans) of every table, concurrently (brainfuck_stark.py:186-187 runs them one after the other)"""
     if max(t.height for t in tables) < _THREAD_ROWS:
         for t in tables:
             t.extend(challenges, initials)
@@ -155,6 +155,8 @@ class Table:
         self.base_codewords = None   # DeviceBuffer, base_width * N
         self.ext_codewords = None    # DeviceBuffer, (full_width - base_width) * 3 * N
         self._coefficients = None    # host copy of the last interpolants (ext_sharing_moduli)
+        self._base_device = None     # DeviceBuffer, base_width * height: the trace columns as uploaded by lde()
+        self._ext_device = None      # DeviceBuffer, (full_width - base_width) * 3 * height: extension columns made by extend_device()
 
     @staticmethod
     def roundup_npo2(integer):
@@ -233,6 +235,68 @@ class Table:
                                             1 if record_before else 0, out.ctypes.data, terminal))
         return out, (int(terminal[0]), int(terminal[1]), int(terminal[2]))
 
+    # ---- column extensions.  A table describes its running products / evaluations as scan specs; `extend` runs them with the
+    # host primitive (bfs_xfe_scan), `extend_device` with the GPU one (bfs_xfe_scan_device) on the trace columns that
+    # Table.lde left in HBM -- the prover's path: the extension columns then never exist on the host.
+    def _scans(self, all_challenges, all_initials):
+        """-> list of dicts: kind (0 product / 1 evaluation), cols (base column indices, up to three), mask (bool array or
+        None), constants (up to four triples), initial (triple), before (record the state before the row's update),
+        shift1 (read the first column `shift1` rows ahead, cyclically)"""
+        raise NotImplementedError
+
+    def _after_extend(self, terminals, all_challenges, read):
+        """terminals: final state of every scan; read(k, row) -> the triple of extension column k at `row`"""
+        raise NotImplementedError
+
+    def extend(self, all_challenges, all_initials):
+        m = self.base_array()
+        futures = []
+        for sp in self._scans(all_challenges, all_initials):
+            cols = [m[c] for c in sp["cols"]]
+            if sp.get("shift1") and len(cols[0]):
+                cols[0] = np.roll(cols[0], -sp["shift1"])
+            futures.append(self.scan_async(sp["kind"], cols, sp["mask"], sp["constants"], sp["initial"], sp["before"]))
+        results = [f.result() for f in futures]
+        self.ext_columns = [r[0] for r in results]
+        self._ext_device = None
+        self._after_extend([r[1] for r in results], all_challenges, lambda k, row: tuple(int(v) for v in self.ext_columns[k][:, row]))
+
+    def extend_device(self, all_challenges, all_initials):
+        """the same columns, computed in HBM from the base columns of the last lde(); needs lde() first"""
+        from .device import gather
+        lib, stream = _lib.load(), current_stream()
+        h, width = self.height, self.full_width - self.base_width
+        specs = self._scans(all_challenges, all_initials)
+        assert len(specs) == width
+        self.ext_columns = None
+        self._ext_device = DeviceBuffer(3 * width * h)
+        if h == 0:
+            self._after_extend([tuple(sp["initial"]) for sp in specs], all_challenges, None)
+            return
+        assert self._base_device is not None, "extend_device() follows lde()"
+        masks = [sp["mask"] for sp in specs if sp["mask"] is not None]
+        d_masks = None
+        if masks:
+            host = np.ascontiguousarray(np.stack(masks), dtype=np.uint8)
+            d_masks = DeviceBuffer((host.size + 7) // 8)
+            _lib.check(lib.bfs_memcpy_h2d(d_masks.ptr, host.ctypes.data, host.size, stream))
+        d_terminals = DeviceBuffer(3 * len(specs))               # read back once, after the last scan
+        k_mask = 0
+        for k, sp in enumerate(specs):
+            ptrs = [self._base_device.ptr + 8 * c * h for c in sp["cols"]] + [None] * (3 - len(sp["cols"]))
+            mask_ptr = None
+            if sp["mask"] is not None:
+                mask_ptr = d_masks.ptr + k_mask * h
+                k_mask += 1
+            flat = [v for c in sp["constants"] for v in c] + [0] * (12 - 3 * len(sp["constants"]))
+            _lib.check(lib.bfs_xfe_scan_device(sp["kind"], ptrs[0], ptrs[1], ptrs[2], sp.get("shift1", 0), mask_ptr, h,
+                                               (_u64 * 12)(*flat), (_u64 * 3)(*sp["initial"]), 1 if sp["before"] else 0,
+                                               self._ext_device.ptr + 8 * 3 * k * h, h, d_terminals.ptr + 24 * k, None, stream))
+        words = [int(v) for v in d_terminals.to_numpy(3 * len(specs))]
+        terminals = [tuple(words[3 * k:3 * k + 3]) for k in range(len(specs))]
+        self._after_extend(terminals, all_challenges,
+                           lambda k, row: tuple(int(v) for v in gather([(self._ext_device.ptr + 8 * (3 * k * h + row), 3, h)])))
+
     @staticmethod
     def scan_async(*args):
         """Table.scan on a worker thread (the native scan releases the GIL; the nine scans of a proof are independent) -> Future"""
@@ -253,7 +317,7 @@ class Table:
         n = domain.length
         self._n = n
         log_n = n.bit_length() - 1
-        ncol, h = columns.shape[0], self.height
+        ncol, h = (columns.count // self.height if self.height else 0) if isinstance(columns, DeviceBuffer) else columns.shape[0], self.height
         out = DeviceBuffer(ncol * n)
         self._coefficients = None
         if ncol == 0:
@@ -264,7 +328,8 @@ class Table:
         omega, offset = domain.omega.value, domain.offset.value
         coeffs = DeviceBuffer(ncol * (h + 1))
         _lib.check(lib.bfs_memset(coeffs.ptr, 0, coeffs.nbytes, stream))
-        d_in = DeviceBuffer.from_numpy(columns.reshape(-1))
+        d_in = columns if isinstance(columns, DeviceBuffer) else DeviceBuffer.from_numpy(columns.reshape(-1))
+        self._last_input = d_in
         omicron_inv = pow(self.omicron.value, P - 2, P)
         raw_ntt(d_in.ptr, h, h, coeffs.ptr, h + 1, h.bit_length() - 1, ncol, omicron_inv, 1, pow(h, P - 2, P), stream)
         n_in = h
@@ -310,12 +375,17 @@ class Table:
         rand = None
         if self.height != 0 and self.num_randomizers:
             rand = [sample_base(urandom(3 * 8)) for _ in range(self.base_width)]
+        self._last_input = None
         self.base_codewords = self._extend_columns(domain, cols, rand)
+        self._base_device = self._last_input          # the trace columns stay in HBM for extend_device()
+        self._last_input = None
         return self.base_codewords
 
     def ldex(self, domain, xfield=None):
         width = self.full_width - self.base_width
-        if self.height:      # ext_columns: one (3, rows) array per extension column -> (column, limb) planes
+        if self.height and getattr(self, "_ext_device", None) is not None:   # after extend_device(): already in HBM, (column, limb) planes
+            cols = self._ext_device
+        elif self.height:      # ext_columns: one (3, rows) array per extension column -> (column, limb) planes
             cols = staging_empty((3 * width, self.height))
             np.concatenate(self.ext_columns, axis=0, out=cols)
         else:
@@ -326,6 +396,7 @@ class Table:
             for _ in range(width):
                 rand.extend(sample_ext(urandom(3 * 8)))
         self.ext_codewords = self._extend_columns(domain, cols, rand, keep_coefficients=True)
+        self._last_input = None
         return self.ext_codewords
 
     def ext_codeword_ptr(self, column):

@@ -703,3 +703,42 @@ def test_zipped_rows_edge_shapes(sb, oracle, n, n_ext, n_base):
             for i in range(n)]
     ref = oracle.MerkleOracle([oracle.salted_leaf_bytes(r, salts[24 * i:24 * i + 24]) for i, r in enumerate(rows)])
     assert nodes.to_numpy(8, offset=8).tobytes() == ref.root()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1, 5, 255, 256, 257, 4099, 70001, (1 << 17) + 3])
+def test_device_scan_matches_the_host_scan(sb, n):
+    """bfs_xfe_scan_device (prefix scan of affine maps, csrc/scan.hip) against the sequential host primitive bfs_xfe_scan on the
+    same columns: both kinds, masks present and absent, recording before / after the update, a shifted first column"""
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.device import DeviceBuffer, current_stream
+    from stark_brainfuck_amd.table import Table
+    lib, stream = _lib.load(), current_stream()
+    P = (1 << 64) - (1 << 32) + 1
+    rng = np.random.default_rng(n)
+    cols = rng.integers(0, P, (3, n), dtype=np.uint64)
+    cols[1, rng.integers(0, n, max(1, n // 7))] = 0
+    d_cols = DeviceBuffer.from_numpy(cols.reshape(-1))
+    mask = rng.integers(0, 4, n) != 0
+    d_mask = DeviceBuffer((n + 7) // 8)
+    m8 = np.ascontiguousarray(mask, dtype=np.uint8)
+    _lib.check(lib.bfs_memcpy_h2d(d_mask.ptr, m8.ctypes.data, n, stream))
+    u64 = ctypes.c_uint64
+    for kind, ncols, use_mask, before, shift1 in [(0, 3, True, True, 0), (0, 3, False, False, 0), (1, 1, True, True, 1),
+                                                  (1, 3, True, False, 0), (1, 1, False, False, 0), (0, 2, True, False, 3 % n)]:
+        constants = [tuple(int(v) for v in rng.integers(0, P, 3, dtype=np.uint64)) for _ in range(1 + ncols)]
+        initial = tuple(int(v) for v in rng.integers(0, P, 3, dtype=np.uint64))
+        host_cols = [cols[c] for c in range(ncols)]
+        if shift1:
+            host_cols[0] = np.roll(host_cols[0], -shift1)
+        want, want_terminal = Table.scan(kind, host_cols, mask if use_mask else None, constants, initial, before)
+        out, d_terminal = DeviceBuffer(3 * n), DeviceBuffer(3)
+        terminal = (u64 * 3)()
+        ptrs = [d_cols.ptr + 8 * c * n for c in range(ncols)] + [None] * (3 - ncols)
+        flat = [v for c in constants for v in c] + [0] * (12 - 3 * len(constants))
+        _lib.check(lib.bfs_xfe_scan_device(kind, ptrs[0], ptrs[1], ptrs[2], shift1, d_mask.ptr if use_mask else None, n,
+                                           (u64 * 12)(*flat), (u64 * 3)(*initial), 1 if before else 0, out.ptr, n, d_terminal.ptr, terminal, stream))
+        got = out.to_numpy(3 * n).reshape(3, n)
+        assert tuple(int(v) for v in terminal) == want_terminal, (kind, ncols, use_mask, before, shift1)
+        assert tuple(int(v) for v in d_terminal.to_numpy(3)) == want_terminal
+        assert (got == want).all(), (kind, ncols, use_mask, before, shift1)

@@ -293,3 +293,31 @@ def test_generic_degree_bound_cache_agrees_with_the_exact_expansion():
     for table in stark.tables:
         table._degree_bounds("transition", small, [air.X0] * 5)
     assert len(Table._generic_totals) == cached             # crafted values: exact path, nothing new cached
+
+
+def test_threaded_extension_equals_the_sequential_one(monkeypatch):
+    """table.extend_all (worker threads, used for long traces) gives the columns and terminals of plain Table.extend calls"""
+    import numpy as np
+    from stark_brainfuck_amd import air, table as table_module
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    program = VirtualMachine.compile("++>+++<[->[->+>+<<]>>[-<<+>>]<<<]>>.")
+    running_time, inputs, outputs = VirtualMachine.run(program)
+    matrices = VirtualMachine.simulate(program, input_data=list(inputs))
+    rng = np.random.default_rng(3)
+    challenges = [tuple(int(v) for v in rng.integers(1, air.P, 3, dtype=np.uint64)) for _ in range(11)]
+    initials = [tuple(int(v) for v in rng.integers(1, air.P, 3, dtype=np.uint64)) for _ in range(2)]
+    results = []
+    for threaded in (False, True):
+        stark = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs)
+        for t, matrix in zip(stark.tables, (matrices[0], matrices[2], matrices[1], matrices[3], matrices[4])):
+            t.matrix = matrix
+            t.pad()
+        if threaded:
+            monkeypatch.setattr(table_module, "_THREAD_ROWS", 1)
+            table_module.extend_all(stark.tables, challenges, initials)
+        else:
+            for t in stark.tables:
+                t.extend(challenges, initials)
+        results.append(([np.concatenate(t.ext_columns).tobytes() if t.height else b"" for t in stark.tables], stark.get_terminals()))
+    assert results[0] == results[1]
