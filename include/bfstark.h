@@ -303,6 +303,27 @@ int bfs_difference_quotient(const uint64_t* d_lhs, const uint64_t* d_rhs, uint64
 int bfs_combination(const bfs_comb_source* h_sources, uint32_t count, const uint64_t* d_randomizer, const uint64_t* h_randomizer_weight,
                     uint64_t* d_out, uint32_t log_n, uint64_t offset, uint64_t omega, void* stream);
 
+/*
+ * The same sum without materialising the quotients (the production path of BrainfuckStark.prove): nobody opens a quotient
+ * codeword -- the verifier recomputes quotient values from opened trace rows (brainfuck_stark.py:470-560) -- so
+ * bfs_air_combine evaluates one table's constraints at every point, divides by the zerofiers and adds
+ *     sum over the table's base columns, extension columns and quotients s of (wa_s + wb_s x^shift_s) * value_s
+ * to d_acc (three limb planes of n).  h_weights: base_width + ext_width + bfs_air_num_quotients(table) entries in that order.
+ * d_randomizer != NULL: d_acc is initialised to w0 * randomizer first (the first call of a proof); otherwise it accumulates.
+ * bfs_difference_combine adds a permutation argument's term (wa + wb x^shift) (lhs - rhs) / (x - 1).
+ * Shifts must fit 32 bits.  Asynchronous on `stream` (the weights travel in the kernel arguments).
+ */
+typedef struct bfs_comb_weight {
+    uint64_t wa[3], wb[3];
+    uint64_t shift;
+} bfs_comb_weight;
+int bfs_air_combine(int table, const uint64_t* d_base, const uint64_t* d_ext, uint32_t log_n, uint64_t unit_distance, uint64_t height,
+                    uint64_t omicron_inv, uint64_t offset, uint64_t omega, const uint64_t* h_challenges, const uint64_t* h_terminals,
+                    const uint64_t* h_params, const bfs_comb_weight* h_weights, const uint64_t* d_randomizer,
+                    const uint64_t* h_randomizer_weight, uint64_t* d_acc, void* stream);
+int bfs_difference_combine(const uint64_t* d_lhs, const uint64_t* d_rhs, uint32_t log_n, uint64_t offset, uint64_t omega,
+                           const bfs_comb_weight* h_weight, uint64_t* d_acc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

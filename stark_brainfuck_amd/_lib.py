@@ -98,6 +98,9 @@ _SIGNATURES = {
     "bfs_air_quotients": (ci, [ci, vp, vp, vp, u32, u64, u64, u64, u64, u64, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64), vp]),
     "bfs_difference_quotient": (ci, [vp, vp, vp, u32, u64, u64, vp]),
     "bfs_combination": (ci, [vp, u32, vp, ctypes.POINTER(u64), vp, u32, u64, u64, vp]),
+    "bfs_air_combine": (ci, [ci, vp, vp, u32, u64, u64, u64, u64, u64, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64), vp, vp,
+                             ctypes.POINTER(u64), vp, vp]),
+    "bfs_difference_combine": (ci, [vp, vp, u32, u64, u64, vp, vp, vp]),
 }
 
 
@@ -114,6 +117,11 @@ class RowColumn(ctypes.Structure):
 class CombSource(ctypes.Structure):
     """bfs_comb_source (include/bfstark.h)"""
     _fields_ = [("ptr", vp), ("is_ext", u32), ("pad", u32), ("shift", u64), ("wa", u64 * 3), ("wb", u64 * 3)]
+
+class CombWeight(ctypes.Structure):
+    """bfs_comb_weight (include/bfstark.h)"""
+    _fields_ = [("wa", u64 * 3), ("wb", u64 * 3), ("shift", u64)]
+
 
 _lib = None
 

@@ -233,12 +233,16 @@ class BrainfuckStark:
         lap("ext_tree")
 
         # quotients (:203-221)
+        # keep_intermediates (tests): the quotient codewords are written out and summed by bfs_combination, as the reference
+        # does; otherwise they only ever exist in registers (bfs_air_combine below).  Same field elements either way.
         quotient_buffers, quotient_degree_bounds = [], []
         for table in self.tables:
-            quotient_buffers.append((table.all_quotients(domain, None, challenges, terminals), table.num_quotients()))
+            if self.keep_intermediates:
+                quotient_buffers.append((table.all_quotients(domain, None, challenges, terminals), table.num_quotients()))
             quotient_degree_bounds += table.all_quotient_degree_bounds(challenges, terminals)
         for pa in self.permutation_arguments:
-            quotient_buffers.append((pa.quotient(domain), 1))
+            if self.keep_intermediates:
+                quotient_buffers.append((pa.quotient(domain), 1))
             quotient_degree_bounds.append(pa.quotient_degree_bound())
 
         lap("quotients")
@@ -270,27 +274,44 @@ class BrainfuckStark:
         weights_seed = proof_stream.prover_fiat_shamir()
         weights = BrainfuckStark._sample_weights(1 + 2 * (num_base + num_ext + num_quot), weights_seed)
 
-        # sources in the order of the reference's `terms` list (:245-293): base, extension, quotient codewords
-        sources = []
-        for t in self.tables:
-            for c in range(t.base_width):
-                sources.append((t.base_codewords.ptr + 8 * c * n, 0))
-        for t in self.tables:
-            for c in range(t.full_width - t.base_width):
-                sources.append((t.ext_codewords.ptr + 8 * 3 * c * n, 1))
-        for buf, count in quotient_buffers:
-            for q in range(count):
-                sources.append((buf.ptr + 8 * 3 * q * n, 1))
+        # terms in the order of the reference's `terms` list (:245-293): base, extension, quotient codewords; term s has the
+        # weights 1 + 2s, 2 + 2s and is shifted to the common degree bound
         bounds = base_degree_bounds + extension_degree_bounds + quotient_degree_bounds
-        assert len(sources) == len(bounds) and 1 + 2 * len(sources) == len(weights)
-        srcs = (_lib.CombSource * len(sources))()
-        for s, ((ptr, is_ext), bound) in enumerate(zip(sources, bounds)):
-            srcs[s].ptr, srcs[s].is_ext, srcs[s].shift = ptr, is_ext, self.max_degree - bound
-            srcs[s].wa = (_u64 * 3)(*weights[1 + 2 * s])
-            srcs[s].wb = (_u64 * 3)(*weights[2 + 2 * s])
+        assert 1 + 2 * len(bounds) == len(weights)
+        term = [(weights[1 + 2 * s], weights[2 + 2 * s], self.max_degree - bound) for s, bound in enumerate(bounds)]
         combination = XArray.empty(n, xf)
-        _lib.check(lib.bfs_combination(srcs, len(sources), randomizer_codeword.ptr, (_u64 * 3)(*weights[0]), combination.ptr,
-                                       log_n, domain.offset.value, domain.omega.value, stream))
+        if self.keep_intermediates:
+            sources = []
+            for t in self.tables:
+                for c in range(t.base_width):
+                    sources.append((t.base_codewords.ptr + 8 * c * n, 0))
+            for t in self.tables:
+                for c in range(t.full_width - t.base_width):
+                    sources.append((t.ext_codewords.ptr + 8 * 3 * c * n, 1))
+            for buf, count in quotient_buffers:
+                for q in range(count):
+                    sources.append((buf.ptr + 8 * 3 * q * n, 1))
+            assert len(sources) == len(bounds)
+            srcs = (_lib.CombSource * len(sources))()
+            for s, (ptr, is_ext) in enumerate(sources):
+                srcs[s].ptr, srcs[s].is_ext, srcs[s].shift = ptr, is_ext, term[s][2]
+                srcs[s].wa = (_u64 * 3)(*term[s][0])
+                srcs[s].wb = (_u64 * 3)(*term[s][1])
+            _lib.check(lib.bfs_combination(srcs, len(sources), randomizer_codeword.ptr, (_u64 * 3)(*weights[0]), combination.ptr,
+                                           log_n, domain.offset.value, domain.omega.value, stream))
+        else:
+            base_at = ext_at = 0
+            quot_at = num_base + num_ext
+            for k, t in enumerate(self.tables):
+                bw, xw, nq = t.base_width, t.full_width - t.base_width, t.num_quotients()
+                mine = term[base_at:base_at + bw] + term[num_base + ext_at:num_base + ext_at + xw] + term[quot_at:quot_at + nq]
+                t.combine_into(domain, challenges, terminals, mine, combination,
+                               randomizer=randomizer_codeword if k == 0 else None, randomizer_weight=weights[0])
+                base_at, ext_at, quot_at = base_at + bw, ext_at + xw, quot_at + nq
+            for pa in self.permutation_arguments:
+                pa.combine_into(domain, term[quot_at], combination)
+                quot_at += 1
+            assert quot_at == len(term)
 
         if not self.keep_intermediates:
             BrainfuckStark._release(randomizer_polynomial, *[buf for buf, _ in quotient_buffers])

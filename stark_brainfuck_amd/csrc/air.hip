@@ -88,35 +88,20 @@ template <> struct AirShape<2> { static constexpr int BW = airgen::MEMORY_BASE_W
 template <> struct AirShape<3> { static constexpr int BW = airgen::INPUT_BASE_WIDTH, XW = airgen::INPUT_EXT_WIDTH, NB = airgen::INPUT_NUM_BOUNDARY, NT = airgen::INPUT_NUM_TRANSITION, NZ = airgen::INPUT_NUM_TERMINAL; };
 template <> struct AirShape<4> { static constexpr int BW = airgen::OUTPUT_BASE_WIDTH, XW = airgen::OUTPUT_EXT_WIDTH, NB = airgen::OUTPUT_NUM_BOUNDARY, NT = airgen::OUTPUT_NUM_TRANSITION, NZ = airgen::OUTPUT_NUM_TERMINAL; };
 
-template <int TABLE>
-__device__ __forceinline__ void air_eval(const u64* bc, const u64* bn, const Xfe* xc, const Xfe* xn, const AirArgs& a, Xfe* out) {
-    if constexpr (TABLE == 0) airgen::air_processor(bc, bn, xc, xn, a.ch, a.tm, a.pr, out);
-    else if constexpr (TABLE == 1) airgen::air_instruction(bc, bn, xc, xn, a.ch, a.tm, a.pr, out);
-    else if constexpr (TABLE == 2) airgen::air_memory(bc, bn, xc, xn, a.ch, a.tm, a.pr, out);
-    else if constexpr (TABLE == 3) airgen::air_input(bc, bn, xc, xn, a.ch, a.tm, a.pr, out);
-    else airgen::air_output(bc, bn, xc, xn, a.ch, a.tm, a.pr, out);
+template <int TABLE, class Sink>
+__device__ __forceinline__ void air_eval(const u64* bc, const u64* bn, const Xfe* xc, const Xfe* xn, const AirArgs& a, Sink& sink) {
+    if constexpr (TABLE == 0) airgen::air_processor(bc, bn, xc, xn, a.ch, a.tm, a.pr, sink);
+    else if constexpr (TABLE == 1) airgen::air_instruction(bc, bn, xc, xn, a.ch, a.tm, a.pr, sink);
+    else if constexpr (TABLE == 2) airgen::air_memory(bc, bn, xc, xn, a.ch, a.tm, a.pr, sink);
+    else if constexpr (TABLE == 3) airgen::air_input(bc, bn, xc, xn, a.ch, a.tm, a.pr, sink);
+    else airgen::air_output(bc, bn, xc, xn, a.ch, a.tm, a.pr, sink);
 }
 
-template <int TABLE>
-__global__ void __launch_bounds__(256) air_quotient_kernel(const AirArgs a) {
-    typedef AirShape<TABLE> S;
-    constexpr int NQ = S::NB + S::NT + S::NZ;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (u64)gridDim.x * blockDim.x) {
-        u64 j = i + a.unit_distance;
-        if (j >= a.n) j -= a.n;
-        u64 bc[S::BW], bn[S::BW];
-        Xfe xc[S::XW], xn[S::XW];
-#pragma unroll
-        for (int c = 0; c < S::BW; ++c) { bc[c] = a.base[(u64)c * a.n + i]; bn[c] = a.base[(u64)c * a.n + j]; }
-#pragma unroll
-        for (int c = 0; c < S::XW; ++c)
-#pragma unroll
-            for (int l = 0; l < 3; ++l) { xc[c].c[l] = a.ext[(u64)(3 * c + l) * a.n + i]; xn[c].c[l] = a.ext[(u64)(3 * c + l) * a.n + j]; }
-        Xfe v[NQ];
-        air_eval<TABLE>(bc, bn, xc, xn, a, v);
-        const u64 x = gl_mul(a.offset, tw_pow(a.w_lo, a.w_hi, a.lo_bits, i));
-        // zerofier inverses with ONE field inversion (Montgomery's trick over a = x - 1, b = x - omicron^-1, c = x^h - 1):
-        //   boundary 1 / a (table.py:153-155), terminal 1 / b (:253-256), transition b / c (:180-188; 0 for an empty table)
+// zerofier inverses at x with ONE field inversion (Montgomery's trick over a = x - 1, b = x - omicron^-1, c = x^h - 1):
+//   boundary 1 / a (table.py:153-155), terminal 1 / b (:253-256), transition b / c (:180-188; 0 for an empty table)
+struct Zerofiers {
+    u64 boundary, transition, terminal;
+    __device__ __forceinline__ Zerofiers(const AirArgs& a, u64 x) {
         const u64 za = gl_sub(x, 1), xo = gl_sub(x, a.omicron_inv);
         u64 zc = 1;
         if (a.height != 0) {
@@ -127,16 +112,156 @@ __global__ void __launch_bounds__(256) air_quotient_kernel(const AirArgs a) {
         const u64 ab = gl_mul(za, xo);
         const u64 iabc = gl_inv(gl_mul(ab, zc));
         const u64 iab = gl_mul(iabc, zc);
-        const u64 zb = gl_mul(iab, xo);
-        const u64 zz = gl_mul(iab, za);
-        const u64 zt = a.height != 0 ? gl_mul(xo, gl_mul(iabc, ab)) : 0;
+        boundary = gl_mul(iab, xo);
+        terminal = gl_mul(iab, za);
+        transition = a.height != 0 ? gl_mul(xo, gl_mul(iabc, ab)) : 0;
+    }
+    template <int TABLE, int Q>
+    __device__ __forceinline__ u64 of() const {
+        typedef AirShape<TABLE> S;
+        return Q < S::NB ? boundary : (Q < S::NB + S::NT ? transition : terminal);
+    }
+};
+
+// the values leave as soon as the generated code has them: scaled by the zerofier inverse and stored ...
+template <int TABLE>
+struct QuotientStore {
+    u64* out;
+    u64 n, i;
+    Zerofiers z;
+    template <int Q> __device__ __forceinline__ void put(const Xfe& v) {
+        const Xfe r = xfe_scale(v, z.template of<TABLE, Q>());
 #pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            const u64 z = q < S::NB ? zb : (q < S::NB + S::NT ? zt : zz);
-            const Xfe r = xfe_scale(v[q], z);
+        for (int l = 0; l < 3; ++l) out[(u64)(3 * Q + l) * n + i] = r.c[l];
+    }
+    template <int Q> __device__ __forceinline__ void put_base(u64 v) {
+        out[(u64)(3 * Q) * n + i] = gl_mul(v, z.template of<TABLE, Q>());
+        out[(u64)(3 * Q + 1) * n + i] = 0;
+        out[(u64)(3 * Q + 2) * n + i] = 0;
+    }
+};
+
+template <int TABLE>
+__global__ void __launch_bounds__(256) air_quotient_kernel(const AirArgs a) {
+    typedef AirShape<TABLE> S;
+    // one point per thread, no grid-stride loop: a loop would let the compiler hoist the (loop-invariant) challenges and weights out
+    // of it into registers -- hundreds of them
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.n) {
+        u64 j = i + a.unit_distance;
+        if (j >= a.n) j -= a.n;
+        u64 bc[S::BW], bn[S::BW];
+        Xfe xc[S::XW], xn[S::XW];
 #pragma unroll
-            for (int l = 0; l < 3; ++l) a.out[(u64)(3 * q + l) * a.n + i] = r.c[l];
-        }
+        for (int c = 0; c < S::BW; ++c) { bc[c] = a.base[(u64)c * a.n + i]; bn[c] = a.base[(u64)c * a.n + j]; }
+#pragma unroll
+        for (int c = 0; c < S::XW; ++c)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) { xc[c].c[l] = a.ext[(u64)(3 * c + l) * a.n + i]; xn[c].c[l] = a.ext[(u64)(3 * c + l) * a.n + j]; }
+        const u64 x = gl_mul(a.offset, tw_pow(a.w_lo, a.w_hi, a.lo_bits, i));
+        QuotientStore<TABLE> sink{a.out, a.n, i, Zerofiers(a, x)};
+        air_eval<TABLE>(bc, bn, xc, xn, a, sink);
+    }
+}
+
+// ---- quotients folded straight into the non-linear combination ---------------------------------------------------
+// The prover never opens a quotient codeword (the verifier recomputes quotient VALUES from the opened trace rows,
+// brainfuck_stark.py:470-560), so the production path does not write them: one kernel per table evaluates the constraints at a
+// point, divides by the zerofiers and adds the table's share of the combination
+//     sum over its base columns, extension columns and quotients s of (wa_s + wb_s x^shift_s) * value_s
+// to the accumulator -- with the trace values it already holds in registers.  Against air_quotient_kernel + combination_kernel
+// this saves writing and re-reading 60 extension codewords and re-reading the 49 trace columns (13 GB at N = 2^22).
+// x^shift = offset^shift * omega^(i * shift mod n): two table loads and two multiplications instead of a square-and-multiply chain.
+struct CombW {
+    Xfe wa, wb;
+    u64 offset_pow;      // offset^shift
+    u64 shift;
+};
+
+template <int TABLE>
+struct AirCombineArgs {
+    AirArgs a;
+    const u64* randomizer;   // non-null: the accumulator starts from w0 * randomizer (first kernel of a proof)
+    Xfe w0;
+    u64* acc;                // three limb planes of n
+    CombW w[AirShape<TABLE>::BW + AirShape<TABLE>::XW + AirShape<TABLE>::NB + AirShape<TABLE>::NT + AirShape<TABLE>::NZ];
+};
+
+struct ShiftPower {
+    const u64 *lo, *hi;
+    u32 lo_bits;
+    u64 i, mask;
+    // no caching of the last power across terms with equal shifts: the (uniform) branch it needs costs ~100 VGPRs in this kernel
+    __device__ __forceinline__ Xfe weight(const CombW& w) const {
+        const u64 value = gl_mul(w.offset_pow, tw_pow(lo, hi, lo_bits, (i * w.shift) & mask));
+        return xfe_add(w.wa, xfe_scale(w.wb, value));
+    }
+};
+
+// ... or weighted and added to the running sum
+template <int TABLE>
+struct CombineSink {
+    Xfe acc;
+    ShiftPower xp;
+    const CombW* w;          // the quotients' weights (kernel arguments)
+    Zerofiers z;
+    template <int Q> __device__ __forceinline__ void put(const Xfe& v) {
+        acc = xfe_add(acc, xfe_mul(xp.weight(w[Q]), xfe_scale(v, z.template of<TABLE, Q>())));
+    }
+    template <int Q> __device__ __forceinline__ void put_base(u64 v) {
+        acc = xfe_add(acc, xfe_scale(xp.weight(w[Q]), gl_mul(v, z.template of<TABLE, Q>())));
+    }
+};
+
+template <int TABLE>
+__global__ void __launch_bounds__(256) air_combine_kernel(const AirCombineArgs<TABLE> A) {
+    typedef AirShape<TABLE> S;
+    const AirArgs& a = A.a;
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.n) {
+        u64 j = i + a.unit_distance;
+        if (j >= a.n) j -= a.n;
+        u64 bc[S::BW], bn[S::BW];
+        Xfe xc[S::XW], xn[S::XW];
+#pragma unroll
+        for (int c = 0; c < S::BW; ++c) { bc[c] = a.base[(u64)c * a.n + i]; bn[c] = a.base[(u64)c * a.n + j]; }
+#pragma unroll
+        for (int c = 0; c < S::XW; ++c)
+#pragma unroll
+            for (int l = 0; l < 3; ++l) { xc[c].c[l] = a.ext[(u64)(3 * c + l) * a.n + i]; xn[c].c[l] = a.ext[(u64)(3 * c + l) * a.n + j]; }
+        Xfe acc;
+        if (A.randomizer) acc = xfe_mul(A.w0, Xfe{{A.randomizer[i], A.randomizer[a.n + i], A.randomizer[2 * a.n + i]}});
+        else acc = Xfe{{A.acc[i], A.acc[a.n + i], A.acc[2 * a.n + i]}};
+        ShiftPower xp;
+        xp.lo = a.w_lo; xp.hi = a.w_hi; xp.lo_bits = a.lo_bits; xp.i = i; xp.mask = a.n - 1;
+#pragma unroll
+        for (int c = 0; c < S::BW; ++c) acc = xfe_add(acc, xfe_scale(xp.weight(A.w[c]), bc[c]));
+#pragma unroll
+        for (int c = 0; c < S::XW; ++c) acc = xfe_add(acc, xfe_mul(xp.weight(A.w[S::BW + c]), xc[c]));
+        const u64 x = gl_mul(a.offset, tw_pow(a.w_lo, a.w_hi, a.lo_bits, i));
+        CombineSink<TABLE> sink{acc, xp, A.w + S::BW + S::XW, Zerofiers(a, x)};
+        air_eval<TABLE>(bc, bn, xc, xn, a, sink);
+        A.acc[i] = sink.acc.c[0];
+        A.acc[a.n + i] = sink.acc.c[1];
+        A.acc[2 * a.n + i] = sink.acc.c[2];
+    }
+}
+
+// acc += (wa + wb x^shift) * (lhs - rhs) / (x - 1)      (the difference quotient of a permutation argument, folded the same way)
+__global__ void difference_combine_kernel(const u64* lhs, const u64* rhs, u64* acc, u64 n, u64 offset, const u64* w_lo, const u64* w_hi,
+                                          u32 lo_bits, CombW w) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 x = gl_mul(offset, tw_pow(w_lo, w_hi, lo_bits, i));
+        const u64 z = gl_inv(gl_sub(x, 1));
+        const u64 xs = gl_mul(w.offset_pow, tw_pow(w_lo, w_hi, lo_bits, (i * w.shift) & (n - 1)));
+        const Xfe weight = xfe_add(w.wa, xfe_scale(w.wb, xs));
+        Xfe q;
+#pragma unroll
+        for (int l = 0; l < 3; ++l) q.c[l] = gl_mul(gl_sub(lhs[(u64)l * n + i], rhs[(u64)l * n + i]), z);
+        const Xfe r = xfe_add(Xfe{{acc[i], acc[n + i], acc[2 * n + i]}}, xfe_mul(weight, q));
+        acc[i] = r.c[0];
+        acc[n + i] = r.c[1];
+        acc[2 * n + i] = r.c[2];
     }
 }
 
@@ -181,6 +306,8 @@ __global__ void __launch_bounds__(256) combination_kernel(const CombSrc* srcs, u
     }
 }
 
+static u32 grid_per_point(u64 n) { return (u32)((n + 255) / 256); }
+
 static u32 grid_for(u64 n) {
     u64 g = (n + 255) / 256;
     return (u32)(g > 8192 ? 8192 : (g ? g : 1));
@@ -221,14 +348,12 @@ int bfs_poly_support(const uint64_t* d_coeffs, uint64_t stride, uint64_t len, ui
     return BFS_OK;
 }
 
-int bfs_air_quotients(int table, const uint64_t* d_base, const uint64_t* d_ext, uint64_t* d_out, uint32_t log_n, uint64_t unit_distance,
-                      uint64_t height, uint64_t omicron_inv, uint64_t offset, uint64_t omega, const uint64_t* h_challenges,
-                      const uint64_t* h_terminals, const uint64_t* h_params, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (table < 0 || table > 4) { set_error("bfs_air_quotients: table index %d", table); return BFS_ERR_BAD_ARG; }
-    if (height & (height - 1)) { set_error("bfs_air_quotients: table height must be zero or a power of two"); return BFS_ERR_NOT_POW2; }
-    AirArgs a{};
-    a.base = d_base; a.ext = d_ext; a.out = d_out;
+static int fill_air_args(AirArgs& a, int table, const uint64_t* d_base, const uint64_t* d_ext, uint32_t log_n, uint64_t unit_distance,
+                         uint64_t height, uint64_t omicron_inv, uint64_t offset, uint64_t omega, const uint64_t* h_challenges,
+                         const uint64_t* h_terminals, const uint64_t* h_params, const char* who) {
+    if (table < 0 || table > 4) { set_error("%s: table index %d", who, table); return BFS_ERR_BAD_ARG; }
+    if (height & (height - 1)) { set_error("%s: table height must be zero or a power of two", who); return BFS_ERR_NOT_POW2; }
+    a.base = d_base; a.ext = d_ext; a.out = nullptr;
     a.n = 1ull << log_n;
     a.unit_distance = unit_distance % a.n;
     a.height = height;
@@ -239,7 +364,18 @@ int bfs_air_quotients(int table, const uint64_t* d_base, const uint64_t* d_ext, 
     for (int i = 0; i < 11; ++i) a.ch[i] = xfe_from(h_challenges + 3 * i);
     for (int i = 0; i < 5; ++i) a.tm[i] = xfe_from(h_terminals + 3 * i);
     a.pr[0] = h_params ? xfe_from(h_params) : Xfe{{1, 0, 0}};
-    const u32 grid = grid_for(a.n);
+    return BFS_OK;
+}
+
+int bfs_air_quotients(int table, const uint64_t* d_base, const uint64_t* d_ext, uint64_t* d_out, uint32_t log_n, uint64_t unit_distance,
+                      uint64_t height, uint64_t omicron_inv, uint64_t offset, uint64_t omega, const uint64_t* h_challenges,
+                      const uint64_t* h_terminals, const uint64_t* h_params, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    AirArgs a{};
+    BFS_TRY(fill_air_args(a, table, d_base, d_ext, log_n, unit_distance, height, omicron_inv, offset, omega, h_challenges, h_terminals,
+                          h_params, "bfs_air_quotients"));
+    a.out = d_out;
+    const u32 grid = grid_per_point(a.n);
     switch (table) {
         case 0: hipLaunchKernelGGL(air_quotient_kernel<0>, dim3(grid), dim3(256), 0, stream, a); break;
         case 1: hipLaunchKernelGGL(air_quotient_kernel<1>, dim3(grid), dim3(256), 0, stream, a); break;
@@ -247,6 +383,70 @@ int bfs_air_quotients(int table, const uint64_t* d_base, const uint64_t* d_ext, 
         case 3: hipLaunchKernelGGL(air_quotient_kernel<3>, dim3(grid), dim3(256), 0, stream, a); break;
         default: hipLaunchKernelGGL(air_quotient_kernel<4>, dim3(grid), dim3(256), 0, stream, a); break;
     }
+    BFS_HIP(hipGetLastError());
+    return BFS_OK;
+}
+
+}  // extern "C"
+
+static CombW comb_weight(const bfs_comb_weight& w, u64 offset) {
+    CombW r;
+    r.wa = xfe_from(w.wa); r.wb = xfe_from(w.wb);
+    r.shift = w.shift;
+    r.offset_pow = gl_pow(offset, w.shift);
+    return r;
+}
+
+template <int TABLE>
+static int air_combine_launch(const AirArgs& a, const bfs_comb_weight* h_weights, const uint64_t* d_randomizer, const uint64_t* h_w0,
+                              uint64_t* d_acc, hipStream_t stream) {
+    typedef AirShape<TABLE> S;
+    AirCombineArgs<TABLE> A{};
+    A.a = a;
+    A.randomizer = d_randomizer;
+    A.w0 = d_randomizer ? xfe_from(h_w0) : Xfe{{0, 0, 0}};
+    A.acc = d_acc;
+    constexpr int count = S::BW + S::XW + S::NB + S::NT + S::NZ;
+    for (int k = 0; k < count; ++k) {
+        if (h_weights[k].shift >> 32) { set_error("bfs_air_combine: shift does not fit 32 bits"); return BFS_ERR_BAD_ARG; }
+        A.w[k] = comb_weight(h_weights[k], a.offset);
+    }
+    static_assert(sizeof(A) <= 4096, "kernel arguments");
+    hipLaunchKernelGGL(air_combine_kernel<TABLE>, dim3(grid_per_point(a.n)), dim3(256), 0, stream, A);
+    BFS_HIP(hipGetLastError());
+    return BFS_OK;
+}
+
+extern "C" {
+
+int bfs_air_combine(int table, const uint64_t* d_base, const uint64_t* d_ext, uint32_t log_n, uint64_t unit_distance, uint64_t height,
+                    uint64_t omicron_inv, uint64_t offset, uint64_t omega, const uint64_t* h_challenges, const uint64_t* h_terminals,
+                    const uint64_t* h_params, const bfs_comb_weight* h_weights, const uint64_t* d_randomizer,
+                    const uint64_t* h_randomizer_weight, uint64_t* d_acc, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (log_n > 32) { set_error("bfs_air_combine: log_n"); return BFS_ERR_BAD_ARG; }
+    AirArgs a{};
+    BFS_TRY(fill_air_args(a, table, d_base, d_ext, log_n, unit_distance, height, omicron_inv, offset, omega, h_challenges, h_terminals,
+                          h_params, "bfs_air_combine"));
+    switch (table) {
+        case 0: return air_combine_launch<0>(a, h_weights, d_randomizer, h_randomizer_weight, d_acc, stream);
+        case 1: return air_combine_launch<1>(a, h_weights, d_randomizer, h_randomizer_weight, d_acc, stream);
+        case 2: return air_combine_launch<2>(a, h_weights, d_randomizer, h_randomizer_weight, d_acc, stream);
+        case 3: return air_combine_launch<3>(a, h_weights, d_randomizer, h_randomizer_weight, d_acc, stream);
+        default: return air_combine_launch<4>(a, h_weights, d_randomizer, h_randomizer_weight, d_acc, stream);
+    }
+}
+
+int bfs_difference_combine(const uint64_t* d_lhs, const uint64_t* d_rhs, uint32_t log_n, uint64_t offset, uint64_t omega,
+                           const bfs_comb_weight* h_weight, uint64_t* d_acc, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const u64 n = 1ull << log_n;
+    if (h_weight->shift >> 32) { set_error("bfs_difference_combine: shift does not fit 32 bits"); return BFS_ERR_BAD_ARG; }
+    const u64 *lo, *hi;
+    u32 lo_bits;
+    BFS_TRY(ntt_power_tables(omega, log_n, &lo, &hi, &lo_bits));
+    hipLaunchKernelGGL(difference_combine_kernel, dim3(grid_for(n)), dim3(256), 0, stream, d_lhs, d_rhs, d_acc, n, offset, lo, hi, lo_bits,
+                       comb_weight(*h_weight, offset));
     BFS_HIP(hipGetLastError());
     return BFS_OK;
 }

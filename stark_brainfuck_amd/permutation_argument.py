@@ -1,6 +1,8 @@
 """Permutation argument between two tables -- mirror of the reference's `permutation_argument.py`
 (/root/reference/code/permutation_argument.py:4-34): the difference of two running-product columns must vanish at
 the first row, so (lhs - rhs) / (x - 1) is a polynomial."""
+import ctypes
+
 from . import _lib
 from .device import DeviceBuffer, current_stream
 
@@ -19,6 +21,17 @@ class PermutationArgument:
         _lib.check(_lib.load().bfs_difference_quotient(lt.ext_codeword_ptr(self.lhs[1]), rt.ext_codeword_ptr(self.rhs[1]), out.ptr,
                                                        n.bit_length() - 1, fri_domain.offset.value, fri_domain.omega.value, current_stream()))
         return out
+
+    def combine_into(self, fri_domain, weight, accumulator):
+        """bfs_difference_combine: accumulator += (wa + wb x^shift) * (lhs - rhs) / (x - 1) without writing the quotient codeword"""
+        n = fri_domain.length
+        wa, wb, shift = weight
+        w = _lib.CombWeight()
+        w.wa, w.wb, w.shift = (ctypes.c_uint64 * 3)(*wa), (ctypes.c_uint64 * 3)(*wb), shift
+        lt, rt = self.all_tables[self.lhs[0]], self.all_tables[self.rhs[0]]
+        _lib.check(_lib.load().bfs_difference_combine(lt.ext_codeword_ptr(self.lhs[1]), rt.ext_codeword_ptr(self.rhs[1]), n.bit_length() - 1,
+                                                      fri_domain.offset.value, fri_domain.omega.value, ctypes.byref(w), accumulator.ptr,
+                                                      current_stream()))
 
     def evaluate_difference(self, points):
         from .air import xsub

@@ -424,6 +424,26 @@ class Table:
                                          domain.offset.value, domain.omega.value, ch, tm, pr, stream))
         return out
 
+    def combine_into(self, domain, challenges, terminals, weights, accumulator, randomizer=None, randomizer_weight=None):
+        """bfs_air_combine: add this table's share of the non-linear combination -- its base columns, extension columns and
+        quotients (in that order; weights: list of (wa, wb, shift)) -- to `accumulator` (XArray) without writing the quotient
+        codewords.  randomizer (XArray) given: the accumulator is initialised to randomizer_weight * randomizer first."""
+        lib, stream = _lib.load(), current_stream()
+        n = domain.length
+        assert len(weights) == self.full_width - self.base_width + self.base_width + self.num_quotients()
+        ws = (_lib.CombWeight * len(weights))()
+        for w, (wa, wb, shift) in zip(ws, weights):
+            w.wa, w.wb, w.shift = (_u64 * 3)(*wa), (_u64 * 3)(*wb), shift
+        ch = (_u64 * 33)(*[v for c in challenges for v in c])
+        tm = (_u64 * 15)(*[v for t in terminals for v in t])
+        params = self.air_params(challenges)
+        pr = (_u64 * 3)(*params[0]) if params else None
+        omicron_inv = pow(self.omicron.value, P - 2, P)
+        _lib.check(lib.bfs_air_combine(self.table_index, self.base_codewords.ptr, self.ext_codewords.ptr, n.bit_length() - 1,
+                                       self.unit_distance(n), self.height, omicron_inv, domain.offset.value, domain.omega.value, ch, tm, pr,
+                                       ws, randomizer.ptr if randomizer is not None else None,
+                                       (_u64 * 3)(*randomizer_weight) if randomizer is not None else None, accumulator.ptr, stream))
+
     _generic_totals = {}      # (table, kind, which challenges / terminals / parameters are zero) -> total degrees per constraint
 
     def _constraint_total_degrees(self, kind, challenges, terminals, params):

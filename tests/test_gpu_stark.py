@@ -86,6 +86,30 @@ def test_prove_matches_reference(name, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", NAMES)
+def test_production_path_writes_the_reference_proof(name, monkeypatch):
+    """the default prover (quotients folded into the combination in registers, bfs_air_combine; buffers handed back to the pool as it
+    goes) on the reference's randomness: the proof must be the reference's, byte for byte -- and again on the same object"""
+    from stark_brainfuck_amd import brainfuck_stark, salted_merkle, table
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    g = json.load(open(os.path.join(GOLDEN, "stark_%s.json" % name)))
+    program = VirtualMachine.compile(g["program"])
+    running_time, input_symbols, output_symbols = VirtualMachine.run(program, input_data=list(g["input"]))
+    matrices = VirtualMachine.simulate(program, input_data=list(input_symbols))
+    stark = BrainfuckStark(running_time, len(matrices[1]), program, input_symbols, output_symbols)
+    assert stark.keep_intermediates is False
+    for attempt in range(2):
+        stream = Stream(name.encode())
+        for mod in (brainfuck_stark, salted_merkle, table):
+            monkeypatch.setattr(mod, "urandom", stream)
+        proof = stark.prove(program, *matrices)
+        assert stream.pos == g["urandom_bytes"]
+        assert len(proof) == g["proof_len"] and hashlib.sha256(proof).hexdigest() == g["proof_sha256"], attempt
+        assert "quotient_buffers" not in stark._last
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
 def test_verify_accepts_reference_proofs_and_rejects_tampering(name):
     """the verifier mirror (brainfuck_stark.py:343-579) on proofs written by the reference itself"""
     from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
