@@ -99,85 +99,76 @@ __global__ void __launch_bounds__(64) row_leaves_kernel(const RowArgs a) {
     }
     const u32 tuple_len = tp->tuple_const_bytes + int_bytes;
     const u32 total = tuple_len + tp->salt_bytes;
-    // pass 2: expand the template into the block buffer, compressing as it fills
+    // pass 2: expand the template block by block.  Every lane fills its 128-byte block, then the wave compresses together:
+    // rows of one pattern differ only in the lengths of their integers, so the lanes drift apart by a few bytes -- with the
+    // compression inside the byte loop each lane would reach it in a different iteration and the wave would run the 2000
+    // instructions of a compression several times over with partial masks.
     u64 h[8];
     blake2b_init(h);
     u64 acc = 0;            // funnel: pending bytes (< 8)
-    u32 fill = 0, wpos = 0;
-    u64 absorbed = 0;
+    u32 fill = 0;
     u32 s = 0, w = 0;       // current segment, word within it
-    while (s < tp->num_segs) {
-        const RowSeg sg = a.segs[tp->first_seg + s];
-        u64 data = 0;
-        u32 nb = 0;
-        if (sg.kind == SEG_CONST) {
-            data = a.pool[sg.a + w];
-            const u32 left = sg.b - 8 * w;
-            nb = left < 8 ? left : 8;
-            if (nb < 8) data &= (1ull << (8 * nb)) - 1;
-            if (8 * (w + 1) >= sg.b) { ++s; w = 0; } else ++w;
-        } else if (sg.kind == SEG_INT) {
-            const u64 v = a.columns[sg.a][(u64)sg.b * a.n + i];
-            u64 lo, hi = 0;
-            u32 len;
-            if (v < (1ull << 8)) { lo = 0x4b | (v << 8); len = 2; }
-            else if (v < (1ull << 16)) { lo = 0x4d | (v << 8); len = 3; }
-            else if (v < (1ull << 31)) { lo = 0x4a | (v << 8); len = 5; }
-            else {
-                const u32 nn = (64 - (u32)__builtin_clzll(v)) / 8 + 1;
-                lo = 0x8a | ((u64)nn << 8) | (v << 16);
-                hi = v >> 48;
-                len = 2 + nn;
+    const u32 nseg = tp->num_segs;
+    const u32 nblocks = total ? (total + 127) / 128 : 1;
+    for (u32 b = 0; b < nblocks; ++b) {
+        u32 wpos = 0;
+        while (wpos < 16 && s < nseg) {
+            const RowSeg sg = a.segs[tp->first_seg + s];
+            u64 data = 0;
+            u32 nb = 0;
+            if (sg.kind == SEG_CONST) {
+                data = a.pool[sg.a + w];
+                const u32 left = sg.b - 8 * w;
+                nb = left < 8 ? left : 8;
+                if (nb < 8) data &= (1ull << (8 * nb)) - 1;
+                if (8 * (w + 1) >= sg.b) { ++s; w = 0; } else ++w;
+            } else if (sg.kind == SEG_INT) {
+                const u64 v = a.columns[sg.a][(u64)sg.b * a.n + i];
+                u64 lo, hi = 0;
+                u32 len;
+                if (v < (1ull << 8)) { lo = 0x4b | (v << 8); len = 2; }
+                else if (v < (1ull << 16)) { lo = 0x4d | (v << 8); len = 3; }
+                else if (v < (1ull << 31)) { lo = 0x4a | (v << 8); len = 5; }
+                else {
+                    const u32 nn = (64 - (u32)__builtin_clzll(v)) / 8 + 1;
+                    lo = 0x8a | ((u64)nn << 8) | (v << 16);
+                    hi = v >> 48;
+                    len = 2 + nn;
+                }
+                if (w == 0) { data = lo; nb = len < 8 ? len : 8; if (len > 8) w = 1; else { ++s; } }
+                else { data = hi; nb = len - 8; ++s; w = 0; }
+            } else if (sg.kind == SEG_FRAMELEN) {
+                data = (u64)tuple_len - 11;
+                nb = 8;
+                ++s;
+            } else {
+                data = a.salts[3 * i + w];
+                nb = 8;
+                if (w == 2) { ++s; w = 0; } else ++w;
             }
-            if (w == 0) { data = lo; nb = len < 8 ? len : 8; if (len > 8) w = 1; else { ++s; } }
-            else { data = hi; nb = len - 8; ++s; w = 0; }
-        } else if (sg.kind == SEG_FRAMELEN) {
-            data = (u64)tuple_len - 11;
-            nb = 8;
-            ++s;
-        } else {
-            data = a.salts[3 * i + w];
-            nb = 8;
-            if (w == 2) { ++s; w = 0; } else ++w;
+            // funnel the nb bytes into 64-bit words of the block buffer
+            acc |= data << (8 * fill);
+            const u32 nf = fill + nb;
+            if (nf >= 8) {
+                blk[wpos * 64 + lane] = acc;
+                ++wpos;
+                acc = fill ? (data >> (8 * (8 - fill))) : 0;
+                fill = nf - 8;
+            } else {
+                fill = nf;
+            }
         }
-        // funnel the nb bytes into 64-bit words of the block buffer
-        acc |= data << (8 * fill);
-        const u32 nf = fill + nb;
-        if (nf >= 8) {
-            if (wpos == 16) {       // the buffer is full and more data follows: not the last block
-                u64 m[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) m[j] = blk[j * 64 + lane];
-                absorbed += 128;
-                blake2b_compress(h, m, absorbed, false);
-                wpos = 0;
-            }
+        if (wpos < 16 && fill) {      // end of the input: the pending bytes, zero padded
             blk[wpos * 64 + lane] = acc;
             ++wpos;
-            acc = fill ? (data >> (8 * (8 - fill))) : 0;
-            fill = nf - 8;
-        } else {
-            fill = nf;
+            acc = 0;
+            fill = 0;
         }
-    }
-    // last block: pending bytes, zero padding, total length as the counter
-    if (fill) {
-        if (wpos == 16) {
-            u64 m[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) m[j] = blk[j * 64 + lane];
-            absorbed += 128;
-            blake2b_compress(h, m, absorbed, false);
-            wpos = 0;
-        }
-        blk[wpos * 64 + lane] = acc;
-        ++wpos;
-    }
-    {
         u64 m[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) m[j] = (u32)j < wpos ? blk[j * 64 + lane] : 0;
-        blake2b_compress(h, m, (u64)total, true);
+        const bool last = b + 1 == nblocks;
+        blake2b_compress(h, m, last ? (u64)total : (u64)128 * (b + 1), last);
     }
     u64* out = a.digests + i * 8;
 #pragma unroll

@@ -158,12 +158,11 @@ class Fri:
                 out = (_u64 * self.num_colinearity_tests)()
                 _lib.check(lib.bfs_fri_query(session, transcript.handle, self.num_colinearity_tests, out, stream))
                 top = [int(x) for x in out]
-            fresh = [transcript.to_python(lib.bfs_ps_object_at(transcript.handle, i), self.field) for i in range(before, transcript.num_objects())]
-            if hasattr(proof_stream, "_adopt"):
-                proof_stream._adopt(transcript, fresh)
+            if hasattr(proof_stream, "_adopt_lazy"):
+                proof_stream._adopt_lazy(transcript, before, transcript.num_objects(), self.field)
             else:
-                for o in fresh:
-                    proof_stream.push(o)
+                for i in range(before, transcript.num_objects()):
+                    proof_stream.push(transcript.to_python(lib.bfs_ps_object_at(transcript.handle, i), self.field))
             rounds = []
             for r in range(lib.bfs_fri_session_rounds(session)):
                 cw, nodes = ctypes.c_void_p(), ctypes.c_void_p()

@@ -189,8 +189,27 @@ def reference_pickle(obj):
 
 class ProofStream:
     def __init__(self):
-        self.objects = []
+        self._objects = []
+        self._pending = None      # (transcript, first, last, field): objects native code appended, not yet turned into Python objects
         self.read_index = 0
+
+    @property
+    def objects(self):
+        """the list of pushed objects, as in the reference.  Objects appended by native code (Fri.prove writes ~10^3 of them)
+        become Python objects only when somebody looks: the prover itself serialises and hashes through the native transcript."""
+        if self._pending is not None:
+            transcript, first, last, field = self._pending
+            self._pending = None
+            new = [transcript.to_python(transcript.lib.bfs_ps_object_at(transcript.handle, i), field) for i in range(first, last)]
+            self._objects += new
+            if getattr(self, "_cached", None) is transcript:
+                self._cached_ids += [id(o) for o in new]
+        return self._objects
+
+    @objects.setter
+    def objects(self, value):
+        self._pending = None
+        self._objects = value
 
     def push(self, obj):
         self.objects += [obj]
@@ -207,6 +226,8 @@ class ProofStream:
         pushed so far); it is rebuilt from scratch whenever an earlier choice could have been wrong: the list was edited
         in place, an extension field shows up after bare base elements, or a coefficient object turns out to be shared
         with an element that was already written in compact form."""
+        if count is None and self._pending is not None and getattr(self, "_cached", None) is self._pending[0]:
+            return self._cached                   # the cached transcript is ahead of the Python list, and complete
         if count is not None and count != len(self.objects):
             return self._build(self.objects[:count])
         t = getattr(self, "_cached", None)
@@ -247,6 +268,13 @@ class ProofStream:
         self.objects += new_objects
         if getattr(self, "_cached", None) is transcript:
             self._cached_ids += [id(o) for o in new_objects]
+
+    def _adopt_lazy(self, transcript, first, last, field):
+        """like _adopt, for objects first..last-1 of the cached transcript, without building them"""
+        if getattr(self, "_cached", None) is not transcript or self._pending is not None:
+            self._adopt(transcript, [transcript.to_python(transcript.lib.bfs_ps_object_at(transcript.handle, i), field) for i in range(first, last)])
+        else:
+            self._pending = (transcript, first, last, field)
 
     def serialize(self):
         return self._native().serialize()
