@@ -11,13 +11,15 @@ Where the time goes in the reference, and where it goes here:
 Scalar steps (padding, running products, Fiat-Shamir sampling, transcript assembly) stay on the host.
 """
 import ctypes
+
+import numpy as np
 from hashlib import blake2b
 from os import urandom          # module-level on purpose: tests patch `brainfuck_stark.urandom` for determinism
 
 from . import _lib, air
 from .algebra import BaseField, BaseFieldElement
 from .arrays import XArray
-from .device import current_stream, gather, synchronize
+from .device import GatherBatch, current_stream, gather, synchronize
 from .evaluation_argument import EvaluationArgument, ProgramEvaluationArgument
 from .extension_field import ExtensionField, ExtensionFieldElement
 from .fri import Fri
@@ -181,9 +183,13 @@ class BrainfuckStark:
         lap("base_lde")
         f2 = BrainfuckStark.field
 
-        def base_row(i):         # only opened rows are ever read back: one gather per row
-            words = gather([(randomizer_codeword.ptr + 8 * i, 3, randomizer_codeword.stride)]
-                           + [(t.base_codewords.ptr + 8 * i, t.base_width, n) for t in self.tables])
+        fetched_base, fetched_ext = {}, {}      # row -> words, filled by the batched gather of the openings
+
+        def base_requests(i):
+            return [(randomizer_codeword.ptr + 8 * i, 3, randomizer_codeword.stride)] + [(t.base_codewords.ptr + 8 * i, t.base_width, n) for t in self.tables]
+
+        def base_row(i):         # only opened rows are ever read back
+            words = fetched_base[i] if i in fetched_base else gather(base_requests(i))
             return tuple([xf.from_limbs([int(v) for v in words[:3]])] + [BaseFieldElement(int(v), f2) for v in words[3:]])
         base_columns = [(randomizer_codeword.ptr, True, 0)]
         for t in self.tables:
@@ -210,8 +216,11 @@ class BrainfuckStark:
         internal = xf.modulus.coefficients[0].field
         shared = [dict() for _ in moduli]          # per column: i mod modulus -> the coefficient objects of that class
 
+        def ext_requests(i):
+            return [(t.ext_codewords.ptr + 8 * i, 3 * (t.full_width - t.base_width), n) for t in self.tables]
+
         def ext_row(i):
-            words = gather([(t.ext_codewords.ptr + 8 * i, 3 * (t.full_width - t.base_width), n) for t in self.tables])
+            words = fetched_ext[i] if i in fetched_ext else gather(ext_requests(i))
             row = []
             for c in range(num_ext_columns):
                 limbs = [int(v) for v in words[3 * c:3 * c + 3]]
@@ -322,6 +331,20 @@ class BrainfuckStark:
         proof_stream.push(combination_tree.root())
         indices = BrainfuckStark.sample_indices(self.security_level, proof_stream.prover_fiat_shamir(), n)
         unit_distances = list(set(table.unit_distance(n) for table in self.tables))
+        # everything the openings read from HBM -- rows, salts, authentication paths, combination leaves -- in one round trip
+        rows = list(dict.fromkeys((index + distance) % n for index in indices for distance in [0] + unit_distances))
+        batch = GatherBatch()
+        row_tickets = {i: ([batch.add(*r) for r in base_requests(i)], [batch.add(*r) for r in ext_requests(i)]) for i in rows}
+        leaf_tickets = {index: batch.add(combination.ptr + 8 * index, 3, combination.stride) for index in dict.fromkeys(indices)}
+        stores = [base_tree.prefetch_salts(rows, batch), extension_tree.prefetch_salts(rows, batch),
+                  base_tree.prefetch_paths(rows, batch), extension_tree.prefetch_paths(rows, batch),
+                  combination_tree.prefetch_paths(indices, batch)]
+        batch.run()
+        for store in stores:
+            store()
+        for i, (tb, te) in row_tickets.items():
+            fetched_base[i] = np.concatenate([batch.words(t) for t in tb])
+            fetched_ext[i] = np.concatenate([batch.words(t) for t in te])
         for index in indices:
             for distance in [0] + unit_distances:
                 idx = (index + distance) % n
@@ -332,7 +355,7 @@ class BrainfuckStark:
         known = {}
         for index in indices:
             if index not in known:                   # the same index twice is the same leaf object twice
-                known[index] = xf.from_limbs([int(v) for v in gather([(combination.ptr + 8 * index, 3, combination.stride)])])
+                known[index] = xf.from_limbs([int(v) for v in batch.words(leaf_tickets[index])])
             leaf = known[index]
             proof_stream.push(leaf)
             proof_stream.push(combination_tree.open(index))

@@ -62,6 +62,27 @@ class DeviceBuffer:
             pass
 
 
+class GatherBatch:
+    """scattered reads collected first and fetched in ONE round trip: add() returns a ticket, run() gathers, words(ticket) gives
+    that request's words.  (A proof opens ~10 rows of three trees; one gather per row and path costs ~30 us each.)"""
+
+    def __init__(self):
+        self._requests, self._spans, self._out = [], [], None
+
+    def add(self, ptr, nwords, stride):
+        start = self._spans[-1][1] if self._spans else 0
+        self._requests.append((ptr, nwords, stride))
+        self._spans.append((start, start + nwords))
+        return len(self._spans) - 1
+
+    def run(self, stream=None):
+        self._out = gather(self._requests, stream)
+
+    def words(self, ticket):
+        lo, hi = self._spans[ticket]
+        return self._out[lo:hi]
+
+
 def pinned_empty(shape):
     """uninitialised uint64 numpy array in pinned host memory from the library's pool (bfs_host_alloc); the memory goes
     back to the pool when the array and every view of it are gone.  H2D copies from it run at link speed."""

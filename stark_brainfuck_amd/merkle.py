@@ -146,6 +146,24 @@ class Merkle:
             path.append(self._node_cache[sib])
         return path
 
+    def prefetch_paths(self, indices, batch):
+        """queue the digests that open(i) will need for every i in `indices` on a GatherBatch; returns a function to call after
+        batch.run() that stores them (open() then finds everything in the cache)"""
+        if self.depth == 0 or self._nodes_host is not None:
+            return lambda: None
+        wanted, tickets = [], []
+        for index in indices:
+            for k in _walk((1 << self.depth) | index):
+                sib = k ^ 1
+                if sib not in self._node_cache and sib not in wanted and sib < self._npo2 + self.num_leafs:
+                    wanted.append(sib)
+                    tickets.append(batch.add(self._nodes.ptr + 64 * sib, 8, 1))
+
+        def store():
+            for sib, ticket in zip(wanted, tickets):
+                self._node_cache[sib] = batch.words(ticket).tobytes()
+        return store
+
     @staticmethod
     def verify(root, index, path, element):
         """verifier side (host, hashlib -- as in the reference, merkle.py:54-63)."""

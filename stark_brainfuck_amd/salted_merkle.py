@@ -85,9 +85,13 @@ class ZippedSaltedMerkle(SaltedMerkle):
             _lib.check(lib.bfs_random_fill(urandom(32), self._salts.ptr, words, stream))
             _lib.check(lib.bfs_merkle_build_rows(cols, len(columns), n, self._salts.ptr, 1, self._nodes.ptr, stream))
 
+            self._salt_cache = {}
+
             def salt_of(i):
                 from .device import gather
-                return gather([(self._salts.ptr + 24 * i, 3, 1)]).tobytes()
+                if i not in self._salt_cache:
+                    self._salt_cache[i] = gather([(self._salts.ptr + 24 * i, 3, 1)]).tobytes()
+                return self._salt_cache[i]
         else:
             salts = urandom(24 * n)                      # the same bytes as n calls of urandom(24)
             keep = ctypes.create_string_buffer(salts, len(salts))
@@ -96,3 +100,16 @@ class ZippedSaltedMerkle(SaltedMerkle):
             def salt_of(i):
                 return salts[24 * i:24 * i + 24]
         self._leafs = _LazyLeafs(n, make_row, salt_of)
+
+    def prefetch_salts(self, indices, batch):
+        """queue the salts of rows `indices` on a GatherBatch (device-made salts only); returns the function that stores them"""
+        cache = getattr(self, "_salt_cache", None)
+        if cache is None:
+            return lambda: None
+        wanted = [i for i in dict.fromkeys(indices) if i not in cache]
+        tickets = [batch.add(self._salts.ptr + 24 * i, 3, 1) for i in wanted]
+
+        def store():
+            for i, ticket in zip(wanted, tickets):
+                cache[i] = batch.words(ticket).tobytes()
+        return store
