@@ -226,6 +226,10 @@ int bfs_fri_query(void* session, void* ps, uint32_t num_colinearity_tests, uint6
  * `element_handle`: BrainfuckStark.prove pushes leaves of the combination codeword before Fri.prove opens the same
  * list (brainfuck_stark.py:325-333), and pickle writes a repeated object as a back-reference.  Call before bfs_fri_query. */
 int bfs_fri_session_alias(void* session, void* ps, uint32_t round, uint64_t index, uint64_t element_handle);
+/* Before bfs_fri_commit: the caller already holds the Merkle tree of the input codeword (2n digests in bfs_merkle_build_xfe's layout,
+ * with its root) -- BrainfuckStark.prove commits to the combination codeword and then hands the same codeword to FRI, whose round 0
+ * would hash it again (brainfuck_stark.py:301, fri.py:108).  The nodes must stay valid while the session is used. */
+int bfs_fri_session_round0_tree(void* session, const uint8_t* d_nodes, const uint8_t h_root[64]);
 int bfs_fri_prove(void* ps, const uint64_t* d_codeword, uint64_t limb_stride, uint32_t log_n, uint64_t offset, uint64_t omega,
                   uint32_t expansion_factor, uint32_t num_colinearity_tests, uint64_t* h_top_level_indices, void* stream);
 /* wall-clock breakdown (ms) of the last commit/query on the calling thread: rounds, last codeword, Fiat-Shamir + sampling,

@@ -85,6 +85,7 @@ _SIGNATURES = {
     "bfs_fri_commit": (ci, [vp, vp, vp, u64, u32, u64, u64, u32, vp]),
     "bfs_fri_query": (ci, [vp, vp, u32, ctypes.POINTER(u64), vp]),
     "bfs_fri_session_alias": (ci, [vp, vp, u32, u64, u64]),
+    "bfs_fri_session_round0_tree": (ci, [vp, vp, ctypes.c_char_p]),
     "bfs_fri_prove": (ci, [vp, vp, u64, u32, u64, u64, u32, u32, ctypes.POINTER(u64), vp]),
     "bfs_fri_last_timing": (None, [ctypes.POINTER(ctypes.c_double)]),
     "bfs_fri_session_rounds": (u32, [vp]),

@@ -128,7 +128,10 @@ class TableAir:
     def terminal(self): raise NotImplementedError
 
     def all(self):
-        return [("boundary", self.boundary()), ("transition", self.transition()), ("terminal", self.terminal())]
+        """the three constraint lists; built once (the graphs are symbolic in challenges, terminals and parameters)"""
+        if getattr(self, "_all", None) is None:
+            self._all = [("boundary", self.boundary()), ("transition", self.transition()), ("terminal", self.terminal())]
+        return self._all
 
 
 class ProcessorAir(TableAir):

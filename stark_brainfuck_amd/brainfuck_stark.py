@@ -361,18 +361,18 @@ class BrainfuckStark:
             proof_stream.push(combination_tree.open(index))
 
         if not self.keep_intermediates:
-            BrainfuckStark._release(base_tree, extension_tree, combination_tree, randomizer_codeword, *self.tables)
-            base_tree = extension_tree = combination_tree = None
+            BrainfuckStark._release(base_tree, extension_tree, randomizer_codeword, *self.tables)
+            base_tree = extension_tree = None
         lap("openings")
         # low-degree test of the combination codeword (:335-336)
-        self.fri.prove(combination, proof_stream, known_leafs=known)
+        self.fri.prove(combination, proof_stream, known_leafs=known, round0_tree=combination_tree)   # round 0 commits to this very tree
         self._last = {"challenges": challenges, "terminals": terminals, "indices": indices, "weights_seed": weights_seed,
                       "quotient_degree_bounds": quotient_degree_bounds}
         if self.keep_intermediates:
             self._last.update({"base_tree": base_tree, "extension_tree": extension_tree, "combination_tree": combination_tree,
                                "quotient_buffers": quotient_buffers, "combination": combination})
         else:
-            BrainfuckStark._release(combination)
+            BrainfuckStark._release(combination, combination_tree)
         lap("fri")
         proof = proof_stream.serialize()
         lap("serialize")

@@ -113,6 +113,8 @@ struct FriSession {
     std::unordered_map<Key, rp::Ref, KeyHash> elements, nodes;
     std::vector<uint64_t> last_handles;
     hipStream_t block_stream = nullptr;
+    const u64* round0_nodes = nullptr;     // a tree over the input codeword that the caller has already built (bfs_fri_session_round0_tree)
+    unsigned char round0_root[64];
     ~FriSession() { if (block) (void)device_release(block, block_stream); }
 };
 
@@ -163,7 +165,10 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
     u64 g = offset;
     for (u32 r = 0; r < R; ++r) {
         FriRound& fr = S.rounds[r];
-        if (fr.length >= 2) {
+        if (r == 0 && S.round0_nodes) {
+            fr.nodes = (u64*)S.round0_nodes;          // the STARK prover has just committed to this very codeword (brainfuck_stark.py:301 / fri.py:108)
+            memcpy(fr.root, S.round0_root, 64);
+        } else if (fr.length >= 2) {
             // the tree kernel writes the root straight into pinned host memory; poll the sequence flag instead of
             // paying a copy command + stream synchronisation per round
             const u64 seq = ++S.mailbox.seq;
@@ -395,6 +400,13 @@ int bfs_gather(const bfs_gather_request* requests, uint32_t count, uint64_t* h_o
     BFS_HIP(hipGetLastError());
     BFS_HIP(hipStreamSynchronize(stream));
     memcpy(h_out, g_res_area.host, nwords * sizeof(u64));
+    return BFS_OK;
+}
+
+int bfs_fri_session_round0_tree(void* session, const uint8_t* d_nodes, const uint8_t h_root[64]) {
+    FriSession* S = (FriSession*)session;
+    S->round0_nodes = (const u64*)d_nodes;
+    memcpy(S->round0_root, h_root, 64);
     return BFS_OK;
 }
 

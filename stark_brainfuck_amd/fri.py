@@ -131,7 +131,7 @@ class Fri:
             return codeword.array
         return codeword if isinstance(codeword, XArray) else XArray.from_elements(list(codeword))
 
-    def _run_native(self, codeword, proof_stream, with_query, known_leafs=None):
+    def _run_native(self, codeword, proof_stream, with_query, known_leafs=None, round0_tree=None):
         lib, stream = _lib.load(), current_stream()
         arr = self._as_xarray(codeword)
         n = len(arr)
@@ -148,6 +148,8 @@ class Fri:
         before = transcript.num_objects()
         session = lib.bfs_fri_session_new()
         try:
+            if round0_tree is not None and round0_tree._nodes_host is None and round0_tree.num_leafs == n:
+                _lib.check(lib.bfs_fri_session_round0_tree(session, round0_tree._nodes.ptr, round0_tree.root()))
             _lib.check(lib.bfs_fri_commit(session, transcript.handle, arr.ptr, arr.stride, n.bit_length() - 1,
                                           _base_value(self.domain.offset), _base_value(self.domain.omega), self.expansion_factor, stream))
             top = None
@@ -217,11 +219,12 @@ class Fri:
             proof_stream.push(current_tree.open(b_indices[s]))
         return a_indices + b_indices
 
-    def prove(self, codeword, proof_stream, known_leafs=None):
+    def prove(self, codeword, proof_stream, known_leafs=None, round0_tree=None):
         """fri.py:178-199: commit + query in one native call; returns the top-level indices.
-        known_leafs: {index: element object} for elements of `codeword` that the caller has already pushed."""
+        known_leafs: {index: element object} for elements of `codeword` that the caller has already pushed.
+        round0_tree: a Merkle tree the caller has already built over `codeword` (round 0 would build the same one)."""
         assert self.domain.length == len(codeword), "initial codeword length does not match length of initial codeword"
-        top, _, session, _ = self._run_native(codeword, proof_stream, with_query=True, known_leafs=known_leafs)
+        top, _, session, _ = self._run_native(codeword, proof_stream, with_query=True, known_leafs=known_leafs, round0_tree=round0_tree)
         _lib.load().bfs_fri_session_free(session)
         return top
 

@@ -121,8 +121,10 @@ class Merkle:
     def root(self):
         if self._nodes_host is not None:
             return self._nodes_host[1]
-        synchronize()
-        return self._nodes.to_numpy(8, offset=8).tobytes()
+        if getattr(self, "_root", None) is None:
+            synchronize()
+            self._root = self._nodes.to_numpy(8, offset=8).tobytes()
+        return self._root
 
     def open(self, index):
         """sibling digests from the leaf level up (merkle.py:46-52).  A node is always returned as the SAME bytes
