@@ -316,6 +316,11 @@ int bfs_combination(const bfs_comb_source* h_sources, uint32_t count, const uint
  * d_randomizer != NULL: d_acc is initialised to w0 * randomizer first (the first call of a proof); otherwise it accumulates.
  * bfs_difference_combine adds a permutation argument's term (wa + wb x^shift) (lhs - rhs) / (x - 1).
  * Shifts must fit 32 bits.  Asynchronous on `stream` (the weights travel in the kernel arguments).
+ * bfs_zerofier_inverses: every table divides by x - 1, x - omicron^-1 and x^h - 1; this computes up to 12 such denominators at every
+ * point of the domain and inverts them together (one field inversion per point instead of one per table): denominator k is
+ * x - h_values[k] (h_is_power[k] == 0) or x^(2^h_values[k]) - 1; d_out receives `count` codewords of n words.  bfs_air_combine takes
+ * d_zerofier_inverses = {1/(x - 1), 1/(x - omicron^-1), 1/(x^height - 1)} (device codewords; the third is ignored for height 0) or
+ * NULL to invert on the spot; bfs_difference_combine takes the codeword of 1/(x - 1) or NULL.
  */
 typedef struct bfs_comb_weight {
     uint64_t wa[3], wb[3];
@@ -324,9 +329,11 @@ typedef struct bfs_comb_weight {
 int bfs_air_combine(int table, const uint64_t* d_base, const uint64_t* d_ext, uint32_t log_n, uint64_t unit_distance, uint64_t height,
                     uint64_t omicron_inv, uint64_t offset, uint64_t omega, const uint64_t* h_challenges, const uint64_t* h_terminals,
                     const uint64_t* h_params, const bfs_comb_weight* h_weights, const uint64_t* d_randomizer,
-                    const uint64_t* h_randomizer_weight, uint64_t* d_acc, void* stream);
+                    const uint64_t* h_randomizer_weight, uint64_t* d_acc, const uint64_t* const* d_zerofier_inverses, void* stream);
 int bfs_difference_combine(const uint64_t* d_lhs, const uint64_t* d_rhs, uint32_t log_n, uint64_t offset, uint64_t omega,
-                           const bfs_comb_weight* h_weight, uint64_t* d_acc, void* stream);
+                           const bfs_comb_weight* h_weight, uint64_t* d_acc, const uint64_t* d_inv_x_minus_1, void* stream);
+int bfs_zerofier_inverses(uint32_t log_n, uint64_t offset, uint64_t omega, uint32_t count, const uint32_t* h_is_power, const uint64_t* h_values,
+                          uint64_t* d_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -100,8 +100,9 @@ _SIGNATURES = {
     "bfs_difference_quotient": (ci, [vp, vp, vp, u32, u64, u64, vp]),
     "bfs_combination": (ci, [vp, u32, vp, ctypes.POINTER(u64), vp, u32, u64, u64, vp]),
     "bfs_air_combine": (ci, [ci, vp, vp, u32, u64, u64, u64, u64, u64, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64), vp, vp,
-                             ctypes.POINTER(u64), vp, vp]),
-    "bfs_difference_combine": (ci, [vp, vp, u32, u64, u64, vp, vp, vp]),
+                             ctypes.POINTER(u64), vp, ctypes.POINTER(vp), vp]),
+    "bfs_difference_combine": (ci, [vp, vp, u32, u64, u64, vp, vp, vp, vp]),
+    "bfs_zerofier_inverses": (ci, [u32, u64, u64, u32, ctypes.POINTER(u32), ctypes.POINTER(u64), vp, vp]),
 }
 
 

@@ -31,7 +31,7 @@ from .merkle import Merkle
 from .permutation_argument import PermutationArgument
 from .processor_table import ProcessorTable
 from .salted_merkle import SaltedMerkle, ZippedSaltedMerkle
-from .table import sample_ext, sample_ext_many
+from .table import sample_ext, sample_ext_many, zerofier_inverses
 from .univariate import Polynomial
 from .vm import VirtualMachine
 
@@ -309,18 +309,20 @@ class BrainfuckStark:
             _lib.check(lib.bfs_combination(srcs, len(sources), randomizer_codeword.ptr, (_u64 * 3)(*weights[0]), combination.ptr,
                                            log_n, domain.offset.value, domain.omega.value, stream))
         else:
+            inverse_buffer, inverses = zerofier_inverses(self.tables, domain)      # all zerofier denominators, one inversion per point
             base_at = ext_at = 0
             quot_at = num_base + num_ext
             for k, t in enumerate(self.tables):
                 bw, xw, nq = t.base_width, t.full_width - t.base_width, t.num_quotients()
                 mine = term[base_at:base_at + bw] + term[num_base + ext_at:num_base + ext_at + xw] + term[quot_at:quot_at + nq]
                 t.combine_into(domain, challenges, terminals, mine, combination,
-                               randomizer=randomizer_codeword if k == 0 else None, randomizer_weight=weights[0])
+                               randomizer=randomizer_codeword if k == 0 else None, randomizer_weight=weights[0], inverses=inverses[t])
                 base_at, ext_at, quot_at = base_at + bw, ext_at + xw, quot_at + nq
             for pa in self.permutation_arguments:
-                pa.combine_into(domain, term[quot_at], combination)
+                pa.combine_into(domain, term[quot_at], combination, inv_x_minus_1=inverses[self.tables[0]][0])
                 quot_at += 1
             assert quot_at == len(term)
+            inverse_buffer.free()
 
         if not self.keep_intermediates:
             BrainfuckStark._release(randomizer_polynomial, *[buf for buf, _ in quotient_buffers])

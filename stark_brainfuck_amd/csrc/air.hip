@@ -116,6 +116,12 @@ struct Zerofiers {
         terminal = gl_mul(iab, za);
         transition = a.height != 0 ? gl_mul(xo, gl_mul(iabc, ab)) : 0;
     }
+    // from precomputed inverse codewords (zerofier_inverses_kernel): no inversion here
+    __device__ __forceinline__ Zerofiers(const AirArgs& a, u64 x, u64 inv_x_minus_1, u64 inv_x_minus_omicron_inv, u64 inv_xh_minus_1) {
+        boundary = inv_x_minus_1;
+        terminal = inv_x_minus_omicron_inv;
+        transition = a.height != 0 ? gl_mul(gl_sub(x, a.omicron_inv), inv_xh_minus_1) : 0;
+    }
     template <int TABLE, int Q>
     __device__ __forceinline__ u64 of() const {
         typedef AirShape<TABLE> S;
@@ -164,6 +170,48 @@ __global__ void __launch_bounds__(256) air_quotient_kernel(const AirArgs a) {
     }
 }
 
+// ---- zerofier inverses for all tables at once --------------------------------------------------------------------
+// Every table divides by x - 1 (boundary), x - omicron^-1 (terminal) and x^h - 1 (transition); with five tables and two
+// permutation arguments that was seven field inversions per point (~2300 instructions each), a third of the combination's
+// arithmetic.  One kernel computes all distinct denominators of a proof at a point and inverts them together (Montgomery's
+// trick: one inversion + 3 (K - 1) multiplications for K <= 12 values); the table kernels read the codewords.
+struct ZerofierSpecs {
+    u32 count;
+    u32 is_power[12];     // 0: x - value      1: x^(2^value) - 1
+    u64 value[12];
+};
+
+__global__ void __launch_bounds__(256) zerofier_inverses_kernel(ZerofierSpecs sp, u64* out, u64 n, u64 offset, const u64* w_lo, const u64* w_hi,
+                                                                u32 lo_bits) {
+    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const u64 x = gl_mul(offset, tw_pow(w_lo, w_hi, lo_bits, i));
+    u64 v[12], prefix[12];
+    u64 running = 1;
+#pragma unroll
+    for (u32 k = 0; k < 12; ++k) {
+        if (k < sp.count) {
+            if (sp.is_power[k]) {
+                u64 xh = x;
+                for (u32 s = 0; s < (u32)sp.value[k]; ++s) xh = gl_sqr(xh);
+                v[k] = gl_sub(xh, 1);
+            } else {
+                v[k] = gl_sub(x, sp.value[k]);
+            }
+            prefix[k] = running;
+            running = gl_mul(running, v[k]);
+        }
+    }
+    u64 inv = gl_inv(running);
+#pragma unroll
+    for (int k = 11; k >= 0; --k) {
+        if ((u32)k < sp.count) {
+            out[(u64)k * n + i] = gl_mul(inv, prefix[k]);
+            inv = gl_mul(inv, v[k]);
+        }
+    }
+}
+
 // ---- quotients folded straight into the non-linear combination ---------------------------------------------------
 // The prover never opens a quotient codeword (the verifier recomputes quotient VALUES from the opened trace rows,
 // brainfuck_stark.py:470-560), so the production path does not write them: one kernel per table evaluates the constraints at a
@@ -184,6 +232,7 @@ struct AirCombineArgs {
     const u64* randomizer;   // non-null: the accumulator starts from w0 * randomizer (first kernel of a proof)
     Xfe w0;
     u64* acc;                // three limb planes of n
+    const u64 *inv_boundary, *inv_terminal, *inv_transition;   // codewords of 1/(x - 1), 1/(x - omicron^-1), 1/(x^h - 1), or all null
     CombW w[AirShape<TABLE>::BW + AirShape<TABLE>::XW + AirShape<TABLE>::NB + AirShape<TABLE>::NT + AirShape<TABLE>::NZ];
 };
 
@@ -239,7 +288,9 @@ __global__ void __launch_bounds__(256) air_combine_kernel(const AirCombineArgs<T
 #pragma unroll
         for (int c = 0; c < S::XW; ++c) acc = xfe_add(acc, xfe_mul(xp.weight(A.w[S::BW + c]), xc[c]));
         const u64 x = gl_mul(a.offset, tw_pow(a.w_lo, a.w_hi, a.lo_bits, i));
-        CombineSink<TABLE> sink{acc, xp, A.w + S::BW + S::XW, Zerofiers(a, x)};
+        CombineSink<TABLE> sink{acc, xp, A.w + S::BW + S::XW,
+                                A.inv_boundary ? Zerofiers(a, x, A.inv_boundary[i], A.inv_terminal[i], a.height != 0 ? A.inv_transition[i] : 0)
+                                               : Zerofiers(a, x)};
         air_eval<TABLE>(bc, bn, xc, xn, a, sink);
         A.acc[i] = sink.acc.c[0];
         A.acc[a.n + i] = sink.acc.c[1];
@@ -249,10 +300,9 @@ __global__ void __launch_bounds__(256) air_combine_kernel(const AirCombineArgs<T
 
 // acc += (wa + wb x^shift) * (lhs - rhs) / (x - 1)      (the difference quotient of a permutation argument, folded the same way)
 __global__ void difference_combine_kernel(const u64* lhs, const u64* rhs, u64* acc, u64 n, u64 offset, const u64* w_lo, const u64* w_hi,
-                                          u32 lo_bits, CombW w) {
+                                          u32 lo_bits, CombW w, const u64* inv_x_minus_1) {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
-        const u64 x = gl_mul(offset, tw_pow(w_lo, w_hi, lo_bits, i));
-        const u64 z = gl_inv(gl_sub(x, 1));
+        const u64 z = inv_x_minus_1 ? inv_x_minus_1[i] : gl_inv(gl_sub(gl_mul(offset, tw_pow(w_lo, w_hi, lo_bits, i)), 1));
         const u64 xs = gl_mul(w.offset_pow, tw_pow(w_lo, w_hi, lo_bits, (i * w.shift) & (n - 1)));
         const Xfe weight = xfe_add(w.wa, xfe_scale(w.wb, xs));
         Xfe q;
@@ -399,13 +449,16 @@ static CombW comb_weight(const bfs_comb_weight& w, u64 offset) {
 
 template <int TABLE>
 static int air_combine_launch(const AirArgs& a, const bfs_comb_weight* h_weights, const uint64_t* d_randomizer, const uint64_t* h_w0,
-                              uint64_t* d_acc, hipStream_t stream) {
+                              uint64_t* d_acc, const uint64_t* const* d_inverses, hipStream_t stream) {
     typedef AirShape<TABLE> S;
     AirCombineArgs<TABLE> A{};
     A.a = a;
     A.randomizer = d_randomizer;
     A.w0 = d_randomizer ? xfe_from(h_w0) : Xfe{{0, 0, 0}};
     A.acc = d_acc;
+    if (d_inverses && d_inverses[0] && d_inverses[1] && (a.height == 0 || d_inverses[2])) {
+        A.inv_boundary = d_inverses[0]; A.inv_terminal = d_inverses[1]; A.inv_transition = d_inverses[2];
+    }
     constexpr int count = S::BW + S::XW + S::NB + S::NT + S::NZ;
     for (int k = 0; k < count; ++k) {
         if (h_weights[k].shift >> 32) { set_error("bfs_air_combine: shift does not fit 32 bits"); return BFS_ERR_BAD_ARG; }
@@ -422,23 +475,50 @@ extern "C" {
 int bfs_air_combine(int table, const uint64_t* d_base, const uint64_t* d_ext, uint32_t log_n, uint64_t unit_distance, uint64_t height,
                     uint64_t omicron_inv, uint64_t offset, uint64_t omega, const uint64_t* h_challenges, const uint64_t* h_terminals,
                     const uint64_t* h_params, const bfs_comb_weight* h_weights, const uint64_t* d_randomizer,
-                    const uint64_t* h_randomizer_weight, uint64_t* d_acc, void* stream_) {
+                    const uint64_t* h_randomizer_weight, uint64_t* d_acc, const uint64_t* const* d_zerofier_inverses, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (log_n > 32) { set_error("bfs_air_combine: log_n"); return BFS_ERR_BAD_ARG; }
     AirArgs a{};
     BFS_TRY(fill_air_args(a, table, d_base, d_ext, log_n, unit_distance, height, omicron_inv, offset, omega, h_challenges, h_terminals,
                           h_params, "bfs_air_combine"));
     switch (table) {
-        case 0: return air_combine_launch<0>(a, h_weights, d_randomizer, h_randomizer_weight, d_acc, stream);
-        case 1: return air_combine_launch<1>(a, h_weights, d_randomizer, h_randomizer_weight, d_acc, stream);
-        case 2: return air_combine_launch<2>(a, h_weights, d_randomizer, h_randomizer_weight, d_acc, stream);
-        case 3: return air_combine_launch<3>(a, h_weights, d_randomizer, h_randomizer_weight, d_acc, stream);
-        default: return air_combine_launch<4>(a, h_weights, d_randomizer, h_randomizer_weight, d_acc, stream);
+        case 0: return air_combine_launch<0>(a, h_weights, d_randomizer, h_randomizer_weight, d_acc, d_zerofier_inverses, stream);
+        case 1: return air_combine_launch<1>(a, h_weights, d_randomizer, h_randomizer_weight, d_acc, d_zerofier_inverses, stream);
+        case 2: return air_combine_launch<2>(a, h_weights, d_randomizer, h_randomizer_weight, d_acc, d_zerofier_inverses, stream);
+        case 3: return air_combine_launch<3>(a, h_weights, d_randomizer, h_randomizer_weight, d_acc, d_zerofier_inverses, stream);
+        default: return air_combine_launch<4>(a, h_weights, d_randomizer, h_randomizer_weight, d_acc, d_zerofier_inverses, stream);
     }
 }
 
+int bfs_zerofier_inverses(uint32_t log_n, uint64_t offset, uint64_t omega, uint32_t count, const uint32_t* h_is_power, const uint64_t* h_values,
+                          uint64_t* d_out, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (count == 0) return BFS_OK;
+    if (count > 12 || log_n > 32) { set_error("bfs_zerofier_inverses: at most 12 denominators, log_n <= 32"); return BFS_ERR_BAD_ARG; }
+    const u64 n = 1ull << log_n;
+    ZerofierSpecs sp{};
+    sp.count = count;
+    for (u32 k = 0; k < count; ++k) {
+        sp.is_power[k] = h_is_power[k] ? 1u : 0u;
+        sp.value[k] = h_values[k];
+        if (h_is_power[k] && h_values[k] > 32) { set_error("bfs_zerofier_inverses: exponent 2^%llu", (unsigned long long)h_values[k]); return BFS_ERR_BAD_ARG; }
+        // the denominators must not vanish on the coset: offset not in the subgroup they cut out (the reference asserts nothing
+        // here and would raise on the division); cheap host check for the linear ones
+        if (!h_is_power[k] && gl_pow(gl_mul(h_values[k] % GL_P, gl_inv(offset)), n) == 1) {
+            set_error("bfs_zerofier_inverses: x - %llu vanishes on the evaluation domain", (unsigned long long)h_values[k]);
+            return BFS_ERR_BAD_ARG;
+        }
+    }
+    const u64 *lo, *hi;
+    u32 lo_bits;
+    BFS_TRY(ntt_power_tables(omega, log_n, &lo, &hi, &lo_bits));
+    hipLaunchKernelGGL(zerofier_inverses_kernel, dim3(grid_per_point(n)), dim3(256), 0, stream, sp, d_out, n, offset, lo, hi, lo_bits);
+    BFS_HIP(hipGetLastError());
+    return BFS_OK;
+}
+
 int bfs_difference_combine(const uint64_t* d_lhs, const uint64_t* d_rhs, uint32_t log_n, uint64_t offset, uint64_t omega,
-                           const bfs_comb_weight* h_weight, uint64_t* d_acc, void* stream_) {
+                           const bfs_comb_weight* h_weight, uint64_t* d_acc, const uint64_t* d_inv_x_minus_1, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const u64 n = 1ull << log_n;
     if (h_weight->shift >> 32) { set_error("bfs_difference_combine: shift does not fit 32 bits"); return BFS_ERR_BAD_ARG; }
@@ -446,7 +526,7 @@ int bfs_difference_combine(const uint64_t* d_lhs, const uint64_t* d_rhs, uint32_
     u32 lo_bits;
     BFS_TRY(ntt_power_tables(omega, log_n, &lo, &hi, &lo_bits));
     hipLaunchKernelGGL(difference_combine_kernel, dim3(grid_for(n)), dim3(256), 0, stream, d_lhs, d_rhs, d_acc, n, offset, lo, hi, lo_bits,
-                       comb_weight(*h_weight, offset));
+                       comb_weight(*h_weight, offset), d_inv_x_minus_1);
     BFS_HIP(hipGetLastError());
     return BFS_OK;
 }

@@ -22,7 +22,7 @@ class PermutationArgument:
                                                        n.bit_length() - 1, fri_domain.offset.value, fri_domain.omega.value, current_stream()))
         return out
 
-    def combine_into(self, fri_domain, weight, accumulator):
+    def combine_into(self, fri_domain, weight, accumulator, inv_x_minus_1=None):
         """bfs_difference_combine: accumulator += (wa + wb x^shift) * (lhs - rhs) / (x - 1) without writing the quotient codeword"""
         n = fri_domain.length
         wa, wb, shift = weight
@@ -31,7 +31,7 @@ class PermutationArgument:
         lt, rt = self.all_tables[self.lhs[0]], self.all_tables[self.rhs[0]]
         _lib.check(_lib.load().bfs_difference_combine(lt.ext_codeword_ptr(self.lhs[1]), rt.ext_codeword_ptr(self.rhs[1]), n.bit_length() - 1,
                                                       fri_domain.offset.value, fri_domain.omega.value, ctypes.byref(w), accumulator.ptr,
-                                                      current_stream()))
+                                                      inv_x_minus_1, current_stream()))
 
     def evaluate_difference(self, points):
         from .air import xsub

@@ -98,6 +98,27 @@ def extend_all(tables, challenges, initials):
         future.result()
 
 
+def zerofier_inverses(tables, domain):
+    """bfs_zerofier_inverses for a set of tables: one kernel inverts every distinct zerofier denominator of the proof at every point.
+    Returns (buffer, {table: (addr of 1/(x-1), addr of 1/(x - omicron^-1), addr of 1/(x^h - 1) or None)})."""
+    lib, stream = _lib.load(), current_stream()
+    n = domain.length
+    specs = [(0, 1)]
+    for t in tables:
+        for spec in ((0, pow(t.omicron.value, P - 2, P)), (1, t.height.bit_length() - 1) if t.height else None):
+            if spec is not None and spec not in specs:
+                specs.append(spec)
+    assert len(specs) <= 12
+    out = DeviceBuffer(len(specs) * n)
+    _lib.check(lib.bfs_zerofier_inverses(n.bit_length() - 1, domain.offset.value, domain.omega.value, len(specs),
+                                         (ctypes.c_uint32 * len(specs))(*[s[0] for s in specs]), (_u64 * len(specs))(*[s[1] for s in specs]),
+                                         out.ptr, stream))
+    where = {spec: out.ptr + 8 * k * n for k, spec in enumerate(specs)}
+    per_table = {t: (where[(0, 1)], where[(0, pow(t.omicron.value, P - 2, P))],
+                     where[(1, t.height.bit_length() - 1)] if t.height else None) for t in tables}
+    return out, per_table
+
+
 def staging_empty(shape):
     """uint64 array for data on its way to HBM: pinned memory from the library's pool when there is a GPU, plain numpy otherwise"""
     if _POOLS.get("pinned", True):
@@ -424,10 +445,11 @@ class Table:
                                          domain.offset.value, domain.omega.value, ch, tm, pr, stream))
         return out
 
-    def combine_into(self, domain, challenges, terminals, weights, accumulator, randomizer=None, randomizer_weight=None):
+    def combine_into(self, domain, challenges, terminals, weights, accumulator, randomizer=None, randomizer_weight=None, inverses=None):
         """bfs_air_combine: add this table's share of the non-linear combination -- its base columns, extension columns and
         quotients (in that order; weights: list of (wa, wb, shift)) -- to `accumulator` (XArray) without writing the quotient
-        codewords.  randomizer (XArray) given: the accumulator is initialised to randomizer_weight * randomizer first."""
+        codewords.  randomizer (XArray) given: the accumulator is initialised to randomizer_weight * randomizer first.
+        inverses: device addresses of the codewords 1/(x - 1), 1/(x - omicron^-1), 1/(x^height - 1) (zerofier_inverses), or None."""
         lib, stream = _lib.load(), current_stream()
         n = domain.length
         assert len(weights) == self.full_width - self.base_width + self.base_width + self.num_quotients()
@@ -442,7 +464,8 @@ class Table:
         _lib.check(lib.bfs_air_combine(self.table_index, self.base_codewords.ptr, self.ext_codewords.ptr, n.bit_length() - 1,
                                        self.unit_distance(n), self.height, omicron_inv, domain.offset.value, domain.omega.value, ch, tm, pr,
                                        ws, randomizer.ptr if randomizer is not None else None,
-                                       (_u64 * 3)(*randomizer_weight) if randomizer is not None else None, accumulator.ptr, stream))
+                                       (_u64 * 3)(*randomizer_weight) if randomizer is not None else None, accumulator.ptr,
+                                       (ctypes.c_void_p * 3)(*inverses) if inverses is not None else None, stream))
 
     _generic_totals = {}      # (table, kind, which challenges / terminals / parameters are zero) -> total degrees per constraint
 
