@@ -34,7 +34,9 @@ struct RowSeg {
     u32 pad;
 };
 struct RowTemplate {
-    u32 code, first_seg, num_segs, tuple_const_bytes, salt_bytes, pad[3];
+    u32 code, first_seg, num_segs, tuple_const_bytes, salt_bytes;
+    u32 pool_first, pool_words;      // the words of the pool its CONST segments point into
+    u32 pad;
 };
 struct RowArgs {
     const u64* const* columns;   // device array of column pointers
@@ -81,20 +83,44 @@ __global__ void row_pattern_kernel(const RowArgs a) {
     atomicOr(a.error + 1, 1u);
 }
 
-__global__ void __launch_bounds__(64) row_leaves_kernel(const RowArgs a) {
-    __shared__ u64 blk[16 * 64];
+// One thread per row, 256 rows per workgroup.  The byte loop below is a chain of dependent loads (segment descriptor, then the
+// constant word or the column value it names): from global memory that chain, not BLAKE2b, set the pace (41 % of the VALU
+// floor).  Rows of a workgroup almost always share one template, so its descriptors and constants are staged in LDS once per
+// workgroup; a row with another pattern (or a template too large to stage) reads from global memory as before.
+constexpr u32 LEAF_THREADS = 256, STAGED_SEGS = 256, STAGED_WORDS = 512;
+__global__ void __launch_bounds__(LEAF_THREADS) row_leaves_kernel(const RowArgs a) {
+    __shared__ u64 blk[16 * LEAF_THREADS];
+    __shared__ RowSeg s_segs[STAGED_SEGS];
+    __shared__ u64 s_pool[STAGED_WORDS];
     const u32 lane = threadIdx.x;
-    const u64 i = (u64)blockIdx.x * 64 + lane;
-    if (i >= a.n) return;
-    const u32 code = row_pattern(a, i);
+    const u64 i = (u64)blockIdx.x * LEAF_THREADS + lane;
+    const bool valid = i < a.n;
+    const u32 code = valid ? row_pattern(a, i) : 0u;
     const RowTemplate* tp = nullptr;
     for (u32 t = 0; t < a.num_templates; ++t)
         if (a.templates[t].code == code) tp = a.templates + t;
+    // the template of the workgroup's first row is the staged one (the first row is always valid)
+    const u32 code0 = row_pattern(a, (u64)blockIdx.x * LEAF_THREADS);
+    const RowTemplate* staged = nullptr;
+    for (u32 t = 0; t < a.num_templates; ++t)
+        if (a.templates[t].code == code0) staged = a.templates + t;
+    if (staged && (staged->num_segs > STAGED_SEGS || staged->pool_words > STAGED_WORDS)) staged = nullptr;
+    if (staged) {
+        for (u32 k = lane; k < staged->num_segs; k += LEAF_THREADS) s_segs[k] = a.segs[staged->first_seg + k];
+        for (u32 k = lane; k < staged->pool_words; k += LEAF_THREADS) s_pool[k] = a.pool[staged->pool_first + k];
+    }
+    __syncthreads();
+    if (!valid) return;
     if (tp == nullptr) { atomicOr(a.error, 1u); return; }
+    const bool cached = tp == staged;
+    const RowSeg* segs = a.segs + tp->first_seg;
+    const u32 pool_first = tp->pool_first;
+    auto segment = [&](u32 k) -> RowSeg { return cached ? s_segs[k] : segs[k]; };
+    auto constant = [&](u32 word) -> u64 { return cached ? s_pool[word - pool_first] : a.pool[word]; };
     // pass 1: length of the tuple pickle = constant bytes + the integer opcodes of this row
     u32 int_bytes = 0;
     for (u32 s = 0; s < tp->num_segs; ++s) {
-        const RowSeg sg = a.segs[tp->first_seg + s];
+        const RowSeg sg = segment(s);
         if (sg.kind == SEG_INT) int_bytes += pickle_int_len(a.columns[sg.a][(u64)sg.b * a.n + i]);
     }
     const u32 tuple_len = tp->tuple_const_bytes + int_bytes;
@@ -113,11 +139,11 @@ __global__ void __launch_bounds__(64) row_leaves_kernel(const RowArgs a) {
     for (u32 b = 0; b < nblocks; ++b) {
         u32 wpos = 0;
         while (wpos < 16 && s < nseg) {
-            const RowSeg sg = a.segs[tp->first_seg + s];
+            const RowSeg sg = segment(s);
             u64 data = 0;
             u32 nb = 0;
             if (sg.kind == SEG_CONST) {
-                data = a.pool[sg.a + w];
+                data = constant(sg.a + w);
                 const u32 left = sg.b - 8 * w;
                 nb = left < 8 ? left : 8;
                 if (nb < 8) data &= (1ull << (8 * nb)) - 1;
@@ -150,7 +176,7 @@ __global__ void __launch_bounds__(64) row_leaves_kernel(const RowArgs a) {
             acc |= data << (8 * fill);
             const u32 nf = fill + nb;
             if (nf >= 8) {
-                blk[wpos * 64 + lane] = acc;
+                blk[wpos * LEAF_THREADS + lane] = acc;
                 ++wpos;
                 acc = fill ? (data >> (8 * (8 - fill))) : 0;
                 fill = nf - 8;
@@ -159,14 +185,14 @@ __global__ void __launch_bounds__(64) row_leaves_kernel(const RowArgs a) {
             }
         }
         if (wpos < 16 && fill) {      // end of the input: the pending bytes, zero padded
-            blk[wpos * 64 + lane] = acc;
+            blk[wpos * LEAF_THREADS + lane] = acc;
             ++wpos;
             acc = 0;
             fill = 0;
         }
         u64 m[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) m[j] = (u32)j < wpos ? blk[j * 64 + lane] : 0;
+        for (int j = 0; j < 16; ++j) m[j] = (u32)j < wpos ? blk[j * LEAF_THREADS + lane] : 0;
         const bool last = b + 1 == nblocks;
         blake2b_compress(h, m, last ? (u64)total : (u64)128 * (b + 1), last);
     }
@@ -249,6 +275,7 @@ static int build_template(const bfs_row_column* cols, u32 ncols, u32 code, bool 
     RowTemplate t{};
     t.code = code;
     t.first_seg = (u32)ht.segs.size();
+    t.pool_first = (u32)ht.pool.size();
     size_t pos = 0;
     u32 const_bytes = 0;
     auto flush = [&](size_t to) { add_const(ht, s, pos, to); const_bytes += (u32)(to - pos); pos = to; };
@@ -277,6 +304,7 @@ static int build_template(const bfs_row_column* cols, u32 ncols, u32 code, bool 
         t.salt_bytes = (u32)ss.size();
     }
     t.num_segs = (u32)ht.segs.size() - t.first_seg;
+    t.pool_words = (u32)ht.pool.size() - t.pool_first;
     ht.templates.push_back(t);
     return BFS_OK;
 }
@@ -378,7 +406,7 @@ extern "C" int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t nco
     a.pool = (const u64*)(tb + tbytes + sbytes);
 
     // 3. leaf digests, then the tree
-    hipLaunchKernelGGL(row_leaves_kernel, dim3((u32)((n + 63) / 64)), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(row_leaves_kernel, dim3((u32)((n + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0, stream, a);
     BFS_HIP(hipGetLastError());
     BFS_TRY(merkle_inner_launch((u64*)d_nodes, depth, n, stream, nullptr, 0));
     u32 err = 0;
