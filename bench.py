@@ -74,9 +74,19 @@ def main():
         # launched by torch.distributed.run: bring up RCCL even for a single rank so that the collective path is the one exercised
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        dist.barrier()                 # RCCL builds its communicators on the first collective (100s of ms): pay that here, not
-        torch.cuda.synchronize()       # between the clock spin-up and the timed region, where the idle GPU would clock down again
+        # this RCCL build prints a version banner on stdout when the first communicator comes up; stdout carries exactly one JSON
+        # line, so the banner is sent to stderr (file-descriptor level: it is written by native code)
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.barrier()             # RCCL builds its communicators on the first collective (100s of ms): pay that here, not
+            torch.cuda.synchronize()   # between the clock spin-up and the timed region, where the idle GPU would clock down again
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
 
     from stark_brainfuck_amd import _lib, shard
     from stark_brainfuck_amd.device import DeviceBuffer

@@ -4,11 +4,15 @@
 
 Where the time goes in the reference, and where it goes here:
   trace interpolation + low-degree extension (:165-172, 194-195)    batched INTT / randomizer fix / coset NTT in HBM (table.py)
-  commitments to zipped codewords (:178-179, 197-198)               leaves pickled on the host, hashed on the GPU
-  quotient codewords (:204-221, 93 % of the reference's time)       one kernel per table (bfs_air_quotients)
-  non-linear combination of 151 terms (:236-298)                    one kernel (bfs_combination)
-  FRI (:336)                                                        fri.Fri.prove (bfs_fri_commit / bfs_fri_query)
-Scalar steps (padding, running products, Fiat-Shamir sampling, transcript assembly) stay on the host.
+  table extension: running products / evaluations (:186-187)        prefix scans on the trace columns in HBM (bfs_xfe_scan_device)
+  commitments to zipped codewords (:178-179, 197-198)               row pickles synthesised and hashed on the GPU (bfs_merkle_build_rows)
+  quotient codewords (:204-221, 93 % of the reference's time)       one kernel per table, folded straight into ...
+  non-linear combination of 151 terms (:236-298)                    ... the combination accumulator (bfs_air_combine); with
+                                                                    keep_intermediates the quotients are written out (bfs_air_quotients,
+                                                                    bfs_combination) so that tests can compare each with the reference's
+  FRI (:336)                                                        fri.Fri.prove (bfs_fri_commit / bfs_fri_query), round 0 on the
+                                                                    combination tree that was just built
+Padding, Fiat-Shamir sampling, transcript assembly and the object-identity bookkeeping of opened rows stay on the host.
 """
 import ctypes
 
