@@ -267,6 +267,23 @@ int bfs_selftest_field(uint32_t log_count, uint64_t* mismatches);
  *     out[i] = w0 * randomizer[i] + sum_s (wa_s + wb_s * x_i^shift_s) * source_s[i].  Synchronises the stream.
  */
 /*
+ * The Brainfuck VM and its execution trace (host): VirtualMachine.simulate (vm.py:172-306) and MemoryTable.derive_matrix
+ * (memory_table.py:20-38).  program: the compiled words (vm.py:78-105), input: the symbols read by `,` as code points.
+ * max_cycles = 0: no limit.  Parts of the trace (bfs_vm_trace_size / bfs_vm_trace_copy, sizes in 64-bit words):
+ *   0 processor matrix (rows x 7: clk ip ci ni mp mv mvi)   1 memory matrix (rows x 4: clk mp mv dummy)
+ *   2 instruction matrix (rows x 3: ip ci ni, sorted by address)   3 input symbols   4 output symbols
+ *   5 / 6 / 7: for the processor's memory-value column / the input symbols / the output symbols, the id of the element OBJECT
+ *   that held the value in the reference (0 = the register's initial zero, 1 = the shared zero of untouched cells, k > 1 = an object
+ *   made by `+`, `-`, `,`): pickle memoises by
+ *   identity and these objects reach the proof through the evaluation terminals (processor_table.py:390-404).
+ * Errors (BFS_ERR_BAD_ARG): unknown instruction, input exhausted ("program reads more input symbols than were supplied").
+ */
+int bfs_vm_trace_new(const uint64_t* program, size_t n_words, const uint32_t* input, size_t n_input, uint64_t max_cycles, void** trace);
+void bfs_vm_trace_free(void* trace);
+int bfs_vm_trace_size(void* trace, int which, size_t* words);
+int bfs_vm_trace_copy(void* trace, int which, uint64_t* out);
+
+/*
  * bfs_xfe_scan (host): the sequential column extensions of Table.extend -- processor_table.py:329-427, instruction_table.py:167-231,
  *     memory_table.py:172-206, io_table.py:77-110.  Over rows i < n with base-field columns x1, x2, x3 (NULL = absent) and an
  *     optional row mask (NULL = every row), constants c0..c3 (4 x 3 limbs):

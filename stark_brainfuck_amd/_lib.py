@@ -91,6 +91,10 @@ _SIGNATURES = {
     "bfs_fri_session_rounds": (u32, [vp]),
     "bfs_fri_session_round": (ci, [vp, u32, ctypes.POINTER(vp), ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(vp), vp]),
     "bfs_selftest_field": (ci, [u32, ctypes.POINTER(u64)]),
+    "bfs_vm_trace_new": (ci, [ctypes.POINTER(u64), sz, ctypes.POINTER(u32), sz, u64, ctypes.POINTER(vp)]),
+    "bfs_vm_trace_free": (None, [vp]),
+    "bfs_vm_trace_size": (ci, [vp, ci, ctypes.POINTER(sz)]),
+    "bfs_vm_trace_copy": (ci, [vp, ci, vp]),
     "bfs_xfe_scan": (ci, [ci, vp, vp, vp, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(u64), ci, vp, ctypes.POINTER(u64)]),
     "bfs_xfe_scan_device": (ci, [ci, vp, vp, vp, u64, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(u64), ci, vp, u64, vp, ctypes.POINTER(u64), vp]),
     "bfs_poly_support": (ci, [vp, u64, u64, u32, ctypes.POINTER(u64), vp]),

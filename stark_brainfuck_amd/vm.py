@@ -14,6 +14,47 @@ class TraceMatrix(list):
     values = None
 
 
+class LazyTraceMatrix:
+    """A matrix in the reference's format -- a sequence of rows of BaseFieldElement -- over a uint64 array (`values`, rows x
+    columns) that makes the element objects of a row only when the row is asked for, and then keeps them (a row read twice is
+    the same objects twice).  One column may carry object ids: entries with equal ids ARE the same object, across rows and across
+    matrices that share the registry -- the reference's memory cells hold element objects, and the memory-value column, the input
+    and the output matrix all point at them (vm.py:266-292); pickle memoises by identity, so this shows in proofs."""
+
+    def __init__(self, values, field, id_column=None, ids=None, registry=None):
+        self.values, self._field, self._rows = values, field, {}
+        self._id_column, self._ids, self._registry = id_column, ids, registry
+
+    def __len__(self):
+        return self.values.shape[0]
+
+    def _row(self, r):
+        row = self._rows.get(r)
+        if row is None:
+            field = self._field
+            row = [BaseFieldElement(int(v), field) for v in self.values[r]]
+            if self._id_column is not None:
+                key = int(self._ids[r])
+                row[self._id_column] = self._registry.setdefault(key, row[self._id_column])
+            self._rows[r] = row
+        return row
+
+    def __getitem__(self, index):
+        if isinstance(index, slice):
+            return [self._row(r) for r in range(*index.indices(len(self)))]
+        if index < 0:
+            index += len(self)
+        if not 0 <= index < len(self):
+            raise IndexError("matrix row out of range")
+        return self._row(index)
+
+    def __iter__(self):
+        return (self._row(r) for r in range(len(self)))
+
+    def __eq__(self, other):
+        return len(self) == len(other) and all(a == b for a, b in zip(self, other))
+
+
 def _matrix(rows, width, field, objects=None):
     import numpy as np
     m = TraceMatrix(objects if objects is not None else [[BaseFieldElement(v, field) for v in r] for r in rows])
@@ -87,7 +128,45 @@ class VirtualMachine:
 
     @staticmethod
     def simulate(program, input_data=[]):
-        """vm.py:172-306 -> (processor_matrix, memory_matrix, instruction_matrix, input_matrix, output_matrix)."""
+        """vm.py:172-306 -> (processor_matrix, memory_matrix, instruction_matrix, input_matrix, output_matrix).
+        The machine runs natively (bfs_vm_trace_new, csrc/vm.cpp: 37 000 cycles in milliseconds instead of seconds of element
+        construction); the matrices are LazyTraceMatrix objects over integer arrays.  `simulate_objects` is the direct
+        restatement that builds every element, kept as the cross-check."""
+        import ctypes
+        import numpy as np
+        from . import _lib
+        lib = _lib.load()
+        field = VirtualMachine.field
+        words = VirtualMachine._words(program)
+        prog = (ctypes.c_uint64 * len(words))(*words)
+        symbols = [ord(c) if isinstance(c, str) else int(c) for c in input_data]
+        inp = (ctypes.c_uint32 * max(len(symbols), 1))(*symbols)
+        handle = ctypes.c_void_p()
+        rc = lib.bfs_vm_trace_new(prog, len(words), inp, len(symbols), 0, ctypes.byref(handle))
+        if rc:
+            message = lib.bfs_last_error().decode("utf-8", "replace")
+            assert False, message          # the reference's asserts: unrecognized instruction / input exhausted
+        try:
+            def part(which, width):
+                n = ctypes.c_size_t()
+                _lib.check(lib.bfs_vm_trace_size(handle, which, ctypes.byref(n)))
+                out = np.empty(n.value, dtype=np.uint64)
+                if n.value:
+                    _lib.check(lib.bfs_vm_trace_copy(handle, which, out.ctypes.data))
+                return out.reshape(n.value // width, width)
+            registry = {}
+            processor = LazyTraceMatrix(part(0, 7), field, 5, part(5, 1).reshape(-1), registry)
+            memory = LazyTraceMatrix(part(1, 4), field)
+            instruction = LazyTraceMatrix(part(2, 3), field)
+            inputs = LazyTraceMatrix(part(3, 1), field, 0, part(6, 1).reshape(-1), registry)
+            outputs = LazyTraceMatrix(part(4, 1), field, 0, part(7, 1).reshape(-1), registry)
+        finally:
+            lib.bfs_vm_trace_free(handle)
+        return processor, memory, instruction, inputs, outputs
+
+    @staticmethod
+    def simulate_objects(program, input_data=[]):
+        """the same five matrices built the reference's way, every element an object (vm.py:172-306)"""
         from .memory_table import MemoryTable
         field = VirtualMachine.field
         prog = VirtualMachine._words(program)

@@ -9,7 +9,9 @@ for outer in (8, 16, 32, 64):
     code = "+" * outer + "[>" + "+" * outer + "[>++++<-]<-]+++."
     program = VirtualMachine.compile(code)
     rt, inp, out = VirtualMachine.run(program)
+    t = time.perf_counter()
     m = VirtualMachine.simulate(program, input_data=inp)
+    t_vm = time.perf_counter() - t
     best, proof = None, None
     for rep in range(2):
         stark = BrainfuckStark(rt, len(m[1]), program, inp, out)
@@ -20,6 +22,6 @@ for outer in (8, 16, 32, 64):
     t = time.perf_counter()
     ok = BrainfuckStark(rt, len(m[1]), program, inp, out).verify(proof)
     tv = time.perf_counter() - t
-    print("running time %6d  memory rows %6d  FRI domain 2^%d  prove %.3f s  verify %.3f s (%s)  proof %d bytes  %s" % (
-        rt, len(m[1]), stark.fri.domain.length.bit_length() - 1, best, tv, ok, len(proof),
+    print("running time %6d  memory rows %6d  FRI domain 2^%d  trace %.3f s  prove %.3f s  verify %.3f s (%s)  proof %d bytes  %s" % (
+        rt, len(m[1]), stark.fri.domain.length.bit_length() - 1, t_vm, best, tv, ok, len(proof),
         {k: round(v * 1e3, 1) for k, v in stark.timing.items() if v > 2e-3}), flush=True)
