@@ -42,6 +42,15 @@ class ExtensionField:
     def __init__(self, modulus):
         self.modulus = modulus
 
+    def _is_cubic(self):
+        """modulus X^3 - X + 1: products are reduced with X^3 = X - 1, X^4 = X^2 - X on integers instead of Polynomial.__mul__ /
+        divide.  Decided on first use (objects read from a proof are rebuilt from their attributes, without __init__)."""
+        flag = self.__dict__.get("_cubic")
+        if flag is None:
+            c = self.modulus.coefficients
+            flag = self.__dict__["_cubic"] = len(c) == 4 and [e.value for e in c] == [1, c[0].field.p - 1, 0, 1]
+        return flag
+
     def _base(self):
         return self.modulus.coefficients[0].field
 
@@ -49,6 +58,19 @@ class ExtensionField:
     def one(self): return ExtensionFieldElement(Polynomial([self._base().one()]), self)
 
     def multiply(self, left, right):
+        lc, rc = left.polynomial.coefficients, right.polynomial.coefficients
+        if lc and rc and len(lc) <= 3 and len(rc) <= 3 and self._is_cubic():
+            # same value, and the same BaseField instance on the result's coefficients, as the generic path below (the product's
+            # coefficients are made by the LEFT operand's coefficient field, univariate.py:57-67 / algebra.py:29)
+            base = lc[0].field
+            p = base.p
+            a0, a1, a2 = [e.value for e in lc] + [0] * (3 - len(lc))
+            b0, b1, b2 = [e.value for e in rc] + [0] * (3 - len(rc))
+            d3, d4 = a1 * b2 + a2 * b1, a2 * b2
+            out = [(a0 * b0 - d3) % p, (a0 * b1 + a1 * b0 + d3 - d4) % p, (a0 * b2 + a1 * b1 + a2 * b0 + d4) % p]
+            while out and out[-1] == 0:
+                out.pop()
+            return ExtensionFieldElement(Polynomial([BaseFieldElement(v, base) for v in out]), self)
         return ExtensionFieldElement((left.polynomial * right.polynomial) % self.modulus, self)
 
     def add(self, left, right): return ExtensionFieldElement(left.polynomial + right.polynomial, self)

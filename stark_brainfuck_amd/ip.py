@@ -283,7 +283,10 @@ class ProofStream:
         return self._native().fiat_shamir(None, num_bytes)
 
     def verifier_fiat_shamir(self, num_bytes=32):
-        return self._native(self.read_index).fiat_shamir(None, num_bytes)
+        # SHAKE256 of pickle.dumps(objects[:read_index]) (ip.py:29-30).  The pickle of a prefix of the list is what the
+        # (cached) transcript of the whole list holds for its first read_index objects -- memo indices and frame cuts only
+        # depend on what came before -- so nothing is re-encoded per call.
+        return self._native().fiat_shamir(self.read_index, num_bytes)
 
     def deserialize(self, bb):
         ps = ProofStream()

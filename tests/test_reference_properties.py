@@ -128,3 +128,24 @@ def test_vm_input_output_tables():
     matrices = VirtualMachine.simulate(program, input_data=list("ax"))
     assert [int(r[0].value) for r in matrices[3]] == [ord("a"), ord("x")]
     assert [int(r[0].value) for r in matrices[4]] == [ord("b"), ord("x")]
+
+
+def test_cubic_multiplication_shortcut_equals_the_generic_reduction():
+    """ExtensionField.multiply reduces with X^3 = X - 1 on integers; value, canonical form and the BaseField instance of the
+    result's coefficients must be those of (left.polynomial * right.polynomial) % modulus (extension_field.py:65-67)"""
+    import random
+    from stark_brainfuck_amd.algebra import BaseField, BaseFieldElement
+    from stark_brainfuck_amd.extension_field import ExtensionFieldElement
+    from stark_brainfuck_amd.univariate import Polynomial
+    xf = sb.ExtensionField.main()
+    other = BaseField(xf.modulus.coefficients[0].field.p)           # a second instance, as the VM's field is
+    rng = random.Random(5)
+    for trial in range(500):
+        a = xf.from_limbs([rng.randrange(0, other.p) for _ in range(rng.randrange(0, 4))])
+        b = ExtensionFieldElement(Polynomial([BaseFieldElement(rng.randrange(0, other.p), other) for _ in range(rng.randrange(0, 4))]), xf)
+        for left, right in ((a, b), (b, a)):
+            fast = left * right
+            slow = ExtensionFieldElement((left.polynomial * right.polynomial) % xf.modulus, xf)
+            assert fast == slow
+            assert [c.value for c in fast.polynomial.coefficients] == [c.value for c in slow.polynomial.coefficients]
+            assert [c.field is other for c in fast.polynomial.coefficients] == [c.field is other for c in slow.polynomial.coefficients]
