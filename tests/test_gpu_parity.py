@@ -742,3 +742,41 @@ def test_device_scan_matches_the_host_scan(sb, n):
         assert tuple(int(v) for v in terminal) == want_terminal, (kind, ncols, use_mask, before, shift1)
         assert tuple(int(v) for v in d_terminal.to_numpy(3)) == want_terminal
         assert (got == want).all(), (kind, ncols, use_mask, before, shift1)
+
+
+@pytest.mark.gpu
+def test_memory_pools(sb):
+    """bfs_malloc_async / bfs_free_async: a freed block is handed out again without going to the driver, the statistics add up,
+    bfs_pool_trim gives the cache back, pinned staging arrays copy correctly, the stream-less pair keeps hipMalloc semantics"""
+    from stark_brainfuck_amd import _lib, device
+    from stark_brainfuck_amd.device import DeviceBuffer
+    lib = _lib.load()
+    device.synchronize()
+    device.pool_trim()
+    live0, cached0 = device.pool_stats()
+    assert cached0 == 0
+    a = DeviceBuffer(3 << 17)                      # 3 MiB -> a size class of its own
+    ptr = a.ptr
+    live1, _ = device.pool_stats()
+    assert live1 - live0 >= 3 << 20
+    a.free()
+    live2, cached2 = device.pool_stats()
+    assert live2 == live0 and cached2 == live1 - live0
+    b = DeviceBuffer(3 << 17)
+    assert b.ptr == ptr and device.pool_stats()[1] == 0          # the same block, straight from the free list
+    data = np.arange(3 << 17, dtype=np.uint64)
+    staged = device.pinned_empty(data.shape)
+    staged[:] = data
+    _lib.check(lib.bfs_memcpy_h2d(b.ptr, staged.ctypes.data, data.nbytes, device.current_stream()))
+    assert (b.to_numpy() == data).all()                          # to_numpy: the staged path for a 3 MiB pageable destination
+    c = DeviceBuffer.from_numpy(data[::-1].copy())               # pageable source, staged through the pinned pool
+    assert (c.to_numpy() == data[::-1]).all()
+    b.free(); c.free()
+    assert device.pool_stats()[1] > 0
+    device.pool_trim()
+    assert device.pool_stats() == (live0, 0)
+    p = ctypes.c_void_p()
+    _lib.check(lib.bfs_malloc(ctypes.byref(p), 1 << 20))
+    _lib.check(lib.bfs_free(p))
+    assert lib.bfs_free(ctypes.c_void_p(12345)) != 0 and b"did not allocate" in lib.bfs_last_error()
+    device.pool_trim()
