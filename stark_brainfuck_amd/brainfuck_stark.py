@@ -189,8 +189,12 @@ class BrainfuckStark:
 
         fetched_base, fetched_ext = {}, {}      # row -> words, filled by the batched gather of the openings
 
+        # the closures below outlive this call inside the trees' lazy leaf lists: they must not hold `self`, or a prover object
+        # kept with its trees (keep_intermediates) becomes a reference cycle and its HBM waits for a full garbage collection
+        tables = self.tables
+
         def base_requests(i):
-            return [(randomizer_codeword.ptr + 8 * i, 3, randomizer_codeword.stride)] + [(t.base_codewords.ptr + 8 * i, t.base_width, n) for t in self.tables]
+            return [(randomizer_codeword.ptr + 8 * i, 3, randomizer_codeword.stride)] + [(t.base_codewords.ptr + 8 * i, t.base_width, n) for t in tables]
 
         def base_row(i):         # only opened rows are ever read back
             words = fetched_base[i] if i in fetched_base else gather(base_requests(i))
@@ -221,7 +225,7 @@ class BrainfuckStark:
         shared = [dict() for _ in moduli]          # per column: i mod modulus -> the coefficient objects of that class
 
         def ext_requests(i):
-            return [(t.ext_codewords.ptr + 8 * i, 3 * (t.full_width - t.base_width), n) for t in self.tables]
+            return [(t.ext_codewords.ptr + 8 * i, 3 * (t.full_width - t.base_width), n) for t in tables]
 
         def ext_row(i):
             words = fetched_ext[i] if i in fetched_ext else gather(ext_requests(i))

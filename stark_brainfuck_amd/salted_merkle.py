@@ -85,13 +85,14 @@ class ZippedSaltedMerkle(SaltedMerkle):
             _lib.check(lib.bfs_random_fill(urandom(32), self._salts.ptr, words, stream))
             _lib.check(lib.bfs_merkle_build_rows(cols, len(columns), n, self._salts.ptr, 1, self._nodes.ptr, stream))
 
-            self._salt_cache = {}
+            cache = self._salt_cache = {}
+            d_salts = self._salts           # the closure must not hold `self`: tree -> leafs -> closure -> tree would be a cycle
 
             def salt_of(i):
                 from .device import gather
-                if i not in self._salt_cache:
-                    self._salt_cache[i] = gather([(self._salts.ptr + 24 * i, 3, 1)]).tobytes()
-                return self._salt_cache[i]
+                if i not in cache:
+                    cache[i] = gather([(d_salts.ptr + 24 * i, 3, 1)]).tobytes()
+                return cache[i]
         else:
             salts = urandom(24 * n)                      # the same bytes as n calls of urandom(24)
             keep = ctypes.create_string_buffer(salts, len(salts))

@@ -127,8 +127,10 @@ class VirtualMachine:
         return running_time, input_data, output_data
 
     @staticmethod
-    def simulate(program, input_data=[]):
+    def simulate(program, input_data=[], max_cycles=0):
         """vm.py:172-306 -> (processor_matrix, memory_matrix, instruction_matrix, input_matrix, output_matrix).
+        max_cycles (not in the reference; 0 = no limit): stop with an AssertionError instead of running on -- `-[-]` counts down
+        from p - 1.
         The machine runs natively (bfs_vm_trace_new, csrc/vm.cpp: 37 000 cycles in milliseconds instead of seconds of element
         construction); the matrices are LazyTraceMatrix objects over integer arrays.  `simulate_objects` is the direct
         restatement that builds every element, kept as the cross-check."""
@@ -142,7 +144,7 @@ class VirtualMachine:
         symbols = [ord(c) if isinstance(c, str) else int(c) for c in input_data]
         inp = (ctypes.c_uint32 * max(len(symbols), 1))(*symbols)
         handle = ctypes.c_void_p()
-        rc = lib.bfs_vm_trace_new(prog, len(words), inp, len(symbols), 0, ctypes.byref(handle))
+        rc = lib.bfs_vm_trace_new(prog, len(words), inp, len(symbols), int(max_cycles), ctypes.byref(handle))
         if rc:
             message = lib.bfs_last_error().decode("utf-8", "replace")
             assert False, message          # the reference's asserts: unrecognized instruction / input exhausted

@@ -173,3 +173,31 @@ def test_prove_and_verify_with_other_protocol_parameters():
     except Exception:
         accepted = False
     assert accepted is False
+
+
+@pytest.mark.gpu
+def test_prover_objects_release_their_memory_without_the_garbage_collector():
+    """no reference cycles through the HBM buffers: dropping a prover that kept its intermediates (trees, quotient codewords)
+    gives every block back to the pool at once -- prove() runs under gc.freeze(), where cyclic garbage would wait indefinitely"""
+    import gc
+    from stark_brainfuck_amd import device
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    program = VirtualMachine.compile("++[>+<-]>.")
+    running_time, inputs, outputs = VirtualMachine.run(program)
+    matrices = VirtualMachine.simulate(program, input_data=inputs)
+    gc.collect()
+    device.synchronize()
+    live_before = device.pool_stats()[0]
+    gc.disable()
+    try:
+        for keep in (True, False):
+            stark = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs)
+            stark.keep_intermediates = keep
+            proof = stark.prove(program, *matrices)
+            if keep:
+                assert device.pool_stats()[0] > live_before          # trees and quotient codewords are alive
+            del stark
+            assert device.pool_stats()[0] == live_before, "keep_intermediates = %s" % keep
+    finally:
+        gc.enable()
