@@ -220,6 +220,7 @@ def main():
             line["fri_prove_2p24"] = bench_fri(lib, _lib, stream, 22)
         if not args.no_stark and not args.no_fri:
             line["stark_prove"] = bench_stark()
+            line["stark_prove_2p22"] = bench_stark("+" * 64 + "[>" + "+" * 64 + "[>++++<-]<-]+++.", "nested loops, 37 254 cycles")
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(log_n)
         print(json.dumps(line), flush=True)
@@ -261,15 +262,20 @@ def bench_fri(lib, _lib, stream, log_d):
             "note": "bfs_fri_prove through the C ABI, codeword resident in HBM, includes host Fiat-Shamir round trips and D2H of openings"}
 
 
-def bench_stark():
+def bench_stark(code=None, label="Hello World!"):
     """config 4: BrainfuckStark.prove on the "Hello World!" program (FRI domain 2^17, 16 base + 10 extension columns, 52
-    quotients), through the Python mirror of the reference's call surface; the proof is checked with verify()."""
+    quotients), through the Python mirror of the reference's call surface; the proof is checked with verify().
+    With another `code`: the same on that program (the 2^22-domain leg uses nested loops, 37 254 cycles)."""
     from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
     from stark_brainfuck_amd.vm import VirtualMachine
-    code = "++++++++[>++++[>++>+++>+++>+<<<<-]>+>+>->>+[<]<-]>>.>---.+++++++..+++.>>.<-.<.+++.------.--------.>>+.>++."
+    if code is None:
+        code = "++++++++[>++++[>++>+++>+++>+<<<<-]>+>+>->>+[<]<-]>>.>---.+++++++..+++.>>.<-.<.+++.------.--------.>>+.>++."
     program = VirtualMachine.compile(code)
     running_time, inputs, outputs = VirtualMachine.run(program)
+    VirtualMachine.simulate(program, input_data=inputs)            # library load etc. outside the trace timing
+    t0 = time.perf_counter()
     matrices = VirtualMachine.simulate(program, input_data=inputs)
+    trace_ms = (time.perf_counter() - t0) * 1e3
     times, timing, proof = [], None, None
     for rep in range(4):
         stark = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs)
@@ -277,12 +283,15 @@ def bench_stark():
         proof = stark.prove(program, *matrices)
         times.append(time.perf_counter() - t0)
         timing = stark.timing
+    t0 = time.perf_counter()
     ok = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs).verify(proof)
-    return {"ms": statistics.median(times[1:]) * 1e3, "program": "Hello World!", "running_time": running_time,
+    verify_ms = (time.perf_counter() - t0) * 1e3
+    return {"ms": statistics.median(times[1:]) * 1e3, "program": label, "running_time": running_time,
             "fri_domain_length": stark.fri.domain.length, "proof_bytes": len(proof), "verified": bool(ok),
+            "trace_ms": trace_ms, "verify_ms": verify_ms,
             "breakdown_ms": {k: round(v * 1e3, 2) for k, v in timing.items()},
-            "reference": "not runnable: > 12 h extrapolated from 361 s at N = 1024 (BASELINE.md); 757 s measured at N = 2048 (tests/golden/stark_loop.json)",
-            "note": "wall clock of prove() incl. host steps (padding, running products, row pickling for the zipped commitments, Fiat-Shamir)"}
+            "reference": "not runnable: > 12 h extrapolated from 361 s at N = 1024 (BASELINE.md); 757 s measured at N = 2048, 6 766 s at N = 16 384 (tests/golden/stark_*.json)",
+            "note": "wall clock of prove() incl. host steps (padding, Fiat-Shamir, transcript); trace_ms = VirtualMachine.simulate (native), verify_ms = verify() on the host"}
 
 
 def cpu_baseline(log_n):
