@@ -3,7 +3,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
 from stark_brainfuck_amd.vm import VirtualMachine
-for outer in (8, 16, 32, 64):
+for outer in (8, 16, 32, 64, 128):
     # nested loops; the printed cell must stay below 256: the claim is about output CHARACTERS (vm.py:149), and the verifier
     # recomputes the output terminal from ord(character) (evaluation_argument.py:7-14)
     code = "+" * outer + "[>" + "+" * outer + "[>++++<-]<-]+++."
