@@ -4,11 +4,17 @@ steps on the GPU:
   interpolate_columns + lde / ldex   (:112-148)  INTT over the omicron subgroup, rank-one randomizer correction
                                                  (bfs_poly_randomize), coset NTT onto the FRI domain -- per table one
                                                  batched call over all columns, codewords stay in HBM
-  all_quotients                      (:148-281)  one kernel per table (bfs_air_quotients, constraints from air.py)
-  *_quotient_degree_bounds           (:170-173, 238-247, 300-304)  exact symbolic expansion on the host (air.expand)
+  extend                             (per table)  the running products / evaluations as scan specs (`_scans`): `extend_device`
+                                                 runs them as prefix scans on the trace columns in HBM (bfs_xfe_scan_device),
+                                                 `extend` on the host primitive (bfs_xfe_scan) for the reference's call surface
+  all_quotients                      (:148-281)  one kernel per table (bfs_air_quotients, constraints from air.py); the prover
+                                                 itself uses `combine_into` (bfs_air_combine: quotients folded into the
+                                                 non-linear combination, never written) with `zerofier_inverses`
+  *_quotient_degree_bounds           (:170-173, 238-247, 300-304)  exact symbolic expansion on the host (air.expand), the generic
+                                                 surviving-monomial pattern cached for sampled challenges
 
-Rows live on the host as Python ints (base columns) and int triples (extension columns): padding and the running
-products / evaluations of `extend` are sequential scans over a few thousand rows, as in the reference.
+Base columns live on the host as uint64 arrays (in pinned staging memory once padded); extension columns exist on the host only
+when `extend` (not `extend_device`) made them.
 """
 import ctypes
 from os import urandom          # module-level on purpose: tests patch `table.urandom` for determinism
