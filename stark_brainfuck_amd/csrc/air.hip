@@ -247,18 +247,29 @@ struct ShiftPower {
     }
 };
 
-// ... or weighted and added to the running sum
+// ... or weighted and added to the running sum.  The constraints arrive kind by kind (boundary, transition, terminal) and all
+// quotients of a kind share their zerofier inverse, so the weighted VALUES of a kind are summed first and the inverse is applied once.
 template <int TABLE>
 struct CombineSink {
     Xfe acc;
     ShiftPower xp;
     const CombW* w;          // the quotients' weights (kernel arguments)
     Zerofiers z;
+    Xfe kind_sum;
+    template <int Q> __device__ __forceinline__ void close_kind() {
+        typedef AirShape<TABLE> S;
+        if constexpr (Q > 0 && (Q == S::NB || Q == S::NB + S::NT || Q == S::NB + S::NT + S::NZ)) {
+            acc = xfe_add(acc, xfe_scale(kind_sum, z.template of<TABLE, Q - 1>()));
+            kind_sum = Xfe{{0, 0, 0}};
+        }
+    }
     template <int Q> __device__ __forceinline__ void put(const Xfe& v) {
-        acc = xfe_add(acc, xfe_mul(xp.weight(w[Q]), xfe_scale(v, z.template of<TABLE, Q>())));
+        close_kind<Q>();
+        kind_sum = xfe_add(kind_sum, xfe_mul(xp.weight(w[Q]), v));
     }
     template <int Q> __device__ __forceinline__ void put_base(u64 v) {
-        acc = xfe_add(acc, xfe_scale(xp.weight(w[Q]), gl_mul(v, z.template of<TABLE, Q>())));
+        close_kind<Q>();
+        kind_sum = xfe_add(kind_sum, xfe_scale(xp.weight(w[Q]), v));
     }
 };
 
@@ -290,8 +301,10 @@ __global__ void __launch_bounds__(256) air_combine_kernel(const AirCombineArgs<T
         const u64 x = gl_mul(a.offset, tw_pow(a.w_lo, a.w_hi, a.lo_bits, i));
         CombineSink<TABLE> sink{acc, xp, A.w + S::BW + S::XW,
                                 A.inv_boundary ? Zerofiers(a, x, A.inv_boundary[i], A.inv_terminal[i], a.height != 0 ? A.inv_transition[i] : 0)
-                                               : Zerofiers(a, x)};
+                                               : Zerofiers(a, x),
+                                Xfe{{0, 0, 0}}};
         air_eval<TABLE>(bc, bn, xc, xn, a, sink);
+        sink.template close_kind<S::NB + S::NT + S::NZ>();
         A.acc[i] = sink.acc.c[0];
         A.acc[a.n + i] = sink.acc.c[1];
         A.acc[2 * a.n + i] = sink.acc.c[2];
