@@ -253,7 +253,8 @@ int bfs_selftest_field(uint32_t log_count, uint64_t* mismatches);
  *     polynomials f0 of h coefficients each (the INTT of a trace column over the omicron subgroup), `stride` >= h+1
  *     apart.  Each becomes the unique interpolant of degree <= h that also takes the value h_values[b] at `point`
  *     (omega of the FRI domain): f = f0 + c (X^h - 1), c = (value - f0(point)) / (point^h - 1).  Extension columns are
- *     passed as three base polynomials with the three limbs of the random value.  Synchronises the stream.
+ *     passed as three base polynomials with the three limbs of the random value.  Asynchronous (the values travel in the
+ *     kernel arguments).
  * bfs_air_quotients   Table.all_quotients (table.py:148-168, 176-236, 249-281) of table 0..4 = processor,
  *     instruction, memory, input, output (constraints: processor_table.py:51-327, instruction_table.py:27-165,
  *     memory_table.py:45-170, io_table.py:32-75; generated into csrc/air_generated.hpp from stark_brainfuck_amd/air.py).

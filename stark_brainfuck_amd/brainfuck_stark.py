@@ -35,7 +35,7 @@ from .merkle import Merkle
 from .permutation_argument import PermutationArgument
 from .processor_table import ProcessorTable
 from .salted_merkle import SaltedMerkle, ZippedSaltedMerkle
-from .table import sample_ext, sample_ext_many, zerofier_inverses
+from .table import extend_tables_device, sample_ext, sample_ext_many, zerofier_inverses
 from .univariate import Polynomial
 from .vm import VirtualMachine
 
@@ -209,8 +209,7 @@ class BrainfuckStark:
         # challenges, initials, table extension, terminals (:181-192)
         challenges = BrainfuckStark._sample_weights(11, proof_stream.prover_fiat_shamir())
         initials = [sample_ext(urandom(3 * 8)) for _ in self.permutation_arguments]
-        for table in self.tables:
-            table.extend_device(challenges, initials)       # prefix scans on the trace columns lde() left in HBM
+        extend_tables_device(self.tables, challenges, initials)       # prefix scans on the trace columns lde() left in HBM
         terminals = self.get_terminals()
         lap("extend")
 

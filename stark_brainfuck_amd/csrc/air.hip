@@ -20,9 +20,13 @@ int ntt_power_tables(u64 root, u32 log_n, const u64** lo, const u64** hi, u32* l
 // generic subproduct-tree routine (ntt.py:82-161).  The interpolant is unique, so it equals
 //     f = f0 + c * (X^h - 1),   f0 = INTT_h(column),   c = (r - f0(omega)) / (omega^h - 1)
 // One workgroup per column: evaluate f0 at `point` (Horner over per-thread chunks), then patch f[0] and f[h].
-__global__ void __launch_bounds__(256) poly_randomize_kernel(u64* coeffs, u64 stride, u64 h, u64 point, u64 inv_den, const u64* r) {
+struct RandomizerValues {
+    u64 v[64];           // the random values travel in the kernel arguments: no copy, no synchronisation
+};
+
+__global__ void __launch_bounds__(256) poly_randomize_kernel(u64* coeffs, u64 stride, u64 h, u64 point, u64 inv_den, RandomizerValues r, u32 first) {
     __shared__ u64 part[256];
-    u64* f = coeffs + (u64)blockIdx.x * stride;
+    u64* f = coeffs + (u64)(first + blockIdx.x) * stride;
     const u32 t = threadIdx.x;
     const u64 chunk = (h + 255) / 256;
     const u64 lo = (u64)t * chunk, hi = lo + chunk < h ? lo + chunk : h;
@@ -38,7 +42,7 @@ __global__ void __launch_bounds__(256) poly_randomize_kernel(u64* coeffs, u64 st
         __syncthreads();
     }
     if (t == 0) {
-        const u64 c = gl_mul(gl_sub(r[blockIdx.x], part[0]), inv_den);
+        const u64 c = gl_mul(gl_sub(r.v[blockIdx.x], part[0]), inv_den);
         f[0] = gl_sub(f[0], c);
         f[h] = c;
     }
@@ -390,12 +394,13 @@ int bfs_poly_randomize(uint64_t* d_coeffs, uint64_t stride, uint64_t h, uint32_t
     if (h == 0 || stride < h + 1) { set_error("bfs_poly_randomize: need h >= 1 and stride >= h + 1"); return BFS_ERR_BAD_ARG; }
     const u64 den = gl_sub(gl_pow(point, h), 1);
     if (den == 0) { set_error("bfs_poly_randomize: the extra point lies on the interpolation subgroup"); return BFS_ERR_BAD_ARG; }
-    void* w = nullptr;
-    BFS_TRY(workspace(3, (size_t)batch * sizeof(u64), stream, &w));
-    BFS_HIP(hipMemcpyAsync(w, h_values, (size_t)batch * sizeof(u64), hipMemcpyHostToDevice, stream));
-    hipLaunchKernelGGL(poly_randomize_kernel, dim3(batch), dim3(256), 0, stream, d_coeffs, stride, h, point, gl_inv(den), (const u64*)w);
-    BFS_HIP(hipGetLastError());
-    BFS_HIP(hipStreamSynchronize(stream));      // h_values may be reused by the caller
+    for (u32 first = 0; first < batch; first += 64) {
+        const u32 part = batch - first < 64 ? batch - first : 64;
+        RandomizerValues r{};
+        for (u32 k = 0; k < part; ++k) r.v[k] = h_values[first + k] % GL_P;
+        hipLaunchKernelGGL(poly_randomize_kernel, dim3(part), dim3(256), 0, stream, d_coeffs, stride, h, point, gl_inv(den), r, first);
+        BFS_HIP(hipGetLastError());
+    }
     return BFS_OK;
 }
 

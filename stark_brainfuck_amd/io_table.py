@@ -26,6 +26,9 @@ class IOTable(Table):
         """io_table.py:77-110: evaluation = evaluation * iota + symbol on every row"""
         return [dict(kind=1, cols=[0], mask=None, constants=[all_challenges[self.challenge_index], (1, 0, 0)], initial=X0, before=False)]
 
+    def _terminal_reads(self):
+        return [(0, self.length - 1)] if self.length else []
+
     def _after_extend(self, terminals, all_challenges, read):
         # the terminal is the value after the last real (unpadded) row
         self.evaluation_terminal = read(0, self.length - 1) if self.length else X0

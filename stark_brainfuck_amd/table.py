@@ -104,6 +104,60 @@ def extend_all(tables, challenges, initials):
         future.result()
 
 
+def extend_tables_device(tables, all_challenges, all_initials):
+    """Table.extend_device for several tables with ONE upload (all row masks), ONE read-back of the terminals and one gather for
+    the values the tables look up afterwards -- a proof has nine scans over five tables, and every separate copy is a round trip."""
+    from .device import GatherBatch
+    lib, stream = _lib.load(), current_stream()
+    plans, masks = [], []
+    for t in tables:
+        specs = t._scans(all_challenges, all_initials)
+        assert len(specs) == t.full_width - t.base_width
+        t.ext_columns = None
+        t._ext_device = DeviceBuffer(3 * len(specs) * t.height)
+        assert t.height == 0 or t._base_device is not None, "extend_device() follows lde()"
+        plans.append((t, specs))
+        if t.height:
+            masks += [np.ascontiguousarray(sp["mask"], dtype=np.uint8) for sp in specs if sp["mask"] is not None]
+    d_masks = None
+    if masks:
+        host = np.concatenate(masks)
+        d_masks = DeviceBuffer((host.size + 7) // 8)
+        _lib.check(lib.bfs_memcpy_h2d(d_masks.ptr, host.ctypes.data, host.size, stream))
+    total = sum(len(specs) for _, specs in plans)
+    d_terminals = DeviceBuffer(3 * max(total, 1))
+    mask_at, slot = 0, 0
+    for t, specs in plans:
+        h = t.height
+        for k, sp in enumerate(specs):
+            if h:
+                ptrs = [t._base_device.ptr + 8 * c * h for c in sp["cols"]] + [None] * (3 - len(sp["cols"]))
+                mask_ptr = None
+                if sp["mask"] is not None:
+                    mask_ptr = d_masks.ptr + mask_at
+                    mask_at += h
+                flat = [v for c in sp["constants"] for v in c] + [0] * (12 - 3 * len(sp["constants"]))
+                _lib.check(lib.bfs_xfe_scan_device(sp["kind"], ptrs[0], ptrs[1], ptrs[2], sp.get("shift1", 0), mask_ptr, h,
+                                                   (_u64 * 12)(*flat), (_u64 * 3)(*sp["initial"]), 1 if sp["before"] else 0,
+                                                   t._ext_device.ptr + 8 * 3 * k * h, h, d_terminals.ptr + 24 * slot, None, stream))
+            slot += 1
+    batch = GatherBatch()
+    terminal_ticket = batch.add(d_terminals.ptr, 3 * max(total, 1), 1)
+    read_tickets = {(t, k, row): batch.add(t._ext_device.ptr + 8 * (3 * k * t.height + row), 3, t.height)
+                    for t, _ in plans if t.height for k, row in t._terminal_reads()}
+    batch.run(stream)
+    words = [int(v) for v in batch.words(terminal_ticket)]
+    slot = 0
+    for t, specs in plans:
+        if t.height:
+            terminals = [tuple(words[3 * (slot + k):3 * (slot + k) + 3]) for k in range(len(specs))]
+        else:
+            terminals = [tuple(sp["initial"]) for sp in specs]
+        slot += len(specs)
+        t._after_extend(terminals, all_challenges,
+                        lambda k, row, t=t: tuple(int(v) for v in batch.words(read_tickets[(t, k, row)])))
+
+
 def zerofier_inverses(tables, domain):
     """bfs_zerofier_inverses for a set of tables: one kernel inverts every distinct zerofier denominator of the proof at every point.
     Returns (buffer, {table: (addr of 1/(x-1), addr of 1/(x - omicron^-1), addr of 1/(x^h - 1) or None)})."""
@@ -290,39 +344,11 @@ class Table:
 
     def extend_device(self, all_challenges, all_initials):
         """the same columns, computed in HBM from the base columns of the last lde(); needs lde() first"""
-        from .device import gather
-        lib, stream = _lib.load(), current_stream()
-        h, width = self.height, self.full_width - self.base_width
-        specs = self._scans(all_challenges, all_initials)
-        assert len(specs) == width
-        self.ext_columns = None
-        self._ext_device = DeviceBuffer(3 * width * h)
-        if h == 0:
-            self._after_extend([tuple(sp["initial"]) for sp in specs], all_challenges, None)
-            return
-        assert self._base_device is not None, "extend_device() follows lde()"
-        masks = [sp["mask"] for sp in specs if sp["mask"] is not None]
-        d_masks = None
-        if masks:
-            host = np.ascontiguousarray(np.stack(masks), dtype=np.uint8)
-            d_masks = DeviceBuffer((host.size + 7) // 8)
-            _lib.check(lib.bfs_memcpy_h2d(d_masks.ptr, host.ctypes.data, host.size, stream))
-        d_terminals = DeviceBuffer(3 * len(specs))               # read back once, after the last scan
-        k_mask = 0
-        for k, sp in enumerate(specs):
-            ptrs = [self._base_device.ptr + 8 * c * h for c in sp["cols"]] + [None] * (3 - len(sp["cols"]))
-            mask_ptr = None
-            if sp["mask"] is not None:
-                mask_ptr = d_masks.ptr + k_mask * h
-                k_mask += 1
-            flat = [v for c in sp["constants"] for v in c] + [0] * (12 - 3 * len(sp["constants"]))
-            _lib.check(lib.bfs_xfe_scan_device(sp["kind"], ptrs[0], ptrs[1], ptrs[2], sp.get("shift1", 0), mask_ptr, h,
-                                               (_u64 * 12)(*flat), (_u64 * 3)(*sp["initial"]), 1 if sp["before"] else 0,
-                                               self._ext_device.ptr + 8 * 3 * k * h, h, d_terminals.ptr + 24 * k, None, stream))
-        words = [int(v) for v in d_terminals.to_numpy(3 * len(specs))]
-        terminals = [tuple(words[3 * k:3 * k + 3]) for k in range(len(specs))]
-        self._after_extend(terminals, all_challenges,
-                           lambda k, row: tuple(int(v) for v in gather([(self._ext_device.ptr + 8 * (3 * k * h + row), 3, h)])))
+        extend_tables_device([self], all_challenges, all_initials)
+
+    def _terminal_reads(self):
+        """(extension column, row) pairs whose value _after_extend will ask for through `read` (fetched in one round trip)"""
+        return []
 
     @staticmethod
     def scan_async(*args):
