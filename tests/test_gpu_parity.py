@@ -676,7 +676,8 @@ def test_device_side_sampling_of_the_randomizer_polynomial(sb):
 @pytest.mark.parametrize("n,n_ext,n_base", [(1, 1, 0), (2, 0, 3), (3, 2, 2), (65, 16, 16), (1000, 2, 2)])
 def test_zipped_rows_edge_shapes(sb, oracle, n, n_ext, n_base):
     """row emitter on tiny, ragged (absent leaf slots) and wide inputs; 32 columns make the row pickle longer than 2.5 KB,
-    with memo back-references beyond index 255 (LONG_BINGET)"""
+    with memo back-references beyond index 255 (LONG_BINGET); the zeroed limbs put several patterns into one workgroup, so
+    rows whose template is not the one staged in LDS take the global-memory path of the leaf kernel"""
     from stark_brainfuck_amd import _lib
     from stark_brainfuck_amd.device import DeviceBuffer
     lib = _lib.load()
