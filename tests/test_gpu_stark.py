@@ -201,3 +201,24 @@ def test_prover_objects_release_their_memory_without_the_garbage_collector():
             assert device.pool_stats()[0] == live_before, "keep_intermediates = %s" % keep
     finally:
         gc.enable()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["two_io", "loop"])
+def test_prove_from_plain_lists_of_elements(name, monkeypatch):
+    """drop-in use: the matrices are plain Python lists of rows of BaseFieldElement, as the reference's VirtualMachine.simulate returns
+    them (no arrays attached, every element an object) -- the proof is still the reference's"""
+    from stark_brainfuck_amd import brainfuck_stark, salted_merkle, table
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    g = json.load(open(os.path.join(GOLDEN, "stark_%s.json" % name)))
+    program = VirtualMachine.compile(g["program"])
+    running_time, input_symbols, output_symbols = VirtualMachine.run(program, input_data=list(g["input"]))
+    matrices = [[list(row) for row in m] for m in VirtualMachine.simulate_objects(program, input_data=list(input_symbols))]
+    assert all(type(m) is list for m in matrices)
+    stream = Stream(name.encode())
+    for mod in (brainfuck_stark, salted_merkle, table):
+        monkeypatch.setattr(mod, "urandom", stream)
+    stark = BrainfuckStark(running_time, len(matrices[1]), program, input_symbols, output_symbols)
+    proof = stark.prove(program, *matrices)
+    assert hashlib.sha256(proof).hexdigest() == g["proof_sha256"]
