@@ -19,21 +19,27 @@ int ntt_power_tables(u64 root, u32 log_n, const u64** lo, const u64** hi, u32* l
 // The reference interpolates each trace column over {omicron^i} plus one extra point (omega, random value r) with a
 // generic subproduct-tree routine (ntt.py:82-161).  The interpolant is unique, so it equals
 //     f = f0 + c * (X^h - 1),   f0 = INTT_h(column),   c = (r - f0(omega)) / (omega^h - 1)
-// One workgroup per column: evaluate f0 at `point` (Horner over per-thread chunks), then patch f[0] and f[h].
+// Two small kernels: evaluate f0 at `point` (strided Horner, several workgroups per column), then patch f[0] and f[h].
 struct RandomizerValues {
     u64 v[64];           // the random values travel in the kernel arguments: no copy, no synchronisation
 };
 
-__global__ void __launch_bounds__(256) poly_randomize_kernel(u64* coeffs, u64 stride, u64 h, u64 point, u64 inv_den, RandomizerValues r, u32 first) {
+// Stage 1, grid (parts, columns): thread g of a column's T = 256 * parts threads sums f_k point^k over k = g, g + T, ... by Horner in
+// point^T (consecutive lanes read consecutive coefficients), times point^g; the block's sum goes to partial[column][part].
+__global__ void __launch_bounds__(256) poly_evaluate_partial_kernel(const u64* coeffs, u64 stride, u64 h, u64 point, u64* partial, u32 first) {
     __shared__ u64 part[256];
-    u64* f = coeffs + (u64)(first + blockIdx.x) * stride;
+    const u64* f = coeffs + (u64)(first + blockIdx.y) * stride;
     const u32 t = threadIdx.x;
-    const u64 chunk = (h + 255) / 256;
-    const u64 lo = (u64)t * chunk, hi = lo + chunk < h ? lo + chunk : h;
+    const u64 T = (u64)gridDim.x * 256, g = (u64)blockIdx.x * 256 + t;
     u64 acc = 0;
-    if (lo < h) {
-        for (u64 k = hi; k-- > lo;) acc = gl_add(gl_mul(acc, point), f[k]);      // sum_{k in chunk} f_k point^(k - lo)
-        acc = gl_mul(acc, gl_pow(point, lo));
+    if (g < h) {
+        const u64 step = gl_pow(point, T);
+        u64 k = g + (h - 1 - g) / T * T;                     // the largest index of this thread's progression
+        for (;; k -= T) {
+            acc = gl_add(gl_mul(acc, step), f[k]);
+            if (k == g) break;
+        }
+        acc = gl_mul(acc, gl_pow(point, g));
     }
     part[t] = acc;
     __syncthreads();
@@ -41,21 +47,30 @@ __global__ void __launch_bounds__(256) poly_randomize_kernel(u64* coeffs, u64 st
         if (t < s) part[t] = gl_add(part[t], part[t + s]);
         __syncthreads();
     }
-    if (t == 0) {
-        const u64 c = gl_mul(gl_sub(r.v[blockIdx.x], part[0]), inv_den);
-        f[0] = gl_sub(f[0], c);
-        f[h] = c;
-    }
+    if (t == 0) partial[(u64)blockIdx.y * gridDim.x + blockIdx.x] = part[0];
+}
+
+// Stage 2, one thread per column: c = (r - f0(point)) / (point^h - 1), then f[0] -= c and f[h] = c.
+__global__ void poly_randomize_finish_kernel(u64* coeffs, u64 stride, u64 h, u64 inv_den, RandomizerValues r, const u64* partial, u32 parts,
+                                             u32 first, u32 count) {
+    const u32 b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= count) return;
+    u64 sum = 0;
+    for (u32 p = 0; p < parts; ++p) sum = gl_add(sum, partial[(u64)b * parts + p]);
+    u64* f = coeffs + (u64)(first + b) * stride;
+    const u64 c = gl_mul(gl_sub(r.v[b], sum), inv_den);
+    f[0] = gl_sub(f[0], c);
+    f[h] = c;
 }
 
 // Which coefficient indices of a polynomial are non-zero, condensed to what the prover needs (table.ext_sharing_moduli): bit 63 =
 // the constant coefficient is non-zero; the low bits = OR over the non-zero indices j > 0 of (j & -j), so the lowest set bit is 2^v
-// with v the 2-adic valuation common to all of them.  One workgroup per polynomial.
+// with v the 2-adic valuation common to all of them.  grid (parts, polynomials); `out` starts at zero.
 __global__ void __launch_bounds__(256) coefficient_support_kernel(const u64* coeffs, u64 stride, u64 len, u64* out) {
     __shared__ u64 part[256];
-    const u64* f = coeffs + (u64)blockIdx.x * stride;
+    const u64* f = coeffs + (u64)blockIdx.y * stride;
     u64 acc = 0;
-    for (u64 j = threadIdx.x; j < len; j += 256)
+    for (u64 j = (u64)blockIdx.x * 256 + threadIdx.x; j < len; j += (u64)gridDim.x * 256)
         if (f[j] != 0) acc |= j ? (j & (0 - j)) : (1ull << 63);
     part[threadIdx.x] = acc;
     __syncthreads();
@@ -63,7 +78,7 @@ __global__ void __launch_bounds__(256) coefficient_support_kernel(const u64* coe
         if (threadIdx.x < s) part[threadIdx.x] |= part[threadIdx.x + s];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = part[0];
+    if (threadIdx.x == 0 && part[0]) atomicOr((unsigned long long*)(out + blockIdx.y), (unsigned long long)part[0]);
 }
 
 // ---- quotients -----------------------------------------------------------------------------------------------------
@@ -394,11 +409,17 @@ int bfs_poly_randomize(uint64_t* d_coeffs, uint64_t stride, uint64_t h, uint32_t
     if (h == 0 || stride < h + 1) { set_error("bfs_poly_randomize: need h >= 1 and stride >= h + 1"); return BFS_ERR_BAD_ARG; }
     const u64 den = gl_sub(gl_pow(point, h), 1);
     if (den == 0) { set_error("bfs_poly_randomize: the extra point lies on the interpolation subgroup"); return BFS_ERR_BAD_ARG; }
+    u32 parts = (u32)((h + 1023) / 1024);
+    if (parts > 64) parts = 64;
+    void* w = nullptr;
+    BFS_TRY(workspace(3, (size_t)64 * parts * sizeof(u64), stream, &w));
     for (u32 first = 0; first < batch; first += 64) {
-        const u32 part = batch - first < 64 ? batch - first : 64;
+        const u32 count = batch - first < 64 ? batch - first : 64;
         RandomizerValues r{};
-        for (u32 k = 0; k < part; ++k) r.v[k] = h_values[first + k] % GL_P;
-        hipLaunchKernelGGL(poly_randomize_kernel, dim3(part), dim3(256), 0, stream, d_coeffs, stride, h, point, gl_inv(den), r, first);
+        for (u32 k = 0; k < count; ++k) r.v[k] = h_values[first + k] % GL_P;
+        hipLaunchKernelGGL(poly_evaluate_partial_kernel, dim3(parts, count), dim3(256), 0, stream, (const u64*)d_coeffs, stride, h, point, (u64*)w, first);
+        hipLaunchKernelGGL(poly_randomize_finish_kernel, dim3((count + 63) / 64), dim3(64), 0, stream, d_coeffs, stride, h, gl_inv(den), r,
+                           (const u64*)w, parts, first, count);
         BFS_HIP(hipGetLastError());
     }
     return BFS_OK;
@@ -409,7 +430,10 @@ int bfs_poly_support(const uint64_t* d_coeffs, uint64_t stride, uint64_t len, ui
     if (batch == 0) return BFS_OK;
     void* w = nullptr;
     BFS_TRY(workspace(3, (size_t)batch * sizeof(u64), stream, &w));
-    hipLaunchKernelGGL(coefficient_support_kernel, dim3(batch), dim3(256), 0, stream, d_coeffs, stride, len, (u64*)w);
+    BFS_HIP(hipMemsetAsync(w, 0, (size_t)batch * sizeof(u64), stream));
+    u32 parts = (u32)((len + 2047) / 2048);
+    if (parts > 64) parts = 64;
+    hipLaunchKernelGGL(coefficient_support_kernel, dim3(parts ? parts : 1, batch), dim3(256), 0, stream, d_coeffs, stride, len, (u64*)w);
     BFS_HIP(hipGetLastError());
     BFS_HIP(hipMemcpyAsync(h_masks, w, (size_t)batch * sizeof(u64), hipMemcpyDeviceToHost, stream));
     BFS_HIP(hipStreamSynchronize(stream));
