@@ -165,6 +165,9 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
     u64 g = offset;
     for (u32 r = 0; r < R; ++r) {
         FriRound& fr = S.rounds[r];
+        unsigned char seed[32];
+        bool have_seed = false, speculating = false;
+        rp::Transcript::Speculation speculation;
         if (r == 0 && S.round0_nodes) {
             fr.nodes = (u64*)S.round0_nodes;          // the STARK prover has just committed to this very codeword (brainfuck_stark.py:301 / fri.py:108)
             memcpy(fr.root, S.round0_root, 64);
@@ -173,6 +176,13 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
             // paying a copy command + stream synchronisation per round
             const u64 seq = ++S.mailbox.seq;
             BFS_TRY(merkle_build_xfe_launch(fr.cw, fr.stride, fr.length, fr.nodes, stream, S.mailbox.dev, seq));  // fri.py:108
+            // While the GPU hashes: the next challenge is SHAKE256 of the WHOLE transcript including this root (fri.py:112-120), tens
+            // of KB -- as long as the tree kernels of the late rounds.  Everything in front of the root's 64 bytes is known already,
+            // so the sponge absorbs it now and only the last block or two wait for the root.
+            if (r + 1 < R) {
+                if (r == 0) { ps.fiat_shamir(ps.objects.size(), seed, 32); have_seed = true; }
+                else { ps.speculate(speculation); speculating = true; }
+            }
             volatile u64* flag = S.mailbox.host + 8;
             u64 spins = 0;
             while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
@@ -188,10 +198,10 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
             BFS_HIP(hipMemcpyAsync(fr.root, fr.nodes + 8, 64, hipMemcpyDeviceToHost, stream));
             BFS_HIP(hipStreamSynchronize(stream));
         }
-        if (r > 0) ps.objects.push_back(rp::mk_bytes(fr.root, 64));  // fri.py:112-113
-        if (r == R - 1) break;                                       // fri.py:116-117
-        unsigned char seed[32];
-        ps.fiat_shamir(ps.objects.size(), seed, 32);                 // fri.py:120
+        if (speculating) ps.resolve(speculation, fr.root, seed, 32);          // the placeholder pushed by speculate() becomes the root
+        else if (r > 0) ps.objects.push_back(rp::mk_bytes(fr.root, 64));      // fri.py:112-113
+        if (r == R - 1) break;                                                // fri.py:116-117
+        if (!speculating && !have_seed) ps.fiat_shamir(ps.objects.size(), seed, 32);   // fri.py:120
         Xfe alpha = rp::sample_xfe(seed, 32);
         FriRound& nx = S.rounds[r + 1];
         const u64 half = fr.length / 2;

@@ -94,12 +94,14 @@ inline void keccak_f1600(uint64_t s[25]) {
     s[19] = a19; s[20] = a20; s[21] = a21; s[22] = a22; s[23] = a23; s[24] = a24;
 }
 
-// SHAKE256: rate 136 bytes, domain suffix 0x1F
-inline void shake256(const void* data, size_t len, unsigned char* out, size_t outlen) {
+// SHAKE256: rate 136 bytes, domain suffix 0x1F.  `resume` / `absorbed`: a sponge that has already absorbed the first `absorbed`
+// bytes (a multiple of the rate) of `data` -- see shake256_absorb_blocks.
+inline void shake256(const void* data, size_t len, unsigned char* out, size_t outlen, const uint64_t* resume = nullptr, size_t absorbed = 0) {
     uint64_t s[25];
-    memset(s, 0, sizeof s);
+    if (resume) memcpy(s, resume, sizeof s); else memset(s, 0, sizeof s);
     const size_t rate = 136;
-    const unsigned char* p = (const unsigned char*)data;
+    const unsigned char* p = (const unsigned char*)data + absorbed;
+    len -= absorbed;
     unsigned char block[136];
     while (len >= rate) {
         for (size_t i = 0; i < rate / 8; ++i) { uint64_t w; memcpy(&w, p + 8 * i, 8); s[i] ^= w; }
@@ -120,6 +122,20 @@ inline void shake256(const void* data, size_t len, unsigned char* out, size_t ou
         off += take;
         if (off < outlen) keccak_f1600(s);
     }
+}
+
+// absorb the whole rate-sized blocks of data[0, limit) into a fresh sponge; returns the number of bytes absorbed
+inline size_t shake256_absorb_blocks(const void* data, size_t limit, uint64_t state[25]) {
+    memset(state, 0, 25 * sizeof(uint64_t));
+    const size_t rate = 136;
+    const unsigned char* p = (const unsigned char*)data;
+    size_t done = 0;
+    while (done + rate <= limit) {
+        for (size_t i = 0; i < rate / 8; ++i) { uint64_t w; memcpy(&w, p + done + 8 * i, 8); state[i] ^= w; }
+        keccak_f1600(state);
+        done += rate;
+    }
+    return done;
 }
 
 }  // namespace bfs

@@ -177,6 +177,9 @@ class Pickler {
         if (++stream_batch_ == BATCH) { op(0x65); stream_batch_ = 0; }   // APPENDS closes it after 1000 items
     }
     size_t stream_items() const { return stream_items_; }
+    // overwrite bytes of the open form (same offsets as in the last stream_bytes() result): a payload that was pickled as a
+    // placeholder and has become known (Transcript::speculate / resolve)
+    void stream_patch(size_t offset, const void* data, size_t len) { memcpy(&out_[offset], data, len); }
     std::string stream_bytes() {
         const size_t size = out_.size(), frame = frame_start_;
         std::string saved_header;
@@ -439,6 +442,43 @@ struct Transcript {
     void fiat_shamir(size_t count, unsigned char* out, size_t num_bytes) const {
         std::string s = serialize(count);
         shake256(s.data(), s.size(), out, num_bytes);
+    }
+
+    // Fiat-Shamir over a stream whose LAST object is a 64-byte digest that is still being computed (a Merkle root on its way from the
+    // GPU).  Every challenge hashes the whole transcript (tens of KB, ip.py:21-25), but the length of the final pickle -- hence its
+    // frame header -- and everything before the digest's payload are known beforehand: speculate() pushes a placeholder, pickles,
+    // and absorbs all SHAKE blocks in front of the payload while the kernel runs; resolve() fills the digest in and finishes.
+    struct Speculation {
+        std::string bytes;
+        size_t payload = 0, absorbed = 0;
+        uint64_t sponge[25];
+        Ref node;
+        bool active = false;
+    };
+    bool speculate(Speculation& sp) {
+        unsigned char sentinel[64];
+        for (int i = 0; i < 64; ++i) sentinel[i] = (unsigned char)(0xC3 ^ (i * 37));
+        sp.node = mk_bytes(sentinel, 64);
+        objects.push_back(sp.node);
+        sp.active = false;
+        if (objects.size() < 2) return false;                       // plain route in serialize(): no open form to patch
+        sp.bytes = serialize(objects.size());
+        // the payload sits in the last ~80 bytes: SHORT_BINBYTES 64 <payload> MEMOIZE [APPENDS] STOP
+        const size_t from = sp.bytes.size() > 96 ? sp.bytes.size() - 96 : 0;
+        const size_t at = sp.bytes.find(std::string((const char*)sentinel, 64), from);
+        if (at == std::string::npos) return false;
+        sp.payload = at;
+        sp.absorbed = shake256_absorb_blocks(sp.bytes.data(), at, sp.sponge);
+        sp.active = true;
+        return true;
+    }
+    void resolve(Speculation& sp, const unsigned char digest[64], unsigned char* out, size_t num_bytes) {
+        sp.node->data.assign((const char*)digest, 64);
+        if (!sp.active) { fiat_shamir(objects.size(), out, num_bytes); return; }
+        memcpy(&sp.bytes[sp.payload], digest, 64);
+        stream.stream_patch(sp.payload, digest, 64);
+        shake256(sp.bytes.data(), sp.bytes.size(), out, num_bytes, sp.sponge, sp.absorbed);
+        sp.active = false;
     }
 };
 
