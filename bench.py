@@ -196,6 +196,16 @@ def main():
             parts = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(parts, t)
             fri_all = [float(p[0]) for p in parts]
+    # STARK prover replicas, the same way: every GPU proves the Hello-World program on its own
+    stark_mine, stark_all = None, None
+    if not args.no_stark and not args.no_fri:
+        stark_mine = bench_stark()
+        stark_all = [stark_mine["ms"]]
+        if dist is not None:
+            t = torch.tensor([stark_mine["ms"]], dtype=torch.float64, device="cuda")
+            parts = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(parts, t)
+            stark_all = [float(p[0]) for p in parts]
     if rank == 0:
         # dominant kernel = ntt_tile_kernel (npass launches per step); algorithmic bytes of one launch =
         # 16 B/element * n * columns / npass (DESIGN.md "Roofline accounting"); HIP events bracket exactly K steps
@@ -219,7 +229,8 @@ def main():
             line["fri_prove_ms"] = max(fri_all)
             line["fri_prove_2p24"] = bench_fri(lib, _lib, stream, 22)
         if not args.no_stark and not args.no_fri:
-            line["stark_prove"] = bench_stark()
+            line["stark_prove"] = stark_mine
+            line["stark_prove"]["replicas"] = {"per_gpu_ms": [round(v, 4) for v in stark_all], "proofs_per_s": world / (max(stark_all) * 1e-3)}
             line["stark_prove_2p22"] = bench_stark("+" * 64 + "[>" + "+" * 64 + "[>++++<-]<-]+++.", "nested loops, 37 254 cycles")
         if world == 1 and not args.no_cpu:
             line["cpu_baseline"] = cpu_baseline(log_n)
