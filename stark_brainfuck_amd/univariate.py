@@ -169,6 +169,14 @@ class Polynomial:
 
 def colinear(points):
     """True iff the points lie on a line of degree exactly 1 (univariate.py:190-194)."""
+    if len(points) == 3:
+        # three points with distinct abscissae: the interpolant has degree exactly 1 iff they are collinear with a non-zero slope --
+        # two cross products instead of a Lagrange interpolation (FRI's verifier asks this once per round and test)
+        (x0, y0), (x1, y1), (x2, y2) = points
+        d1, d2, dx = x1 - x0, x2 - x0, x2 - x1
+        if not (d1.is_zero() or d2.is_zero() or dx.is_zero()):
+            e1 = y1 - y0
+            return (not e1.is_zero()) and (y2 - y0) * d1 == e1 * d2
     poly = Polynomial.interpolate_domain([p[0] for p in points], [p[1] for p in points])
     return poly.degree() == 1
 

@@ -149,3 +149,20 @@ def test_cubic_multiplication_shortcut_equals_the_generic_reduction():
             assert fast == slow
             assert [c.value for c in fast.polynomial.coefficients] == [c.value for c in slow.polynomial.coefficients]
             assert [c.field is other for c in fast.polynomial.coefficients] == [c.field is other for c in slow.polynomial.coefficients]
+
+
+def test_three_point_colinearity_shortcut_equals_interpolation():
+    """colinear() on three points uses cross products; the verdict must be that of the reference's definition -- the Lagrange
+    interpolant has degree exactly 1 (univariate.py:190-194) -- for lines, constants, zero and generic points"""
+    import random
+    from stark_brainfuck_amd.univariate import Polynomial
+    xf, f = sb.ExtensionField.main(), sb.BaseField.main()
+    rng = random.Random(9)
+    rnd = lambda: xf.from_limbs([rng.randrange(0, f.p) for _ in range(3)])
+    slow = lambda pts: Polynomial.interpolate_domain([p[0] for p in pts], [p[1] for p in pts]).degree() == 1
+    for trial in range(120):
+        xs = [rnd() for _ in range(3)]
+        a, b = rnd(), rnd()
+        ys = [[a * x + b for x in xs], [b for _ in xs], [rnd() for _ in xs], [xf.zero() for _ in xs]][trial % 4]
+        points = list(zip(xs, ys))
+        assert sb.colinear(points) == slow(points) == (trial % 4 == 0)
