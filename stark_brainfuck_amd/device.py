@@ -8,11 +8,17 @@ import numpy as np
 from . import _lib
 
 
+_TORCH = []          # [torch module] once a GPU context has been seen (the availability probe costs microseconds per call)
+
+
 def current_stream():
     """HIP stream handle to enqueue on: torch's current stream when torch has a GPU context, else the default stream."""
+    if _TORCH:
+        return int(_TORCH[0].cuda.current_stream().cuda_stream)
     try:
         import torch
         if torch.cuda.is_available() and torch.cuda.is_initialized():
+            _TORCH.append(torch)
             return int(torch.cuda.current_stream().cuda_stream)
     except ImportError:
         pass
