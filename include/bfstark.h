@@ -135,6 +135,9 @@ size_t bfs_ps_num_objects(void* ps);
 uint64_t bfs_ps_object_at(void* ps, size_t index);
 int bfs_ps_serialize(void* ps, size_t count, uint8_t* out, size_t capacity, size_t* length);
 int bfs_ps_fiat_shamir(void* ps, size_t count, uint8_t* out, size_t num_bytes);
+/* push(bytes(digest)) followed by fiat_shamir over everything, computed the way bfs_fri_commit overlaps it with a tree kernel: the
+ * SHAKE256 blocks in front of the digest's payload are absorbed before the digest is known (same result as the two calls). */
+int bfs_ps_push_digest_fiat_shamir(void* ps, const uint8_t digest[64], uint8_t* out, size_t num_bytes);
 /* pickle.dumps(obj) of one object on its own (leaf preimages: merkle.py:30, salted_merkle.py:32-33); two-call pattern */
 int bfs_ps_obj_dumps(void* ps, uint64_t handle, uint8_t* out, size_t capacity, size_t* length);
 /* introspection (to hand objects created by bfs_fri_prove back to the host language):

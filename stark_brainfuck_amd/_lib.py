@@ -63,6 +63,7 @@ _SIGNATURES = {
     "bfs_ps_object_at": (u64, [vp, sz]),
     "bfs_ps_serialize": (ci, [vp, sz, vp, sz, ctypes.POINTER(sz)]),
     "bfs_ps_fiat_shamir": (ci, [vp, sz, vp, sz]),
+    "bfs_ps_push_digest_fiat_shamir": (ci, [vp, ctypes.c_char_p, vp, sz]),
     "bfs_ps_obj_dumps": (ci, [vp, u64, vp, sz, ctypes.POINTER(sz)]),
     "bfs_ps_obj_kind": (ci, [vp, u64]),
     "bfs_ps_obj_len": (sz, [vp, u64]),

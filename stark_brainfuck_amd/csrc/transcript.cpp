@@ -97,6 +97,15 @@ int bfs_ps_fiat_shamir(void* ps, size_t count, uint8_t* out, size_t num_bytes) {
     return BFS_OK;
 }
 
+// push a 64-byte digest and return the Fiat-Shamir bytes over the stream including it, the way the FRI prover does while a tree
+// kernel runs: placeholder pushed and everything in front of its payload absorbed first, the digest filled in afterwards
+int bfs_ps_push_digest_fiat_shamir(void* ps, const uint8_t digest[64], uint8_t* out, size_t num_bytes) {
+    rp::Transcript::Speculation sp;
+    T(ps)->speculate(sp);
+    T(ps)->resolve(sp, digest, out, num_bytes);
+    return BFS_OK;
+}
+
 int bfs_ps_obj_kind(void* ps, uint64_t handle) {
     Ref r = T(ps)->get(handle);
     if (!r) return -1;

@@ -176,3 +176,32 @@ def test_sample_indices(sb):
     assert fri.num_rounds() == 4
     with pytest.raises(AssertionError, match="less than one round"):
         sb.Fri(F.generator(), F.primitive_nth_root(4), 4, 4, 1, XF)
+
+
+def test_speculative_fiat_shamir_equals_hashing_afterwards(sb):
+    """what the FRI prover does while a tree kernel runs (Transcript::speculate / resolve): a placeholder digest is pushed, the SHAKE256
+    blocks in front of its payload are absorbed, then the digest is filled in.  Bytes and challenge must equal CPython's
+    pickle + hashlib on the finished list -- for streams of any length, across the 64 KiB frame boundary of pickle protocol 4"""
+    import ctypes
+    import hashlib
+    import pickle
+    import random
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.ip import NativeTranscript
+    lib = _lib.load()
+    rng = random.Random(3)
+    for prefix in (0, 1, 2, 7, 60, 1100):
+        t = NativeTranscript()
+        objects = []
+        for k in range(prefix):
+            obj = bytes(rng.randrange(256) for _ in range(rng.choice((0, 5, 64, 136, 137))))
+            objects.append(obj)
+            t.push(obj)
+        for step in range(40):
+            digest = bytes(rng.randrange(256) for _ in range(64))
+            out = ctypes.create_string_buffer(32)
+            _lib.check(lib.bfs_ps_push_digest_fiat_shamir(t.handle, digest, out, 32))
+            objects.append(digest)
+            want = pickle.dumps(objects, protocol=4)
+            assert t.serialize() == want, (prefix, step)
+            assert out.raw == hashlib.shake_256(want).digest(32), (prefix, step)
