@@ -273,15 +273,18 @@ int bfs_selftest_field(uint32_t log_count, uint64_t* mismatches);
 /*
  * The Brainfuck VM and its execution trace (host): VirtualMachine.simulate (vm.py:172-306) and MemoryTable.derive_matrix
  * (memory_table.py:20-38).  program: the compiled words (vm.py:78-105), input: the symbols read by `,` as code points.
- * max_cycles = 0: no limit.  Parts of the trace (bfs_vm_trace_size / bfs_vm_trace_copy, sizes in 64-bit words):
+ * max_cycles: the machine stops with an error after that many cycles; 0 = BFS_VM_DEFAULT_MAX_CYCLES (a trace costs ~130 bytes per
+ * cycle and a program such as `-[-]` runs for p - 1 iterations; pass UINT64_MAX to run without a limit).  Parts of the trace (bfs_vm_trace_size / bfs_vm_trace_copy, sizes in 64-bit words):
  *   0 processor matrix (rows x 7: clk ip ci ni mp mv mvi)   1 memory matrix (rows x 4: clk mp mv dummy)
  *   2 instruction matrix (rows x 3: ip ci ni, sorted by address)   3 input symbols   4 output symbols
  *   5 / 6 / 7: for the processor's memory-value column / the input symbols / the output symbols, the id of the element OBJECT
  *   that held the value in the reference (0 = the register's initial zero, 1 = the shared zero of untouched cells, k > 1 = an object
  *   made by `+`, `-`, `,`): pickle memoises by
  *   identity and these objects reach the proof through the evaluation terminals (processor_table.py:390-404).
- * Errors (BFS_ERR_BAD_ARG): unknown instruction, input exhausted ("program reads more input symbols than were supplied").
+ * Errors (BFS_ERR_BAD_ARG): unknown instruction, input exhausted ("program reads more input symbols than were supplied"),
+ * cycle limit reached ("program runs for more than N cycles").
  */
+#define BFS_VM_DEFAULT_MAX_CYCLES (1ull << 24)
 int bfs_vm_trace_new(const uint64_t* program, size_t n_words, const uint32_t* input, size_t n_input, uint64_t max_cycles, void** trace);
 void bfs_vm_trace_free(void* trace);
 int bfs_vm_trace_size(void* trace, int which, size_t* words);

@@ -36,19 +36,62 @@ def up_to_date():
     return all(os.path.getmtime(f) <= t for f in _deps())
 
 
+OBJ = os.path.join(HERE, "_build")
+
+
+def _stale(obj, dep, key):
+    """an object is rebuilt when it, its dependency file or the flag record is missing, or any file it included is newer"""
+    if not (os.path.exists(obj) and os.path.exists(dep) and os.path.exists(obj + ".flags")):
+        return True
+    if open(obj + ".flags").read() != key:
+        return True
+    t = os.path.getmtime(obj)
+    text = open(dep).read().replace("\\\n", " ")
+    files = text.split(":", 1)[1].split() if ":" in text else []
+    return any((not os.path.exists(f)) or os.path.getmtime(f) > t for f in files)
+
+
 def build_library(force=False, verbose=False, extra_flags=()):
+    """one object per translation unit (compiled in parallel, rebuilt only when a file it includes changed), then one link"""
     if not force and up_to_date():
         return LIB
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + list(extra_flags) + ["-o", LIB + ".tmp"] + sources()
+    os.makedirs(OBJ, exist_ok=True)
+    compile_flags = [f for f in FLAGS if f != "-shared"] + list(extra_flags)
+    key = " ".join([hipcc] + compile_flags)
+    jobs, objects = [], []
+    for src in sources():
+        obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+        dep = obj + ".d"
+        objects.append(obj)
+        if force or _stale(obj, dep, key):
+            jobs.append((src, obj, dep))
+
+    def compile_one(job):
+        src, obj, dep = job
+        cmd = [hipcc] + compile_flags + ["-c", "-MD", "-MF", dep, "-o", obj, src]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        res = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if res.returncode == 0:
+            open(obj + ".flags", "w").write(key)
+        return src, res
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        results = list(pool.map(compile_one, jobs))
+    failed = [(src, res) for src, res in results if res.returncode != 0]
+    for src, res in results:
+        if res.stdout and (verbose or res.returncode != 0):
+            sys.stderr.write(res.stdout)
+    if failed:
+        raise RuntimeError("hipcc failed building " + ", ".join(os.path.basename(src) for src, _ in failed))
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB + ".tmp"] + objects
     if verbose:
         print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout)
-        raise RuntimeError("hipcc failed building libbfstark_hip.so")
-    if verbose and res.stdout:
-        print(res.stdout)
+        raise RuntimeError("hipcc failed linking libbfstark_hip.so")
     os.replace(LIB + ".tmp", LIB)
     return LIB
 

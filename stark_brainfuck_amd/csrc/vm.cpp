@@ -37,6 +37,8 @@ extern "C" {
 
 int bfs_vm_trace_new(const uint64_t* program, size_t n, const uint32_t* input, size_t n_input, uint64_t max_cycles, void** trace) {
     if (n == 0) { set_error("bfs_vm_trace_new: empty program"); return BFS_ERR_BAD_ARG; }
+    // the trace grows by ~130 bytes per cycle and `-[-]` counts down from p - 1: never run unbounded by default
+    if (max_cycles == 0) max_cycles = BFS_VM_DEFAULT_MAX_CYCLES;
     struct Cell { u64 value, id; };
     std::unordered_map<u64, Cell> memory;
     VmTrace* t = new VmTrace();
@@ -58,7 +60,7 @@ int bfs_vm_trace_new(const uint64_t* program, size_t n, const uint32_t* input, s
         return it == memory.end() ? Cell{0, 1} : it->second;
     };
     while (ip < n) {
-        if (max_cycles && clk >= max_cycles) { delete t; set_error("bfs_vm_trace_new: more than %llu cycles", (unsigned long long)max_cycles); return BFS_ERR_BAD_ARG; }
+        if (clk >= max_cycles) { delete t; set_error("program runs for more than %llu cycles", (unsigned long long)max_cycles); return BFS_ERR_BAD_ARG; }
         row();
         switch (ci) {
             case '[': ip = mv.value == 0 ? program[ip + 1] % GL_P : ip + 2; break;

@@ -64,6 +64,10 @@ def _matrix(rows, width, field, objects=None):
 
 class VirtualMachine:
     field = BaseField.main()
+    # not in the reference: every entry point that runs a program stops with an AssertionError after this many cycles unless
+    # the caller asks for another limit (`-[-]` counts down from p - 1 and a trace costs ~130 bytes per cycle natively,
+    # several hundred as element objects).  = BFS_VM_DEFAULT_MAX_CYCLES of include/bfstark.h
+    DEFAULT_MAX_CYCLES = 1 << 24
 
     @staticmethod
     def execute(brainfuck_code):
@@ -92,10 +96,11 @@ class VirtualMachine:
         return [w.value if hasattr(w, "value") else int(w) for w in program]
 
     @staticmethod
-    def run(program, input_data=[]):
+    def run(program, input_data=[], max_cycles=None):
         """vm.py:107-165 -> (running_time, input_data, output_data).  Input symbols that are not supplied cannot be
-        read from a terminal here: running out of input is an error."""
+        read from a terminal here: running out of input is an error.  max_cycles: see DEFAULT_MAX_CYCLES."""
         prog = VirtualMachine._words(program)
+        limit = VirtualMachine.DEFAULT_MAX_CYCLES if max_cycles is None else int(max_cycles)
         ip, mp, memory = 0, 0, {}
         output_data, input_data, input_counter = [], list(input_data), 0
         running_time = 1
@@ -124,13 +129,14 @@ class VirtualMachine:
             else:
                 assert False, f"unrecognized instruction at {ip}: {w}"
             running_time += 1
+            assert running_time <= limit, f"program runs for more than {limit} cycles"
         return running_time, input_data, output_data
 
     @staticmethod
-    def simulate(program, input_data=[], max_cycles=0):
+    def simulate(program, input_data=[], max_cycles=None):
         """vm.py:172-306 -> (processor_matrix, memory_matrix, instruction_matrix, input_matrix, output_matrix).
-        max_cycles (not in the reference; 0 = no limit): stop with an AssertionError instead of running on -- `-[-]` counts down
-        from p - 1.
+        max_cycles (not in the reference; default DEFAULT_MAX_CYCLES): stop with an AssertionError instead of running on --
+        `-[-]` counts down from p - 1 and the trace would grow until the process is killed.
         The machine runs natively (bfs_vm_trace_new, csrc/vm.cpp: 37 000 cycles in milliseconds instead of seconds of element
         construction); the matrices are LazyTraceMatrix objects over integer arrays.  `simulate_objects` is the direct
         restatement that builds every element, kept as the cross-check."""
@@ -144,7 +150,9 @@ class VirtualMachine:
         symbols = [ord(c) if isinstance(c, str) else int(c) for c in input_data]
         inp = (ctypes.c_uint32 * max(len(symbols), 1))(*symbols)
         handle = ctypes.c_void_p()
-        rc = lib.bfs_vm_trace_new(prog, len(words), inp, len(symbols), int(max_cycles), ctypes.byref(handle))
+        limit = VirtualMachine.DEFAULT_MAX_CYCLES if max_cycles is None else int(max_cycles)
+        assert limit > 0, "max_cycles must be positive"
+        rc = lib.bfs_vm_trace_new(prog, len(words), inp, len(symbols), limit, ctypes.byref(handle))
         if rc:
             message = lib.bfs_last_error().decode("utf-8", "replace")
             assert False, message          # the reference's asserts: unrecognized instruction / input exhausted
@@ -167,8 +175,9 @@ class VirtualMachine:
         return processor, memory, instruction, inputs, outputs
 
     @staticmethod
-    def simulate_objects(program, input_data=[]):
-        """the same five matrices built the reference's way, every element an object (vm.py:172-306)"""
+    def simulate_objects(program, input_data=[], max_cycles=1 << 20):
+        """the same five matrices built the reference's way, every element an object (vm.py:172-306); cycle limit as in
+        `simulate`, lower by default because every cycle builds seven element objects"""
         from .memory_table import MemoryTable
         field = VirtualMachine.field
         prog = VirtualMachine._words(program)
@@ -218,6 +227,7 @@ class VirtualMachine:
             else:
                 assert False, f"unrecognized instruction at {ip}: '{chr(ci)}'"
             clk += 1
+            assert clk <= max_cycles, f"program runs for more than {max_cycles} cycles"
             ci = prog[ip] if ip < n else 0
             ni = prog[ip + 1] if ip < n - 1 else 0
             mv = memory.get(mp, zero)

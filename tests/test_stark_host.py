@@ -324,23 +324,43 @@ def test_threaded_extension_equals_the_sequential_one(monkeypatch):
 
 
 def _random_program(rng, length):
-    """a random well-bracketed Brainfuck program that terminates quickly: loops only of the form [-] or [->+<]"""
-    out = []
+    """-> (code, input string) of a random well-bracketed Brainfuck program that terminates quickly.  The generator runs the
+    machine while it writes the program: `-` is only emitted on a cell that stays >= 0 and `<` only right of cell 0, so every loop
+    ([-] and [->+<]) starts on a small non-negative cell.  (Decrementing below zero wraps to p - 1 and a loop on such a cell
+    runs ~1.8e19 iterations; that case is covered by the cycle-limit test, not here.)"""
+    out, inputs = [], []
+    cells, mp = {}, 0
     while len(out) < length:
         k = rng.integers(0, 10)
         if k < 4:
-            out.append("+-"[rng.integers(0, 2)] * int(rng.integers(1, 4)))
+            count = int(rng.integers(1, 4))
+            if rng.integers(0, 2) and cells.get(mp, 0) >= count:
+                out.append("-" * count)
+                cells[mp] = cells.get(mp, 0) - count
+            else:
+                out.append("+" * count)
+                cells[mp] = cells.get(mp, 0) + count
         elif k < 6:
-            out.append("><"[rng.integers(0, 2)])
+            if rng.integers(0, 2) and mp > 0:
+                out.append("<")
+                mp -= 1
+            else:
+                out.append(">")
+                mp += 1
         elif k == 6:
             out.append(",")
+            inputs.append(int(rng.integers(1, 120)))
+            cells[mp] = inputs[-1]
         elif k == 7:
             out.append(".")
         elif k == 8:
             out.append("[-]")
+            cells[mp] = 0
         else:
             out.append("[->+<]")
-    return "".join(out)
+            cells[mp + 1] = cells.get(mp + 1, 0) + cells.get(mp, 0)
+            cells[mp] = 0
+    return "".join(out), "".join(chr(c) for c in inputs)
 
 
 def test_native_vm_equals_the_object_building_one():
@@ -351,8 +371,7 @@ def test_native_vm_equals_the_object_building_one():
     rng = np.random.default_rng(11)
     cases = [(golden(name)["program"], golden(name)["input"]) for name in NAMES]
     for _ in range(25):
-        code = _random_program(rng, int(rng.integers(1, 40)))
-        cases.append((code, "".join(chr(int(c)) for c in rng.integers(1, 120, code.count(",")))))
+        cases.append(_random_program(rng, int(rng.integers(1, 40))))
     cases.append(("-<-.", ""))                       # wraps the memory pointer and the value below zero (mod p)
     for code, inp in cases:
         program = VirtualMachine.compile(code)
@@ -373,3 +392,28 @@ def test_native_vm_equals_the_object_building_one():
     # the reference's error behaviour
     with pytest.raises(AssertionError, match="more input symbols"):
         VirtualMachine.simulate(VirtualMachine.compile(",,"), input_data=["a"])
+
+
+def test_runaway_programs_stop_at_the_cycle_limit():
+    """`-[-]` counts down from p - 1 (~1.8e19 iterations): every entry point that runs a program gives up with an AssertionError
+    at its cycle limit -- quickly, and without growing a trace until the process is killed (not in the reference, whose
+    vm.py:107-165 / 172-306 would simply never return)"""
+    import time
+    from stark_brainfuck_amd.vm import VirtualMachine
+    program = VirtualMachine.compile("-[-]")
+    t0 = time.perf_counter()
+    with pytest.raises(AssertionError, match="more than 100000 cycles"):
+        VirtualMachine.simulate(program, max_cycles=100000)
+    with pytest.raises(AssertionError, match="more than 100000 cycles"):
+        VirtualMachine.run(program, max_cycles=100000)
+    with pytest.raises(AssertionError, match="more than 5000 cycles"):
+        VirtualMachine.simulate_objects(program, max_cycles=5000)
+    assert time.perf_counter() - t0 < 1.0
+    # the default limit (no argument) is finite as well: 2^24 cycles of the native machine
+    assert VirtualMachine.DEFAULT_MAX_CYCLES == 1 << 24
+    t0 = time.perf_counter()
+    with pytest.raises(AssertionError, match=f"more than {1 << 24} cycles"):
+        VirtualMachine.simulate(program)
+    assert time.perf_counter() - t0 < 20.0
+    # a program that stays under the limit is not affected by it
+    assert len(VirtualMachine.simulate(VirtualMachine.compile("+++[-]"), max_cycles=100)[0]) == 11
