@@ -379,7 +379,8 @@ class BrainfuckStark:
                       "quotient_degree_bounds": quotient_degree_bounds}
         if self.keep_intermediates:
             self._last.update({"base_tree": base_tree, "extension_tree": extension_tree, "combination_tree": combination_tree,
-                               "quotient_buffers": quotient_buffers, "combination": combination})
+                               "quotient_buffers": quotient_buffers, "combination": combination,
+                               "randomizer_codeword": randomizer_codeword})
         else:
             BrainfuckStark._release(combination, combination_tree)
         lap("fri")

@@ -89,17 +89,31 @@ def test_config2_2p20_forward_inverse_golden(sb, oracle):
 
 
 def test_config5_2p24_columns(sb, oracle):
-    """BASELINE config 5 shape: 2^24-point columns.  Column 0 against the oracle, the batch through round trip and
-    linearity (size-independent properties)."""
-    logn, n, cols = 24, 1 << 24, 3
+    """BASELINE config 5: eight 2^24-point columns (column c = felt(seed + c * 2^32, i)) in one batched call.
+    Every column's SHA-256 against the oracle's known answers (tests/golden/ntt24_oracle.json, made by gen_ntt24_oracle.py),
+    columns 0 and 5 against the oracle run live on this box, then the size-independent properties on the whole batch:
+    inverse round trip and linearity.  The same columns one at a time must give the same bytes (the sharded layout)."""
+    g = load_golden("ntt24_oracle.json")
+    logn, n, cols = 24, 1 << 24, 8
+    assert g["log_n"] == logn and len(g["columns"]) == cols
     w = oracle.primitive_nth_root(n)
+    assert w == g["root"]
     v = np.concatenate([oracle.felt_array(SEED + (c << 32), 0, n) for c in range(cols)])
     fw = raw_ntt(sb, v, logn, w, batch=cols)
-    assert (fw[:n] == oracle.ntt(w, v[:n])).all()
+    for c in range(cols):
+        assert sha_u64(v[c * n:(c + 1) * n]) == g["columns"][c]["input_sha256"], c
+        assert sha_u64(fw[c * n:(c + 1) * n]) == g["columns"][c]["output_sha256"], c
+        assert [int(x) for x in fw[c * n:c * n + 3]] == g["columns"][c]["output_head"]
+    for c in (0, 5):
+        assert (fw[c * n:(c + 1) * n] == oracle.ntt(w, v[c * n:(c + 1) * n])).all(), c
     back = raw_ntt(sb, fw, logn, oracle.inv(w), 1, oracle.inv(n), batch=cols)
     assert (back == v).all()
-    # linearity: NTT(a + b) = NTT(a) + NTT(b) (mod p), on columns 1 and 2
-    assert (raw_ntt(sb, addmod(v[n:2 * n], v[2 * n:]), logn, w) == addmod(fw[n:2 * n], fw[2 * n:])).all()
+    # linearity: NTT(a + b) = NTT(a) + NTT(b) (mod p), on column pairs (1, 2), (3, 4), (6, 7)
+    for a, b in ((1, 2), (3, 4), (6, 7)):
+        assert (raw_ntt(sb, addmod(v[a * n:(a + 1) * n], v[b * n:(b + 1) * n]), logn, w) == addmod(fw[a * n:(a + 1) * n], fw[b * n:(b + 1) * n])).all()
+    # a column transformed on its own (what a rank of the sharded run does) is the same bytes as inside the batch
+    for c in (3, 7):
+        assert sha_u64(raw_ntt(sb, v[c * n:(c + 1) * n], logn, w)) == g["columns"][c]["output_sha256"]
 
 
 def test_ntt_other_roots_and_batches(sb, oracle):
