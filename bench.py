@@ -3,13 +3,18 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-Workload (config 5 of BASELINE.json, weak scaling): every GPU holds `--columns` (default 8) independent trace
-columns of 2^24 base-field elements resident in HBM; one step = the forward NTT of all its columns
-(one bfs_gl_ntt call, batch = columns).  value = total field elements transformed per second over all ranks,
-timed over exactly K steps between barrier + device synchronisation on both sides, max over ranks.
+Workload (config 5 of BASELINE.json): `--total-columns` (default 8) independent trace columns of 2^24 base-field elements,
+sharded over the ranks by stark_brainfuck_amd.shard (column c lives on rank c mod N: 8 / 4 / 2 / 1 columns per GPU at N = 1 / 2 /
+4 / 8 -- strong scaling, the default, which is config 5 as written), resident in HBM; one step = the forward NTT of all columns of
+a rank (one bfs_gl_ntt call, batch = its columns).  `--scaling weak` gives every GPU `--columns` columns instead.
+value = total field elements transformed per second over all ranks, timed over exactly K steps between barrier + device
+synchronisation on both sides, max over ranks.  After the timed region every rank commits to its output columns and the 64-byte
+roots are all-gathered (shard.gather_roots over RCCL: the only collective of the design, never inside the timed region).
 Extra keys on the same JSON line:
     roofline      dominant kernel (the NTT tile kernel) vs the 8 TB/s HBM roofline, from HIP events on the kernel's stream
-    cpu_baseline  the CPU oracle (oracle/gl_oracle.c, plain C port of ntt.py, 1 core) on a bounded sample, rank 0, N=1 only
+    cpu_baseline  the CPU oracle (oracle/gl_oracle.c, plain C port of ntt.py, 1 core) on a bounded sample, rank 0, N=1 only;
+                  cpu_baseline.reference_python carries the reference's own CPython figure (measured in the build container)
+    single_column_2p24  one 2^24-point column on its own (128 MiB: the transform north_star's target sentence is about)
     fri_prove     Fri.prove on a random degree-2^18 codeword, expansion 4 (config 3), through the C ABI, median of 5;
                   fri_prove_2p24: the same at N = 2^24 (degree 2^22)
 Before the W warmup steps the device is spun up with untimed steps for --spinup-ms of wall time: after idle the
@@ -50,7 +55,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log-n", type=int, default=24)
-    ap.add_argument("--columns", type=int, default=8, help="columns per GPU")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong: --total-columns columns sharded over the ranks (BASELINE config 5); weak: --columns per GPU")
+    ap.add_argument("--total-columns", type=int, default=8, help="strong scaling: columns of the whole job")
+    ap.add_argument("--columns", type=int, default=8, help="weak scaling: columns per GPU")
     ap.add_argument("--spinup-ms", type=float, default=300.0,
                     help="untimed steps run before the W warmup steps until this much wall time has passed, so that the "
                          "device clocks have ramped (the first ~10 steps after idle run ~10 %% slower); 0 disables")
@@ -93,11 +101,14 @@ def main():
     lib = _lib.load()
     _lib.check(lib.bfs_set_device(local_rank))
 
-    log_n, cols = args.log_n, args.columns
+    log_n = args.log_n
     n = 1 << log_n
     root = lib.bfs_gl_primitive_root(log_n)
-    total_cols = cols * world
-    my_cols = [rank * cols + j for j in range(cols)]        # weak scaling: every rank owns `cols` columns
+    total_cols = args.total_columns if args.scaling == "strong" else args.columns * world
+    my_cols = shard.assign_columns(total_cols, world, rank)          # column c -> rank c mod world (the product's sharding)
+    cols = len(my_cols)
+    if cols == 0:
+        raise SystemExit("rank %d owns no column: --total-columns (%d) must be >= the number of GPUs (%d)" % (rank, total_cols, world))
     host_in = np.concatenate([felt_array(SEED + (c << 32), 0, n) for c in my_cols])
     d_in = DeviceBuffer.from_numpy(host_in)
     d_out = DeviceBuffer(n * cols)
@@ -157,15 +168,14 @@ def main():
         for j, c in enumerate(my_cols):
             pref = BaseArray(DeviceBuffer.from_numpy(d_out.to_numpy(small, offset=j * n)), small)
             local_roots[c] = Merkle(pref).root()
-    if dist is not None and not args.no_check:
-        width = cols
-        send = torch.from_numpy(np.frombuffer(b"".join(local_roots[c] for c in my_cols), dtype=np.uint8).copy()).cuda()
-        recv = [torch.empty_like(send) for _ in range(world)]
-        dist.all_gather(recv, send)                           # RCCL over xGMI: 64-byte roots only
-        all_roots = b"".join(r.cpu().numpy().tobytes() for r in recv)
-        assert len(all_roots) == 64 * total_cols and all_roots[64 * rank * width:64 * (rank + 1) * width] == send.cpu().numpy().tobytes()
+    world_roots = None
+    if not args.no_check:
+        # the one collective of the design: all-gather of the per-column roots (RCCL over xGMI when world > 1)
+        world_roots = shard.gather_roots(local_roots, total_cols, world, rank, device=torch.device("cuda", local_rank) if dist is not None else None)
+        assert len(world_roots) == total_cols and all(len(r) == 64 for r in world_roots)
+        assert all(world_roots[c] == local_roots[c] for c in my_cols)
 
-    elems = n * cols * world * args.steps
+    elems = n * total_cols * args.steps
     value = elems / elapsed
     line = {
         "metric": "goldilocks_ntt_field_elements_per_sec",
@@ -176,12 +186,14 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "u64 (mod 2^64-2^32+1)",
         "data": "synthetic (splitmix64 mod p, seed 0x5EED)",
-        "config": {"workload": "forward NTT, 2^%d-point base-field columns, %d columns per GPU resident in HBM (BASELINE config 5 shape)" % (log_n, cols),
-                   "log_n": log_n, "columns_per_gpu": cols, "parallelism": "columns sharded %d-way, no data-path collective" % world},
+        "config": {"workload": "forward NTT of %d independent 2^%d-point base-field columns resident in HBM (BASELINE config 5)" % (total_cols, log_n),
+                   "log_n": log_n, "total_columns": total_cols, "columns_per_gpu": shard.columns_per_rank(total_cols, world),
+                   "parallelism": "column c on rank c mod %d (shard.assign_columns), no data-path collective; roots all-gathered after the timed region" % world},
+        "roots_sha256": __import__("hashlib").sha256(b"".join(world_roots)).hexdigest() if world_roots else None,
         "algorithmic_GBps": 16.0 * elems / elapsed / 1e9,
         "clock_spinup": {"ms": args.spinup_ms, "untimed_steps": spin_steps},
     }

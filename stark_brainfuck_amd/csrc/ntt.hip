@@ -1,17 +1,13 @@
 // ntt.hip -- gfx950 kernels and launcher for bfs_gl_ntt() (algorithm and reference citations: ntt_core.hpp)
-#include <cstdlib>
-
 #include "runtime.hpp"
 
 namespace bfs {
-
-constexpr u32 NTT_TILE_LOG_DEFAULT = 12;
 
 // One workgroup per tile: T/16 threads hold 16 elements each.  LDS = tile (padded) + the stage-1 -> stage-2 twiddles.
 // (A persistent variant with next-tile prefetch and 16-byte paired-lane accesses was measured slower: the kernel is
 //  VALU-issue bound at the time and hardware workgroup turnover already overlaps HBM latency)
 template <int B1, int B2, int B3, int LOGC, int MODE>
-__global__ void __launch_bounds__((TileCfg<B1, B2, B3, LOGC, MODE>::W > 256 ? TileCfg<B1, B2, B3, LOGC, MODE>::W : 256)) ntt_tile_kernel(const PassArgs a) {
+__global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) u64 smem[];
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     u64* tw = smem + (B2 > 0 ? ((Cfg::LDS_WORDS + 1) & ~1) : 0);
@@ -22,15 +18,15 @@ __global__ void __launch_bounds__((TileCfg<B1, B2, B3, LOGC, MODE>::W > 256 ? Ti
         __syncthreads();
     }
     const u64* rowtw = nullptr;
-    if (a.tb.row != nullptr) {
-        // this tile's row of the inter-pass twiddle table -> LDS (one coalesced 2^S-entry read per workgroup)
-        u64* rw = tw + Cfg::TW_WORDS;
-        u64 K;
-        if constexpr (MODE == PASS_COLUMN) K = a.pass_index ? digit_reverse((u64)(blockIdx.x >> a.lognl), a.pass_bits, 0, (int)a.pass_index - 1) : 0;
-        else K = a.mid_bits ? digit_reverse((u64)(blockIdx.x >> a.logch), a.pass_bits, 1, (int)a.npass - 2) : 0;
-        for (u32 i = threadIdx.x; i < (1u << Cfg::S); i += blockDim.x) rw[i] = a.tb.row[(K << Cfg::S) + i];
-        rowtw = rw;
-        __syncthreads();
+    if constexpr (MODE == PASS_COLUMN) {
+        if (a.tb.row != nullptr) {
+            // this tile's row of the inter-pass twiddle table -> LDS (one coalesced 2^S-entry read per workgroup)
+            u64* rw = tw + Cfg::TW_WORDS;
+            const u64 K = a.pass_index ? digit_reverse((u64)(blockIdx.x >> a.lognl), a.pass_bits, 0, (int)a.pass_index - 1) : 0;
+            for (u32 i = threadIdx.x; i < (1u << Cfg::S); i += blockDim.x) rw[i] = a.tb.row[(K << Cfg::S) + i];
+            rowtw = rw;
+            __syncthreads();
+        }
     }
     ntt_stage1<B1, B2, B3, LOGC, MODE>(a, smem, tw, rowtw, threadIdx.x, blockIdx.x, blockIdx.y);
     if constexpr (B2 > 0) {
@@ -48,29 +44,24 @@ __global__ void ntt_small_kernel(const SmallArgs a) { ntt_small_body(a, threadId
 template <int B1, int B2, int B3, int LOGC, int MODE>
 static int launch_tile(const PassArgs& a, u32 grid_x, u32 batch, hipStream_t stream) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
-    const size_t row_words = a.tb.row != nullptr ? (1u << Cfg::S) : 0;
+    const size_t row_words = (MODE == PASS_COLUMN && a.tb.row != nullptr) ? (1u << Cfg::S) : 0;
     const size_t lds = (size_t)((B2 > 0 ? ((Cfg::LDS_WORDS + 1) & ~1) + Cfg::TW_WORDS : 0) + row_words) * sizeof(u64);
     hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, LOGC, MODE>), dim3(grid_x, batch), dim3(Cfg::W), lds, stream, a);
     BFS_HIP(hipGetLastError());
     return BFS_OK;
 }
 
-// multi-pass plans use 4096- or 8192-element tiles (logC = tile_log - S, S = 4..8); single-pass plans one column of 2^S rows (S = 4..12)
+// multi-pass plans use 4096-element tiles (logC = 12 - S, S = 4..8); single-pass plans one column of 2^S rows (S = 4..12)
 template <int MODE>
-static int dispatch_multi(const PassArgs& a, u32 S, u32 logC, u32 grid_x, u32 batch, hipStream_t stream) {
-    switch ((S << 4) | logC) {
-        case 0x48: return launch_tile<4, 0, 0, 8, MODE>(a, grid_x, batch, stream);
-        case 0x57: return launch_tile<4, 1, 0, 7, MODE>(a, grid_x, batch, stream);
-        case 0x66: return launch_tile<4, 2, 0, 6, MODE>(a, grid_x, batch, stream);
-        case 0x75: return launch_tile<4, 3, 0, 5, MODE>(a, grid_x, batch, stream);
-        case 0x84: return launch_tile<4, 4, 0, 4, MODE>(a, grid_x, batch, stream);
-        case 0x49: return launch_tile<4, 0, 0, 9, MODE>(a, grid_x, batch, stream);
-        case 0x58: return launch_tile<4, 1, 0, 8, MODE>(a, grid_x, batch, stream);
-        case 0x67: return launch_tile<4, 2, 0, 7, MODE>(a, grid_x, batch, stream);
-        case 0x76: return launch_tile<4, 3, 0, 6, MODE>(a, grid_x, batch, stream);
-        case 0x85: return launch_tile<4, 4, 0, 5, MODE>(a, grid_x, batch, stream);
+static int dispatch_multi(const PassArgs& a, u32 S, u32 grid_x, u32 batch, hipStream_t stream) {
+    switch (S) {
+        case 4: return launch_tile<4, 0, 0, 8, MODE>(a, grid_x, batch, stream);
+        case 5: return launch_tile<4, 1, 0, 7, MODE>(a, grid_x, batch, stream);
+        case 6: return launch_tile<4, 2, 0, 6, MODE>(a, grid_x, batch, stream);
+        case 7: return launch_tile<4, 3, 0, 5, MODE>(a, grid_x, batch, stream);
+        case 8: return launch_tile<4, 4, 0, 4, MODE>(a, grid_x, batch, stream);
     }
-    set_error("internal: no tile kernel for a %u-bit digit with 2^%u columns", S, logC);
+    set_error("internal: no tile kernel for a %u-bit digit of a multi-pass plan", S);
     return BFS_ERR_BAD_ARG;
 }
 
@@ -92,42 +83,30 @@ static int dispatch_single(const PassArgs& a, u32 S, u32 batch, hipStream_t stre
 
 static int dispatch_tile(const NttPlan& p, u32 t, const PassArgs& a, u32 grid_x, u32 batch, hipStream_t stream) {
     if (p.npass == 1) return dispatch_single(a, p.pass_bits[0], batch, stream);
-    if (t + 1 == p.npass) return dispatch_multi<PASS_FINAL>(a, p.pass_bits[t], p.logC[t], grid_x, batch, stream);
-    return dispatch_multi<PASS_COLUMN>(a, p.pass_bits[t], p.logC[t], grid_x, batch, stream);
+    if (t + 1 == p.npass) return dispatch_multi<PASS_FINAL>(a, p.pass_bits[t], grid_x, batch, stream);
+    return dispatch_multi<PASS_COLUMN>(a, p.pass_bits[t], grid_x, batch, stream);
 }
 
-// elements per tile of a multi-pass plan: 2^12 or 2^13 (BFS_NTT_TILE_LOG overrides the default; read once)
-static u32 ntt_tile_log() {
-    static const u32 v = [] {
-        const char* e = getenv("BFS_NTT_TILE_LOG");
-        const int x = e ? atoi(e) : 0;
-        return (u32)((x == 12 || x == 13) ? x : NTT_TILE_LOG_DEFAULT);
-    }();
-    return v;
-}
+enum { TBL_W_LO = 1, TBL_W_HI, TBL_T_IN, TBL_T_IN_LAST, TBL_S_LO, TBL_S_HI, TBL_ROW };
 
-enum { TBL_W_LO = 1, TBL_W_HI, TBL_T_IN, TBL_T_IN_LAST, TBL_S_LO, TBL_S_HI, TBL_ROW, TBL_STORE };
-
-// inter-pass twiddle tables (ntt_plan.hpp): the row table of pass t and the store table of pass 0, <= 2^16 entries each
-// (512 KiB, L2 resident), cached per (root, log_n)
+// row table of column pass t >= 1: row[K * 2^S + r] = w_{N_t}^(K r), N_t = 2^done <= 2^16 (512 KiB, L2 resident)
 static int get_row_table(const NttPlan& p, u32 t, u64 root, const u64** d_row) {
     *d_row = nullptr;
-    if (ntt_load_tw(p, t, false) != LOAD_TW_ROW) return BFS_OK;
+    u32 done = 0;
+    for (u32 v = 0; v <= t; ++v) done += p.pass_bits[v];
+    if (t == 0 || t + 1 == p.npass || done > 16) return BFS_OK;
     const u64 key = ((u64)p.log_n << 8) | TBL_ROW;
     if (cached_table_lookup(root, key, t, d_row)) return BFS_OK;
-    std::vector<u64> host;
-    ntt_build_row_table(p, t, root, host);
+    const u32 S = p.pass_bits[t];
+    const u64 wN = gl_pow(root, 1ull << (p.log_n - done));
+    std::vector<u64> host((size_t)1 << done);
+    u64 wK = 1;                                  // w_N^K
+    for (u64 K = 0; K < (1ull << (done - S)); ++K) {
+        u64 v = 1;
+        for (u64 r = 0; r < (1ull << S); ++r) { host[(K << S) + r] = v; v = gl_mul(v, wK); }
+        wK = gl_mul(wK, wN);
+    }
     return cached_table(root, key, t, host.data(), host.size(), d_row);
-}
-
-static int get_store_table(const NttPlan& p, u64 root, const u64** d_store) {
-    *d_store = nullptr;
-    if (!ntt_uses_store_table(p)) return BFS_OK;
-    const u64 key = ((u64)p.log_n << 8) | TBL_STORE;
-    if (cached_table_lookup(root, key, 0, d_store)) return BFS_OK;
-    std::vector<u64> host;
-    ntt_build_store_table(p, root, host);
-    return cached_table(root, key, 0, host.data(), host.size(), d_store);
 }
 
 static int get_tables(const NttPlan& p, u64 root, u64 shift, u64 post_scale, NttTables& tb) {
@@ -160,7 +139,7 @@ static int get_tables(const NttPlan& p, u64 root, u64 shift, u64 post_scale, Ntt
 // two-level power tables of `root` (order 2^log_n): root^e = lo[e & mask] * hi[e >> lo_bits]; shared with the fold kernel
 int ntt_power_tables(u64 root, u32 log_n, const u64** lo, const u64** hi, u32* lo_bits) {
     NttPlan p;
-    if (!ntt_make_plan(log_n, root, p, ntt_tile_log())) { set_error("no table plan for log_n = %u", log_n); return BFS_ERR_BAD_ARG; }
+    if (!ntt_make_plan(log_n, root, p)) { set_error("no table plan for log_n = %u", log_n); return BFS_ERR_BAD_ARG; }
     NttTables tb;
     BFS_TRY(get_tables(p, root, 1, 1, tb));
     *lo = tb.w_lo; *hi = tb.w_hi; *lo_bits = tb.lo_bits;
@@ -187,7 +166,7 @@ int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_str
     if (rc == BFS_ERR_NOT_ROOT) { set_error("primitive root must be nth root of unity, where n is %llu", (unsigned long long)n); return rc; }
     if (rc == BFS_ERR_NOT_PRIMITIVE) { set_error("primitive root %llu is not primitive nth root of unity, where n is %llu", (unsigned long long)root, (unsigned long long)n); return rc; }
     NttPlan p;
-    if (!ntt_make_plan(log_n, root, p, ntt_tile_log())) { set_error("no NTT plan for log_n = %u", log_n); return BFS_ERR_BAD_ARG; }
+    if (!ntt_make_plan(log_n, root, p)) { set_error("no NTT plan for log_n = %u", log_n); return BFS_ERR_BAD_ARG; }
     if (p.npass == 0) {
         SmallArgs a{d_in, d_out, in_stride, out_stride, n_in, log_n, root, shift, post_scale};
         hipLaunchKernelGGL(ntt_small_kernel, dim3(1, batch), dim3(64), 0, stream, a);
@@ -205,7 +184,6 @@ int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_str
     for (u32 t = 0; t < p.npass; ++t) {
         const bool first = t == 0, last = t + 1 == p.npass;
         BFS_TRY(get_row_table(p, t, root, &tb.row));
-        if (first) BFS_TRY(get_store_table(p, root, &tb.store));
         PassArgs a = ntt_pass_args(p, t, first ? d_in : ws, last ? d_out : ws, first ? in_stride : n, last ? out_stride : n,
                                    first ? n_in : n, tb, shift != 1, shift, post_scale);
         u32 grid_x = (u32)((n >> p.pass_bits[t]) >> p.logC[t]);

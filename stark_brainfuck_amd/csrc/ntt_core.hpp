@@ -114,15 +114,10 @@ struct NttTables {
     const u64* t_in_last;  // Omega^i * post_scale (used for the last inner twiddle of the final pass)
     const u64* s_lo;       // coset shift s: s^i, i < 2^lo_bits (null when no coset)
     const u64* s_hi;       // s^(i * 2^lo_bits)
-    const u64* row;        // inter-pass twiddles of a pass whose tiles see ONE row of a table (null: none / chain):
-                           //   column pass t >= 1 with N_t <= 2^16: row[K * 2^S + r] = w_{N_t}^(K r)
-                           //   final pass of a 3-pass plan:          row[k_2 * 2^S + r] = w_{N / n_1}^(k_2 r)
-    const u64* store;      // pass 0 of a 2- or 3-pass plan multiplies its OUTPUT by store[(k_1 << store_bits) + j_last] = w^(k_1 j_last),
-    u32 store_bits;        // j_last = the last input digit (the low store_bits bits of the column index); null: nothing at the store
+    const u64* row;        // column pass t >= 1 with N_t <= 2^16: row[K * 2^S + r] = w_{N_t}^(K r)  (null: use the chain)
 };
 
 enum { PASS_COLUMN = 0, PASS_FINAL = 1 };
-enum { LOAD_TW_NONE = 0, LOAD_TW_CHAIN = 1, LOAD_TW_ROW = 2 };      // how a pass applies its inter-pass twiddle (or the coset shift) while loading
 
 // everything a pass needs, precomputed on the host (ntt_plan.hpp) so that the kernel does no planning arithmetic
 struct PassArgs {
@@ -143,7 +138,6 @@ struct PassArgs {
     u32 n1_bits, mid_bits, logch;
     u32 uinv;            // u^-1 mod 16 where w^(n/16) = 2^(12u)
     u32 has_coset;       // pass 0: multiply input j by s^j
-    u32 load_tw;         // LOAD_TW_*
     u64 coset_delta;     // s^(stride of the stage-1 register index)
     u64 post_scale;      // multiplied in at the final store when the final pass has a single stage
     NttTables tb;
@@ -212,8 +206,7 @@ struct TileGeom {
     u64* out;
     u64 row0;         // COLUMN: h*2^(S+logL) + c0 ; FINAL multi: ((c0 << mid_bits) + mid) << S ; single: 0
     u64 kbase;        // COLUMN: exponent step of the inter-pass twiddle ; FINAL: c0 + (kmid << n1_bits)
-    u64 K;            // row of the twiddle table: COLUMN: digit-reversed previous output digits ; FINAL: kmid
-    u64 col0;         // COLUMN: first column of the tile inside its row (c0)
+    u64 K;            // COLUMN: digit-reversed previous output digits (row of the twiddle table)
 };
 
 template <typename Cfg, int LOGC, int MODE>
@@ -228,20 +221,17 @@ BFS_HD TileGeom tile_geom(const PassArgs& a, u32 bid_x, u32 bid_y) {
         const u64 K = a.pass_index ? digit_reverse(h, a.pass_bits, 0, (int)a.pass_index - 1) : 0;
         g.kbase = (K << a.tw_shift) & ((1ull << a.log_n) - 1);
         g.K = K;
-        g.col0 = c0;
     } else if (a.npass > 1) {
         const u64 c0 = (u64)(bid_x & ((1u << a.logch) - 1)) << LOGC;
         const u64 mid = bid_x >> a.logch;
         g.row0 = ((c0 << a.mid_bits) + mid) << Cfg::S;
         const u64 kmid = a.mid_bits ? digit_reverse(mid, a.pass_bits, 1, (int)a.npass - 2) : 0;
         g.kbase = c0 + (kmid << a.n1_bits);
-        g.K = kmid;
     } else {
         g.row0 = 0;
         g.kbase = 0;
-        g.K = 0;
     }
-    if constexpr (MODE != PASS_COLUMN) g.col0 = 0;
+    if constexpr (MODE != PASS_COLUMN) g.K = 0;
     return g;
 }
 
@@ -255,20 +245,6 @@ BFS_HD void final_store(const PassArgs& a, const TileGeom& g, const u64* x, u32 
     if constexpr (MODE == PASS_COLUMN) {
         tp = g.out + g.row0 + ((u64)klow << a.logL) + c;
         step_log = (u32)kshift + a.logL;
-        if (a.tb.store != nullptr) {
-            // pass 0 of a 2- / 3-pass plan: the part w^(k_1 j_last) of the LAST pass' inter-pass twiddle is applied here, where it
-            // is one table entry per element read in the very pattern of the store itself (row k_1, 2^LOGC adjacent columns), and
-            // where the pass has VALU time to spare; the last pass is then left with a tile-uniform row (or nothing) instead of
-            // a two-multiplication chain per element
-            const u32 sb = a.tb.store_bits;
-            const u64* ta = a.tb.store + ((u64)klow << sb) + ((g.col0 + c) & ((1ull << sb) - 1));
-            BFS_UNROLL
-            for (int m = 0; m < Q; ++m) {
-                const u64 off = (u64)perm_digit<BQ>(m, a.uinv);
-                tp[off << step_log] = gl_mul(x[m], ta[off << ((u32)kshift + sb)]);
-            }
-            return;
-        }
     } else {
         tp = g.out + g.kbase + c + ((u64)klow << (a.log_n - Cfg::S));
         step_log = (u32)kshift + (a.log_n - Cfg::S);
@@ -323,11 +299,11 @@ BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, const u64* tw, const u64* r
             }
         }
 #ifndef BFS_ABL_NO_CHAIN
-        if (a.load_tw == LOAD_TW_ROW) {
-            // the inter-pass twiddles of this tile are one row of a table (its row index is the same for the whole tile)
+        if (MODE == PASS_COLUMN && rowtw != nullptr) {
+            // middle pass: the inter-pass twiddles of this tile are one row of a table (K is the same for the whole tile)
             BFS_UNROLL
             for (int d = 0; d < Q; ++d) x[d] = gl_mul(x[d], rowtw[((u32)d << Cfg::SH1) | o]);
-        } else if (a.load_tw == LOAD_TW_CHAIN) {
+        } else if (a.pass_index > 0 || a.has_coset) {
             // factor of row r = (d << SH1) | o is beta^r = gamma * delta^d: a geometric chain per thread
             u64 gam, del;
             if (a.pass_index > 0) {

@@ -11,8 +11,7 @@
 namespace bfs {
 
 
-constexpr u32 NTT_TILE_LOG = 12;      // single-pass plans: one tile of <= 4096 elements (32 KiB)
-constexpr u32 NTT_TILE_LOG_MAX = 13;  // multi-pass plans: 4096- or 8192-element tiles (8192: 256-byte row segments for 8-bit digits)
+constexpr u32 NTT_TILE_LOG = 12;      // 4096 elements (32 KiB) per tile in the multi-pass regime
 constexpr u32 NTT_MAX_PASS_BITS = 8;  // digits of a multi-pass plan are <= 2^8 so tiles keep >= 16 columns (128 B segments)
 constexpr u32 NTT_SMALL_LOG = 3;
       // n <= 8 goes through the direct small kernel
@@ -49,8 +48,7 @@ inline u32 ntt_uinv(u64 root, u32 log_n) {
     return 1;
 }
 
-// tile_log: elements per tile of a multi-pass plan (12 or 13); when no split is feasible with 13 the planner falls back to 12
-inline bool ntt_make_plan(u32 log_n, u64 root, NttPlan& p, u32 tile_log = NTT_TILE_LOG) {
+inline bool ntt_make_plan(u32 log_n, u64 root, NttPlan& p) {
     p = NttPlan();
     p.log_n = log_n;
     p.uinv = ntt_uinv(root, log_n);
@@ -63,9 +61,7 @@ inline bool ntt_make_plan(u32 log_n, u64 root, NttPlan& p, u32 tile_log = NTT_TI
     }
     u32 m = (log_n + NTT_MAX_PASS_BITS - 1) / NTT_MAX_PASS_BITS;
     if (m > 4) return false;
-    if (tile_log < NTT_TILE_LOG) tile_log = NTT_TILE_LOG;
-    if (tile_log > NTT_TILE_LOG_MAX) tile_log = NTT_TILE_LOG_MAX;
-    // enumerate splits S_0..S_{m-1} in [4,8]; tiles of 2^tile_log elements; pick the most balanced feasible one
+    // enumerate splits S_0..S_{m-1} in [4,8]; keep tiles at 4096 elements; pick the most balanced feasible one
     u32 best[4] = {0, 0, 0, 0};
     u32 best_score = ~0u;
     u32 s[4];
@@ -79,16 +75,16 @@ inline bool ntt_make_plan(u32 log_n, u64 root, NttPlan& p, u32 tile_log = NTT_TI
         u32 done = 0;
         for (u32 t = 0; t + 1 < m && ok; ++t) {
             done += s[t];
-            if (tile_log - s[t] > log_n - done) ok = false;      // C_t <= L_t
+            if (NTT_TILE_LOG - s[t] > log_n - done) ok = false;  // C_t <= L_t
         }
-        if (tile_log - s[m - 1] > s[0]) ok = false;              // final pass: C <= n_1
+        if (NTT_TILE_LOG - s[m - 1] > s[0]) ok = false;          // final pass: C <= n_1
         if (!ok) continue;
         u32 score = (mx - mn) * 16 + (8 - s[m - 1]);             // balanced first, then a long last digit
         if (score < best_score) { best_score = score; for (u32 i = 0; i < m; ++i) best[i] = s[i]; }
     }
-    if (best_score == ~0u) return tile_log > NTT_TILE_LOG ? ntt_make_plan(log_n, root, p, tile_log - 1) : false;
+    if (best_score == ~0u) return false;
     p.npass = m;
-    for (u32 i = 0; i < m; ++i) { p.pass_bits[i] = best[i]; p.logC[i] = tile_log - best[i]; }
+    for (u32 i = 0; i < m; ++i) { p.pass_bits[i] = best[i]; p.logC[i] = NTT_TILE_LOG - best[i]; }
     return true;
 }
 
@@ -110,58 +106,6 @@ inline void ntt_build_tables(const NttPlan& p, u64 root, u64 post_scale, NttHost
     u64 omega = gl_pow(root, 1ull << (p.log_n - p.t_in_log));
     fill_powers(t.t_in, 1ull << p.t_in_log, omega, 1);
     fill_powers(t.t_in_last, 1ull << p.t_in_log, omega, post_scale);
-}
-
-// ---- inter-pass twiddle tables.  With K_t = k_1 + n_1 k_2 + ... the element entering pass t+1 (1-based) carries
-// w_{N_{t+1}}^(j_{t+1} K_t).  Tiles of a column pass t >= 2 see one K_{t-1}: one row of row[K][r] = w_{N_t}^(K r) (N_t <= 2^16).
-// The LAST pass of a 3-pass plan sees C values of k_1 and one k_2; its twiddle w^(j_3 (k_1 + n_1 k_2)) is split into
-//   w^(j_3 k_1)           applied by pass 1 at its store   (store table, n_1 x n_3 entries, read in the store's own pattern)
-//   w_{N/n_1}^(j_3 k_2)   one row of a table at the load   (n_2 x n_3 entries)
-// and the last pass of a 2-pass plan, w^(j_2 k_1), is applied entirely by pass 1 at its store.  Plans with 4 passes keep the
-// per-thread geometric chain (two multiplications per element) in their last pass.
-inline bool ntt_uses_store_table(const NttPlan& p) { return p.npass == 2 || p.npass == 3; }
-
-inline u32 ntt_load_tw(const NttPlan& p, u32 t, bool has_coset) {
-    if (t == 0) return has_coset ? LOAD_TW_CHAIN : LOAD_TW_NONE;
-    const bool last = t + 1 == p.npass;
-    if (last && ntt_uses_store_table(p)) return p.npass == 3 ? LOAD_TW_ROW : LOAD_TW_NONE;
-    u32 done = 0;
-    for (u32 v = 0; v <= t; ++v) done += p.pass_bits[v];
-    return (!last && done <= 16) ? LOAD_TW_ROW : LOAD_TW_CHAIN;
-}
-
-// row table of pass t (empty when the pass does not use one)
-inline void ntt_build_row_table(const NttPlan& p, u32 t, u64 root, std::vector<u64>& out) {
-    out.clear();
-    if (t == 0 || ntt_load_tw(p, t, false) != LOAD_TW_ROW) return;
-    const u32 S = p.pass_bits[t];
-    u32 done = 0;
-    for (u32 v = 0; v <= t; ++v) done += p.pass_bits[v];
-    const bool last = t + 1 == p.npass;
-    // column pass: K < N_{t-1}, root w_{N_t};  last pass of a 3-pass plan: k_2 < n_2, root w_{N / n_1}
-    const u32 k_bits = last ? p.pass_bits[1] : done - S;
-    const u64 w = last ? gl_pow(root, 1ull << p.pass_bits[0]) : gl_pow(root, 1ull << (p.log_n - done));
-    out.resize((size_t)1 << (k_bits + S));
-    u64 wK = 1;
-    for (u64 K = 0; K < (1ull << k_bits); ++K) {
-        u64 v = 1;
-        for (u64 r = 0; r < (1ull << S); ++r) { out[(K << S) + r] = v; v = gl_mul(v, wK); }
-        wK = gl_mul(wK, w);
-    }
-}
-
-// store table of pass 0: store[(k_1 << S_last) + j_last] = w^(k_1 j_last)
-inline void ntt_build_store_table(const NttPlan& p, u64 root, std::vector<u64>& out) {
-    out.clear();
-    if (!ntt_uses_store_table(p)) return;
-    const u32 S0 = p.pass_bits[0], SL = p.pass_bits[p.npass - 1];
-    out.resize((size_t)1 << (S0 + SL));
-    u64 wk = 1;
-    for (u64 k = 0; k < (1ull << S0); ++k) {
-        u64 v = 1;
-        for (u64 j = 0; j < (1ull << SL); ++j) { out[(k << SL) + j] = v; v = gl_mul(v, wk); }
-        wk = gl_mul(wk, root);
-    }
 }
 
 struct CosetHostTables {
@@ -210,12 +154,8 @@ inline PassArgs ntt_pass_args(const NttPlan& p, u32 t, const u64* in, u64* out, 
     }
     a.uinv = p.uinv;
     a.has_coset = (t == 0 && has_coset) ? 1 : 0;
-    a.load_tw = ntt_load_tw(p, t, has_coset);
     a.post_scale = final_pass ? post_scale : 1;
     a.tb = tb;
-    if (a.load_tw != LOAD_TW_ROW) a.tb.row = nullptr;
-    if (t != 0 || !ntt_uses_store_table(p)) a.tb.store = nullptr;
-    a.tb.store_bits = p.pass_bits[p.npass - 1];
     if (a.has_coset) {
         u32 b1 = S < 4 ? S : 4;
         u32 sh1 = S - b1;

@@ -22,9 +22,8 @@ static void run_pass(const PassArgs& a, u32 grid_x, u32 batch) {
         for (u32 bx = 0; bx < grid_x; ++bx) {
             const u64* rowtw = nullptr;
             std::vector<u64> row;
-            if (a.tb.row != nullptr) {
-                const u64 K = MODE == PASS_COLUMN ? (a.pass_index ? digit_reverse((u64)(bx >> a.lognl), a.pass_bits, 0, (int)a.pass_index - 1) : 0)
-                                                  : (a.mid_bits ? digit_reverse((u64)(bx >> a.logch), a.pass_bits, 1, (int)a.npass - 2) : 0);
+            if (MODE == PASS_COLUMN && a.tb.row != nullptr) {
+                const u64 K = a.pass_index ? digit_reverse((u64)(bx >> a.lognl), a.pass_bits, 0, (int)a.pass_index - 1) : 0;
                 row.assign(a.tb.row + (K << Cfg::S), a.tb.row + (K << Cfg::S) + (1u << Cfg::S));
                 rowtw = row.data();
             }
@@ -35,18 +34,13 @@ static void run_pass(const PassArgs& a, u32 grid_x, u32 batch) {
 }
 
 template <int MODE>
-static void dispatch_multi(const PassArgs& a, u32 S, u32 logC, u32 grid_x, u32 batch) {
-    switch ((S << 4) | logC) {
-        case 0x48: run_pass<4, 0, 0, 8, MODE>(a, grid_x, batch); break;
-        case 0x57: run_pass<4, 1, 0, 7, MODE>(a, grid_x, batch); break;
-        case 0x66: run_pass<4, 2, 0, 6, MODE>(a, grid_x, batch); break;
-        case 0x75: run_pass<4, 3, 0, 5, MODE>(a, grid_x, batch); break;
-        case 0x84: run_pass<4, 4, 0, 4, MODE>(a, grid_x, batch); break;
-        case 0x49: run_pass<4, 0, 0, 9, MODE>(a, grid_x, batch); break;
-        case 0x58: run_pass<4, 1, 0, 8, MODE>(a, grid_x, batch); break;
-        case 0x67: run_pass<4, 2, 0, 7, MODE>(a, grid_x, batch); break;
-        case 0x76: run_pass<4, 3, 0, 6, MODE>(a, grid_x, batch); break;
-        case 0x85: run_pass<4, 4, 0, 5, MODE>(a, grid_x, batch); break;
+static void dispatch_multi(const PassArgs& a, u32 S, u32 grid_x, u32 batch) {
+    switch (S) {
+        case 4: run_pass<4, 0, 0, 8, MODE>(a, grid_x, batch); break;
+        case 5: run_pass<4, 1, 0, 7, MODE>(a, grid_x, batch); break;
+        case 6: run_pass<4, 2, 0, 6, MODE>(a, grid_x, batch); break;
+        case 7: run_pass<4, 3, 0, 5, MODE>(a, grid_x, batch); break;
+        case 8: run_pass<4, 4, 0, 4, MODE>(a, grid_x, batch); break;
         default: abort();
     }
 }
@@ -66,14 +60,14 @@ static void dispatch_single(const PassArgs& a, u32 S, u32 batch) {
     }
 }
 
-extern "C" int emu_gl_ntt_tiled(const u64* in, u64 n_in, u64 in_stride, u64* out, u64 out_stride, u32 log_n, u32 batch,
-                                u64 root, u64 shift, u64 post_scale, u32 tile_log) {
+extern "C" int emu_gl_ntt(const u64* in, u64 n_in, u64 in_stride, u64* out, u64 out_stride, u32 log_n, u32 batch,
+                          u64 root, u64 shift, u64 post_scale) {
     int rc = ntt_check_root(root, log_n);
     if (rc) return rc;
     const u64 n = 1ull << log_n;
     if (n_in > n) return BFS_ERR_TOO_MANY_COEFFS;
     NttPlan p;
-    if (!ntt_make_plan(log_n, root, p, tile_log)) return BFS_ERR_BAD_ARG;
+    if (!ntt_make_plan(log_n, root, p)) return BFS_ERR_BAD_ARG;
     if (p.npass == 0) {
         SmallArgs a{in, out, in_stride, out_stride, n_in, log_n, root, shift, post_scale};
         for (u32 b = 0; b < batch; ++b)
@@ -86,42 +80,44 @@ extern "C" int emu_gl_ntt_tiled(const u64* in, u64 n_in, u64 in_stride, u64* out
     const bool coset = shift != 1;
     if (coset) ntt_build_coset_tables(p, shift, ct);
     NttTables tb{ht.w_lo.data(), ht.w_hi.data(), p.lo_bits, p.t_in_log, ht.t_in.data(), ht.t_in_last.data(),
-                 coset ? ct.s_lo.data() : nullptr, coset ? ct.s_hi.data() : nullptr, nullptr, nullptr, 0};
+                 coset ? ct.s_lo.data() : nullptr, coset ? ct.s_hi.data() : nullptr, nullptr};
     std::vector<u64> ws;
     if (p.npass > 1) ws.resize((size_t)n * batch);
     std::vector<std::vector<u64>> rows(p.npass);
-    std::vector<u64> store;
-    ntt_build_store_table(p, root, store);
     for (u32 t = 0; t < p.npass; ++t) {
         const bool first = t == 0, last = t + 1 == p.npass;
         const u64* src = first ? in : ws.data();
         u64* dst = last ? out : ws.data();
-        ntt_build_row_table(p, t, root, rows[t]);
-        tb.row = rows[t].empty() ? nullptr : rows[t].data();
-        tb.store = store.empty() ? nullptr : store.data();
+        tb.row = nullptr;
+        {
+            u32 done = 0;
+            for (u32 v = 0; v <= t; ++v) done += p.pass_bits[v];
+            if (t > 0 && !last && done <= 16) {
+                const u32 S = p.pass_bits[t];
+                const u64 wN = gl_pow(root, 1ull << (log_n - done));
+                rows[t].resize((size_t)1 << done);
+                u64 wK = 1;
+                for (u64 K = 0; K < (1ull << (done - S)); ++K) {
+                    u64 v = 1;
+                    for (u64 r = 0; r < (1ull << S); ++r) { rows[t][(K << S) + r] = v; v = gl_mul(v, wK); }
+                    wK = gl_mul(wK, wN);
+                }
+                tb.row = rows[t].data();
+            }
+        }
         PassArgs a = ntt_pass_args(p, t, src, dst, first ? in_stride : n, last ? out_stride : n, first ? n_in : n, tb,
                                    coset, shift, post_scale);
         u32 grid_x = (u32)((n >> p.pass_bits[t]) >> p.logC[t]);
         if (p.npass == 1) dispatch_single(a, p.pass_bits[0], batch);
-        else if (last) dispatch_multi<PASS_FINAL>(a, p.pass_bits[t], p.logC[t], grid_x, batch);
-        else dispatch_multi<PASS_COLUMN>(a, p.pass_bits[t], p.logC[t], grid_x, batch);
+        else if (last) dispatch_multi<PASS_FINAL>(a, p.pass_bits[t], grid_x, batch);
+        else dispatch_multi<PASS_COLUMN>(a, p.pass_bits[t], grid_x, batch);
     }
     return 0;
 }
 
-extern "C" int emu_gl_ntt(const u64* in, u64 n_in, u64 in_stride, u64* out, u64 out_stride, u32 log_n, u32 batch,
-                          u64 root, u64 shift, u64 post_scale) {
-    return emu_gl_ntt_tiled(in, n_in, in_stride, out, out_stride, log_n, batch, root, shift, post_scale, NTT_TILE_LOG);
-}
-
-extern "C" int emu_plan_tiled(u32 log_n, u64 root, u32 tile_log, u32* npass, u32* bits, u32* logc, u32* uinv);
 extern "C" int emu_plan(u32 log_n, u64 root, u32* npass, u32* bits, u32* logc, u32* uinv) {
-    return emu_plan_tiled(log_n, root, NTT_TILE_LOG, npass, bits, logc, uinv);
-}
-
-extern "C" int emu_plan_tiled(u32 log_n, u64 root, u32 tile_log, u32* npass, u32* bits, u32* logc, u32* uinv) {
     NttPlan p;
-    if (!ntt_make_plan(log_n, root, p, tile_log)) return 1;
+    if (!ntt_make_plan(log_n, root, p)) return 1;
     *npass = p.npass; *uinv = p.uinv;
     for (int i = 0; i < 4; ++i) { bits[i] = p.pass_bits[i]; logc[i] = p.logC[i]; }
     return 0;

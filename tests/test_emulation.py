@@ -27,18 +27,16 @@ def emu():
     lib = ctypes.CDLL(so)
     lib.emu_gl_ntt.argtypes = [vp, u64, u64, vp, u64, ctypes.c_uint32, ctypes.c_uint32, u64, u64, u64]
     lib.emu_plan.argtypes = [ctypes.c_uint32, u64, vp, vp, vp, vp]
-    lib.emu_gl_ntt_tiled.argtypes = [vp, u64, u64, vp, u64, ctypes.c_uint32, ctypes.c_uint32, u64, u64, u64, ctypes.c_uint32]
-    lib.emu_plan_tiled.argtypes = [ctypes.c_uint32, u64, ctypes.c_uint32, vp, vp, vp, vp]
     lib.emu_merkle_xfe.argtypes = [vp, u64, u64, vp]
     return lib
 
 
-def emu_ntt(lib, v, logn, root, shift=1, scale=1, n_in=None, batch=1, tile_log=12):
+def emu_ntt(lib, v, logn, root, shift=1, scale=1, n_in=None, batch=1):
     n = 1 << logn
     v = np.ascontiguousarray(v, dtype=np.uint64)
     n_in = n if n_in is None else n_in
     out = np.zeros(n * batch, dtype=np.uint64)
-    rc = lib.emu_gl_ntt_tiled(v.ctypes.data, n_in, n_in, out.ctypes.data, n, logn, batch, root, shift, scale, tile_log)
+    rc = lib.emu_gl_ntt(v.ctypes.data, n_in, n_in, out.ctypes.data, n, logn, batch, root, shift, scale)
     assert rc == 0, rc
     return out
 
@@ -52,23 +50,6 @@ def test_tile_kernels_match_oracle(emu, oracle, logn):
     assert (emu_ntt(emu, v, logn, oracle.inv(w), 1, oracle.inv(n)) == oracle.intt(w, v)).all()
     d = max(1, n // 4)
     assert (emu_ntt(emu, v[:d], logn, w, 7, 1, n_in=d) == oracle.fast_coset_evaluate(v[:d], 7, w, n)).all()
-
-
-@pytest.mark.parametrize("logn", [13, 14, 15, 16, 17, 18, 19, 20])
-def test_tile_kernels_8192_element_tiles(emu, oracle, logn):
-    """the multi-pass plans with 2^13-element tiles (256-byte row segments for 8-bit digits): same results"""
-    n = 1 << logn
-    v = oracle.felt_array(SEED + 1, 0, n)
-    w = oracle.primitive_nth_root(n)
-    assert (emu_ntt(emu, v, logn, w, tile_log=13) == oracle.ntt(w, v)).all()
-    assert (emu_ntt(emu, v, logn, oracle.inv(w), 1, oracle.inv(n), tile_log=13) == oracle.intt(w, v)).all()
-    d = n // 4
-    assert (emu_ntt(emu, v[:d], logn, w, 7, 1, n_in=d, tile_log=13) == oracle.fast_coset_evaluate(v[:d], 7, w, n)).all()
-    npass, uinv = ctypes.c_uint32(), ctypes.c_uint32()
-    bits, logc = (ctypes.c_uint32 * 4)(), (ctypes.c_uint32 * 4)()
-    assert emu.emu_plan_tiled(logn, w, 13, ctypes.byref(npass), bits, logc, ctypes.byref(uinv)) == 0
-    # 2^17 splits into three digits of <= 6 bits: a final-pass tile of 2^13 elements would need more than n_1 columns -> 4096
-    assert all(bits[i] + logc[i] == (12 if logn == 17 else 13) for i in range(npass.value))
 
 
 def test_tile_kernels_batch_and_other_roots(emu, oracle):

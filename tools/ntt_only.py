@@ -62,6 +62,11 @@ if not args.no_check and args.logn == 24:
         got = hashlib.sha256(dst.to_numpy(n, offset=c * n).tobytes()).hexdigest()
         assert got == g["columns"][c]["output_sha256"], "column %d differs from the oracle's known answer" % c
     checked = min(cols, 8)
+import time  # noqa: E402
+t0 = time.perf_counter()
+while time.perf_counter() - t0 < 0.4:          # clock spin-up: the first steps after idle run ~10 % slower
+    step()
+    synchronize(0)
 for _ in range(args.warmup):
     step()
 e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
@@ -74,6 +79,6 @@ lib.bfs_event_record(e1, 0)
 ms = ctypes.c_float()
 lib.bfs_event_elapsed_ms(e0, e1, ctypes.byref(ms))
 per = ms.value / args.steps
-print(json.dumps({"workload": "%d x 2^%d forward NTT" % (cols, args.logn), "tile_log": os.environ.get("BFS_NTT_TILE_LOG", "default"),
+print(json.dumps({"workload": "%d x 2^%d forward NTT" % (cols, args.logn), "tile_log": os.environ.get("BFS_NTT_TILE_LOG", "default"), "store_table": os.environ.get("BFS_NTT_STORE_TABLE", "default"),
                   "ms_per_step": round(per, 4), "elements_per_s": round(n * cols / per * 1e3), "algorithmic_GBps": round(16 * n * cols / per / 1e6, 1),
                   "roofline_frac_of_8TBps": round(16 * n * cols / per / 1e6 / 8000, 4), "columns_checked_vs_oracle": checked}))

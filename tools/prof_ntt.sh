@@ -4,7 +4,7 @@
 # usage: tools/prof_ntt.sh <tag> [tile logs...]
 set -u
 TAG=${1:-ntt}; shift || true
-TILES=${@:-12 13}
+TILES=${@:-12}
 ROOT=$GRAFT_REPO_ROOT
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
