@@ -52,8 +52,8 @@ def felt_array(seed, start, n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--log-n", type=int, default=24)
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="strong: --total-columns columns sharded over the ranks (BASELINE config 5); weak: --columns per GPU")
@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--no-fri", action="store_true")
     ap.add_argument("--no-stark", action="store_true", help="skip BrainfuckStark.prove on Hello World (config 4)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-column 2^24 leg")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run round-trip check and root gather (PMC collection runs)")
     args = ap.parse_args()
 
@@ -124,6 +125,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # the CPU leg first (rank 0, N = 1): the GPU legs then run back to back to the end of the process
+    cpu_line = cpu_baseline(log_n) if (rank == 0 and world == 1 and not args.no_cpu) else None
     spin_t0, spin_steps = time.perf_counter(), 0
     while args.spinup_ms > 0 and (time.perf_counter() - spin_t0) * 1e3 < args.spinup_ms:
         step()
@@ -226,15 +229,25 @@ def main():
         avg_launch_s = kern * 1e-3 / launches
         bytes_per_launch = 16.0 * n * cols / npass
         achieved = bytes_per_launch / avg_launch_s / 1e9
-        traffic = None
+        # HBM traffic and VALU counters are NOT measured by this run: they come from the tracked PMC summary of the NTT-only
+        # command (tools/prof_ntt.sh -> profiles/ntt_traffic.json, separate rocprofv3 --pmc passes, gfx950 FETCH_SIZE correction)
+        traffic, tsrc, valu_frac = None, None, None
         tpath = os.path.join(ROOT, "profiles", "ntt_traffic.json")
-        if os.path.exists(tpath):       # HBM bytes per launch from rocprofv3 PMC passes of this same command (tools/pmc.sh)
+        if os.path.exists(tpath):
             t = json.load(open(tpath))
             if t.get("log_n") == log_n and t.get("columns") == cols:
                 traffic = t["hbm_bytes_per_launch"]
+                tsrc = "static: profiles/ntt_traffic.json (%s)" % t.get("source", "rocprofv3 PMC")
+                valu_frac = t.get("valu_issue_frac")
         line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                            "traffic": traffic, "kernel": "ntt_tile_kernel<4,4,0>", "launches_per_step": npass,
-                            "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch}
+                            "traffic": traffic, "traffic_source": tsrc,
+                            "wasted_traffic_ratio": (traffic / bytes_per_launch) if traffic else None,
+                            "valu_issue_frac": valu_frac,
+                            "kernel": "ntt_tile_kernel<4,4,0,4,MODE>", "launches_per_step": npass,
+                            "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
+                            "note": "three HBM passes move 3x the algorithmic bytes; the kernel is co-limited by integer VALU issue (DESIGN.md 4.1)"}
+        if log_n == 24 and not args.no_single:
+            line["single_column_2p24"] = bench_single_column(lib, _lib, d_in, d_out, n, log_n, root, stream)
         if not args.no_fri:
             line["fri_prove"] = mine
             line["fri_prove"]["replicas"] = {"per_gpu_ms": [round(v, 4) for v in fri_all], "proofs_per_s": world / (max(fri_all) * 1e-3)}
@@ -244,12 +257,33 @@ def main():
             line["stark_prove"] = stark_mine
             line["stark_prove"]["replicas"] = {"per_gpu_ms": [round(v, 4) for v in stark_all], "proofs_per_s": world / (max(stark_all) * 1e-3)}
             line["stark_prove_2p22"] = bench_stark("+" * 64 + "[>" + "+" * 64 + "[>++++<-]<-]+++.", "nested loops, 37 254 cycles")
-        if world == 1 and not args.no_cpu:
-            line["cpu_baseline"] = cpu_baseline(log_n)
+        if cpu_line is not None:
+            line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_single_column(lib, _lib, d_in, d_out, n, log_n, root, stream, steps=200):
+    """one 2^24-point column on its own (128 MiB in, 128 MiB out: the transform north_star's target sentence is about)"""
+    def one():
+        _lib.check(lib.bfs_gl_ntt(d_in.ptr, n, n, d_out.ptr, n, log_n, 1, root, 1, 1, stream))
+    for _ in range(20):
+        one()
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    lib.bfs_event_create(ctypes.byref(e0)); lib.bfs_event_create(ctypes.byref(e1))
+    lib.bfs_event_record(e0, stream)
+    for _ in range(steps):
+        one()
+    lib.bfs_event_record(e1, stream)
+    _lib.check(lib.bfs_stream_synchronize(stream))
+    ms = ctypes.c_float()
+    _lib.check(lib.bfs_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+    per = ms.value / steps
+    gbs = 16.0 * n / per / 1e6
+    return {"ms": per, "elements_per_s": n / per * 1e3, "algorithmic_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "steps": steps,
+            "note": "forward NTT of one column, batch 1, HIP events over %d back-to-back transforms" % steps}
 
 
 def bench_fri(lib, _lib, stream, log_d):
@@ -331,7 +365,12 @@ def cpu_baseline(log_n):
         t += time.perf_counter() - t0
     return {"value": n * sample_cols / t, "unit": "elements/s", "cores": 1, "kind": "port",
             "sample": "%d column(s) of 2^%d elements, forward NTT, oracle/gl_oracle.c (gcc -O2), %.1f s" % (sample_cols, log_n, t),
-            "host_cpus": os.cpu_count()}
+            "host_cpus": os.cpu_count(),
+            # the reference itself cannot travel to the GPU box; its own figure, measured in the build container (BASELINE.md section 2,
+            # tests/golden/ntt20.json ref_seconds): CPython 3.10, 1 core, ntt.py on 2^20 elements in 242.7 s
+            "reference_python": {"value": 4320.0, "unit": "elements/s", "cores": 1,
+                                 "provenance": "BASELINE.md: /root/reference/code/ntt.py, n = 2^20, 242.7 s, CPython 3.10.12, build container (8-core host); "
+                                               "2^24 extrapolated there to ~2.6 k elements/s (1.8 h per column)"}}
 
 
 if __name__ == "__main__":

@@ -52,23 +52,22 @@ __global__ void gather_requests_kernel(const GatherReq* req, u32 count, u64* out
     }
 }
 
-// pinned staging area shared by the prover calls of this process (grow-only)
-struct PinnedArea {
+// pinned, device-visible staging for one gather call: a lease on a block of the pooled pinned-host allocator (runtime.cpp:
+// mutex-guarded, size classes, no hipHostMalloc / hipHostFree on the hot path).  One lease per call, so that concurrent provers
+// -- threads, or several devices driven by one process -- never share a staging buffer; the lease goes back when the call returns.
+struct PinnedLease {
     void* host = nullptr;
     void* dev = nullptr;
-    size_t bytes = 0;
-    int ensure(size_t need) {
-        if (need <= bytes) return BFS_OK;
-        if (host) (void)hipHostFree(host);
-        host = dev = nullptr; bytes = 0;
-        size_t sz = need < (1u << 20) ? (1u << 20) : need * 2;
-        BFS_HIP(hipHostMalloc(&host, sz, hipHostMallocMapped | hipHostMallocCoherent));
+    int get(size_t need) {
+        BFS_TRY(host_alloc(need < 4096 ? 4096 : need, &host));
         BFS_HIP(hipHostGetDevicePointer(&dev, host, 0));
-        bytes = sz;
         return BFS_OK;
     }
+    ~PinnedLease() { if (host) (void)host_release(host); }
+    PinnedLease() = default;
+    PinnedLease(const PinnedLease&) = delete;
+    PinnedLease& operator=(const PinnedLease&) = delete;
 };
-static PinnedArea g_req_area, g_res_area;
 
 // wall-clock breakdown of the last bfs_fri_commit / bfs_fri_query on this thread (ms): see bfs_fri_last_timing
 static thread_local double g_fri_timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -319,15 +318,16 @@ int fri_query(FriSession& S, rp::Transcript& ps, u32 t, u64* h_top, hipStream_t 
     g_fri_timing[3] = now_ms() - t_begin - g_fri_timing[2];   // planning the openings
     const double t_gather = now_ms();
     const u64* words = nullptr;
+    PinnedLease req_area, res_area;
     if (!reqs.empty()) {
-        BFS_TRY(g_req_area.ensure(reqs.size() * sizeof(GatherReq)));
-        BFS_TRY(g_res_area.ensure(nwords * sizeof(u64)));
-        memcpy(g_req_area.host, reqs.data(), reqs.size() * sizeof(GatherReq));
+        BFS_TRY(req_area.get(reqs.size() * sizeof(GatherReq)));
+        BFS_TRY(res_area.get(nwords * sizeof(u64)));
+        memcpy(req_area.host, reqs.data(), reqs.size() * sizeof(GatherReq));
         u32 grid = (u32)((reqs.size() + 255) / 256);
-        hipLaunchKernelGGL(gather_requests_kernel, dim3(grid), dim3(256), 0, stream, (const GatherReq*)g_req_area.dev, (u32)reqs.size(), (u64*)g_res_area.dev);
+        hipLaunchKernelGGL(gather_requests_kernel, dim3(grid), dim3(256), 0, stream, (const GatherReq*)req_area.dev, (u32)reqs.size(), (u64*)res_area.dev);
         BFS_HIP(hipGetLastError());
         BFS_HIP(hipStreamSynchronize(stream));
-        words = (const u64*)g_res_area.host;
+        words = (const u64*)res_area.host;
     }
     g_fri_timing[4] = now_ms() - t_gather;   // gather kernel + synchronisation
     const double t_build = now_ms();
@@ -403,13 +403,14 @@ int bfs_gather(const bfs_gather_request* requests, uint32_t count, uint64_t* h_o
         reqs[i] = GatherReq{requests[i].d_base, requests[i].nwords, requests[i].stride, nwords};
         nwords += requests[i].nwords;
     }
-    BFS_TRY(g_req_area.ensure(reqs.size() * sizeof(GatherReq)));
-    BFS_TRY(g_res_area.ensure(nwords * sizeof(u64)));
-    memcpy(g_req_area.host, reqs.data(), reqs.size() * sizeof(GatherReq));
-    hipLaunchKernelGGL(gather_requests_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, (const GatherReq*)g_req_area.dev, count, (u64*)g_res_area.dev);
+    PinnedLease req_area, res_area;
+    BFS_TRY(req_area.get(reqs.size() * sizeof(GatherReq)));
+    BFS_TRY(res_area.get(nwords * sizeof(u64)));
+    memcpy(req_area.host, reqs.data(), reqs.size() * sizeof(GatherReq));
+    hipLaunchKernelGGL(gather_requests_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, (const GatherReq*)req_area.dev, count, (u64*)res_area.dev);
     BFS_HIP(hipGetLastError());
     BFS_HIP(hipStreamSynchronize(stream));
-    memcpy(h_out, g_res_area.host, nwords * sizeof(u64));
+    memcpy(h_out, res_area.host, nwords * sizeof(u64));
     return BFS_OK;
 }
 

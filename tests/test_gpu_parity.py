@@ -795,3 +795,40 @@ def test_memory_pools(sb):
     _lib.check(lib.bfs_free(p))
     assert lib.bfs_free(ctypes.c_void_p(12345)) != 0 and b"did not allocate" in lib.bfs_last_error()
     device.pool_trim()
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 255, 256, 2047, 2048, 2049, 100003, (1 << 20) + 5])
+def test_batch_inverse_and_scale_ragged_sizes(sb, oracle, n):
+    """bfs_gl_batch_inverse (one inversion per 2048 elements, Montgomery's trick across a workgroup) and bfs_gl_scale (power tables of
+    an arbitrary factor built on the device) on sizes that leave threads and workgroups partly empty; in place as well (ntt.py:177-188,
+    univariate.py:168-169)"""
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.device import DeviceBuffer, synchronize
+    lib = _lib.load()
+    P = (1 << 64) - (1 << 32) + 1
+    a = oracle.felt_array(SEED + n, 0, n)
+    a = np.where(a == 0, np.uint64(1), a)
+    a[n // 2] = P - 1
+    a[0] = 1
+    da, dc = DeviceBuffer.from_numpy(a), DeviceBuffer(n)
+    _lib.check(lib.bfs_gl_batch_inverse(da.ptr, dc.ptr, n, 0))
+    want = oracle.batch_inverse(a)
+    assert (dc.to_numpy() == want).all()
+    _lib.check(lib.bfs_gl_batch_inverse(da.ptr, da.ptr, n, 0))          # in place (fast_coset_divide does this)
+    assert (da.to_numpy() == want).all()
+    # a zero anywhere is the reference's assertion, and the other elements are still inverted
+    z = a.copy()
+    z[n - 1] = 0
+    dz = DeviceBuffer.from_numpy(z)
+    rc = lib.bfs_gl_batch_inverse(dz.ptr, dc.ptr, n, 0)
+    assert rc != 0 and b"batch inverse does not work when input contains a zero" in lib.bfs_last_error()
+    got = dc.to_numpy()
+    assert got[n - 1] == 0 and (got[:n - 1] == want[:n - 1]).all()
+    # scale by an arbitrary factor, two columns with a stride
+    factor = int(oracle.felt_array(SEED, n, 1)[0]) | 1
+    two = DeviceBuffer.from_numpy(np.concatenate([a, a[::-1]]))
+    out = DeviceBuffer(2 * n)
+    _lib.check(lib.bfs_gl_scale(two.ptr, out.ptr, n, n, 2, factor, 0))
+    synchronize(0)
+    res = out.to_numpy()
+    assert (res[:n] == oracle.scale(factor, a)).all() and (res[n:] == oracle.scale(factor, a[::-1].copy())).all()

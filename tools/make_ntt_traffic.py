@@ -1,0 +1,41 @@
+"""profiles/ntt_traffic.json from the NTT-only PMC summary and timing that tools/prof_ntt.sh wrote (development tool).
+    python tools/make_ntt_traffic.py gpurun_out/<tag> [tile_log]
+HBM bytes per launch = 2 * FETCH_SIZE * 1024 (gfx950: FETCH_SIZE counts 128-byte requests as 64 bytes, MI355X_MICROARCH.md "HBM") +
+WRITE_SIZE * 1024, averaged over the launches of a step; valu_issue_frac = VALU wave-instructions per step * 4 cycles / (1024 SIMDs *
+2.4 GHz) / step time."""
+import ast
+import json
+import os
+import re
+import sys
+
+d = sys.argv[1]
+tl = sys.argv[2] if len(sys.argv) > 2 else "12"
+vals = {}
+for line in open(os.path.join(d, "ntt_only_pmc_tile%s.txt" % tl)):
+    m = re.match(r"(.*) dispatches (\d+) (\{.*\})", line.strip())
+    if not m or "ntt_tile_kernel" not in m.group(1):
+        continue
+    kind = "final" if re.search(r", 1>\s*$", m.group(1).strip()) else "column"
+    for k, v in ast.literal_eval(m.group(3)).items():
+        vals.setdefault(k, {})[kind] = v
+plain = json.loads(open(os.path.join(d, "plain_tile%s.json" % tl)).read().strip().split("\n")[-1])
+col = 2 * vals["FETCH_SIZE"]["column"] * 1024 + vals["WRITE_SIZE"]["column"] * 1024
+fin = 2 * vals["FETCH_SIZE"]["final"] * 1024 + vals["WRITE_SIZE"]["final"] * 1024
+valu_step = 2 * vals["SQ_INSTS_VALU"]["column"] + vals["SQ_INSTS_VALU"]["final"]
+ms = plain["ms_per_step"]
+out = {
+    "log_n": 24, "columns": 8,
+    "kernel": "ntt_tile_kernel<4,4,0,4,MODE> (2 column launches + 1 final launch per step)",
+    "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
+    "correction": "gfx950: FETCH_SIZE reports 1/2 of streamed bytes (MI355X_MICROARCH.md, HBM) -> reads = 2*FETCH_SIZE*1024; WRITE_SIZE*1024 as is",
+    "hbm_bytes_per_launch": (2 * col + fin) / 3, "hbm_bytes_per_launch_column": col, "hbm_bytes_per_launch_final": fin,
+    "algorithmic_bytes_per_launch": 16.0 * (1 << 24) * 8 / 3,
+    "SQ_INSTS_VALU_per_launch": vals["SQ_INSTS_VALU"], "valu_wave_instructions_per_step": valu_step,
+    "ms_per_step_of_the_same_run": ms,
+    "valu_issue_frac": valu_step * 4 / (1024 * 2.4e9) / (ms * 1e-3),
+    "SQ_LDS_BANK_CONFLICT": vals.get("SQ_LDS_BANK_CONFLICT"),
+    "source": "tools/prof_ntt.sh (rocprofv3 --pmc, one counter per pass, on `python tools/ntt_only.py`: the 8 x 2^24 NTT step alone); raw: profiles/r02/ntt_only_pmc.txt",
+}
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "ntt_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
