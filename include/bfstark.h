@@ -63,6 +63,11 @@ int bfs_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes, void* stream);
 int bfs_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream);
 int bfs_memset(void* d_dst, int value, size_t bytes, void* stream);
 int bfs_stream_synchronize(void* stream);
+/* a HIP stream of the current device for callers without a HIP runtime of their own (a foreign hipStream_t / torch stream handle is
+ * accepted wherever `stream` is taken; 0 is the default stream).  Independent provers on different streams may run concurrently,
+ * also from different host threads. */
+int bfs_stream_create(void** stream);
+int bfs_stream_destroy(void* stream);
 /* hipEvent-based timing on `stream` (bench.py: torch.cuda.Event only sees torch's own stream) */
 int bfs_event_create(void** event);
 int bfs_event_destroy(void* event);

@@ -37,6 +37,8 @@ _SIGNATURES = {
     "bfs_memcpy_d2d": (ci, [vp, vp, sz, vp]),
     "bfs_memset": (ci, [vp, ci, sz, vp]),
     "bfs_stream_synchronize": (ci, [vp]),
+    "bfs_stream_create": (ci, [ctypes.POINTER(vp)]),
+    "bfs_stream_destroy": (ci, [vp]),
     "bfs_event_create": (ci, [ctypes.POINTER(vp)]),
     "bfs_event_destroy": (ci, [vp]),
     "bfs_event_record": (ci, [vp, vp]),

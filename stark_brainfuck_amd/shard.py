@@ -19,12 +19,13 @@ def columns_per_rank(num_columns, world_size):
     return [len(assign_columns(num_columns, world_size, r)) for r in range(world_size)]
 
 
-def gather_roots(local_roots, num_columns, world_size, rank, group=None, device=None):
+def gather_roots(local_roots, num_columns, world_size, rank, group=None, device=None, force_collective=False):
     """all-gather of per-column 64-byte roots.  local_roots: {global column index: 64 bytes} for the columns of this
-    rank.  Returns the list of all `num_columns` roots, identical on every rank."""
+    rank.  Returns the list of all `num_columns` roots, identical on every rank.  device: where the exchanged tensors live
+    (a CUDA device for RCCL, None for gloo); force_collective: run the all_gather even for a single rank (tests)."""
     mine = assign_columns(num_columns, world_size, rank)
     assert sorted(local_roots) == mine, "rank %d must supply exactly its own columns %r" % (rank, mine)
-    if world_size == 1:
+    if world_size == 1 and not force_collective:
         return [bytes(local_roots[c]) for c in range(num_columns)]
     import torch
     import torch.distributed as dist

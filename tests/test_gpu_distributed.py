@@ -1,0 +1,112 @@
+"""The multi-GPU path on the hardware that is there (one MI355X): the collective of the design under RCCL with a single rank, the
+benchmark's sharded run launched the way the driver launches it, and concurrent provers inside one process.  World size 2 runs on
+CPU under gloo (tests/test_distributed_cpu.py)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_gather_roots_over_rccl_single_rank():
+    """shard.gather_roots with device tensors through the nccl (= RCCL) backend, world size 1, in a subprocess of its own"""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from stark_brainfuck_amd import shard
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+roots = {c: bytes([c + 1]) * 64 for c in range(5)}
+# world size 1 short-circuits inside gather_roots; force the collective path through the private helper
+out = shard.gather_roots(roots, 5, 1, 0, device=torch.device("cuda", 0), force_collective=True)
+assert out == [roots[c] for c in range(5)], out
+dist.barrier(); dist.destroy_process_group()
+print("ok")
+''' % ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout + res.stderr
+
+
+@pytest.mark.parametrize("scaling", ["strong", "weak"])
+def test_bench_under_torchrun_single_rank(scaling):
+    """bench.py launched exactly as the driver launches N > 1 (torch.distributed.run, RCCL process group), with the one rank this
+    box has: sharding through shard.assign_columns, the all-gather of the roots, one JSON line with the contract's keys"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1",
+           "--scaling", scaling, "--total-columns", "4", "--columns", "2", "--log-n", "20", "--no-fri", "--no-cpu", "--spinup-ms", "0"]
+    res = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in line, key
+    assert line["scaling"] == scaling and line["n_gpus"] == 1 and line["steps"] == 3
+    assert line["config"]["total_columns"] == (4 if scaling == "strong" else 2)
+    assert line["roots_sha256"] and len(line["roots_sha256"]) == 64
+    assert line["value"] > 1e9
+
+
+def test_concurrent_provers_in_one_process(oracle):
+    """two threads, each with its own stream, run Fri.prove on different codewords at the same time: the transcripts must be the
+    oracle's (the gather staging is leased per call, the scratch areas are keyed by (device, stream))"""
+    import ctypes
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.device import DeviceBuffer
+    lib = _lib.load()
+    N, d, t, expansion = 1 << 12, 1 << 10, 4, 4
+    log_n = 12
+    omega = oracle.primitive_nth_root(N)
+    results, errors = {}, []
+
+    def worker(k):
+        try:
+            stream = ctypes.c_void_p()
+            _lib.check(lib.bfs_stream_create(ctypes.byref(stream)))
+            coeffs = oracle.felt_array(0x5EED + 77 * k, 0, 3 * d).reshape(d, 3).T.copy()
+            soa = oracle.xevaluate_soa(coeffs, 7, omega, N)
+            cw = DeviceBuffer.from_numpy(np.ascontiguousarray(soa).reshape(-1))
+            for rep in range(6):
+                ps = lib.bfs_ps_new()
+                out = (ctypes.c_uint64 * t)()
+                _lib.check(lib.bfs_fri_prove(ps, cw.ptr, N, log_n, 7, omega, expansion, t, out, stream))
+                size = ctypes.c_size_t()
+                _lib.check(lib.bfs_ps_serialize(ps, 1 << 62, None, 0, ctypes.byref(size)))
+                buf = ctypes.create_string_buffer(size.value)
+                _lib.check(lib.bfs_ps_serialize(ps, 1 << 62, buf, size.value, ctypes.byref(size)))
+                lib.bfs_ps_free(ps)
+                results.setdefault(k, []).append(([int(v) for v in out], buf.raw[:size.value]))
+            results[(k, "soa")] = soa
+            _lib.check(lib.bfs_stream_synchronize(stream))
+            _lib.check(lib.bfs_stream_destroy(stream))
+        except Exception as e:              # noqa: BLE001
+            errors.append(repr(e))
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(3)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    for k in range(3):
+        ref = oracle.fri_prove(results[(k, "soa")], 7, omega, expansion, t)
+        for idx, raw in results[k]:
+            assert idx == ref["indices"]
+            assert raw == ref["proof_stream"].serialize()
