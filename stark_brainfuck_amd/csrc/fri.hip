@@ -108,8 +108,36 @@ struct FriSession {
         Key(u32 round, u64 index) : v(((u64)round << 48) | index) {}
         bool operator==(const Key& o) const { return v == o.v; }
     };
-    struct KeyHash { size_t operator()(const Key& k) const { return (size_t)(k.v * 0x9E3779B97F4A7C15ULL >> 16); } };
-    std::unordered_map<Key, rp::Ref, KeyHash> elements, nodes;
+    // open-addressing table (linear probing, power-of-two capacity): a proof makes ~4 000 look-ups and insertions here, and
+    // std::unordered_map's node allocations were 0.2 ms of a 1.9 ms proof
+    struct KeyMap {
+        std::vector<u64> keys;          // key.v + 1; 0 = empty slot
+        std::vector<u32> slots;         // index into vals
+        std::vector<rp::Ref> vals;      // in insertion order
+        void reserve(size_t n) { size_t cap = 64; while (cap < 2 * n) cap <<= 1; if (cap > keys.size()) rehash(cap); vals.reserve(n); }
+        void rehash(size_t cap) {
+            std::vector<u64> k2(cap, 0);
+            std::vector<u32> s2(cap, 0);
+            for (size_t i = 0; i < keys.size(); ++i)
+                if (keys[i]) { size_t j = slot_of(keys[i], cap); while (k2[j]) j = (j + 1) & (cap - 1); k2[j] = keys[i]; s2[j] = slots[i]; }
+            keys.swap(k2); slots.swap(s2);
+        }
+        static size_t slot_of(u64 stored, size_t cap) { return (size_t)((stored * 0x9E3779B97F4A7C15ULL) >> 20) & (cap - 1); }
+        // the slot of `key`: existing, or the empty one where it goes
+        size_t find(const Key& key) const {
+            size_t j = slot_of(key.v + 1, keys.size());
+            while (keys[j] && keys[j] != key.v + 1) j = (j + 1) & (keys.size() - 1);
+            return j;
+        }
+        bool count(const Key& key) const { return !keys.empty() && keys[find(key)] != 0; }
+        rp::Ref& operator[](const Key& key) {
+            if (2 * (vals.size() + 1) > keys.size()) rehash(keys.empty() ? 64 : 2 * keys.size());
+            const size_t j = find(key);
+            if (!keys[j]) { keys[j] = key.v + 1; slots[j] = (u32)vals.size(); vals.emplace_back(); }
+            return vals[slots[j]];
+        }
+    };
+    KeyMap elements, nodes;
     std::vector<uint64_t> last_handles;
     hipStream_t block_stream = nullptr;
     const u64* round0_nodes = nullptr;     // a tree over the input codeword that the caller has already built (bfs_fri_session_round0_tree)
@@ -162,12 +190,34 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
     BFS_TRY(ntt_power_tables(gl_inv(omega), log_n, &winv_lo, &winv_hi, &lo_bits));
     const u64 half_inv = gl_inv(2);
     u64 g = offset;
+    FriFoldArgs pending{};                         // the fold that produces round r's codeword, when round r runs fused
+    pending.in = nullptr;
     for (u32 r = 0; r < R; ++r) {
         FriRound& fr = S.rounds[r];
         unsigned char seed[32];
         bool have_seed = false, speculating = false;
         rp::Transcript::Speculation speculation;
-        if (r == 0 && S.round0_nodes) {
+        const bool fused = fr.length >= 2 && fr.length <= FRI_FUSED_MAX && !(r == 0 && S.round0_nodes);
+        if (fused) {
+            // small codeword: fold (of the previous round) + leaves + subtrees in one launch, root through the mailbox
+            const u64 seq = ++S.mailbox.seq;
+            BFS_TRY(fri_round_fused_launch(pending, (u64*)fr.cw, fr.stride, fr.length, fr.nodes, stream, S.mailbox.dev, seq));
+            pending.in = nullptr;
+            if (r + 1 < R) {
+                if (r == 0) { ps.fiat_shamir(ps.objects.size(), seed, 32); have_seed = true; }
+                else { ps.speculate(speculation); speculating = true; }
+            }
+            volatile u64* flag = S.mailbox.host + 8;
+            u64 spins = 0;
+            while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+                if (++spins > (1ull << 22)) {
+                    BFS_HIP(hipStreamSynchronize(stream));
+                    if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) { set_error("root mailbox was not written"); return BFS_ERR_HIP; }
+                    break;
+                }
+            }
+            memcpy(fr.root, S.mailbox.host, 64);
+        } else if (r == 0 && S.round0_nodes) {
             fr.nodes = (u64*)S.round0_nodes;          // the STARK prover has just committed to this very codeword (brainfuck_stark.py:301 / fri.py:108)
             memcpy(fr.root, S.round0_root, 64);
         } else if (fr.length >= 2) {
@@ -204,11 +254,16 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
         Xfe alpha = rp::sample_xfe(seed, 32);
         FriRound& nx = S.rounds[r + 1];
         const u64 half = fr.length / 2;
-        u32 grid = (u32)((half + 255) / 256);
-        if (grid > 4096) grid = 4096;
-        hipLaunchKernelGGL(fri_fold_kernel, dim3(grid), dim3(256), 0, stream, fr.cw, fr.stride, (u64*)nx.cw, nx.stride, half, alpha,
-                           gl_mul(half_inv, gl_inv(g)), winv_lo, winv_hi, lo_bits, r);
-        BFS_HIP(hipGetLastError());
+        if (half >= 2 && half <= FRI_FUSED_MAX) {
+            // the next round folds while it builds its tree (fri_round_quad_kernel)
+            pending = FriFoldArgs{fr.cw, fr.stride, half, alpha, gl_mul(half_inv, gl_inv(g)), winv_lo, winv_hi, lo_bits, r};
+        } else {
+            u32 grid = (u32)((half + 255) / 256);
+            if (grid > 4096) grid = 4096;
+            hipLaunchKernelGGL(fri_fold_kernel, dim3(grid), dim3(256), 0, stream, fr.cw, fr.stride, (u64*)nx.cw, nx.stride, half, alpha,
+                               gl_mul(half_inv, gl_inv(g)), winv_lo, winv_hi, lo_bits, r);
+            BFS_HIP(hipGetLastError());
+        }
         g = gl_sqr(g);  // fri.py:130-131 (omega is squared implicitly through round_shift)
     }
     g_fri_timing[0] = now_ms() - t_begin;   // rounds: trees, roots, challenges, folds
@@ -279,7 +334,12 @@ int fri_query(FriSession& S, rp::Transcript& ps, u32 t, u64* h_top, hipStream_t 
 
     g_fri_timing[2] = now_ms() - t_begin;   // Fiat-Shamir + index sampling
     typedef FriSession::Key Key;
-    S.elements.reserve(1024); S.nodes.reserve(8192);
+    {   // what the openings can touch at most: 3 elements and 3 authentication paths per colinearity check and layer
+        size_t depth_sum = 0;
+        for (u32 r = 0; r < R; ++r) depth_sum += 64 - (size_t)__builtin_clzll(S.rounds[r].length);
+        S.elements.reserve(S.elements.vals.size() + (size_t)3 * t * R + 8);
+        S.nodes.reserve((size_t)3 * t * depth_sum / 2 + 64);
+    }
     std::vector<GatherReq> reqs;                 // what to fetch
     std::vector<std::pair<int, Key>> order;      // what the fetched words are: (0 = element | 1 = tree node, key)
     reqs.reserve(4096); order.reserve(4096);

@@ -169,6 +169,39 @@ __global__ void __launch_bounds__(1024) merkle_top_quad_kernel(u64* nodes, u32 w
 #endif
 }
 
+// nine levels in one launch: every 1024-thread workgroup takes 512 adjacent digests of a complete level of `children` nodes
+// (heap indices children .. 2 children - 1) and builds the subtree above them in LDS, down to its single root at the level of
+// children / 512 nodes.  Same dependent chain of hashes as one launch per level (~2.3 us per level with a quad per hash), but
+// without a launch boundary and a ramp-up per level: levels of <= 65536 parents are latency-bound, not throughput-bound.
+__global__ void __launch_bounds__(1024) merkle_subtree_quad_kernel(u64* nodes, u64 children) {
+#if defined(__HIP_DEVICE_COMPILE__)   // DPP builtins exist only in the device pass
+    __shared__ u64 bufA[512 * 8];
+    __shared__ u64 bufB[256 * 8];
+    const u32 tid = threadIdx.x, q = tid >> 2, j = tid & 3;
+    const QuadLane ql = quad_lane(tid);
+    const u64* in = nodes + (children + (u64)blockIdx.x * 512) * 8;
+    for (u32 i = tid; i < 512 * 8; i += 1024) bufA[i] = in[i];
+    __syncthreads();
+    u64* src = bufA;
+    u64* dst = bufB;
+    u64 level = children >> 1;                       // nodes of the level being written = heap index of its first node
+    for (u32 w = 256; w >= 1; w >>= 1, level >>= 1) {
+        if (q < w) {
+            u64 hl, hh;
+            blake2b_init_quad(ql, hl, hh);
+            blake2b_compress_quad(ql, hl, hh, src + q * 16, 128, true);
+            dst[q * 8 + j] = hl;
+            dst[q * 8 + 4 + j] = hh;
+            u64* g = nodes + (level + (u64)blockIdx.x * w + q) * 8;
+            g[j] = hl;
+            g[4 + j] = hh;
+        }
+        __syncthreads();
+        u64* tmp = src; src = dst; dst = tmp;
+    }
+#endif
+}
+
 // leaves with one quad per leaf (small codewords: late FRI rounds): lane 0 of the quad assembles the preimage in LDS,
 // the four lanes hash it
 __global__ void __launch_bounds__(256) merkle_leaves_xfe_quad_kernel(const u64* limbs, u64 limb_stride, u64 n, u64* leaf_digests, const u64* midstates) {
@@ -208,7 +241,111 @@ __global__ void __launch_bounds__(256) merkle_leaves_xfe_quad_kernel(const u64* 
 #endif
 }
 
+// ---- one FRI round on a small codeword in one launch (fri.py:108 + 127-128) ----
+// A late FRI round is a chain of dependent hashes -- 3 compressions per leaf, one per tree level, ~2 us each with a quad per
+// hash -- and used to be 3-6 launches (fold, leaves, one per level down to 256 parents, top): launch gaps and ramp-up were as
+// long as the work.  Here one 1024-thread workgroup takes 256 leaves: it first PRODUCES them (the split-and-fold step of the
+// previous round, when `f.in` is set; the folded codeword also goes to HBM for the openings), hashes them with one quad per
+// leaf and builds the 8 levels above them in LDS.  A codeword of <= 256 elements is finished by a single workgroup, which
+// also drops the root into the host mailbox; larger ones leave one digest per workgroup to merkle_top_quad_kernel.
+// n must be a power of two (FRI codewords are).
+BFS_HD u64 gl_half_m(u64 x) { return (x >> 1) + ((x & 1) ? 0x7FFFFFFF80000001ULL : 0); }  // x / 2 mod p
+
+constexpr u32 FRI_WG_LEAVES = 256;
+
+__global__ void __launch_bounds__(1024) fri_round_quad_kernel(FriFoldArgs f, u64* cw, u64 cw_stride, u64 n, u64* nodes, const u64* midstates,
+                                                              u64* root_out, u64 seq) {
+#if defined(__HIP_DEVICE_COMPILE__)   // DPP builtins exist only in the device pass
+    constexpr int WORDS = 48;                        // 3 blocks of 16 words per leaf (bytes 128..409)
+    __shared__ u64 stage[FRI_WG_LEAVES * WORDS];
+    __shared__ u64 bufA[FRI_WG_LEAVES * 8];
+    __shared__ u64 bufB[FRI_WG_LEAVES * 4];
+    __shared__ u64 limbs[3 * FRI_WG_LEAVES];
+    const u32 tid = threadIdx.x, q = tid >> 2, j = tid & 3;
+    const QuadLane ql = quad_lane(tid);
+    const u32 local = n < FRI_WG_LEAVES ? (u32)n : FRI_WG_LEAVES;     // leaves of this workgroup
+    const u64 first = (u64)blockIdx.x * FRI_WG_LEAVES;
+    if (tid < local) {
+        const u64 i = first + tid;
+        u64 c0, c1, c2;
+        if (f.in != nullptr) {
+            const Xfe a{{f.in[i], f.in[f.in_stride + i], f.in[2 * f.in_stride + i]}};
+            const Xfe b{{f.in[f.half + i], f.in[f.in_stride + f.half + i], f.in[2 * f.in_stride + f.half + i]}};
+            const u64 sc = gl_mul(f.scal, tw_pow(f.winv_lo, f.winv_hi, f.lo_bits, i << f.round_shift));
+            const Xfe beta = xfe_scale(f.alpha, sc);
+            const Xfe sum = xfe_add(a, b), diff = xfe_sub(a, b);
+            const Xfe prod = xfe_mul(beta, diff);
+            c0 = gl_add(gl_half_m(sum.c[0]), prod.c[0]);
+            c1 = gl_add(gl_half_m(sum.c[1]), prod.c[1]);
+            c2 = gl_add(gl_half_m(sum.c[2]), prod.c[2]);
+            cw[i] = c0; cw[cw_stride + i] = c1; cw[2 * cw_stride + i] = c2;
+        } else {
+            c0 = cw[i]; c1 = cw[cw_stride + i]; c2 = cw[2 * cw_stride + i];
+        }
+        limbs[tid] = c0; limbs[FRI_WG_LEAVES + tid] = c1; limbs[2 * FRI_WG_LEAVES + tid] = c2;
+    }
+    __syncthreads();
+    // leaf digests: one quad per leaf (as merkle_leaves_xfe_quad_kernel)
+    if (q < local) {
+        u64* m = stage + q * WORDS;
+        const u64 c0 = limbs[q], c1 = limbs[FRI_WG_LEAVES + q], c2 = limbs[2 * FRI_WG_LEAVES + q];
+        const u32 k = xfe_leaf_k(c0, c1, c2);
+        u64 hl, hh;
+        if (k == 0) {
+            hl = midstates[(size_t)2 * LEAF_MS_LEN * 8 + j];
+            hh = midstates[(size_t)2 * LEAF_MS_LEN * 8 + 4 + j];
+        } else {
+            const u32 body = xfe_leaf_body_len(k, c0, c1, c2), total = body + 11;
+            const u32 nblk = (total + 127) / 128;
+            const u64* ms = midstates + ((size_t)(k == 1 ? 0 : 1) * LEAF_MS_LEN + body) * 8;
+            hl = ms[j];
+            hh = ms[4 + j];
+            if (j == 0) {
+                LeafWriter w;
+                w.init(m, 1);
+                encode_xfe_leaf_tail(w, k, c0, c1, c2);
+                for (u32 x = w.wpos; x < (nblk - 1) * 16; ++x) m[x] = 0;   // zero padding of the final block
+            }
+            for (u32 b = 1; b < nblk; ++b) {
+                const bool last = b + 1 == nblk;
+                blake2b_compress_quad(ql, hl, hh, m + 16 * (b - 1), last ? (u64)total : (u64)(b + 1) * 128, last);
+            }
+        }
+        u64* g = nodes + (n + first + q) * 8;        // leaf i sits at heap index npo2 + i, npo2 = n
+        g[j] = hl; g[4 + j] = hh;
+        bufA[q * 8 + j] = hl; bufA[q * 8 + 4 + j] = hh;
+    }
+    __syncthreads();
+    // the levels above this workgroup's leaves, ping-pong in LDS (as merkle_top_quad_kernel)
+    u64* src = bufA;
+    u64* dst = bufB;
+    const u64 groups = n / local;                    // workgroups = subtrees
+    const bool whole_tree = groups == 1;
+    for (u32 w = local >> 1; w >= 1; w >>= 1) {
+        if (q < w) {
+            u64 hl, hh;
+            blake2b_init_quad(ql, hl, hh);
+            blake2b_compress_quad(ql, hl, hh, src + q * 16, 128, true);
+            dst[q * 8 + j] = hl; dst[q * 8 + 4 + j] = hh;
+            u64* g = nodes + (groups * w + (u64)blockIdx.x * w + q) * 8;   // this level has groups * w nodes, first at that heap index
+            g[j] = hl; g[4 + j] = hh;
+            if (w == 1 && whole_tree && root_out != nullptr) {
+                __hip_atomic_store(root_out + j, hl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(root_out + 4 + j, hh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+        __syncthreads();
+        u64* tmp = src; src = dst; dst = tmp;
+    }
+    if (tid == 0 && whole_tree && root_out != nullptr) {
+        __threadfence_system();
+        __hip_atomic_store(root_out + 8, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+#endif
+}
+
 constexpr u64 QUAD_PARENTS_MAX = 8192;   // levels with at most this many parents use one quad per hash
+constexpr u64 SUBTREE_PARENTS_MAX = 65536;    // levels of at most this many parents start a nine-level subtree launch
 constexpr u64 QUAD_LEAVES_MAX = 8192;
 
 // build all inner nodes above a leaf level of npo2 = 2^depth slots of which n_leaves hold digests
@@ -217,6 +354,14 @@ int merkle_inner_launch(u64* d_nodes, u32 depth, u64 n_leaves, hipStream_t strea
     u64 present = n_leaves;
     for (u32 lvl = depth; lvl-- > 0;) {
         const u64 count = 1ull << lvl;
+        if (present == 2 * count && count >= 512 && count <= SUBTREE_PARENTS_MAX) {
+            // a complete level of 2 * count digests: nine levels per launch (merkle_subtree_quad_kernel)
+            hipLaunchKernelGGL(merkle_subtree_quad_kernel, dim3((u32)(count / 256)), dim3(1024), 0, stream, d_nodes, 2 * count);
+            BFS_HIP(hipGetLastError());
+            lvl -= 8;                                // levels lvl .. lvl - 8 are done; the loop goes on below them
+            present = 2 * (count >> 9);
+            continue;
+        }
         if (count <= 256) {
             hipLaunchKernelGGL(merkle_top_quad_kernel, dim3(1), dim3(1024), 0, stream, d_nodes, (u32)count, present, root_out, seq);
             BFS_HIP(hipGetLastError());
@@ -253,6 +398,21 @@ int merkle_build_xfe_launch(const u64* d_limbs, u64 limb_stride, u64 n, u64* d_n
                            d_limbs, limb_stride, n, d_nodes + npo2 * 8, d_ms);
     BFS_HIP(hipGetLastError());
     return merkle_inner_launch(d_nodes, depth, n, stream, root_out, seq);
+}
+
+// Fri.commit's tree over a round's codeword, fused with the fold that produces the codeword (see fri_round_quad_kernel).
+// fold.in == nullptr: the codeword is already at d_cw.  Returns BFS_ERR_BAD_ARG for sizes the fused path does not take.
+int fri_round_fused_launch(const FriFoldArgs& fold, u64* d_cw, u64 cw_stride, u64 n, u64* d_nodes, hipStream_t stream, u64* root_out, u64 seq) {
+    if (n < 2 || n > FRI_FUSED_MAX || (n & (n - 1))) { set_error("internal: fused FRI round on %llu elements", (unsigned long long)n); return BFS_ERR_BAD_ARG; }
+    const u64* d_ms = nullptr;
+    BFS_TRY(get_leaf_midstates(&d_ms));
+    const u32 groups = (u32)(n <= FRI_WG_LEAVES ? 1 : n / FRI_WG_LEAVES);
+    hipLaunchKernelGGL(fri_round_quad_kernel, dim3(groups), dim3(1024), 0, stream, fold, d_cw, cw_stride, n, d_nodes, d_ms, root_out, seq);
+    BFS_HIP(hipGetLastError());
+    if (groups == 1) return BFS_OK;
+    u32 depth = 0;
+    while ((1ull << depth) < groups) ++depth;
+    return merkle_inner_launch(d_nodes, depth, groups, stream, root_out, seq);     // the level of the subtree roots plays the leaf level
 }
 
 int merkle_build_bfe_launch(const u64* d_values, u64 n, u64* d_nodes, hipStream_t stream) {

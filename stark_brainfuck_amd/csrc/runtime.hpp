@@ -54,6 +54,19 @@ int copy_d2h(void* h, const void* d, size_t bytes, hipStream_t stream);
 int cached_table(uint64_t key_a, uint64_t key_b, uint64_t key_c, const u64* host, size_t count, const u64** d_out);
 bool cached_table_lookup(uint64_t key_a, uint64_t key_b, uint64_t key_c, const u64** d_out);
 
+// ---- FRI rounds on small codewords, one launch (merkle.hip: fri_round_quad_kernel) ----
+struct FriFoldArgs {
+    const u64* in;             // previous round's codeword (null: this round's codeword is already at cw)
+    u64 in_stride, half;       // half = length of this round's codeword
+    Xfe alpha;                 // fri.py:120
+    u64 scal;                  // 2^-1 * offset_r^-1
+    const u64* winv_lo;        // two-level powers of the round-0 omega^-1
+    const u64* winv_hi;
+    u32 lo_bits, round_shift;
+};
+constexpr u64 FRI_FUSED_MAX = 16384;     // up to 64 workgroups of 256 leaves
+int fri_round_fused_launch(const FriFoldArgs& fold, u64* d_cw, u64 cw_stride, u64 n, u64* d_nodes, hipStream_t stream, u64* root_out, u64 seq);
+
 // ---- internal entry points (device pointers, current device) ----
 int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_stride, u32 log_n, u32 batch, u64 root,
                u64 shift, u64 post_scale, hipStream_t stream);
