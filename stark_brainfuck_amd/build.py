@@ -96,7 +96,24 @@ def build_library(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
+def build_fastlist(force=False):
+    """the CPython helper for list <-> buffer conversions (cpyext/fastlist.c), compiled in-tree with gcc"""
+    import sysconfig
+    src = os.path.join(HERE, "cpyext", "fastlist.c")
+    out = os.path.join(HERE, "_fastlist" + sysconfig.get_config_var("EXT_SUFFIX"))
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= os.path.getmtime(src):
+        return out
+    cmd = [os.environ.get("CC", "gcc"), "-O2", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"], "-o", out + ".tmp", src]
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout)
+        raise RuntimeError("gcc failed building _fastlist")
+    os.replace(out + ".tmp", out)
+    return out
+
+
 if __name__ == "__main__":
     build_library(force="--force" in sys.argv, verbose="--verbose" in sys.argv or True,
                   extra_flags=["-Rpass-analysis=kernel-resource-usage"] if "--resources" in sys.argv else [])
     print("built", LIB)
+    print("built", build_fastlist(force="--force" in sys.argv))

@@ -205,3 +205,57 @@ def test_speculative_fiat_shamir_equals_hashing_afterwards(sb):
             want = pickle.dumps(objects, protocol=4)
             assert t.serialize() == want, (prefix, step)
             assert out.raw == hashlib.shake_256(want).digest(32), (prefix, step)
+
+
+def test_fastlist_conversions_match_the_python_loops():
+    """cpyext/fastlist.c: lists of element objects <-> uint64 buffers.  Same values, same object structure (trimmed coefficient
+    lists, field references) -- checked through CPython's pickle of both results -- and the fallbacks for odd inputs."""
+    import pickle
+    import time
+    import numpy as np
+    from stark_brainfuck_amd import arrays
+    from stark_brainfuck_amd.algebra import BaseField, BaseFieldElement
+    from stark_brainfuck_amd.extension_field import ExtensionField, ExtensionFieldElement
+    from stark_brainfuck_amd.univariate import Polynomial
+    fl = arrays._fastlist
+    assert fl is not None, "the helper is built by __graft_entry__.build()"
+    P = (1 << 64) - (1 << 32) + 1
+    rng = np.random.default_rng(5)
+    n = 5000
+    vals = rng.integers(0, P, n, dtype=np.uint64)
+    vals[:6] = [0, 1, 255, 1 << 31, 1 << 63, P - 1]
+    F = BaseField.main()
+    elems = [BaseFieldElement(int(v), F) for v in vals]
+    out = np.empty(n, dtype=np.uint64)
+    assert fl.pack_base(elems, out) == n and (out == vals).all()
+    assert fl.pack_base(tuple(elems[:7]), out) == 7                       # any sequence
+    back = fl.unpack_base(vals, BaseFieldElement, F)
+    assert [e.value for e in back] == [int(v) for v in vals] and all(e.field is F for e in back) and type(back[0]) is BaseFieldElement
+    assert pickle.dumps(back) == pickle.dumps(elems)
+    XF = ExtensionField.main()
+    soa = rng.integers(0, P, (3, n), dtype=np.uint64)
+    soa[:, 0] = 0                               # the zero element: no coefficients
+    soa[1:, 1] = 0                              # one coefficient
+    soa[2, 2] = 0                               # two
+    soa[0, 3] = 0                               # a zero in front stays (only trailing zeros are trimmed)
+    xs = [XF.from_limbs([int(soa[0, i]), int(soa[1, i]), int(soa[2, i])]) for i in range(n)]
+    got = fl.unpack_ext(np.ascontiguousarray(soa), ExtensionFieldElement, Polynomial, BaseFieldElement, XF, XF._base())
+    assert [len(e.polynomial.coefficients) for e in got[:4]] == [0, 1, 2, 3]
+    assert pickle.dumps(got) == pickle.dumps(xs)
+    out3 = np.empty((3, n), dtype=np.uint64)
+    assert fl.pack_ext(xs, out3) == n and (out3 == soa).all()
+    # out-of-range values go to the Python path
+    with pytest.raises(OverflowError):
+        fl.pack_base([BaseFieldElement(1 << 64, F)], out)
+    with pytest.raises(OverflowError):
+        fl.pack_base([BaseFieldElement(-1, F)], out)
+    with pytest.raises(AttributeError):
+        fl.pack_base([object()], out)
+    with pytest.raises(ValueError):
+        fl.pack_base(elems, np.empty(3, dtype=np.uint64))
+    # and it is the point of the exercise: an order of magnitude faster than the loops (measured: base 170 ns vs 2.2 us per element
+    # out, 60 vs 150 ns in; extension 1.1 vs 26 us out, 0.3 vs 1.4 us in)
+    big = np.tile(vals, 20)
+    t0 = time.perf_counter(); fl.unpack_base(big, BaseFieldElement, F); t_c = time.perf_counter() - t0
+    t0 = time.perf_counter(); [BaseFieldElement(int(v), F) for v in big]; t_py = time.perf_counter() - t0
+    assert t_c * 3 < t_py, (t_c, t_py)
