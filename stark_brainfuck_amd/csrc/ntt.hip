@@ -1,4 +1,6 @@
 // ntt.hip -- gfx950 kernels and launcher for bfs_gl_ntt() (algorithm and reference citations: ntt_core.hpp)
+#include <cstdlib>
+
 #include "runtime.hpp"
 
 namespace bfs {
@@ -7,28 +9,49 @@ namespace bfs {
 // (A persistent variant with next-tile prefetch and 16-byte paired-lane accesses was measured slower: the kernel is
 //  VALU-issue bound at the time and hardware workgroup turnover already overlaps HBM latency)
 template <int B1, int B2, int B3, int LOGC, int MODE>
-__global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a) {
+__global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a, const int early_loads) {
     extern __shared__ __attribute__((aligned(16))) u64 smem[];
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     u64* tw = smem + (B2 > 0 ? ((Cfg::LDS_WORDS + 1) & ~1) : 0);
-    if constexpr (Cfg::U >= 2) {
-        // dense copy of the stage-1 -> stage-2 twiddles w_M^e, M = 2^(B1+B2) <= 256 (n^-1 folded in when it is the last one)
-        const u64* tab = (Cfg::U == 2 && MODE == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;
-        for (u32 i = threadIdx.x; i < (1u << (B1 + B2)); i += blockDim.x) tw[i] = tab[(u64)i << (a.tb.t_in_log - (B1 + B2))];
-        __syncthreads();
-    }
-    const u64* rowtw = nullptr;
+    // Everything a workgroup needs from memory is requested up front: its entries of the two twiddle tables first (so that
+    // waiting for them -- vmcnt counts in order -- does not wait for the data), then the 16 elements of every thread; the
+    // tables go to LDS behind ONE barrier while the data is still in flight.  (With the table copies and their two barriers in
+    // front of the loads, a workgroup spent an L2 round trip and a half before its HBM loads were even issued.)
+    static_assert(B1 == 4, "one sub-group of 16 elements per thread");
+    constexpr u32 TW_N = Cfg::U >= 2 ? (1u << (B1 + B2)) : 0;
+    const u64* tab = (Cfg::U == 2 && MODE == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;   // n^-1 folded in when it is the last inner twiddle
+    const u32 tw_shift = a.tb.t_in_log - (B1 + B2);
+    const bool early = early_loads != 0;
+    const u32 tid = threadIdx.x;
+    bool has_row = false;
+    const u64* row = nullptr;
     if constexpr (MODE == PASS_COLUMN) {
         if (a.tb.row != nullptr) {
-            // this tile's row of the inter-pass twiddle table -> LDS (one coalesced 2^S-entry read per workgroup)
-            u64* rw = tw + Cfg::TW_WORDS;
+            // this tile's row of the inter-pass twiddle table (one coalesced 2^S-entry read per workgroup)
             const u64 K = a.pass_index ? digit_reverse((u64)(blockIdx.x >> a.lognl), a.pass_bits, 0, (int)a.pass_index - 1) : 0;
-            for (u32 i = threadIdx.x; i < (1u << Cfg::S); i += blockDim.x) rw[i] = a.tb.row[(K << Cfg::S) + i];
-            rowtw = rw;
-            __syncthreads();
+            row = a.tb.row + (K << Cfg::S);
+            has_row = true;
         }
     }
-    ntt_stage1<B1, B2, B3, LOGC, MODE>(a, smem, tw, rowtw, threadIdx.x, blockIdx.x, blockIdx.y);
+    u64 tw0 = 0, rw0 = 0;
+    if (early) {
+        if (TW_N && tid < TW_N) tw0 = tab[(u64)tid << tw_shift];
+        if (has_row && tid < (1u << Cfg::S)) rw0 = row[tid];
+    }
+    u64 x[16];
+    if (early) ntt_stage1_load<B1, B2, B3, LOGC, MODE>(a, tid, blockIdx.x, blockIdx.y, 0, x);
+    u64* rw = tw + Cfg::TW_WORDS;
+    if (early) {
+        if (TW_N && tid < TW_N) tw[tid] = tw0;
+        if (has_row && tid < (1u << Cfg::S)) rw[tid] = rw0;
+    }
+    for (u32 i = tid + (early ? blockDim.x : 0); i < TW_N; i += blockDim.x) tw[i] = tab[(u64)i << tw_shift];
+    if (has_row)
+        for (u32 i = tid + (early ? blockDim.x : 0); i < (1u << Cfg::S); i += blockDim.x) rw[i] = row[i];
+    const u64* rowtw = has_row ? rw : nullptr;
+    if (Cfg::U >= 2 || has_row) __syncthreads();
+    if (!early) ntt_stage1_load<B1, B2, B3, LOGC, MODE>(a, tid, blockIdx.x, blockIdx.y, 0, x);
+    ntt_stage1_compute<B1, B2, B3, LOGC, MODE>(a, smem, tw, rowtw, threadIdx.x, blockIdx.x, blockIdx.y, 0, x);
     if constexpr (B2 > 0) {
         __syncthreads();
         ntt_stage2<B1, B2, B3, LOGC, MODE>(a, smem, threadIdx.x, blockIdx.x, blockIdx.y);
@@ -46,7 +69,8 @@ static int launch_tile(const PassArgs& a, u32 grid_x, u32 batch, hipStream_t str
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     const size_t row_words = (MODE == PASS_COLUMN && a.tb.row != nullptr) ? (1u << Cfg::S) : 0;
     const size_t lds = (size_t)((B2 > 0 ? ((Cfg::LDS_WORDS + 1) & ~1) + Cfg::TW_WORDS : 0) + row_words) * sizeof(u64);
-    hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, LOGC, MODE>), dim3(grid_x, batch), dim3(Cfg::W), lds, stream, a);
+    static const int early = [] { const char* e = getenv("BFS_NTT_EARLY_LOADS"); return (e && e[0] == '0') ? 0 : 1; }();   // A/B switch
+    hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, LOGC, MODE>), dim3(grid_x, batch), dim3(Cfg::W), lds, stream, a, early);
     BFS_HIP(hipGetLastError());
     return BFS_OK;
 }

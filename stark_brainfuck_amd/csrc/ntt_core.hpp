@@ -260,89 +260,119 @@ BFS_HD void final_store(const PassArgs& a, const TileGeom& g, const u64* x, u32 
 }
 
 // ---- stage 1: global load (+ coset / inter-pass twiddle), first radix, inner twiddle, LDS write (or final store)
+// Split into the load (ntt_stage1_load: address arithmetic and the 2^B1 global loads of a thread) and the rest
+// (ntt_stage1_compute), so that the kernel can issue the loads FIRST and copy its twiddle tables to LDS while they are in
+// flight (ntt.hip).  sub: which of the 16 / 2^B1 sub-groups of a thread (always 0 for B1 = 4).
+template <int B1, int B2, int B3, int LOGC, int MODE>
+struct Stage1Pos {
+    u32 o, c;         // o: the row bits below this stage's digit, c: column
+    u32 step_log;     // element d of this thread sits at tp[d << step_log]
+    u64 idx0;         // index of element d = 0 inside the transform (also the n_in predicate and the coset exponent)
+};
+
+template <int B1, int B2, int B3, int LOGC, int MODE>
+BFS_HD Stage1Pos<B1, B2, B3, LOGC, MODE> stage1_pos(const PassArgs& a, const TileGeom& g, u32 tid, int sub) {
+    typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
+    Stage1Pos<B1, B2, B3, LOGC, MODE> p;
+    const u32 G = (u32)sub * Cfg::W + tid;
+    if constexpr (MODE == PASS_COLUMN) {
+        p.c = G & ((1u << LOGC) - 1); p.o = G >> LOGC;
+        p.idx0 = g.row0 + ((u64)p.o << a.logL) + p.c;
+        p.step_log = Cfg::SH1 + a.logL;
+    } else {
+        p.o = G & ((1u << Cfg::SH1) - 1); p.c = G >> Cfg::SH1;
+        p.idx0 = g.row0 + ((u64)p.c << (a.mid_bits + Cfg::S)) + p.o;
+        p.step_log = Cfg::SH1;
+    }
+    return p;
+}
+
+template <int B1, int B2, int B3, int LOGC, int MODE>
+BFS_HD void ntt_stage1_load(const PassArgs& a, u32 tid, u32 bid_x, u32 bid_y, int sub, u64* x) {
+    typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
+    constexpr int Q = 1 << B1;
+    const TileGeom g = tile_geom<Cfg, LOGC, MODE>(a, bid_x, bid_y);
+    const Stage1Pos<B1, B2, B3, LOGC, MODE> p = stage1_pos<B1, B2, B3, LOGC, MODE>(a, g, tid, sub);
+    const u64* tp = g.in + p.idx0;
+    if (a.partial) {
+        BFS_UNROLL
+        for (int d = 0; d < Q; ++d) x[d] = (p.idx0 + ((u64)d << p.step_log) < a.n_in) ? tp[(u64)d << p.step_log] : 0;
+    } else {
+        BFS_UNROLL
+        for (int d = 0; d < Q; ++d) {
+#ifdef BFS_ABL_NO_MEM
+            x[d] = (p.idx0 + d) * 0x9E3779B97F4A7C15ULL >> 1;
+#else
+            x[d] = tp[(u64)d << p.step_log];
+#endif
+        }
+    }
+}
+
 // tw: dense inner-twiddle table for the stage 1 -> 2 exchange (2^(B1+B2) entries, in LDS on the GPU)
 template <int B1, int B2, int B3, int LOGC, int MODE>
-BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, const u64* tw, const u64* rowtw, u32 tid, u32 bid_x, u32 bid_y) {
+BFS_HD void ntt_stage1_compute(const PassArgs& a, u64* smem, const u64* tw, const u64* rowtw, u32 tid, u32 bid_x, u32 bid_y, int sub, u64* x) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
-    constexpr int Q = 1 << B1, SG = 16 / Q;
+    constexpr int Q = 1 << B1;
     const TileGeom g = tile_geom<Cfg, LOGC, MODE>(a, bid_x, bid_y);
     const u64 nmask = (1ull << a.log_n) - 1;
-    BFS_UNROLL
-    for (int s = 0; s < SG; ++s) {
-        const u32 G = (u32)s * Cfg::W + tid;
-        u32 o, c;      // o: the row bits below this stage's digit, c: column
-        if constexpr (MODE == PASS_COLUMN) { c = G & ((1u << LOGC) - 1); o = G >> LOGC; }
-        else { o = G & ((1u << Cfg::SH1) - 1); c = G >> Cfg::SH1; }
-        // element d of this thread sits at tp[d << step_log]
-        u32 step_log;
-        u64 idx0;      // index of element d = 0 inside the transform (also the n_in predicate and the coset exponent)
-        if constexpr (MODE == PASS_COLUMN) {
-            idx0 = g.row0 + ((u64)o << a.logL) + c;
-            step_log = Cfg::SH1 + a.logL;
-        } else {
-            idx0 = g.row0 + ((u64)c << (a.mid_bits + Cfg::S)) + o;
-            step_log = Cfg::SH1;
-        }
-        const u64* tp = g.in + idx0;
-        u64 x[Q];
-        if (a.partial) {
-            BFS_UNROLL
-            for (int d = 0; d < Q; ++d) x[d] = (idx0 + ((u64)d << step_log) < a.n_in) ? tp[(u64)d << step_log] : 0;
-        } else {
-            BFS_UNROLL
-            for (int d = 0; d < Q; ++d) {
-#ifdef BFS_ABL_NO_MEM
-                x[d] = (idx0 + d) * 0x9E3779B97F4A7C15ULL >> 1;
-#else
-                x[d] = tp[(u64)d << step_log];
-#endif
-            }
-        }
+    const Stage1Pos<B1, B2, B3, LOGC, MODE> p = stage1_pos<B1, B2, B3, LOGC, MODE>(a, g, tid, sub);
+    const u32 o = p.o, c = p.c;
 #ifndef BFS_ABL_NO_CHAIN
-        if (MODE == PASS_COLUMN && rowtw != nullptr) {
-            // middle pass: the inter-pass twiddles of this tile are one row of a table (K is the same for the whole tile)
-            BFS_UNROLL
-            for (int d = 0; d < Q; ++d) x[d] = gl_mul(x[d], rowtw[((u32)d << Cfg::SH1) | o]);
-        } else if (a.pass_index > 0 || a.has_coset) {
-            // factor of row r = (d << SH1) | o is beta^r = gamma * delta^d: a geometric chain per thread
-            u64 gam, del;
-            if (a.pass_index > 0) {
-                const u64 ks = (MODE == PASS_COLUMN) ? g.kbase : (g.kbase + c);
-                gam = tw_pow(a.tb.w_lo, a.tb.w_hi, a.tb.lo_bits, ((u64)o * ks) & nmask);
-                del = tw_pow(a.tb.w_lo, a.tb.w_hi, a.tb.lo_bits, (ks << Cfg::SH1) & nmask);
-            } else {
-                gam = tw_pow(a.tb.s_lo, a.tb.s_hi, a.tb.lo_bits, idx0);
-                del = a.coset_delta;
-            }
-            u64 f = gam;
-            BFS_UNROLL
-            for (int d = 0; d < Q; ++d) {
-                x[d] = gl_mul(x[d], f);
-                if (d + 1 < Q) f = gl_mul_lazy(f, del);   // only ever multiplied again: no canonical form needed
-            }
+    if (MODE == PASS_COLUMN && rowtw != nullptr) {
+        // middle pass: the inter-pass twiddles of this tile are one row of a table (K is the same for the whole tile)
+        BFS_UNROLL
+        for (int d = 0; d < Q; ++d) x[d] = gl_mul(x[d], rowtw[((u32)d << Cfg::SH1) | o]);
+    } else if (a.pass_index > 0 || a.has_coset) {
+        // factor of row r = (d << SH1) | o is beta^r = gamma * delta^d: a geometric chain per thread
+        u64 gam, del;
+        if (a.pass_index > 0) {
+            const u64 ks = (MODE == PASS_COLUMN) ? g.kbase : (g.kbase + c);
+            gam = tw_pow(a.tb.w_lo, a.tb.w_hi, a.tb.lo_bits, ((u64)o * ks) & nmask);
+            del = tw_pow(a.tb.w_lo, a.tb.w_hi, a.tb.lo_bits, (ks << Cfg::SH1) & nmask);
+        } else {
+            gam = tw_pow(a.tb.s_lo, a.tb.s_hi, a.tb.lo_bits, p.idx0);
+            del = a.coset_delta;
         }
+        u64 f = gam;
+        BFS_UNROLL
+        for (int d = 0; d < Q; ++d) {
+            x[d] = gl_mul(x[d], f);
+            if (d + 1 < Q) f = gl_mul_lazy(f, del);   // only ever multiplied again: no canonical form needed
+        }
+    }
 #endif
 #ifndef BFS_ABL_NO_DIF
-        dif<Q>(x);
+    dif<Q>(x);
 #endif
-        if constexpr (Cfg::U == 1) {
-            final_store<Cfg, LOGC, MODE, B1>(a, g, x, 0, 0, c);
-        } else {
-            const u32 i2 = o >> B3;
-            BFS_UNROLL
-            for (int m = 0; m < Q; ++m) {
-                const u32 k1 = perm_digit<B1>(m, a.uinv);                      // wave-uniform
-                const u32 e = mul24(i2, k1) & ((1u << (B1 + B2)) - 1);         // exponent of w_M, M = 2^(B1+B2)
+    if constexpr (Cfg::U == 1) {
+        final_store<Cfg, LOGC, MODE, B1>(a, g, x, 0, 0, c);
+    } else {
+        const u32 i2 = o >> B3;
+        BFS_UNROLL
+        for (int m = 0; m < Q; ++m) {
+            const u32 k1 = perm_digit<B1>(m, a.uinv);                      // wave-uniform
+            const u32 e = mul24(i2, k1) & ((1u << (B1 + B2)) - 1);         // exponent of w_M, M = 2^(B1+B2)
 #ifdef BFS_ABL_NO_INNER
-                const u64 v = x[m] + e;
+            const u64 v = x[m] + e;
 #else
-                // register 0 holds output digit 0: its twiddle is w^0, which is 1 unless n^-1 is folded into the table
-                const bool unit = (m == 0) && !(Cfg::U == 2 && MODE == PASS_FINAL);
-                const u64 v = unit ? x[m] : gl_mul(x[m], tw[e]);
+            // register 0 holds output digit 0: its twiddle is w^0, which is 1 unless n^-1 is folded into the table
+            const bool unit = (m == 0) && !(Cfg::U == 2 && MODE == PASS_FINAL);
+            const u64 v = unit ? x[m] : gl_mul(x[m], tw[e]);
 #endif
-                smem[lds_addr<Cfg, LOGC>((k1 << Cfg::SH1) | o, c)] = v;
-            }
+            smem[lds_addr<Cfg, LOGC>((k1 << Cfg::SH1) | o, c)] = v;
         }
+    }
+}
+
+template <int B1, int B2, int B3, int LOGC, int MODE>
+BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, const u64* tw, const u64* rowtw, u32 tid, u32 bid_x, u32 bid_y) {
+    constexpr int Q = 1 << B1, SG = 16 / Q;
+    BFS_UNROLL
+    for (int s = 0; s < SG; ++s) {
+        u64 x[Q];
+        ntt_stage1_load<B1, B2, B3, LOGC, MODE>(a, tid, bid_x, bid_y, s, x);
+        ntt_stage1_compute<B1, B2, B3, LOGC, MODE>(a, smem, tw, rowtw, tid, bid_x, bid_y, s, x);
     }
 }
 
