@@ -64,9 +64,10 @@ class ZippedSaltedMerkle(SaltedMerkle):
 
     Salts: when `salted_merkle.urandom` is the operating system's (the normal case) they are expanded on the GPU from 32
     bytes of it and never visit the host (bfs_random_fill); when a test has replaced `urandom` to reproduce the reference's
-    byte stream they are drawn from it, 24 bytes per leaf in leaf order (salted_merkle.py:25)."""
+    byte stream they are drawn from it, 24 bytes per leaf in leaf order (salted_merkle.py:25); `salts` (24 n bytes) supplies them
+    directly (the row-sharded commitment of shard.py hands every rank its slice of one stream)."""
 
-    def __init__(self, columns, n, make_row):
+    def __init__(self, columns, n, make_row, salts=None):
         import os
         assert n & (n - 1) == 0 and n > 0, f"in SaltedMerkle.__init__, next_power_of_two = {n} =/= 1 << self.depth"
         lib, stream = _lib.load(), current_stream()
@@ -79,7 +80,7 @@ class ZippedSaltedMerkle(SaltedMerkle):
         cols = (_lib.RowColumn * len(columns))()
         for c, (ptr, is_ext, field_id) in zip(cols, columns):
             c.d_values, c.is_ext, c.field_id = ptr, int(is_ext), field_id
-        if urandom is os.urandom:
+        if salts is None and urandom is os.urandom:
             words = (3 * n + 7) // 8 * 8
             self._salts = DeviceBuffer(words)
             _lib.check(lib.bfs_random_fill(urandom(32), self._salts.ptr, words, stream))
@@ -94,7 +95,9 @@ class ZippedSaltedMerkle(SaltedMerkle):
                     cache[i] = gather([(d_salts.ptr + 24 * i, 3, 1)]).tobytes()
                 return cache[i]
         else:
-            salts = urandom(24 * n)                      # the same bytes as n calls of urandom(24)
+            if salts is None:
+                salts = urandom(24 * n)                  # the same bytes as n calls of urandom(24)
+            assert len(salts) == 24 * n, "24 bytes of salt per leaf"
             keep = ctypes.create_string_buffer(salts, len(salts))
             _lib.check(lib.bfs_merkle_build_rows(cols, len(columns), n, ctypes.cast(keep, ctypes.c_void_p), 0, self._nodes.ptr, stream))
 

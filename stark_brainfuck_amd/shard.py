@@ -44,3 +44,138 @@ def gather_roots(local_roots, num_columns, world_size, rank, group=None, device=
         for slot, c in enumerate(assign_columns(num_columns, world_size, r)):
             out[c] = rows[slot].tobytes()
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# One commitment, several GPUs: SaltedMerkle(list(zip(*codewords))) with the codewords' columns spread over the ranks
+# (/root/reference/code/brainfuck_stark.py:178-180, 197-199).  A leaf is the pickle of a whole ROW, so the rows
+# have to be brought together: every rank sends, of each of its columns, the slice of rows [s n/G, (s+1) n/G) to rank s (ONE
+# all-to-all over RCCL / xGMI: (G-1)/G of the codeword bytes cross the links once), hashes the leaves of its own row range and
+# builds the subtree above them; the G subtree roots (64 bytes each) are all-gathered and every rank finishes the top log2(G)
+# levels on the host.  Bit-exact with the single-GPU tree: node k of the reference's heap (merkle.py:26-44) at depth log2(G) is
+# exactly the root of rank (k - G)'s subtree.  Salts: rank s draws the salts of its rows (they are random); a caller that has to
+# reproduce a given salt stream passes `salts` (24 bytes per leaf, leaf order), of which every rank uses its slice.
+
+def row_range(n, world_size, rank):
+    assert n % world_size == 0, "the number of rows must be a multiple of the number of ranks"
+    m = n // world_size
+    return rank * m, m
+
+
+def exchange_rows(local_columns, planes, n, world_size, rank, group=None):
+    """the all-to-all row transpose.  local_columns: {global column c: int64 tensor (planes[c], n)} for the columns of this rank
+    (CPU tensors under gloo, CUDA tensors under RCCL; uint64 values viewed as int64).  planes[c] = 1 for a base column, 3 for an
+    extension column (limb planes), for ALL columns.  Returns [tensor (planes[c], n / G) for c in all columns]: this rank's rows."""
+    import torch
+    import torch.distributed as dist
+    num_columns = len(planes)
+    mine = assign_columns(num_columns, world_size, rank)
+    assert sorted(local_columns) == mine, "rank %d must supply exactly its own columns %r" % (rank, mine)
+    first, m = row_range(n, world_size, rank)
+    if world_size == 1:
+        return [local_columns[c][:, first:first + m].contiguous() for c in range(num_columns)]
+    some = next(iter(local_columns.values())) if local_columns else torch.empty(0, dtype=torch.int64)
+    # to rank s: for each of my columns (ascending), its planes, rows of s
+    send = torch.cat([local_columns[c][:, s * m:(s + 1) * m].reshape(-1) for s in range(world_size) for c in mine]) if mine \
+        else torch.empty(0, dtype=torch.int64, device=some.device)
+    my_words = sum(planes[c] for c in mine) * m
+    in_splits = [my_words] * world_size
+    out_splits = [sum(planes[c] for c in assign_columns(num_columns, world_size, r)) * m for r in range(world_size)]
+    recv = torch.empty(sum(out_splits), dtype=torch.int64, device=send.device)
+    dist.all_to_all_single(recv, send.contiguous(), out_splits, in_splits, group=group)
+    out, pos = [None] * num_columns, 0
+    for r in range(world_size):
+        for c in assign_columns(num_columns, world_size, r):
+            out[c] = recv[pos:pos + planes[c] * m].reshape(planes[c], m)
+            pos += planes[c] * m
+    return out
+
+
+def _blake2b_pair(left, right):
+    from hashlib import blake2b
+    return blake2b(left + right).digest()
+
+
+class ShardedZippedMerkle:
+    """the zipped, salted commitment over row-sharded leaves.
+
+    local_columns / planes / n: see exchange_rows.  build_subtree(rows, first_row, salts) -> an object with .root() and
+    .open(i) -> (salt, path) over the m rows this rank received (rows: list over ALL columns of (planes[c], m) tensors); the
+    product's builder hashes them on the GPU (gpu_subtree_builder), tests pass a CPU oracle.  salts: None, or 24 n bytes."""
+
+    def __init__(self, local_columns, planes, n, world_size, rank, build_subtree, group=None, salts=None, device=None):
+        import torch
+        import torch.distributed as dist
+        self.n, self.world_size, self.rank, self.group = n, world_size, rank, group
+        self.first, self.m = row_range(n, world_size, rank)
+        assert world_size & (world_size - 1) == 0, "the top levels are a binary tree over the ranks"
+        self.rows = exchange_rows(local_columns, planes, n, world_size, rank, group)
+        my_salts = None if salts is None else salts[24 * self.first:24 * (self.first + self.m)]
+        self.subtree = build_subtree(self.rows, self.first, my_salts)
+        mine = self.subtree.root()
+        if world_size == 1:
+            roots = [mine]
+        else:
+            send = torch.frombuffer(bytearray(mine), dtype=torch.uint8)
+            if device is not None:
+                send = send.to(device)
+            recv = [torch.empty_like(send) for _ in range(world_size)]
+            dist.all_gather(recv, send, group=group)
+            roots = [r.cpu().numpy().tobytes() for r in recv]
+        # heap of the top levels: top[G + r] = subtree root of rank r, top[k] = H(top[2k] || top[2k+1])   (merkle.py:35-41)
+        self.top = [None] * (2 * world_size)
+        for r in range(world_size):
+            self.top[world_size + r] = roots[r]
+        for k in range(world_size - 1, 0, -1):
+            self.top[k] = _blake2b_pair(self.top[2 * k], self.top[2 * k + 1])
+
+    def root(self):
+        return self.top[1]
+
+    def owner(self, index):
+        return index // self.m
+
+    def top_path(self, index):
+        """the authentication-path nodes above the owner's subtree, bottom up"""
+        k, path = self.world_size + self.owner(index), []
+        while k > 1:
+            path.append(self.top[k ^ 1])
+            k >>= 1
+        return path
+
+    def open(self, index):
+        """(salt, path) of leaf `index` (salted_merkle.py:47-49): a COLLECTIVE call -- the owner of the row supplies the salt and the
+        part of the path inside its subtree, every rank appends the top levels."""
+        import torch.distributed as dist
+        owner = self.owner(index)
+        box = [None]
+        if self.rank == owner:
+            salt, path = self.subtree.open(index - self.first)
+            box = [(bytes(salt), [bytes(p) for p in path])]
+        if self.world_size > 1:
+            dist.broadcast_object_list(box, src=owner, group=self.group)
+        salt, path = box[0]
+        return salt, path + self.top_path(index)
+
+
+def gpu_subtree_builder(ext_flags, make_row=None):
+    """build_subtree for ShardedZippedMerkle on the MI355X: the received row slices are hashed by the zipped-row leaf kernel
+    (bfs_merkle_build_rows, csrc/rows.hip) where they are -- CUDA tensors -- or after one upload (CPU tensors of a gloo run)."""
+    def build(rows, first_row, salts):
+        import numpy as np
+        from .device import DeviceBuffer
+        from .salted_merkle import ZippedSaltedMerkle
+        m = rows[0].shape[1]
+        keep, columns = [], []
+        for t, is_ext in zip(rows, ext_flags):
+            if t.is_cuda:
+                keep.append(t.contiguous())
+                ptr = keep[-1].data_ptr()
+            else:
+                keep.append(DeviceBuffer.from_numpy(np.ascontiguousarray(t.numpy()).view(np.uint64).reshape(-1)))
+                ptr = keep[-1].ptr
+            columns.append((ptr, bool(is_ext), 0))
+        tree = ZippedSaltedMerkle(columns, m, make_row or (lambda i: None), salts=salts)
+        tree._keep_alive = keep
+        return tree
+    return build

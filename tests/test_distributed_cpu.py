@@ -72,3 +72,143 @@ def test_assignment_is_a_partition():
             assert cols == list(range(ncols))
             assert sum(columns_per_rank(ncols, world)) == ncols
     assert gather_roots({0: b"\1" * 64, 1: b"\2" * 64}, 2, 1, 0) == [b"\1" * 64, b"\2" * 64]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# one commitment over several ranks (shard.ShardedZippedMerkle): the base commitment of the reference's own proofs, rebuilt
+# under world-size-2 and -4 gloo with the CPU oracle doing each rank's hashing, must give the reference's root
+
+def _base_codewords_by_the_oracle(name):
+    """the 17 columns of the reference's first commitment (brainfuck_stark.py:162-180) for golden `name`, recomputed on the CPU:
+    the product's host code pads the trace and samples the randomizers from the golden's byte stream, the oracle interpolates
+    (INTT over the omicron subgroup + the rank-one randomizer correction) and evaluates on the FRI coset.  Returns
+    (golden, planes, [uint64 array (planes, n)], salts)."""
+    import hashlib
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    from oracle import ref_oracle as o
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.table import sample_base, sample_ext_many
+    from stark_brainfuck_amd.vm import VirtualMachine
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "stark_%s.json" % name)))
+    buf = hashlib.shake_256(b"bfs-golden-urandom" + name.encode()).digest(g["urandom_bytes"] + 64)
+    pos = [0]
+
+    def urandom(k):
+        pos[0] += k
+        return buf[pos[0] - k:pos[0]]
+    P = o.P
+    program = VirtualMachine.compile(g["program"])
+    running_time, inputs, outputs = VirtualMachine.run(program, input_data=list(g["input"]))
+    pm, mm, im, inm, om = VirtualMachine.simulate(program, input_data=list(inputs))
+    stark = BrainfuckStark(running_time, len(mm), program, inputs, outputs)
+    for table, matrix in zip(stark.tables, (pm, im, mm, inm, om)):
+        table.matrix = matrix
+    for table in (stark.processor_table, stark.memory_table, stark.instruction_table, stark.input_table, stark.output_table):
+        table.pad()
+    n = stark.fri.domain.length
+    offset, omega = stark.fri.domain.offset.value, stark.fri.domain.omega.value
+    count = stark.max_degree + 1
+    rc = sample_ext_many(urandom(27 * count), count, 9)                              # randomizer polynomial (:162-165)
+    columns, planes = [np.stack([o.fast_coset_evaluate(np.ascontiguousarray(rc[k]), offset, omega, n) for k in range(3)])], [3]
+    for t in stark.tables:
+        h = t.height
+        cols = t.base_array().reshape(t.base_width, h) if h else None
+        rand = [sample_base(urandom(24)) for _ in range(t.base_width)] if h and t.num_randomizers else None
+        for c in range(t.base_width):
+            if h == 0:
+                columns.append(np.zeros((1, n), dtype=np.uint64))
+            else:
+                f0 = o.intt(t.omicron.value, np.ascontiguousarray(cols[c]))
+                coeffs = np.zeros(h + 1, dtype=np.uint64)
+                coeffs[:h] = f0
+                if rand is not None:
+                    acc = 0
+                    for v in f0[::-1]:
+                        acc = (acc * omega + int(v)) % P                              # f0(omega)
+                    cc = (rand[c] - acc) * pow((pow(omega, h, P) - 1) % P, P - 2, P) % P
+                    coeffs[0] = (int(coeffs[0]) - cc) % P                             # f = f0 + c (X^h - 1)
+                    coeffs[h] = cc
+                columns.append(o.fast_coset_evaluate(coeffs, offset, omega, n).reshape(1, n))
+            planes.append(1)
+    salts = urandom(24 * n)
+    return g, planes, columns, salts
+
+
+def _sharded_worker(rank, world, port, name, q):
+    import hashlib
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle import ref_oracle as o
+    from stark_brainfuck_amd import shard
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g, planes, columns, salts = _base_codewords_by_the_oracle(name)
+    n = columns[0].shape[1]
+    # the reconstruction is the reference's: per-column digests of the golden
+    for c, col in enumerate(columns):
+        limbs = np.ascontiguousarray(col.T, dtype="<u8")
+        assert hashlib.sha256(limbs.tobytes()).hexdigest() == g["base_tree"]["columns_sha"][c], c
+    mine = shard.assign_columns(len(planes), world, rank)
+    local = {c: torch.from_numpy(columns[c].view(np.int64).copy()) for c in mine}
+
+    class OracleSubtree:                                  # salted_merkle.py:25-35 + merkle.py:26-52 on this rank's rows
+        def __init__(self, rows, first, my_salts):
+            m = rows[0].shape[1]
+            self.salts = [my_salts[24 * i:24 * i + 24] for i in range(m)]
+            leaves = []
+            for i in range(m):
+                items = []
+                for t in rows:
+                    v = t[:, i].numpy().view(np.uint64)
+                    items.append(o.make_xfe([int(x) for x in v]) if len(v) == 3 else o.make_bfe(int(v[0])))
+                leaves.append(o.salted_leaf_bytes(tuple(items), self.salts[i]))
+            self.tree = o.MerkleOracle(leaves)
+
+        def root(self):
+            return self.tree.root()
+
+        def open(self, i):
+            return self.salts[i], self.tree.open(i)
+    tree = shard.ShardedZippedMerkle(local, planes, n, world, rank, OracleSubtree, salts=salts)
+    # openings are collective; every rank gets the full path of every leaf
+    paths = {i: tree.open(i) for i in (0, 1, n // 2 - 1, n // 2, n - 1)}
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, tree.root().hex(), g["base_tree"]["root"], {i: (s.hex(), [p.hex() for p in path]) for i, (s, path) in paths.items()},
+           g["base_tree"]["salt0"], g["base_tree"]["salt_last"]))
+
+
+@pytest.mark.parametrize("name,world", [("plus1", 2), ("loop", 2), ("loop", 4)])
+def test_row_sharded_commitment_reproduces_the_reference_root(name, world):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    import hashlib
+    for rank, root, want, paths, salt0, salt_last in got:
+        assert root == want, "rank %d" % rank
+        assert paths == got[0][3]
+        assert paths[0][0] == salt0 and paths[max(paths)][0] == salt_last
+    # the paths are the single tree's: they lead from the leaf digest ... to the root; check the lengths and the top node
+    some = got[0][3]
+    depth = len(some[0][1])
+    assert all(len(p[1]) == depth for p in some.values())
+
+
+def test_exchange_rows_is_a_transpose_for_one_rank():
+    import torch
+    from stark_brainfuck_amd import shard
+    cols = {c: torch.arange(3 * 8 if c == 0 else 8, dtype=torch.int64).reshape(3 if c == 0 else 1, 8) + 100 * c for c in range(3)}
+    out = shard.exchange_rows(cols, [3, 1, 1], 8, 1, 0)
+    assert all((out[c] == cols[c]).all() for c in range(3))
+    assert shard.row_range(16, 4, 3) == (12, 4)

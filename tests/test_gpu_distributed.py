@@ -110,3 +110,56 @@ def test_concurrent_provers_in_one_process(oracle):
         for idx, raw in results[k]:
             assert idx == ref["indices"]
             assert raw == ref["proof_stream"].serialize()
+
+
+def _gpu_sharded_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from stark_brainfuck_amd import shard
+    from stark_brainfuck_amd.device import DeviceBuffer
+    from stark_brainfuck_amd.salted_merkle import ZippedSaltedMerkle
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks compute on the one GPU; the exchange runs over gloo
+    P = (1 << 64) - (1 << 32) + 1
+    n = 1 << 12
+    rng = np.random.default_rng(99)
+    planes = [3, 1, 1, 3, 1, 1, 3]
+    columns = [rng.integers(0, P, (p, n), dtype=np.uint64) for p in planes]
+    columns[3][1:, ::3] = 0                                            # extension elements with fewer stored coefficients
+    columns[1][0, ::5] = 7
+    salts = rng.integers(0, 256, 24 * n, dtype=np.uint8).tobytes()
+    mine = shard.assign_columns(len(planes), world, rank)
+    local = {c: torch.from_numpy(columns[c].view(np.int64).copy()) for c in mine}
+    tree = shard.ShardedZippedMerkle(local, planes, n, world, rank, shard.gpu_subtree_builder([p == 3 for p in planes]), salts=salts)
+    opened = {i: tree.open(i) for i in (0, n // world - 1, n // world, n - 1)}
+    whole = None
+    if rank == 0:
+        bufs = [DeviceBuffer.from_numpy(np.ascontiguousarray(c).reshape(-1)) for c in columns]
+        full = ZippedSaltedMerkle([(b.ptr, p == 3, 0) for b, p in zip(bufs, planes)], n, lambda i: None, salts=salts)
+        whole = (full.root().hex(), {i: (full.open(i)[0].hex(), [x.hex() for x in full.open(i)[1]]) for i in opened})
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, tree.root().hex(), {i: (s.hex(), [x.hex() for x in p]) for i, (s, p) in opened.items()}, whole))
+
+
+@pytest.mark.parametrize("world", [1, 2, 4])
+def test_row_sharded_commitment_on_the_gpu(world):
+    """shard.ShardedZippedMerkle with the zipped-row leaf kernel hashing each rank's row range: root and authentication paths equal
+    those of the one tree over all rows (bfs_merkle_build_rows), for 1, 2 and 4 ranks sharing this GPU"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_sharded_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    root, paths = got[0][3]
+    for rank, r, opened, _ in got:
+        assert r == root, rank
+        assert opened == paths, rank
