@@ -147,6 +147,7 @@ class ShardedZippedMerkle:
         """(salt, path) of leaf `index` (salted_merkle.py:47-49): a COLLECTIVE call -- the owner of the row supplies the salt and the
         part of the path inside its subtree, every rank appends the top levels."""
         import torch.distributed as dist
+        assert 0 <= index < self.n, "leaf index out of range"
         owner = self.owner(index)
         box = [None]
         if self.rank == owner:
