@@ -354,12 +354,12 @@ int merkle_inner_launch(u64* d_nodes, u32 depth, u64 n_leaves, hipStream_t strea
     u64 present = n_leaves;
     for (u32 lvl = depth; lvl-- > 0;) {
         const u64 count = 1ull << lvl;
-        if (present == 2 * count && count >= 512 && count <= SUBTREE_PARENTS_MAX) {
+        if (present >= 2 * count && count >= 512 && count <= SUBTREE_PARENTS_MAX) {      // (`present` is >= 2 * count for every complete level)
             // a complete level of 2 * count digests: nine levels per launch (merkle_subtree_quad_kernel)
             hipLaunchKernelGGL(merkle_subtree_quad_kernel, dim3((u32)(count / 256)), dim3(1024), 0, stream, d_nodes, 2 * count);
             BFS_HIP(hipGetLastError());
             lvl -= 8;                                // levels lvl .. lvl - 8 are done; the loop goes on below them
-            present = 2 * (count >> 9);
+            present = 2 * count;
             continue;
         }
         if (count <= 256) {
