@@ -62,6 +62,76 @@ __global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a, const i
     }
 }
 
+// Two-stage tiles of multi-pass plans: the SAME kernel, but the stage 1 -> 2 exchange goes through LDS in two halves -- the low
+// 32-bit words of all 4096 values, then the high words -- so that the tile buffer is 17 KiB instead of 34 and a workgroup needs
+// 21.5 KiB of LDS instead of 39.  With 39 KiB four workgroups (4 waves per SIMD) fit a CU, and a SIMD whose four waves are all
+// waiting -- for their loads, at a barrier -- idles: VALU issue was 82 % of the time.  A timing-only experiment (the same kernel
+// launched with less LDS than it indexes) put five or more workgroups per CU at 1.34 ms against 1.51 (profiles/r02).  The
+// price: 32 + 32 four-byte LDS accesses per thread instead of 16 + 16 eight-byte ones and two more barriers per tile.
+template <int B1, int B2, int B3, int LOGC, int MODE>
+__global__ void __launch_bounds__(256) ntt_tile_kernel_split(const PassArgs a) {
+    static_assert(B1 == 4 && B2 > 0 && B3 == 0, "two register stages, 16 elements per thread");
+    extern __shared__ __attribute__((aligned(16))) u64 smem[];
+    typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
+    constexpr u32 TILE_BYTES = (Cfg::LDS_WORDS * 4 + 15) & ~15u;
+    u32* tile = (u32*)smem;
+    u64* tw = (u64*)((char*)smem + TILE_BYTES);
+    constexpr u32 TW_N = 1u << (B1 + B2);
+    const u64* tab = (MODE == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;      // U == 2: n^-1 folded into the last inner twiddle
+    const u32 tw_shift = a.tb.t_in_log - (B1 + B2);
+    const u32 tid = threadIdx.x;
+    bool has_row = false;
+    const u64* row = nullptr;
+    if constexpr (MODE == PASS_COLUMN) {
+        if (a.tb.row != nullptr) {
+            const u64 K = a.pass_index ? digit_reverse((u64)(blockIdx.x >> a.lognl), a.pass_bits, 0, (int)a.pass_index - 1) : 0;
+            row = a.tb.row + (K << Cfg::S);
+            has_row = true;
+        }
+    }
+    // table entries first, then the data (see ntt_tile_kernel); W = 256 >= both table sizes
+    u64 tw0 = 0, rw0 = 0;
+    if (tid < TW_N) tw0 = tab[(u64)tid << tw_shift];
+    if (has_row && tid < (1u << Cfg::S)) rw0 = row[tid];
+    u64 x[16];
+    ntt_stage1_load<B1, B2, B3, LOGC, MODE>(a, tid, blockIdx.x, blockIdx.y, 0, x);
+    u64* rw = tw + Cfg::TW_WORDS;
+    if (tid < TW_N) tw[tid] = tw0;
+    if (has_row && tid < (1u << Cfg::S)) rw[tid] = rw0;
+    __syncthreads();
+    ntt_stage1_values<B1, B2, B3, LOGC, MODE>(a, tw, has_row ? rw : nullptr, tid, blockIdx.x, blockIdx.y, 0, x);
+    constexpr int Q2 = 1 << B2, SG2 = 16 / Q2;
+    BFS_UNROLL
+    for (int m = 0; m < 16; ++m) tile[stage1_out_index<B1, B2, B3, LOGC, MODE>(a, tid, 0, m)] = (u32)x[m];
+    __syncthreads();
+    u32 lo[16];
+    BFS_UNROLL
+    for (int s = 0; s < SG2; ++s)
+        BFS_UNROLL
+        for (int d = 0; d < Q2; ++d) lo[s * Q2 + d] = tile[stage2_in_index<B1, B2, B3, LOGC, MODE>(tid, s, d)];
+    __syncthreads();
+    BFS_UNROLL
+    for (int m = 0; m < 16; ++m) tile[stage1_out_index<B1, B2, B3, LOGC, MODE>(a, tid, 0, m)] = (u32)(x[m] >> 32);
+    __syncthreads();
+    BFS_UNROLL
+    for (int s = 0; s < SG2; ++s) {
+        u64 y[Q2];
+        BFS_UNROLL
+        for (int d = 0; d < Q2; ++d) y[d] = ((u64)tile[stage2_in_index<B1, B2, B3, LOGC, MODE>(tid, s, d)] << 32) | lo[s * Q2 + d];
+        ntt_stage2_from<B1, B2, B3, LOGC, MODE>(a, smem, tid, blockIdx.x, blockIdx.y, s, y);
+    }
+}
+
+template <int B1, int B2, int B3, int LOGC, int MODE>
+static int launch_tile_split(const PassArgs& a, u32 grid_x, u32 batch, hipStream_t stream) {
+    typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
+    const size_t row_words = (MODE == PASS_COLUMN && a.tb.row != nullptr) ? (1u << Cfg::S) : 0;
+    const size_t lds = ((Cfg::LDS_WORDS * 4 + 15) & ~15u) + (Cfg::TW_WORDS + row_words) * sizeof(u64);
+    hipLaunchKernelGGL((ntt_tile_kernel_split<B1, B2, B3, LOGC, MODE>), dim3(grid_x, batch), dim3(Cfg::W), lds, stream, a);
+    BFS_HIP(hipGetLastError());
+    return BFS_OK;
+}
+
 __global__ void ntt_small_kernel(const SmallArgs a) { ntt_small_body(a, threadIdx.x, blockIdx.y); }
 
 template <int B1, int B2, int B3, int LOGC, int MODE>
@@ -78,6 +148,15 @@ static int launch_tile(const PassArgs& a, u32 grid_x, u32 batch, hipStream_t str
 // multi-pass plans use 4096-element tiles (logC = 12 - S, S = 4..8); single-pass plans one column of 2^S rows (S = 4..12)
 template <int MODE>
 static int dispatch_multi(const PassArgs& a, u32 S, u32 grid_x, u32 batch, hipStream_t stream) {
+    static const bool split = [] { const char* e = getenv("BFS_NTT_SPLIT"); return !(e && e[0] == '0'); }();   // A/B switch (tools/ab_ntt.sh)
+    if (split) {
+        switch (S) {
+            case 5: return launch_tile_split<4, 1, 0, 7, MODE>(a, grid_x, batch, stream);
+            case 6: return launch_tile_split<4, 2, 0, 6, MODE>(a, grid_x, batch, stream);
+            case 7: return launch_tile_split<4, 3, 0, 5, MODE>(a, grid_x, batch, stream);
+            case 8: return launch_tile_split<4, 4, 0, 4, MODE>(a, grid_x, batch, stream);
+        }
+    }
     switch (S) {
         case 4: return launch_tile<4, 0, 0, 8, MODE>(a, grid_x, batch, stream);
         case 5: return launch_tile<4, 1, 0, 7, MODE>(a, grid_x, batch, stream);

@@ -309,9 +309,40 @@ BFS_HD void ntt_stage1_load(const PassArgs& a, u32 tid, u32 bid_x, u32 bid_y, in
     }
 }
 
+// (o, c) of stage-1 thread `tid`: o = the row bits below the stage's digit, c = column (stage1_pos without the tile geometry)
+template <int B1, int B2, int B3, int LOGC, int MODE>
+BFS_HD void stage1_oc(u32 tid, int sub, u32& o, u32& c) {
+    typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
+    const u32 G = (u32)sub * Cfg::W + tid;
+    if constexpr (MODE == PASS_COLUMN) { c = G & ((1u << LOGC) - 1); o = G >> LOGC; }
+    else { o = G & ((1u << Cfg::SH1) - 1); c = G >> Cfg::SH1; }
+}
+
+// The stage 1 -> 2 exchange: register m of stage-1 thread `tid` goes to tile word stage1_out_index, and register d of sub-group s
+// of stage-2 thread `tid` comes from stage2_in_index (word indices of the padded tile layout, lds_addr).
+template <int B1, int B2, int B3, int LOGC, int MODE>
+BFS_HD u32 stage1_out_index(const PassArgs& a, u32 tid, int sub, int m) {
+    typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
+    u32 o, c;
+    stage1_oc<B1, B2, B3, LOGC, MODE>(tid, sub, o, c);
+    return lds_addr<Cfg, LOGC>((perm_digit<B1>(m, a.uinv) << Cfg::SH1) | o, c);
+}
+
+template <int B1, int B2, int B3, int LOGC, int MODE>
+BFS_HD u32 stage2_in_index(u32 tid, int s, int d) {
+    typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
+    const u32 G = (u32)s * Cfg::W + tid;
+    const u32 c = G & ((1u << LOGC) - 1);
+    const u32 rest = G >> LOGC;
+    const u32 f1 = rest & ((1u << B1) - 1), f3 = rest >> B1;
+    return lds_addr<Cfg, LOGC>((f1 << Cfg::SH1) | ((u32)d << Cfg::SH2) | f3, c);
+}
+
+// stage 1 without the exchange: load-time twiddle, first radix and (U >= 2) the inner twiddle; x[m] is left holding the value
+// that stage1_out_index(m) receives.  U == 1: the values are final and are stored.
 // tw: dense inner-twiddle table for the stage 1 -> 2 exchange (2^(B1+B2) entries, in LDS on the GPU)
 template <int B1, int B2, int B3, int LOGC, int MODE>
-BFS_HD void ntt_stage1_compute(const PassArgs& a, u64* smem, const u64* tw, const u64* rowtw, u32 tid, u32 bid_x, u32 bid_y, int sub, u64* x) {
+BFS_HD void ntt_stage1_values(const PassArgs& a, const u64* tw, const u64* rowtw, u32 tid, u32 bid_x, u32 bid_y, int sub, u64* x) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     constexpr int Q = 1 << B1;
     const TileGeom g = tile_geom<Cfg, LOGC, MODE>(a, bid_x, bid_y);
@@ -354,14 +385,23 @@ BFS_HD void ntt_stage1_compute(const PassArgs& a, u64* smem, const u64* tw, cons
             const u32 k1 = perm_digit<B1>(m, a.uinv);                      // wave-uniform
             const u32 e = mul24(i2, k1) & ((1u << (B1 + B2)) - 1);         // exponent of w_M, M = 2^(B1+B2)
 #ifdef BFS_ABL_NO_INNER
-            const u64 v = x[m] + e;
+            x[m] = x[m] + e;
 #else
             // register 0 holds output digit 0: its twiddle is w^0, which is 1 unless n^-1 is folded into the table
             const bool unit = (m == 0) && !(Cfg::U == 2 && MODE == PASS_FINAL);
-            const u64 v = unit ? x[m] : gl_mul(x[m], tw[e]);
+            if (!unit) x[m] = gl_mul(x[m], tw[e]);
 #endif
-            smem[lds_addr<Cfg, LOGC>((k1 << Cfg::SH1) | o, c)] = v;
         }
+    }
+}
+
+template <int B1, int B2, int B3, int LOGC, int MODE>
+BFS_HD void ntt_stage1_compute(const PassArgs& a, u64* smem, const u64* tw, const u64* rowtw, u32 tid, u32 bid_x, u32 bid_y, int sub, u64* x) {
+    typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
+    ntt_stage1_values<B1, B2, B3, LOGC, MODE>(a, tw, rowtw, tid, bid_x, bid_y, sub, x);
+    if constexpr (Cfg::U >= 2) {
+        BFS_UNROLL
+        for (int m = 0; m < (1 << B1); ++m) smem[stage1_out_index<B1, B2, B3, LOGC, MODE>(a, tid, sub, m)] = x[m];
     }
 }
 
@@ -377,36 +417,45 @@ BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, const u64* tw, const u64* r
 }
 
 // ---- stage 2: LDS read, second radix, (inner twiddle + LDS write) or final store
+// ntt_stage2_from: sub-group s of thread `tid` once its 2^B2 values are in x[] (however they got there)
 template <int B1, int B2, int B3, int LOGC, int MODE>
-BFS_HD void ntt_stage2(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid_y) {
+BFS_HD void ntt_stage2_from(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid_y, int s, u64* x) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     if constexpr (B2 > 0) {
-        constexpr int Q = 1 << B2, SG = 16 / Q;
+        constexpr int Q = 1 << B2;
         const TileGeom g = tile_geom<Cfg, LOGC, MODE>(a, bid_x, bid_y);
+        const u32 G = (u32)s * Cfg::W + tid;
+        const u32 c = G & ((1u << LOGC) - 1);
+        const u32 rest = G >> LOGC;
+        const u32 f1 = rest & ((1u << B1) - 1), f3 = rest >> B1;
+#ifndef BFS_ABL_NO_DIF
+        dif<Q>(x);
+#endif
+        if constexpr (Cfg::U == 2) {
+            final_store<Cfg, LOGC, MODE, B2>(a, g, x, f1, B1, c);
+        } else {
+            const u64* tab = (MODE == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;
+            BFS_UNROLL
+            for (int m = 0; m < Q; ++m) {
+                const u32 k2 = perm_digit<B2>(m, a.uinv);
+                const u32 e = mul24(f3, f1 + (k2 << B1)) & ((1u << Cfg::S) - 1);
+                const u64 v = gl_mul(x[m], tab[(u64)e << (a.tb.t_in_log - Cfg::S)]);
+                smem[lds_addr<Cfg, LOGC>((f1 << Cfg::SH1) | (k2 << Cfg::SH2) | f3, c)] = v;
+            }
+        }
+    }
+}
+
+template <int B1, int B2, int B3, int LOGC, int MODE>
+BFS_HD void ntt_stage2(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid_y) {
+    if constexpr (B2 > 0) {
+        constexpr int Q = 1 << B2, SG = 16 / Q;
         BFS_UNROLL
         for (int s = 0; s < SG; ++s) {
-            const u32 G = (u32)s * Cfg::W + tid;
-            const u32 c = G & ((1u << LOGC) - 1);
-            const u32 rest = G >> LOGC;
-            const u32 f1 = rest & ((1u << B1) - 1), f3 = rest >> B1;
             u64 x[Q];
             BFS_UNROLL
-            for (int d = 0; d < Q; ++d) x[d] = smem[lds_addr<Cfg, LOGC>((f1 << Cfg::SH1) | ((u32)d << Cfg::SH2) | f3, c)];
-#ifndef BFS_ABL_NO_DIF
-            dif<Q>(x);
-#endif
-            if constexpr (Cfg::U == 2) {
-                final_store<Cfg, LOGC, MODE, B2>(a, g, x, f1, B1, c);
-            } else {
-                const u64* tab = (MODE == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;
-                BFS_UNROLL
-                for (int m = 0; m < Q; ++m) {
-                    const u32 k2 = perm_digit<B2>(m, a.uinv);
-                    const u32 e = mul24(f3, f1 + (k2 << B1)) & ((1u << Cfg::S) - 1);
-                    const u64 v = gl_mul(x[m], tab[(u64)e << (a.tb.t_in_log - Cfg::S)]);
-                    smem[lds_addr<Cfg, LOGC>((f1 << Cfg::SH1) | (k2 << Cfg::SH2) | f3, c)] = v;
-                }
-            }
+            for (int d = 0; d < Q; ++d) x[d] = smem[stage2_in_index<B1, B2, B3, LOGC, MODE>(tid, s, d)];
+            ntt_stage2_from<B1, B2, B3, LOGC, MODE>(a, smem, tid, bid_x, bid_y, s, x);
         }
     }
 }
