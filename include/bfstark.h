@@ -199,6 +199,11 @@ typedef struct bfs_row_column {
     int32_t is_ext;
     int32_t field_id;
 } bfs_row_column;
+/* bfs_merkle_build_rows_range: the same over a RANGE of n rows of longer columns: d_values point at the first row of the range, the
+ * limb planes of an extension column are limb_stride words apart (the full column length), salts are those of the range.  The tree
+ * it writes is the subtree over these rows: a rank of a row-sharded commitment hashes its rows with this (stark_brainfuck_amd/shard.py). */
+int bfs_merkle_build_rows_range(const bfs_row_column* columns, uint32_t ncols, uint64_t n, uint64_t limb_stride, const uint8_t* salts,
+                                int salts_on_device, uint8_t* d_nodes, void* stream);
 int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n, const uint8_t* salts, int salts_on_device,
                           uint8_t* d_nodes, void* stream);
 /* nwords (a multiple of 8) pseudo-random words in HBM: 64-byte block j = BLAKE2b-512(seed || j).  For salts that never visit

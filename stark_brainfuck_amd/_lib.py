@@ -80,6 +80,7 @@ _SIGNATURES = {
     "bfs_merkle_build_bytes": (ci, [vp, vp, vp, u64, vp, vp]),
     "bfs_merkle_open": (ci, [vp, u32, u64, vp, vp]),
     "bfs_merkle_build_rows": (ci, [vp, u32, u64, vp, ci, vp, vp]),
+    "bfs_merkle_build_rows_range": (ci, [vp, u32, u64, u64, vp, ci, vp, vp]),
     "bfs_random_fill": (ci, [ctypes.c_char_p, vp, u64, vp]),
     "bfs_xfe_sample_fill": (ci, [ctypes.c_char_p, vp, u64, u64, vp]),
     "bfs_xfe_fold": (ci, [vp, u64, vp, u64, u32, ctypes.POINTER(u64), u64, u64, vp]),

@@ -121,6 +121,23 @@ class BrainfuckStark:
     # ------------------------------------------------------------------------------------------------------------
     keep_intermediates = False      # True: prove() leaves trees, quotient codewords and the combination codeword in `_last` (tests)
 
+    # ---- several GPUs on one proof (shard.RowShardedSaltedMerkle): every rank runs the polynomial stages on all columns and hashes
+    # only its range of the zipped rows; set by cooperate() and used inside shard.shared_randomness()
+    _cooperation = None
+
+    def cooperate(self, world_size, rank, group=None, device=None):
+        """this prover is one of `world_size` identical provers (one per GPU) working on the SAME proof: the zipped commitments are
+        built cooperatively, every rank returns the same proof bytes.  Call prove() inside `with shard.shared_randomness(...)`."""
+        self._cooperation = (int(world_size), int(rank), group, device) if world_size > 1 else None
+        return self
+
+    def _zipped_tree(self, columns, n, make_row):
+        if self._cooperation is None:
+            return ZippedSaltedMerkle(columns, n, make_row)
+        from .shard import RowShardedSaltedMerkle
+        world_size, rank, group, device = self._cooperation
+        return RowShardedSaltedMerkle(columns, n, make_row, world_size, rank, group=group, device=device)
+
     @staticmethod
     def _release(*holders):
         """hand device memory back to the pool now instead of when the garbage collector gets to it (the blocks are
@@ -202,7 +219,7 @@ class BrainfuckStark:
         base_columns = [(randomizer_codeword.ptr, True, 0)]
         for t in self.tables:
             base_columns += [(t.base_codewords.ptr + 8 * c * n, False, 0) for c in range(t.base_width)]
-        base_tree = ZippedSaltedMerkle(base_columns, n, base_row)
+        base_tree = self._zipped_tree(base_columns, n, base_row)
         proof_stream.push(base_tree.root())
         lap("base_tree")
 
@@ -244,7 +261,7 @@ class BrainfuckStark:
         ext_columns = []
         for t in self.tables:
             ext_columns += [(t.ext_codewords.ptr + 8 * 3 * c * n, True, 0) for c in range(t.full_width - t.base_width)]
-        extension_tree = ZippedSaltedMerkle(ext_columns, n, ext_row)
+        extension_tree = self._zipped_tree(ext_columns, n, ext_row)
         proof_stream.push(extension_tree.root())
         lap("ext_tree")
 

@@ -42,7 +42,9 @@ struct RowArgs {
     const u64* const* columns;   // device array of column pointers
     const u32* is_ext;           // device array
     u32 ncols;
-    u64 n;
+    u64 n;                       // rows to hash
+    u64 limb_stride;             // distance between the limb planes of an extension column (n, or the full column length when
+                                 // the rows are a range of longer columns)
     const u64* salts;            // n x 3 words, or null
     const RowTemplate* templates;
     u32 num_templates;
@@ -58,7 +60,7 @@ __device__ __forceinline__ u32 row_pattern(const RowArgs& a, u64 i) {
     for (u32 c = 0; c < a.ncols; ++c) {
         if (!a.is_ext[c]) continue;
         const u64* p = a.columns[c];
-        const u32 k = p[2 * a.n + i] ? 3u : (p[a.n + i] ? 2u : (p[i] ? 1u : 0u));
+        const u32 k = p[2 * a.limb_stride + i] ? 3u : (p[a.limb_stride + i] ? 2u : (p[i] ? 1u : 0u));
         code |= k << shift;
         shift += 2;
     }
@@ -121,7 +123,7 @@ __global__ void __launch_bounds__(LEAF_THREADS) row_leaves_kernel(const RowArgs 
     u32 int_bytes = 0;
     for (u32 s = 0; s < tp->num_segs; ++s) {
         const RowSeg sg = segment(s);
-        if (sg.kind == SEG_INT) int_bytes += pickle_int_len(a.columns[sg.a][(u64)sg.b * a.n + i]);
+        if (sg.kind == SEG_INT) int_bytes += pickle_int_len(a.columns[sg.a][(u64)sg.b * a.limb_stride + i]);
     }
     const u32 tuple_len = tp->tuple_const_bytes + int_bytes;
     const u32 total = tuple_len + tp->salt_bytes;
@@ -149,7 +151,7 @@ __global__ void __launch_bounds__(LEAF_THREADS) row_leaves_kernel(const RowArgs 
                 if (nb < 8) data &= (1ull << (8 * nb)) - 1;
                 if (8 * (w + 1) >= sg.b) { ++s; w = 0; } else ++w;
             } else if (sg.kind == SEG_INT) {
-                const u64 v = a.columns[sg.a][(u64)sg.b * a.n + i];
+                const u64 v = a.columns[sg.a][(u64)sg.b * a.limb_stride + i];
                 u64 lo, hi = 0;
                 u32 len;
                 if (v < (1ull << 8)) { lo = 0x4b | (v << 8); len = 2; }
@@ -337,7 +339,13 @@ extern "C" int bfs_xfe_sample_fill(const uint8_t seed[32], uint64_t* d_out, uint
 
 extern "C" int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n, const uint8_t* salts, int salts_on_device,
                                      uint8_t* d_nodes, void* stream_) {
+    return bfs_merkle_build_rows_range(columns, ncols, n, n, salts, salts_on_device, d_nodes, stream_);
+}
+
+extern "C" int bfs_merkle_build_rows_range(const bfs_row_column* columns, uint32_t ncols, uint64_t n, uint64_t limb_stride, const uint8_t* salts,
+                                           int salts_on_device, uint8_t* d_nodes, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (limb_stride < n) { set_error("bfs_merkle_build_rows_range: limb_stride < n"); return BFS_ERR_BAD_ARG; }
     const uint8_t* h_salts = salts_on_device ? nullptr : salts;
     const bool salted = salts != nullptr;
     if (n == 0) return BFS_OK;
@@ -372,7 +380,7 @@ extern "C" int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t nco
     if (h_salts) BFS_TRY(copy_h2d(d_salts, h_salts, salt_words * sizeof(u64), stream));   // test mode: the reference's byte stream
 
     RowArgs a{};
-    a.columns = d_cols; a.is_ext = d_ext; a.ncols = ncols; a.n = n;
+    a.columns = d_cols; a.is_ext = d_ext; a.ncols = ncols; a.n = n; a.limb_stride = limb_stride;
     a.salts = h_salts ? d_salts : (salted ? (const u64*)salts : nullptr);
     a.digests = (u64*)d_nodes + npo2 * 8;
     a.pattern_set = d_set; a.error = d_err;

@@ -67,10 +67,15 @@ class ZippedSaltedMerkle(SaltedMerkle):
     byte stream they are drawn from it, 24 bytes per leaf in leaf order (salted_merkle.py:25); `salts` (24 n bytes) supplies them
     directly (the row-sharded commitment of shard.py hands every rank its slice of one stream)."""
 
-    def __init__(self, columns, n, make_row, salts=None):
+    def __init__(self, columns, n, make_row, salts=None, limb_stride=None, salt_offset=0, total_rows=None):
+        """limb_stride / salt_offset / total_rows: the rows are the range [salt_offset, salt_offset + n) of columns of total_rows
+        elements (a rank of a row-sharded commitment, shard.RowShardedSaltedMerkle): `columns` point at the first row of the range,
+        extension limb planes are limb_stride words apart, and the salts are the range's slice of the stream for ALL rows."""
         import os
         assert n & (n - 1) == 0 and n > 0, f"in SaltedMerkle.__init__, next_power_of_two = {n} =/= 1 << self.depth"
         lib, stream = _lib.load(), current_stream()
+        limb_stride = n if limb_stride is None else int(limb_stride)
+        total_rows = n if total_rows is None else int(total_rows)
         self.num_leafs = n
         self._npo2, self.depth = n, n.bit_length() - 1
         self._data = None
@@ -80,26 +85,30 @@ class ZippedSaltedMerkle(SaltedMerkle):
         cols = (_lib.RowColumn * len(columns))()
         for c, (ptr, is_ext, field_id) in zip(cols, columns):
             c.d_values, c.is_ext, c.field_id = ptr, int(is_ext), field_id
-        if salts is None and urandom is os.urandom:
-            words = (3 * n + 7) // 8 * 8
+        if salts is None and (urandom is os.urandom or getattr(urandom, "expand_on_device", False)):
+            # one stream for all total_rows leaves, expanded from 32 bytes (every rank of a sharded commitment expands the same one)
+            words = (3 * total_rows + 7) // 8 * 8
             self._salts = DeviceBuffer(words)
             _lib.check(lib.bfs_random_fill(urandom(32), self._salts.ptr, words, stream))
-            _lib.check(lib.bfs_merkle_build_rows(cols, len(columns), n, self._salts.ptr, 1, self._nodes.ptr, stream))
+            first = self._salts.ptr + 24 * salt_offset
+            _lib.check(lib.bfs_merkle_build_rows_range(cols, len(columns), n, limb_stride, first, 1, self._nodes.ptr, stream))
 
             cache = self._salt_cache = {}
             d_salts = self._salts           # the closure must not hold `self`: tree -> leafs -> closure -> tree would be a cycle
+            self._salt_base = first
 
             def salt_of(i):
                 from .device import gather
                 if i not in cache:
-                    cache[i] = gather([(d_salts.ptr + 24 * i, 3, 1)]).tobytes()
+                    cache[i] = gather([(d_salts.ptr + 24 * (salt_offset + i), 3, 1)]).tobytes()
                 return cache[i]
         else:
             if salts is None:
-                salts = urandom(24 * n)                  # the same bytes as n calls of urandom(24)
+                salts = urandom(24 * total_rows)[24 * salt_offset:24 * (salt_offset + n)]   # the same bytes as one urandom(24) per leaf
             assert len(salts) == 24 * n, "24 bytes of salt per leaf"
             keep = ctypes.create_string_buffer(salts, len(salts))
-            _lib.check(lib.bfs_merkle_build_rows(cols, len(columns), n, ctypes.cast(keep, ctypes.c_void_p), 0, self._nodes.ptr, stream))
+            _lib.check(lib.bfs_merkle_build_rows_range(cols, len(columns), n, limb_stride, ctypes.cast(keep, ctypes.c_void_p), 0,
+                                                       self._nodes.ptr, stream))
 
             def salt_of(i):
                 return salts[24 * i:24 * i + 24]
@@ -111,7 +120,7 @@ class ZippedSaltedMerkle(SaltedMerkle):
         if cache is None:
             return lambda: None
         wanted = [i for i in dict.fromkeys(indices) if i not in cache]
-        tickets = [batch.add(self._salts.ptr + 24 * i, 3, 1) for i in wanted]
+        tickets = [batch.add(self._salt_base + 24 * i, 3, 1) for i in wanted]
 
         def store():
             for i, ticket in zip(wanted, tickets):

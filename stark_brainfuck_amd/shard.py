@@ -103,13 +103,14 @@ class ShardedZippedMerkle:
     .open(i) -> (salt, path) over the m rows this rank received (rows: list over ALL columns of (planes[c], m) tensors); the
     product's builder hashes them on the GPU (gpu_subtree_builder), tests pass a CPU oracle.  salts: None, or 24 n bytes."""
 
-    def __init__(self, local_columns, planes, n, world_size, rank, build_subtree, group=None, salts=None, device=None):
+    def __init__(self, local_columns, planes, n, world_size, rank, build_subtree, group=None, salts=None, device=None, rows=None):
+        """rows: skip the exchange -- the caller already holds this rank's rows (RowShardedSaltedMerkle)"""
         import torch
         import torch.distributed as dist
         self.n, self.world_size, self.rank, self.group = n, world_size, rank, group
         self.first, self.m = row_range(n, world_size, rank)
         assert world_size & (world_size - 1) == 0, "the top levels are a binary tree over the ranks"
-        self.rows = exchange_rows(local_columns, planes, n, world_size, rank, group)
+        self.rows = exchange_rows(local_columns, planes, n, world_size, rank, group) if rows is None else rows
         my_salts = None if salts is None else salts[24 * self.first:24 * (self.first + self.m)]
         self.subtree = build_subtree(self.rows, self.first, my_salts)
         mine = self.subtree.root()
@@ -180,3 +181,107 @@ def gpu_subtree_builder(ext_flags, make_row=None):
         tree._keep_alive = keep
         return tree
     return build
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# One proof, several GPUs, no data movement: every rank runs the (cheap) polynomial stages of BrainfuckStark.prove on all columns
+# and the (expensive: half of a large proof) zipped-row leaf hashing on its own RANGE of rows only; the ranks exchange nothing but
+# 64-byte subtree roots and, for the few opened rows, the owner's salt and inner authentication path.  The proof is the single-GPU
+# proof, byte for byte, on every rank.  Everything random in the proof must be the same on all ranks: shared_randomness().
+
+class RowShardedSaltedMerkle:
+    """SaltedMerkle(list(zip(*codewords))) where every rank holds ALL the columns (device pointers) but hashes only rows
+    [rank n/G, (rank+1) n/G).  Same interface as salted_merkle.ZippedSaltedMerkle as far as the prover uses it: root(), leafs[i],
+    open(i) (collective), prefetch_salts / prefetch_paths (nothing to prefetch: the owner serves openings)."""
+
+    def __init__(self, columns, n, make_row, world_size, rank, group=None, device=None):
+        from .salted_merkle import ZippedSaltedMerkle, _LazyLeafs
+        first, m = row_range(n, world_size, rank)
+        # extension columns: (pointer to limb plane 0, True, id); the planes are n words apart whatever the range
+        local = [(ptr + 8 * first, is_ext, field_id) for ptr, is_ext, field_id in columns]
+        sub = ZippedSaltedMerkle(local, m, lambda i: make_row(first + i), limb_stride=n, salt_offset=first, total_rows=n)
+
+        class _Sub:                         # what ShardedZippedMerkle expects of a subtree
+            def root(self_inner): return sub.root()
+            def open(self_inner, i): return sub.open(i)
+        self._sub = sub
+        self._tree = ShardedZippedMerkle({}, [], n, world_size, rank, lambda rows, f, s: _Sub(), group=group, device=device, rows=[])
+        self.num_leafs, self.depth = n, n.bit_length() - 1
+        self._opened = {}
+        tree = self
+
+        def salt_of(i):
+            return tree.open(i)[0]
+        self._leafs = _LazyLeafs(n, make_row, salt_of)
+
+    @property
+    def leafs(self):
+        return self._leafs
+
+    def root(self):
+        return self._tree.root()
+
+    def open(self, index):
+        if index not in self._opened:
+            self._opened[index] = self._tree.open(index)
+        return self._opened[index]
+
+    def prefetch_salts(self, indices, batch):
+        return lambda: None
+
+    def prefetch_paths(self, indices, batch):
+        return lambda: None
+
+    def free(self):
+        for name in ("_nodes", "_salts"):
+            b = getattr(self._sub, name, None)
+            if hasattr(b, "free"):
+                b.free()
+
+
+class _SharedStream:
+    """os.urandom replaced by SHAKE-256 of a seed that rank 0 drew and broadcast: every rank of a cooperative proof sees the same bytes
+    (randomizers, salts, initials), so the ranks' transcripts cannot diverge.  expand_on_device: bulk randomness (24 bytes of salt
+    per leaf) is still expanded on the GPU from 32 bytes of this stream, as with the operating system's urandom."""
+    expand_on_device = True
+
+    def __init__(self, seed):
+        import hashlib
+        self._xof, self._pos, self._buf = hashlib.shake_256(b"bfs-shared-randomness" + seed), 0, b""
+
+    def __call__(self, count):
+        end = self._pos + count
+        if end > len(self._buf):
+            self._buf = self._xof.digest(max(2 * end, 1 << 12))
+        out = self._buf[self._pos:end]
+        self._pos = end
+        return out
+
+
+class shared_randomness:
+    """context manager: inside it the prover modules draw their randomness from one stream shared by the ranks of `group`
+    (process-global: it replaces the module-level `urandom` of brainfuck_stark, table and salted_merkle for its duration)."""
+
+    def __init__(self, world_size, rank, group=None, seed=None):
+        self.world_size, self.rank, self.group, self.seed = world_size, rank, group, seed
+
+    def __enter__(self):
+        import os
+        from . import brainfuck_stark, salted_merkle, table
+        seed = self.seed
+        if seed is None:
+            box = [os.urandom(32) if self.rank == 0 else None]
+            if self.world_size > 1:
+                import torch.distributed as dist
+                dist.broadcast_object_list(box, src=0, group=self.group)
+            seed = box[0]
+        stream = _SharedStream(seed)
+        self._saved = [(m, m.urandom) for m in (brainfuck_stark, salted_merkle, table)]
+        for m, _ in self._saved:
+            m.urandom = stream
+        return stream
+
+    def __exit__(self, *exc):
+        for m, f in self._saved:
+            m.urandom = f
+        return False

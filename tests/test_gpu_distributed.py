@@ -173,3 +173,70 @@ def test_row_sharded_commitment_on_the_gpu(world):
     for rank, r, opened, _ in got:
         assert r == root, rank
         assert opened == paths, rank
+
+
+def _coop_worker(rank, world, port, name, q):
+    import hashlib
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from stark_brainfuck_amd import brainfuck_stark, salted_merkle, shard, table
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    from test_gpu_stark import Stream
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "stark_%s.json" % name)))
+    program = VirtualMachine.compile(g["program"])
+    running_time, inputs, outputs = VirtualMachine.run(program, input_data=list(g["input"]))
+    matrices = VirtualMachine.simulate(program, input_data=list(inputs))
+    # (1) the reference's byte stream as os.urandom on every rank: the cooperative proof must be the reference's proof
+    stream = Stream(name.encode())
+    for mod in (brainfuck_stark, salted_merkle, table):
+        mod.urandom = stream
+    stark = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs).cooperate(world, rank)
+    proof = stark.prove(program, *matrices)
+    golden_ok = hashlib.sha256(proof).hexdigest() == g["proof_sha256"] and stream.pos == g["urandom_bytes"]
+    # (2) production randomness: one seed from rank 0, shared
+    import os as _os
+    for mod in (brainfuck_stark, salted_merkle, table):
+        mod.urandom = _os.urandom
+    with shard.shared_randomness(world, rank):
+        fresh = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs).cooperate(world, rank).prove(program, *matrices)
+    assert brainfuck_stark.urandom is _os.urandom
+    verified = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs).verify(fresh)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, golden_ok, hashlib.sha256(fresh).hexdigest(), bool(verified), len(proof)))
+
+
+@pytest.mark.parametrize("name,world", [("loop", 2), ("two_io", 4)])
+def test_cooperative_proof_is_the_reference_proof(name, world):
+    """BrainfuckStark.cooperate(): `world` provers (sharing this GPU, exchanging over gloo) hash disjoint row ranges of the zipped
+    commitments and exchange subtree roots and opened paths; with the reference's randomness every rank writes the reference's
+    proof (tests/golden), with shared fresh randomness all ranks write the same proof and verify() accepts it"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_coop_worker, args=(r, world, port, name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = []
+    for _ in procs:
+        for attempt in range(150):
+            try:
+                got.append(q.get(timeout=2))
+                break
+            except Exception:
+                assert all(p.is_alive() or p.exitcode == 0 for p in procs), "a worker failed: %r" % [p.exitcode for p in procs]
+        else:
+            raise AssertionError("timed out")
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _, _, _ in got), "a rank's proof differs from the reference's"
+    assert len({h for _, _, h, _, _ in got}) == 1, "the ranks wrote different proofs"
+    assert all(v for _, _, _, v, _ in got)
