@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--no-stark", action="store_true", help="skip BrainfuckStark.prove on Hello World (config 4)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-single", action="store_true", help="skip the single-column 2^24 leg")
+    ap.add_argument("--cooperative", action="store_true",
+                    help="N > 1: additionally time ONE BrainfuckStark.prove carried by all ranks together (BrainfuckStark.cooperate: every rank "
+                         "hashes its range of the zipped rows; opt-in, the default legs run independent replicas)")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run round-trip check and root gather (PMC collection runs)")
     args = ap.parse_args()
 
@@ -221,6 +224,9 @@ def main():
             parts = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(parts, t)
             stark_all = [float(p[0]) for p in parts]
+    coop = None
+    if args.cooperative and dist is not None and world > 1 and (world & (world - 1)) == 0:
+        coop = bench_stark_cooperative(world, rank, torch.device("cuda", local_rank), dist, torch)
     if rank == 0:
         # dominant kernel = ntt_tile_kernel (npass launches per step); algorithmic bytes of one launch =
         # 16 B/element * n * columns / npass (DESIGN.md "Roofline accounting"); HIP events bracket exactly K steps
@@ -257,6 +263,8 @@ def main():
             line["stark_prove"] = stark_mine
             line["stark_prove"]["replicas"] = {"per_gpu_ms": [round(v, 4) for v in stark_all], "proofs_per_s": world / (max(stark_all) * 1e-3)}
             line["stark_prove_2p22"] = bench_stark("+" * 64 + "[>" + "+" * 64 + "[>++++<-]<-]+++.", "nested loops, 37 254 cycles")
+        if coop is not None:
+            line["stark_prove_cooperative"] = coop
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)
@@ -349,6 +357,31 @@ def bench_stark(code=None, label="Hello World!"):
             "breakdown_ms": {k: round(v * 1e3, 2) for k, v in timing.items()},
             "reference": "not runnable: > 12 h extrapolated from 361 s at N = 1024 (BASELINE.md); 757 s measured at N = 2048, 6 766 s at N = 16 384 (tests/golden/stark_*.json)",
             "note": "wall clock of prove() incl. host steps (padding, Fiat-Shamir, transcript); trace_ms = VirtualMachine.simulate (native), verify_ms = verify() on the host"}
+
+
+def bench_stark_cooperative(world, rank, device, dist, torch):
+    """one proof of the 37 254-cycle program (FRI domain 2^22) by all ranks together: shard.shared_randomness + BrainfuckStark.cooperate"""
+    from stark_brainfuck_amd import shard
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    program = VirtualMachine.compile("+" * 64 + "[>" + "+" * 64 + "[>++++<-]<-]+++.")
+    running_time, inputs, outputs = VirtualMachine.run(program)
+    matrices = VirtualMachine.simulate(program, input_data=inputs)
+    times, proof = [], None
+    for rep in range(3):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with shard.shared_randomness(world, rank):
+            stark = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs).cooperate(world, rank, device=device)
+            proof = stark.prove(program, *matrices)
+        times.append(time.perf_counter() - t0)
+    t = torch.tensor([min(times[1:])], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    ok = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs).verify(proof) if rank == 0 else None
+    return {"ms": float(t[0]) * 1e3, "ranks": world, "fri_domain_length": stark.fri.domain.length, "proof_bytes": len(proof), "verified": ok,
+            "note": "every rank runs the polynomial stages on all columns and hashes 1/N of the rows of the two zipped commitments; "
+                    "64-byte subtree roots and the opened paths are the only exchange"}
 
 
 def cpu_baseline(log_n):

@@ -207,7 +207,7 @@ class RowShardedSaltedMerkle:
         self._sub = sub
         self._tree = ShardedZippedMerkle({}, [], n, world_size, rank, lambda rows, f, s: _Sub(), group=group, device=device, rows=[])
         self.num_leafs, self.depth = n, n.bit_length() - 1
-        self._opened = {}
+        self._opened, self._salt_objects, self._node_objects = {}, {}, {}
         tree = self
 
         def salt_of(i):
@@ -222,9 +222,19 @@ class RowShardedSaltedMerkle:
         return self._tree.root()
 
     def open(self, index):
+        """(salt, path) like ZippedSaltedMerkle.open -- including which objects are SHARED between calls, because the proof is a
+        pickle and pickle memoises by identity: one bytes object per tree node and per salt however often it is opened, a new path
+        list and a new tuple per call (merkle.py:46-52 on the reference's `nodes` list, salted_merkle.py:47-49)."""
         if index not in self._opened:
-            self._opened[index] = self._tree.open(index)
-        return self._opened[index]
+            salt, path = self._tree.open(index)                      # collective
+            self._opened[index] = (salt, path)
+        salt, raw = self._opened[index]
+        salt = self._salt_objects.setdefault(index, salt)
+        k, path = self.num_leafs + index, []
+        for node in raw:
+            path.append(self._node_objects.setdefault(k ^ 1, node))  # keyed by heap index of the sibling
+            k >>= 1
+        return salt, path
 
     def prefetch_salts(self, indices, batch):
         return lambda: None
