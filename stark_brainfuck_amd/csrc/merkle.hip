@@ -244,16 +244,19 @@ __global__ void __launch_bounds__(256) merkle_leaves_xfe_quad_kernel(const u64* 
 // ---- one FRI round on a small codeword in one launch (fri.py:108 + 127-128) ----
 // A late FRI round is a chain of dependent hashes -- 3 compressions per leaf, one per tree level, ~2 us each with a quad per
 // hash -- and used to be 3-6 launches (fold, leaves, one per level down to 256 parents, top): launch gaps and ramp-up were as
-// long as the work.  Here one 1024-thread workgroup takes 256 leaves: it first PRODUCES them (the split-and-fold step of the
+// long as the work.  Here one workgroup takes FRI_WG_LEAVES leaves: it first PRODUCES them (the split-and-fold step of the
 // previous round, when `f.in` is set; the folded codeword also goes to HBM for the openings), hashes them with one quad per
-// leaf and builds the 8 levels above them in LDS.  A codeword of <= 256 elements is finished by a single workgroup, which
+// leaf and builds the levels above them in LDS.  A codeword of <= FRI_WG_LEAVES elements is finished by a single workgroup, which
 // also drops the root into the host mailbox; larger ones leave one digest per workgroup to merkle_top_quad_kernel.
 // n must be a power of two (FRI codewords are).
 BFS_HD u64 gl_half_m(u64 x) { return (x >> 1) + ((x & 1) ? 0x7FFFFFFF80000001ULL : 0); }  // x / 2 mod p
 
-constexpr u32 FRI_WG_LEAVES = 256;
+// 64 leaves = 64 quads = 4 waves per workgroup: ONE wave per SIMD, so that every compression of the chain runs at the speed of a
+// lone wave (~2 us).  With 256 leaves in a 1024-thread workgroup the leaf phase and the two widest levels had 4 and 2 waves per SIMD
+// taking turns: a 256-element round took 36 us against 11 compressions x 2.2 us.
+constexpr u32 FRI_WG_LEAVES = 64;
 
-__global__ void __launch_bounds__(1024) fri_round_quad_kernel(FriFoldArgs f, u64* cw, u64 cw_stride, u64 n, u64* nodes, const u64* midstates,
+__global__ void __launch_bounds__(4 * FRI_WG_LEAVES) fri_round_quad_kernel(FriFoldArgs f, u64* cw, u64 cw_stride, u64 n, u64* nodes, const u64* midstates,
                                                               u64* root_out, u64 seq) {
 #if defined(__HIP_DEVICE_COMPILE__)   // DPP builtins exist only in the device pass
     constexpr int WORDS = 48;                        // 3 blocks of 16 words per leaf (bytes 128..409)
@@ -407,7 +410,7 @@ int fri_round_fused_launch(const FriFoldArgs& fold, u64* d_cw, u64 cw_stride, u6
     const u64* d_ms = nullptr;
     BFS_TRY(get_leaf_midstates(&d_ms));
     const u32 groups = (u32)(n <= FRI_WG_LEAVES ? 1 : n / FRI_WG_LEAVES);
-    hipLaunchKernelGGL(fri_round_quad_kernel, dim3(groups), dim3(1024), 0, stream, fold, d_cw, cw_stride, n, d_nodes, d_ms, root_out, seq);
+    hipLaunchKernelGGL(fri_round_quad_kernel, dim3(groups), dim3(4 * FRI_WG_LEAVES), 0, stream, fold, d_cw, cw_stride, n, d_nodes, d_ms, root_out, seq);
     BFS_HIP(hipGetLastError());
     if (groups == 1) return BFS_OK;
     u32 depth = 0;

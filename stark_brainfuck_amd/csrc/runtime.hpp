@@ -64,7 +64,7 @@ struct FriFoldArgs {
     const u64* winv_hi;
     u32 lo_bits, round_shift;
 };
-constexpr u64 FRI_FUSED_MAX = 16384;     // up to 64 workgroups of 256 leaves
+constexpr u64 FRI_FUSED_MAX = 16384;     // up to 256 workgroups of 64 leaves (their roots: one top kernel)
 int fri_round_fused_launch(const FriFoldArgs& fold, u64* d_cw, u64 cw_stride, u64 n, u64* d_nodes, hipStream_t stream, u64* root_out, u64 seq);
 
 // ---- internal entry points (device pointers, current device) ----
