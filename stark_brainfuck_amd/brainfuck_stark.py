@@ -35,6 +35,7 @@ from .merkle import Merkle
 from .permutation_argument import PermutationArgument
 from .processor_table import ProcessorTable
 from .salted_merkle import SaltedMerkle, ZippedSaltedMerkle
+from .algebra import P_GOLDILOCKS
 from .table import extend_tables_device, sample_ext, sample_ext_many, zerofier_inverses
 from .univariate import Polynomial
 from .vm import VirtualMachine
@@ -101,7 +102,13 @@ class BrainfuckStark:
 
     @staticmethod
     def _sample_weights(number, randomness):
-        return [sample_ext(blake2b(randomness + bytes(i)).digest()) for i in range(number)]
+        """:104-112: weight i = ExtensionField.sample(blake2b(randomness + bytes(i)).digest()), i.e. the three 21-byte big-endian
+        chunks of the digest mod p (extension_field.py:100-111; the 64th byte is not used).  One integer conversion per digest."""
+        out, mask = [], (1 << 168) - 1
+        for i in range(number):
+            v = int.from_bytes(blake2b(randomness + bytes(i)).digest()[:63], "big")
+            out.append(((v >> 336) % P_GOLDILOCKS, ((v >> 168) & mask) % P_GOLDILOCKS, (v & mask) % P_GOLDILOCKS))
+        return out
 
     def sample_weights(self, number, randomness):
         """:111-112, as extension-field element objects"""
