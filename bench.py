@@ -80,7 +80,13 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d): launch with torch.distributed.run --nproc-per-node N" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the hot path")
+    # test hooks (tests/test_gpu_distributed.py runs two ranks on the one GPU of a gpurun box): BFS_BENCH_BACKEND=gloo exchanges CPU
+    # tensors instead of going through RCCL, BFS_BENCH_DEVICE pins every rank to that device.  The driver sets neither.
+    backend = os.environ.get("BFS_BENCH_BACKEND", "nccl")
+    if "BFS_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["BFS_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
+    coll_device = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ or os.environ.get("BFS_BENCH_FORCE_DIST"):
         # launched by torch.distributed.run: bring up RCCL even for a single rank so that the collective path is the one exercised
@@ -92,7 +98,10 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world)
             dist.barrier()             # RCCL builds its communicators on the first collective (100s of ms): pay that here, not
             torch.cuda.synchronize()   # between the clock spin-up and the timed region, where the idle GPU would clock down again
         finally:
@@ -153,7 +162,7 @@ def main():
     kern_ms = ctypes.c_float()
     _lib.check(lib.bfs_event_elapsed_ms(ev0, ev1, ctypes.byref(kern_ms)))
     if dist is not None:
-        t = torch.tensor([elapsed, kern_ms.value], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed, kern_ms.value], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, kern = float(t[0]), float(t[1])
     else:
@@ -177,7 +186,7 @@ def main():
     world_roots = None
     if not args.no_check:
         # the one collective of the design: all-gather of the per-column roots (RCCL over xGMI when world > 1)
-        world_roots = shard.gather_roots(local_roots, total_cols, world, rank, device=torch.device("cuda", local_rank) if dist is not None else None)
+        world_roots = shard.gather_roots(local_roots, total_cols, world, rank, device=coll_device if (dist is not None and backend == "nccl") else None)
         assert len(world_roots) == total_cols and all(len(r) == 64 for r in world_roots)
         assert all(world_roots[c] == local_roots[c] for c in my_cols)
 
@@ -210,7 +219,7 @@ def main():
         mine = bench_fri(lib, _lib, stream, 18)
         fri_all = [mine["ms"]]
         if dist is not None:
-            t = torch.tensor([mine["ms"]], dtype=torch.float64, device="cuda")
+            t = torch.tensor([mine["ms"]], dtype=torch.float64, device=coll_device)
             parts = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(parts, t)
             fri_all = [float(p[0]) for p in parts]
@@ -220,13 +229,13 @@ def main():
         stark_mine = bench_stark()
         stark_all = [stark_mine["ms"]]
         if dist is not None:
-            t = torch.tensor([stark_mine["ms"]], dtype=torch.float64, device="cuda")
+            t = torch.tensor([stark_mine["ms"]], dtype=torch.float64, device=coll_device)
             parts = [torch.zeros_like(t) for _ in range(world)]
             dist.all_gather(parts, t)
             stark_all = [float(p[0]) for p in parts]
     coop = None
     if args.cooperative and dist is not None and world > 1 and (world & (world - 1)) == 0:
-        coop = bench_stark_cooperative(world, rank, torch.device("cuda", local_rank), dist, torch)
+        coop = bench_stark_cooperative(world, rank, coll_device if backend == "nccl" else None, dist, torch)
     if rank == 0:
         # dominant kernel = ntt_tile_kernel (npass launches per step); algorithmic bytes of one launch =
         # 16 B/element * n * columns / npass (DESIGN.md "Roofline accounting"); HIP events bracket exactly K steps
@@ -376,7 +385,7 @@ def bench_stark_cooperative(world, rank, device, dist, torch):
             stark = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs).cooperate(world, rank, device=device)
             proof = stark.prove(program, *matrices)
         times.append(time.perf_counter() - t0)
-    t = torch.tensor([min(times[1:])], dtype=torch.float64, device=device)
+    t = torch.tensor([min(times[1:])], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     ok = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs).verify(proof) if rank == 0 else None
     return {"ms": float(t[0]) * 1e3, "ranks": world, "fri_domain_length": stark.fri.domain.length, "proof_bytes": len(proof), "verified": ok,

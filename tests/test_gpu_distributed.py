@@ -240,3 +240,22 @@ def test_cooperative_proof_is_the_reference_proof(name, world):
     assert all(ok for _, ok, _, _, _ in got), "a rank's proof differs from the reference's"
     assert len({h for _, _, h, _, _ in got}) == 1, "the ranks wrote different proofs"
     assert all(v for _, _, _, v, _ in got)
+
+
+def test_bench_with_two_ranks_on_one_gpu():
+    """the N > 1 code path of bench.py -- columns split by shard.assign_columns, max over ranks, replicas' all-gathers, the all-gather of
+    the roots, and the cooperative proof -- with two ranks that share this GPU and exchange over gloo (BFS_BENCH_BACKEND / _DEVICE)"""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--total-columns", "4", "--log-n", "20", "--no-cpu", "--spinup-ms", "0", "--cooperative"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BFS_BENCH_BACKEND="gloo", BFS_BENCH_DEVICE="0")
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["columns_per_gpu"] == [2, 2]
+    assert len(line["fri_prove"]["replicas"]["per_gpu_ms"]) == 2 and len(line["stark_prove"]["replicas"]["per_gpu_ms"]) == 2
+    assert line["stark_prove"]["verified"] is True
+    assert line["stark_prove_cooperative"]["ranks"] == 2 and line["stark_prove_cooperative"]["verified"] is True
+    assert line["roots_sha256"]
