@@ -217,6 +217,11 @@ def test_fastlist_conversions_match_the_python_loops():
     from stark_brainfuck_amd.algebra import BaseField, BaseFieldElement
     from stark_brainfuck_amd.extension_field import ExtensionField, ExtensionFieldElement
     from stark_brainfuck_amd.univariate import Polynomial
+    if arrays._fastlist is None:             # a tree where build() has not run yet: build the helper now (gcc, a second)
+        import importlib
+        from stark_brainfuck_amd import build
+        build.build_fastlist()
+        importlib.reload(arrays)
     fl = arrays._fastlist
     assert fl is not None, "the helper is built by __graft_entry__.build()"
     P = (1 << 64) - (1 << 32) + 1
