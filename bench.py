@@ -14,6 +14,8 @@ Extra keys on the same JSON line:
     roofline      dominant kernel (the NTT tile kernel) vs the 8 TB/s HBM roofline, from HIP events on the kernel's stream
     cpu_baseline  the CPU oracle (oracle/gl_oracle.c, plain C port of ntt.py, 1 core) on a bounded sample, rank 0, N=1 only;
                   cpu_baseline.reference_python carries the reference's own CPython figure (measured in the build container)
+    sustained     the same step back to back for the seconds the CPU baseline leg takes (second thread, untimed, N = 1): steady-state
+                  clocks, and the GPU is busy while the host core is
     single_column_2p24  one 2^24-point column on its own (128 MiB: the transform north_star's target sentence is about)
     fri_prove     Fri.prove on a random degree-2^18 codeword, expansion 4 (config 3), through the C ABI, median of 5;
                   fri_prove_2p24: the same at N = 2^24 (degree 2^22)
@@ -137,8 +139,32 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # the CPU leg first (rank 0, N = 1): the GPU legs then run back to back to the end of the process
-    cpu_line = cpu_baseline(log_n) if (rank == 0 and world == 1 and not args.no_cpu) else None
+    # the CPU leg first (rank 0, N = 1).  While the host core works through it, the GPU runs the same NTT step back to back from a
+    # second thread: an untimed SUSTAINED leg (seconds instead of the milliseconds of the timed region: clocks and temperature at
+    # their steady state, and the GPU visibly busy to whoever samples rocm-smi during the run); the timed region follows it.
+    cpu_line, sustained = None, None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        import threading
+        stop, count = threading.Event(), [0, 0.0]
+
+        def sustain():
+            t0 = time.perf_counter()
+            while not stop.is_set():
+                for _ in range(32):
+                    step()
+                _lib.check(lib.bfs_stream_synchronize(stream))
+                count[0] += 32
+            count[1] = time.perf_counter() - t0
+        worker = threading.Thread(target=sustain)
+        worker.start()
+        try:
+            cpu_line = cpu_baseline(log_n)
+        finally:
+            stop.set()
+            worker.join()
+        sustained = {"seconds": count[1], "steps": count[0], "ms_per_step": count[1] / max(count[0], 1) * 1e3,
+                     "elements_per_s": n * cols * count[0] / max(count[1], 1e-9),
+                     "note": "untimed: the NTT step back to back from a second thread for as long as the CPU baseline leg runs"}
     spin_t0, spin_steps = time.perf_counter(), 0
     while args.spinup_ms > 0 and (time.perf_counter() - spin_t0) * 1e3 < args.spinup_ms:
         step()
@@ -274,6 +300,8 @@ def main():
             line["stark_prove_2p22"] = bench_stark("+" * 64 + "[>" + "+" * 64 + "[>++++<-]<-]+++.", "nested loops, 37 254 cycles")
         if coop is not None:
             line["stark_prove_cooperative"] = coop
+        if sustained is not None:
+            line["sustained"] = sustained
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
         print(json.dumps(line), flush=True)
