@@ -220,8 +220,14 @@ class BrainfuckStark:
         def base_requests(i):
             return [(randomizer_codeword.ptr + 8 * i, 3, randomizer_codeword.stride)] + [(t.base_codewords.ptr + 8 * i, t.base_width, n) for t in tables]
 
+        from .arrays import _fastlist
+        internal_field = xf.modulus.coefficients[0].field
+
         def base_row(i):         # only opened rows are ever read back
             words = fetched_base[i] if i in fetched_base else gather(base_requests(i))
+            if _fastlist is not None:     # the same objects, made in C (cpyext/fastlist.c): 16 elements in 3 us instead of 16
+                tail = _fastlist.unpack_base(np.ascontiguousarray(words[3:], dtype=np.uint64), BaseFieldElement, f2)
+                return tuple([xf.from_limbs([int(v) for v in words[:3]])] + tail)
             return tuple([xf.from_limbs([int(v) for v in words[:3]])] + [BaseFieldElement(int(v), f2) for v in words[3:]])
         base_columns = [(randomizer_codeword.ptr, True, 0)]
         for t in self.tables:
@@ -250,10 +256,20 @@ class BrainfuckStark:
         def ext_requests(i):
             return [(t.ext_codewords.ptr + 8 * i, 3 * (t.full_width - t.base_width), n) for t in tables]
 
+        plain_columns = [c for c in range(num_ext_columns) if moduli[c] is None]
+
         def ext_row(i):
             words = fetched_ext[i] if i in fetched_ext else gather(ext_requests(i))
             row = []
+            made = None
+            if _fastlist is not None and plain_columns:
+                # the elements without shared coefficient objects, all at once: limb planes (3, k) -> k ExtensionFieldElements
+                soa = np.ascontiguousarray(np.asarray(words, dtype=np.uint64).reshape(num_ext_columns, 3)[plain_columns].T)
+                made = dict(zip(plain_columns, _fastlist.unpack_ext(soa, ExtensionFieldElement, Polynomial, BaseFieldElement, xf, internal_field)))
             for c in range(num_ext_columns):
+                if made is not None and c in made:
+                    row.append(made[c])
+                    continue
                 limbs = [int(v) for v in words[3 * c:3 * c + 3]]
                 if moduli[c] is None:
                     row.append(xf.from_limbs(limbs))
