@@ -190,6 +190,7 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
     BFS_TRY(ntt_power_tables(gl_inv(omega), log_n, &winv_lo, &winv_hi, &lo_bits));
     const u64 half_inv = gl_inv(2);
     u64 g = offset;
+    constexpr u64 FRI_FOLD_IN_LEAVES_MIN = 16384;     // = FRI_FUSED_MAX: every round >= 1 folds inside its leaf kernel (must exceed QUAD_LEAVES_MAX)
     FriFoldArgs pending{};                         // the fold that produces round r's codeword, when round r runs fused
     pending.in = nullptr;
     for (u32 r = 0; r < R; ++r) {
@@ -224,7 +225,12 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
             // the tree kernel writes the root straight into pinned host memory; poll the sequence flag instead of
             // paying a copy command + stream synchronisation per round
             const u64 seq = ++S.mailbox.seq;
-            BFS_TRY(merkle_build_xfe_launch(fr.cw, fr.stride, fr.length, fr.nodes, stream, S.mailbox.dev, seq));  // fri.py:108
+            if (pending.in != nullptr) {               // the leaf kernel folds the previous round's codeword on the way
+                BFS_TRY(merkle_build_xfe_fold_launch(pending, (u64*)fr.cw, fr.stride, fr.length, fr.nodes, stream, S.mailbox.dev, seq));
+                pending.in = nullptr;
+            } else {
+                BFS_TRY(merkle_build_xfe_launch(fr.cw, fr.stride, fr.length, fr.nodes, stream, S.mailbox.dev, seq));  // fri.py:108
+            }
             // While the GPU hashes: the next challenge is SHAKE256 of the WHOLE transcript including this root (fri.py:112-120), tens
             // of KB -- as long as the tree kernels of the late rounds.  Everything in front of the root's 64 bytes is known already,
             // so the sponge absorbs it now and only the last block or two wait for the root.
@@ -254,8 +260,8 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
         Xfe alpha = rp::sample_xfe(seed, 32);
         FriRound& nx = S.rounds[r + 1];
         const u64 half = fr.length / 2;
-        if (half >= 2 && half <= FRI_FUSED_MAX) {
-            // the next round folds while it builds its tree (fri_round_quad_kernel)
+        if (half >= 2 && (half <= FRI_FUSED_MAX || half > FRI_FOLD_IN_LEAVES_MIN)) {
+            // the next round folds while it builds its tree (fri_round_quad_kernel, or merkle_leaves_xfe_fold_kernel for large rounds)
             pending = FriFoldArgs{fr.cw, fr.stride, half, alpha, gl_mul(half_inv, gl_inv(g)), winv_lo, winv_hi, lo_bits, r};
         } else {
             u32 grid = (u32)((half + 255) / 256);

@@ -27,6 +27,33 @@ __global__ void __launch_bounds__(LEAF_THREADS) merkle_leaves_xfe_kernel(const u
     for (int j = 0; j < 8; ++j) out[j] = d[j];
 }
 
+// the same for a FRI round whose codeword does not exist yet: every thread first PRODUCES its element (the split-and-fold step of the
+// previous round, fri.py:127-128), stores it for the later openings and hashes it -- one launch and one pass over the codeword less
+__global__ void __launch_bounds__(LEAF_THREADS) merkle_leaves_xfe_fold_kernel(FriFoldArgs f, u64* cw, u64 cw_stride, u64 n, u64* leaf_digests, const u64* midstates) {
+    __shared__ u64 stage[XFE_TAIL_MAX_WORDS * LEAF_THREADS];
+    const u64 i = (u64)blockIdx.x * LEAF_THREADS + threadIdx.x;
+    if (i >= n) return;
+    {
+        const Xfe a{{f.in[i], f.in[f.in_stride + i], f.in[2 * f.in_stride + i]}};
+        const Xfe b{{f.in[f.half + i], f.in[f.in_stride + f.half + i], f.in[2 * f.in_stride + f.half + i]}};
+        const u64 sc = gl_mul(f.scal, tw_pow(f.winv_lo, f.winv_hi, f.lo_bits, i << f.round_shift));
+        const Xfe beta = xfe_scale(f.alpha, sc);
+        const Xfe sum = xfe_add(a, b), diff = xfe_sub(a, b);
+        const Xfe prod = xfe_mul(beta, diff);
+        const u64 x = (sum.c[0] >> 1) + ((sum.c[0] & 1) ? 0x7FFFFFFF80000001ULL : 0);      // / 2 mod p
+        const u64 y = (sum.c[1] >> 1) + ((sum.c[1] & 1) ? 0x7FFFFFFF80000001ULL : 0);
+        const u64 z = (sum.c[2] >> 1) + ((sum.c[2] & 1) ? 0x7FFFFFFF80000001ULL : 0);
+        cw[i] = gl_add(x, prod.c[0]);
+        cw[cw_stride + i] = gl_add(y, prod.c[1]);
+        cw[2 * cw_stride + i] = gl_add(z, prod.c[2]);
+    }
+    u64 d[8];
+    merkle_leaf_xfe_body(cw, cw_stride, i, stage + threadIdx.x, LEAF_THREADS, d, midstates);     // reads back this thread's own stores
+    u64* out = leaf_digests + i * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = d[j];
+}
+
 __global__ void __launch_bounds__(LEAF_THREADS) merkle_leaves_bfe_kernel(const u64* values, u64 n, u64* leaf_digests) {
     __shared__ u64 stage[BFE_LEAF_MAX_WORDS * LEAF_THREADS];
     const u64 i = (u64)blockIdx.x * LEAF_THREADS + threadIdx.x;
@@ -416,6 +443,20 @@ int fri_round_fused_launch(const FriFoldArgs& fold, u64* d_cw, u64 cw_stride, u6
     u32 depth = 0;
     while ((1ull << depth) < groups) ++depth;
     return merkle_inner_launch(d_nodes, depth, groups, stream, root_out, seq);     // the level of the subtree roots plays the leaf level
+}
+
+// Merkle(codeword) of a FRI round with more than FRI_FUSED_MAX elements, the fold that produces the codeword done by the leaf kernel
+int merkle_build_xfe_fold_launch(const FriFoldArgs& fold, u64* d_cw, u64 cw_stride, u64 n, u64* d_nodes, hipStream_t stream, u64* root_out, u64 seq) {
+    if (fold.in == nullptr || n <= QUAD_LEAVES_MAX) { set_error("internal: fused fold + leaves on %llu elements", (unsigned long long)n); return BFS_ERR_BAD_ARG; }
+    const u64* d_ms = nullptr;
+    BFS_TRY(get_leaf_midstates(&d_ms));
+    u32 depth = 0;
+    while ((1ull << depth) < n) ++depth;
+    const u64 npo2 = 1ull << depth;
+    hipLaunchKernelGGL(merkle_leaves_xfe_fold_kernel, dim3((u32)((n + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0, stream,
+                       fold, d_cw, cw_stride, n, d_nodes + npo2 * 8, d_ms);
+    BFS_HIP(hipGetLastError());
+    return merkle_inner_launch(d_nodes, depth, n, stream, root_out, seq);
 }
 
 int merkle_build_bfe_launch(const u64* d_values, u64 n, u64* d_nodes, hipStream_t stream) {

@@ -65,6 +65,7 @@ struct FriFoldArgs {
     u32 lo_bits, round_shift;
 };
 constexpr u64 FRI_FUSED_MAX = 16384;     // up to 256 workgroups of 64 leaves (their roots: one top kernel)
+int merkle_build_xfe_fold_launch(const FriFoldArgs& fold, u64* d_cw, u64 cw_stride, u64 n, u64* d_nodes, hipStream_t stream, u64* root_out, u64 seq);
 int fri_round_fused_launch(const FriFoldArgs& fold, u64* d_cw, u64 cw_stride, u64 n, u64* d_nodes, hipStream_t stream, u64* root_out, u64 seq);
 
 // ---- internal entry points (device pointers, current device) ----
