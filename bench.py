@@ -425,7 +425,7 @@ def cpu_baseline(log_n):
     """the oracle's C restatement of ntt.py (recursive radix-2, one core) on a bounded sample of the same workload."""
     from oracle import ref_oracle as o
     n = 1 << log_n
-    sample_cols = 2 if log_n >= 24 else 4
+    sample_cols = 3 if log_n >= 24 else 4          # ~12 s on one host core at 2^24
     w = o.primitive_nth_root(n)
     t = 0.0
     for c in range(sample_cols):
