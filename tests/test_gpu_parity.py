@@ -832,3 +832,16 @@ def test_batch_inverse_and_scale_ragged_sizes(sb, oracle, n):
     synchronize(0)
     res = out.to_numpy()
     assert (res[:n] == oracle.scale(factor, a)).all() and (res[n:] == oracle.scale(factor, a[::-1].copy())).all()
+
+
+def test_four_pass_plan_2p25(sb, oracle):
+    """n = 2^25 takes four HBM passes (7 + 6 + 6 + 6 bits) and keeps the per-thread twiddle chain in its last two passes: forward,
+    inverse with the n^-1 scaling, and a zero-padded coset evaluation against the oracle"""
+    logn, n = 25, 1 << 25
+    w = oracle.primitive_nth_root(n)
+    v = oracle.felt_array(SEED + 25, 0, n)
+    fwd = raw_ntt(sb, v, logn, w)
+    assert (fwd == oracle.ntt(w, v)).all()
+    assert (raw_ntt(sb, fwd, logn, oracle.inv(w), 1, oracle.inv(n)) == v).all()
+    d = n // 4 + 3
+    assert (raw_ntt(sb, v[:d], logn, w, 7, 1, n_in=d) == oracle.fast_coset_evaluate(v[:d], 7, w, n)).all()
