@@ -166,6 +166,24 @@ typedef struct bfs_gather_request {
     uint64_t out_offset;
 } bfs_gather_request;
 int bfs_gather(const bfs_gather_request* requests, uint32_t count, uint64_t* h_out, void* stream);
+/*
+ * bfs_stark_push_openings   the openings of BrainfuckStark.prove (brainfuck_stark.py:315-333) pushed onto the proof stream natively:
+ *     for every index and every distance (the first distance is 0, then the tables' unit distances): base row at index + distance,
+ *     its (salt, path), extension row, its (salt, path); then per index the combination leaf and its path.
+ *     base_row / ext_row: the gather requests of row 0 (d_base is advanced by the row index): the base row's first three words are
+ *     an ExtensionFieldElement (the randomizer codeword), every further word a BaseFieldElement of BaseField instance base_field_id; the
+ *     extension row holds n_ext_cols elements of three words, ext_moduli[c] != 0 meaning that the rows i = i' mod ext_moduli[c] share
+ *     their coefficient objects in column c.  Trees: 2 n digests each (merkle.py layout); salts: 24 bytes per leaf, in HBM
+ *     (*_salts_on_device != 0) or on the host.  out_leaf_handles[a] = handle of the combination leaf of indices[a] (for
+ *     bfs_fri_session_alias).  One gather for everything; synchronises the stream.
+ */
+int bfs_stark_push_openings(void* ps, const bfs_gather_request* base_row, uint32_t n_base_req, int32_t base_field_id,
+                            const bfs_gather_request* ext_row, uint32_t n_ext_req, const uint64_t* ext_moduli, uint32_t n_ext_cols,
+                            uint64_t n, const uint8_t* d_base_nodes, const uint8_t* base_salts, int base_salts_on_device,
+                            const uint8_t* d_ext_nodes, const uint8_t* ext_salts, int ext_salts_on_device,
+                            const uint64_t* d_combination, uint64_t combination_stride, const uint8_t* d_combination_nodes,
+                            const uint64_t* indices, uint32_t n_indices, const uint64_t* distances, uint32_t n_distances,
+                            uint64_t* out_leaf_handles, void* stream);
 
 /* ---- Merkle trees ------------------------------------------------------------------------------------------- */
 /*

@@ -80,6 +80,8 @@ _SIGNATURES = {
     "bfs_merkle_build_bytes": (ci, [vp, vp, vp, u64, vp, vp]),
     "bfs_merkle_open": (ci, [vp, u32, u64, vp, vp]),
     "bfs_merkle_build_rows": (ci, [vp, u32, u64, vp, ci, vp, vp]),
+    "bfs_stark_push_openings": (ci, [vp, vp, u32, ctypes.c_int32, vp, u32, ctypes.POINTER(u64), u32, u64, vp, vp, ci, vp, vp, ci, vp, u64, vp,
+                                     ctypes.POINTER(u64), u32, ctypes.POINTER(u64), u32, ctypes.POINTER(u64), vp]),
     "bfs_merkle_build_rows_range": (ci, [vp, u32, u64, u64, vp, ci, vp, vp]),
     "bfs_random_fill": (ci, [ctypes.c_char_p, vp, u64, vp]),
     "bfs_xfe_sample_fill": (ci, [ctypes.c_char_p, vp, u64, u64, vp]),

@@ -145,6 +145,80 @@ class BrainfuckStark:
         world_size, rank, group, device = self._cooperation
         return RowShardedSaltedMerkle(columns, n, make_row, world_size, rank, group=group, device=device)
 
+    def _openings_python(self, proof_stream, base_tree, extension_tree, combination, combination_tree, base_requests, ext_requests,
+                         fetched_base, fetched_ext, indices, unit_distances, n, xf):
+        """the openings (:315-333) through Python objects: used when the transcript cannot take them natively (a foreign proof
+        stream class, the row-sharded trees of a cooperative proof)"""
+        # everything the openings read from HBM -- rows, salts, authentication paths, combination leaves -- in one round trip
+        rows = list(dict.fromkeys((index + distance) % n for index in indices for distance in [0] + unit_distances))
+        batch = GatherBatch()
+        row_tickets = {i: ([batch.add(*r) for r in base_requests(i)], [batch.add(*r) for r in ext_requests(i)]) for i in rows}
+        leaf_tickets = {index: batch.add(combination.ptr + 8 * index, 3, combination.stride) for index in dict.fromkeys(indices)}
+        stores = [base_tree.prefetch_salts(rows, batch), extension_tree.prefetch_salts(rows, batch),
+                  base_tree.prefetch_paths(rows, batch), extension_tree.prefetch_paths(rows, batch),
+                  combination_tree.prefetch_paths(indices, batch)]
+        batch.run()
+        for store in stores:
+            store()
+        for i, (tb, te) in row_tickets.items():
+            fetched_base[i] = np.concatenate([batch.words(t) for t in tb])
+            fetched_ext[i] = np.concatenate([batch.words(t) for t in te])
+        for index in indices:
+            for distance in [0] + unit_distances:
+                idx = (index + distance) % n
+                proof_stream.push(base_tree.leafs[idx][0])
+                proof_stream.push(base_tree.open(idx))
+                proof_stream.push(extension_tree.leafs[idx][0])
+                proof_stream.push(extension_tree.open(idx))
+        known = {}
+        for index in indices:
+            if index not in known:                   # the same index twice is the same leaf object twice
+                known[index] = xf.from_limbs([int(v) for v in batch.words(leaf_tickets[index])])
+            leaf = known[index]
+            proof_stream.push(leaf)
+            proof_stream.push(combination_tree.open(index))
+
+        return known
+
+    def _openings_native(self, proof_stream, base_tree, extension_tree, combination, combination_tree, base_row, ext_row, moduli,
+                         indices, unit_distances, n, f2, xf, lib, stream):
+        """the same through bfs_stark_push_openings: rows, salts, paths and leaves go from HBM into the native transcript in one
+        call, and become Python objects only if somebody looks at proof_stream.objects (ip.ProofStream._adopt_lazy).  Returns
+        {index: handle of the combination leaf} for Fri.prove, or None when this route is not available."""
+        if self._cooperation is not None or type(base_tree) is not ZippedSaltedMerkle or type(extension_tree) is not ZippedSaltedMerkle:
+            return None
+        if not hasattr(proof_stream, "_adopt_lazy") or combination_tree._nodes_host is not None or combination_tree.num_leafs != n:
+            return None
+        transcript = proof_stream._native()
+        if getattr(proof_stream, "_cached", None) is not transcript or (transcript.xfield is not None and transcript.xfield is not xf):
+            return None
+        if transcript.xfield is None:
+            transcript.xfield = xf
+
+        def requests(reqs):
+            arr = (_lib.GatherRequest * len(reqs))()
+            for a, (ptr, nwords, stride) in zip(arr, reqs):
+                a.d_base, a.nwords, a.stride, a.out_offset = ptr, nwords, stride, 0
+            return arr
+
+        def salts(tree):
+            if getattr(tree, "_salt_cache", None) is not None:
+                return ctypes.c_void_p(tree._salt_base), 1
+            return ctypes.cast(tree._salt_host, ctypes.c_void_p), 0
+        base_arr, ext_arr = requests(base_row), requests(ext_row)
+        mods = (_u64 * max(len(moduli), 1))(*[0 if m is None else int(m) for m in moduli])
+        idx = (_u64 * len(indices))(*indices)
+        dist = (_u64 * (1 + len(unit_distances)))(0, *unit_distances)
+        out = (_u64 * len(indices))()
+        (bs, bs_dev), (es, es_dev) = salts(base_tree), salts(extension_tree)
+        before = transcript.num_objects()
+        _lib.check(lib.bfs_stark_push_openings(transcript.handle, base_arr, len(base_row), transcript._field_id(f2), ext_arr, len(ext_row), mods,
+                                               len(moduli), n, base_tree._nodes.ptr, bs, bs_dev, extension_tree._nodes.ptr, es, es_dev,
+                                               combination.ptr, combination.stride, combination_tree._nodes.ptr, idx, len(indices), dist, len(dist),
+                                               out, stream))
+        proof_stream._adopt_lazy(transcript, before, transcript.num_objects(), xf)
+        return {index: int(handle) for index, handle in zip(indices, out)}
+
     @staticmethod
     def _release(*holders):
         """hand device memory back to the pool now instead of when the garbage collector gets to it (the blocks are
@@ -380,34 +454,11 @@ class BrainfuckStark:
         proof_stream.push(combination_tree.root())
         indices = BrainfuckStark.sample_indices(self.security_level, proof_stream.prover_fiat_shamir(), n)
         unit_distances = list(set(table.unit_distance(n) for table in self.tables))
-        # everything the openings read from HBM -- rows, salts, authentication paths, combination leaves -- in one round trip
-        rows = list(dict.fromkeys((index + distance) % n for index in indices for distance in [0] + unit_distances))
-        batch = GatherBatch()
-        row_tickets = {i: ([batch.add(*r) for r in base_requests(i)], [batch.add(*r) for r in ext_requests(i)]) for i in rows}
-        leaf_tickets = {index: batch.add(combination.ptr + 8 * index, 3, combination.stride) for index in dict.fromkeys(indices)}
-        stores = [base_tree.prefetch_salts(rows, batch), extension_tree.prefetch_salts(rows, batch),
-                  base_tree.prefetch_paths(rows, batch), extension_tree.prefetch_paths(rows, batch),
-                  combination_tree.prefetch_paths(indices, batch)]
-        batch.run()
-        for store in stores:
-            store()
-        for i, (tb, te) in row_tickets.items():
-            fetched_base[i] = np.concatenate([batch.words(t) for t in tb])
-            fetched_ext[i] = np.concatenate([batch.words(t) for t in te])
-        for index in indices:
-            for distance in [0] + unit_distances:
-                idx = (index + distance) % n
-                proof_stream.push(base_tree.leafs[idx][0])
-                proof_stream.push(base_tree.open(idx))
-                proof_stream.push(extension_tree.leafs[idx][0])
-                proof_stream.push(extension_tree.open(idx))
-        known = {}
-        for index in indices:
-            if index not in known:                   # the same index twice is the same leaf object twice
-                known[index] = xf.from_limbs([int(v) for v in batch.words(leaf_tickets[index])])
-            leaf = known[index]
-            proof_stream.push(leaf)
-            proof_stream.push(combination_tree.open(index))
+        known = self._openings_native(proof_stream, base_tree, extension_tree, combination, combination_tree, base_requests(0),
+                                      ext_requests(0), moduli, indices, unit_distances, n, f2, xf, lib, stream)
+        if known is None:
+            known = self._openings_python(proof_stream, base_tree, extension_tree, combination, combination_tree, base_requests,
+                                          ext_requests, fetched_base, fetched_ext, indices, unit_distances, n, xf)
 
         if not self.keep_intermediates:
             BrainfuckStark._release(base_tree, extension_tree, randomizer_codeword, *self.tables)

@@ -3,6 +3,7 @@
 // host, the Fiat-Shamir challenge from the transcript (host: pickle + SHAKE256, ip.py:21-22), the split-and-fold
 // step (GPU, fri.py:127-128); then index sampling (fri.py:62-86) and one batched gather of every revealed leaf and
 // authentication-path node.
+#include <algorithm>
 #include <chrono>
 #include <map>
 #include <unordered_map>
@@ -457,6 +458,142 @@ int bfs_fri_prove(void* ps, const uint64_t* d_codeword, uint64_t limb_stride, ui
     S.use_workspace = true;
     BFS_TRY(fri_commit(S, *(rp::Transcript*)ps, d_codeword, limb_stride, log_n, offset, omega, expansion_factor, (hipStream_t)stream));
     return fri_query(S, *(rp::Transcript*)ps, num_colinearity_tests, h_top_level_indices, (hipStream_t)stream);
+}
+
+// The openings of BrainfuckStark.prove (brainfuck_stark.py:315-333) written into the transcript without a Python object in between:
+// for every sampled index and every distance d in (0, unit distances...): the base row at index + d, its (salt, path), the extension
+// row, its (salt, path); then for every index the combination leaf and its path.  Everything the GPU holds -- row words, salts made
+// on the device, tree nodes -- comes back through ONE gather; the objects are built here with the identities the reference's objects
+// have (pickle memoises by identity): a row opened twice is one tuple object, a tree node or a salt one bytes object however often it
+// appears, every (salt, path) tuple and path list is new, extension elements of a column whose interpolant has all its non-zero
+// coefficients at multiples of 2^v share their coefficient objects with the rows i' = i mod modulus (table.ext_sharing_moduli).
+int bfs_stark_push_openings(void* ps_, const bfs_gather_request* base_row, uint32_t n_base_req, int32_t base_field_id,
+                            const bfs_gather_request* ext_row, uint32_t n_ext_req, const uint64_t* ext_moduli, uint32_t n_ext_cols,
+                            uint64_t n, const uint8_t* d_base_nodes, const uint8_t* base_salts, int base_salts_on_device,
+                            const uint8_t* d_ext_nodes, const uint8_t* ext_salts, int ext_salts_on_device,
+                            const uint64_t* d_combination, uint64_t combination_stride, const uint8_t* d_combination_nodes,
+                            const uint64_t* indices, uint32_t n_indices, const uint64_t* distances, uint32_t n_distances,
+                            uint64_t* out_leaf_handles, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    rp::Transcript& ps = *(rp::Transcript*)ps_;
+    if (n == 0 || (n & (n - 1))) { set_error("bfs_stark_push_openings: n must be a power of two"); return BFS_ERR_BAD_ARG; }
+    u32 base_words = 0, ext_words = 0;
+    for (u32 k = 0; k < n_base_req; ++k) base_words += base_row[k].nwords;
+    for (u32 k = 0; k < n_ext_req; ++k) ext_words += ext_row[k].nwords;
+    if (base_words < 3 || ext_words != 3 * n_ext_cols) { set_error("bfs_stark_push_openings: row layout"); return BFS_ERR_BAD_ARG; }
+    // unique rows in order of first use, unique indices
+    std::vector<u64> rows, uniq_idx;
+    for (u32 a = 0; a < n_indices; ++a) {
+        for (u32 b = 0; b < n_distances; ++b) {
+            const u64 r = (indices[a] + distances[b]) % n;
+            if (std::find(rows.begin(), rows.end(), r) == rows.end()) rows.push_back(r);
+        }
+        if (std::find(uniq_idx.begin(), uniq_idx.end(), indices[a]) == uniq_idx.end()) uniq_idx.push_back(indices[a]);
+    }
+    // ---- one gather
+    std::vector<GatherReq> reqs;
+    u64 nwords = 0;
+    auto want = [&](const u64* base, u32 words, u32 stride) { reqs.push_back(GatherReq{base, words, stride, nwords}); const u64 at = nwords; nwords += words; return at; };
+    struct RowAt { u64 base, ext, base_salt, ext_salt; };
+    std::vector<RowAt> row_at(rows.size());
+    typedef FriSession::Key Key;
+    FriSession::KeyMap node_at[3];                      // (tree, heap index) -> offset of the digest in the gathered words (stored as a K_INT node)
+    std::vector<std::pair<int, u64>> node_list;        // order of first use
+    std::vector<u64> node_off;
+    const uint8_t* tree_nodes[3] = {d_base_nodes, d_ext_nodes, d_combination_nodes};
+    auto want_path = [&](int tree, u64 leaf) {
+        for (u64 k = n | leaf; k > 1; k >>= 1) {
+            const Key key(0, k ^ 1);
+            if (node_at[tree].count(key)) continue;
+            node_at[tree][key] = rp::mk_int(node_off.size());
+            node_list.push_back({tree, k ^ 1});
+            node_off.push_back(want((const u64*)(tree_nodes[tree] + 64 * (k ^ 1)), 8, 1));
+        }
+    };
+    for (size_t r = 0; r < rows.size(); ++r) {
+        const u64 i = rows[r];
+        row_at[r].base = nwords;
+        for (u32 k = 0; k < n_base_req; ++k) want(base_row[k].d_base + i, base_row[k].nwords, base_row[k].stride);
+        row_at[r].ext = nwords;
+        for (u32 k = 0; k < n_ext_req; ++k) want(ext_row[k].d_base + i, ext_row[k].nwords, ext_row[k].stride);
+        row_at[r].base_salt = base_salts_on_device ? want((const u64*)(base_salts + 24 * i), 3, 1) : 0;
+        row_at[r].ext_salt = ext_salts_on_device ? want((const u64*)(ext_salts + 24 * i), 3, 1) : 0;
+        want_path(0, i);
+        want_path(1, i);
+    }
+    std::vector<u64> leaf_at(uniq_idx.size());
+    for (size_t a = 0; a < uniq_idx.size(); ++a) {
+        leaf_at[a] = want(d_combination + uniq_idx[a], 3, (u32)combination_stride);
+        want_path(2, uniq_idx[a]);
+    }
+    PinnedLease req_area, res_area;
+    BFS_TRY(req_area.get(reqs.size() * sizeof(GatherReq)));
+    BFS_TRY(res_area.get(nwords * sizeof(u64)));
+    memcpy(req_area.host, reqs.data(), reqs.size() * sizeof(GatherReq));
+    hipLaunchKernelGGL(gather_requests_kernel, dim3((u32)((reqs.size() + 255) / 256)), dim3(256), 0, stream, (const GatherReq*)req_area.dev, (u32)reqs.size(),
+                       (u64*)res_area.dev);
+    BFS_HIP(hipGetLastError());
+    BFS_HIP(hipStreamSynchronize(stream));
+    const u64* words = (const u64*)res_area.host;
+    // ---- objects
+    std::vector<rp::Ref> node_obj(node_list.size());
+    for (size_t k = 0; k < node_list.size(); ++k) node_obj[k] = rp::mk_bytes(words + node_off[k], 64);
+    auto path_obj = [&](int tree, u64 leaf) {
+        std::vector<rp::Ref> items;
+        for (u64 k = n | leaf; k > 1; k >>= 1) items.push_back(node_obj[node_at[tree][Key(0, k ^ 1)]->ival]);
+        return rp::mk_list(items);
+    };
+    const rp::Ref base_field = ps.world.base_field(base_field_id);
+    std::vector<rp::Ref> base_rows(rows.size()), ext_rows(rows.size()), base_salt_obj(rows.size()), ext_salt_obj(rows.size());
+    std::vector<FriSession::KeyMap> shared(n_ext_cols);          // per column: i mod modulus -> list node holding the coefficient objects
+    for (size_t r = 0; r < rows.size(); ++r) {
+        const u64 i = rows[r];
+        const u64* bw = words + row_at[r].base;
+        std::vector<rp::Ref> items;
+        u64 l[3] = {bw[0], bw[1], bw[2]};
+        items.push_back(ps.world.xfe_compact(l));                                    // the randomizer codeword's element
+        for (u32 k = 3; k < base_words; ++k) items.push_back(ps.world.bfe_in(bw[k], base_field));
+        base_rows[r] = rp::mk_tuple(items);
+        const u64* ew = words + row_at[r].ext;
+        items.clear();
+        for (u32 c = 0; c < n_ext_cols; ++c) {
+            u64 e[3] = {ew[3 * c], ew[3 * c + 1], ew[3 * c + 2]};
+            if (ext_moduli[c] == 0) { items.push_back(ps.world.xfe_compact(e)); continue; }
+            const Key cls(0, i % ext_moduli[c]);
+            if (!shared[c].count(cls)) {
+                const int k = e[2] ? 3 : (e[1] ? 2 : (e[0] ? 1 : 0));
+                std::vector<rp::Ref> coeffs;
+                for (int j = 0; j < k; ++j) coeffs.push_back(ps.world.bfe(e[j], true));
+                shared[c][cls] = rp::mk_list(coeffs);
+            }
+            items.push_back(ps.world.xfe_from(shared[c][cls]->items));
+        }
+        ext_rows[r] = rp::mk_tuple(items);
+        base_salt_obj[r] = base_salts_on_device ? rp::mk_bytes(words + row_at[r].base_salt, 24) : rp::mk_bytes(base_salts + 24 * i, 24);
+        ext_salt_obj[r] = ext_salts_on_device ? rp::mk_bytes(words + row_at[r].ext_salt, 24) : rp::mk_bytes(ext_salts + 24 * i, 24);
+    }
+    // ---- pushes, in the reference's order
+    for (u32 a = 0; a < n_indices; ++a)
+        for (u32 b = 0; b < n_distances; ++b) {
+            const u64 i = (indices[a] + distances[b]) % n;
+            const size_t r = (size_t)(std::find(rows.begin(), rows.end(), i) - rows.begin());
+            ps.objects.push_back(base_rows[r]);
+            ps.objects.push_back(rp::mk_tuple({base_salt_obj[r], path_obj(0, i)}));
+            ps.objects.push_back(ext_rows[r]);
+            ps.objects.push_back(rp::mk_tuple({ext_salt_obj[r], path_obj(1, i)}));
+        }
+    std::vector<rp::Ref> leaf_obj(uniq_idx.size());
+    for (size_t a = 0; a < uniq_idx.size(); ++a) {
+        u64 l[3] = {words[leaf_at[a]], words[leaf_at[a] + 1], words[leaf_at[a] + 2]};
+        leaf_obj[a] = ps.world.xfe_compact(l);
+    }
+    for (u32 a = 0; a < n_indices; ++a) {
+        const size_t u = (size_t)(std::find(uniq_idx.begin(), uniq_idx.end(), indices[a]) - uniq_idx.begin());
+        ps.objects.push_back(leaf_obj[u]);
+        ps.objects.push_back(path_obj(2, indices[a]));
+        out_leaf_handles[a] = ps.add(leaf_obj[u]);
+    }
+    return BFS_OK;
 }
 
 int bfs_gather(const bfs_gather_request* requests, uint32_t count, uint64_t* h_out, void* stream_) {

@@ -155,7 +155,8 @@ class Fri:
             top = None
             for index, obj in (known_leafs or {}).items():
                 # element objects of this codeword that are already in the stream keep their identity (pickle memoises by id)
-                _lib.check(lib.bfs_fri_session_alias(session, transcript.handle, 0, index, transcript.to_native(obj)))
+                # (an int is the handle of an element native code has already put into the transcript)
+                _lib.check(lib.bfs_fri_session_alias(session, transcript.handle, 0, index, obj if isinstance(obj, int) else transcript.to_native(obj)))
             if with_query:
                 out = (_u64 * self.num_colinearity_tests)()
                 _lib.check(lib.bfs_fri_query(session, transcript.handle, self.num_colinearity_tests, out, stream))

@@ -271,7 +271,9 @@ class ProofStream:
 
     def _adopt_lazy(self, transcript, first, last, field):
         """like _adopt, for objects first..last-1 of the cached transcript, without building them"""
-        if getattr(self, "_cached", None) is not transcript or self._pending is not None:
+        if self._pending is not None and self._pending[0] is transcript and self._pending[2] == first and getattr(self, "_cached", None) is transcript:
+            self._pending = (transcript, self._pending[1], last, field)          # native code went on appending: one longer range
+        elif getattr(self, "_cached", None) is not transcript or self._pending is not None:
             self._adopt(transcript, [transcript.to_python(transcript.lib.bfs_ps_object_at(transcript.handle, i), field) for i in range(first, last)])
         else:
             self._pending = (transcript, first, last, field)

@@ -107,6 +107,7 @@ class ZippedSaltedMerkle(SaltedMerkle):
                 salts = urandom(24 * total_rows)[24 * salt_offset:24 * (salt_offset + n)]   # the same bytes as one urandom(24) per leaf
             assert len(salts) == 24 * n, "24 bytes of salt per leaf"
             keep = ctypes.create_string_buffer(salts, len(salts))
+            self._salt_host = keep                   # bfs_stark_push_openings reads opened salts from here
             _lib.check(lib.bfs_merkle_build_rows_range(cols, len(columns), n, limb_stride, ctypes.cast(keep, ctypes.c_void_p), 0,
                                                        self._nodes.ptr, stream))
 
