@@ -143,6 +143,12 @@ int bfs_ps_fiat_shamir(void* ps, size_t count, uint8_t* out, size_t num_bytes);
 /* push(bytes(digest)) followed by fiat_shamir over everything, computed the way bfs_fri_commit overlaps it with a tree kernel: the
  * SHAKE256 blocks in front of the digest's payload are absorbed before the digest is known (same result as the two calls). */
 int bfs_ps_push_digest_fiat_shamir(void* ps, const uint8_t digest[64], uint8_t* out, size_t num_bytes);
+/* the same for `count` digests in a row (digests: count * 64 bytes; out: count * num_bytes bytes, the Fiat-Shamir bytes after each
+ * push), computed the way bfs_fri_commit does behind a long transcript: every challenge hashes the whole stream again under a new
+ * frame header (ip.py:21-25), so the pickles of all `count` coming streams are laid out up front and helper threads absorb their
+ * prefixes side by side (BFS_HELPER_THREADS, default 4; 0 = off).  *used_lookahead (optional): 0 when it fell back to one at a time
+ * (fewer than two objects in the stream, or no helper threads). */
+int bfs_ps_push_digests_fiat_shamir(void* ps, const uint8_t* digests, size_t count, uint8_t* out, size_t num_bytes, int* used_lookahead);
 /* pickle.dumps(obj) of one object on its own (leaf preimages: merkle.py:30, salted_merkle.py:32-33); two-call pattern */
 int bfs_ps_obj_dumps(void* ps, uint64_t handle, uint8_t* out, size_t capacity, size_t* length);
 /* introspection (to hand objects created by bfs_fri_prove back to the host language):
@@ -338,6 +344,21 @@ int bfs_xfe_scan(int kind, const uint64_t* x1, const uint64_t* x2, const uint64_
 int bfs_xfe_scan_device(int kind, const uint64_t* d_x1, const uint64_t* d_x2, const uint64_t* d_x3, uint64_t shift1,
                         const uint8_t* d_mask, uint64_t n, const uint64_t constants[12], const uint64_t initial[3],
                         int record_before, uint64_t* d_out, uint64_t out_stride, uint64_t* d_terminal, uint64_t* terminal, void* stream);
+/* several scans in one call (a proof has nine, over short tables: three launches instead of twenty-seven).  Fields as the arguments
+ * of bfs_xfe_scan_device; n >= 1.  Synchronises the stream. */
+typedef struct bfs_scan_spec {
+    int32_t kind, record_before;
+    const uint64_t *d_x1, *d_x2, *d_x3;
+    uint64_t shift1;
+    const uint8_t* d_mask;
+    uint64_t n;
+    uint64_t constants[12];
+    uint64_t initial[3];
+    uint64_t* d_out;
+    uint64_t out_stride;
+    uint64_t* d_terminal;
+} bfs_scan_spec;
+int bfs_xfe_scan_device_many(const bfs_scan_spec* specs, uint32_t count, void* stream);
 
 typedef struct bfs_comb_source {
     const uint64_t* ptr;   /* device: n words (base codeword) or 3n words (extension codeword, limb planes) */

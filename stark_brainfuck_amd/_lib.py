@@ -66,6 +66,7 @@ _SIGNATURES = {
     "bfs_ps_serialize": (ci, [vp, sz, vp, sz, ctypes.POINTER(sz)]),
     "bfs_ps_fiat_shamir": (ci, [vp, sz, vp, sz]),
     "bfs_ps_push_digest_fiat_shamir": (ci, [vp, ctypes.c_char_p, vp, sz]),
+    "bfs_ps_push_digests_fiat_shamir": (ci, [vp, ctypes.c_char_p, sz, vp, sz, ctypes.POINTER(ci)]),
     "bfs_ps_obj_dumps": (ci, [vp, u64, vp, sz, ctypes.POINTER(sz)]),
     "bfs_ps_obj_kind": (ci, [vp, u64]),
     "bfs_ps_obj_len": (sz, [vp, u64]),
@@ -102,6 +103,7 @@ _SIGNATURES = {
     "bfs_vm_trace_size": (ci, [vp, ci, ctypes.POINTER(sz)]),
     "bfs_vm_trace_copy": (ci, [vp, ci, vp]),
     "bfs_xfe_scan": (ci, [ci, vp, vp, vp, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(u64), ci, vp, ctypes.POINTER(u64)]),
+    "bfs_xfe_scan_device_many": (ci, [vp, ctypes.c_uint32, vp]),
     "bfs_xfe_scan_device": (ci, [ci, vp, vp, vp, u64, vp, u64, ctypes.POINTER(u64), ctypes.POINTER(u64), ci, vp, u64, vp, ctypes.POINTER(u64), vp]),
     "bfs_poly_support": (ci, [vp, u64, u64, u32, ctypes.POINTER(u64), vp]),
     "bfs_poly_randomize": (ci, [vp, u64, u64, u32, u64, ctypes.POINTER(u64), vp]),
@@ -129,6 +131,13 @@ class RowColumn(ctypes.Structure):
 class CombSource(ctypes.Structure):
     """bfs_comb_source (include/bfstark.h)"""
     _fields_ = [("ptr", vp), ("is_ext", u32), ("pad", u32), ("shift", u64), ("wa", u64 * 3), ("wb", u64 * 3)]
+
+class ScanSpec(ctypes.Structure):
+    """bfs_scan_spec (include/bfstark.h)"""
+    _fields_ = [("kind", ctypes.c_int32), ("record_before", ctypes.c_int32), ("d_x1", vp), ("d_x2", vp), ("d_x3", vp), ("shift1", u64),
+                ("d_mask", vp), ("n", u64), ("constants", u64 * 12), ("initial", u64 * 3), ("d_out", vp), ("out_stride", u64),
+                ("d_terminal", vp)]
+
 
 class CombWeight(ctypes.Structure):
     """bfs_comb_weight (include/bfstark.h)"""

@@ -194,10 +194,20 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
     constexpr u64 FRI_FOLD_IN_LEAVES_MIN = 16384;     // = FRI_FUSED_MAX: every round >= 1 folds inside its leaf kernel (must exceed QUAD_LEAVES_MAX)
     FriFoldArgs pending{};                         // the fold that produces round r's codeword, when round r runs fused
     pending.in = nullptr;
+    // Fiat-Shamir look-ahead: with a long transcript in front (a STARK proof: tens of KB), helper threads absorb the SHAKE256 prefix of
+    // every coming challenge now (Transcript::Lookahead); rounds 1 .. R-2 push a root and draw a challenge
+    rp::Transcript::Lookahead look;
+    static const bool lookahead_on = getenv("BFS_FRI_LOOKAHEAD") == nullptr || atoi(getenv("BFS_FRI_LOOKAHEAD")) != 0;
+    static const bool trace = getenv("BFS_FRI_TRACE") != nullptr;      // development aid: host timeline of every round on stderr
+    const double t_look = trace ? now_ms() : 0;
+    const bool looking = lookahead_on && R >= 3 && ps.lookahead_begin(look, R - 2);
+    if (trace) fprintf(stderr, "fri look-ahead %s: %.1f us, %zu objects in front\n", looking ? "on" : "off", 1e3 * (now_ms() - t_look), ps.objects.size());      // development aid: host timeline of every round on stderr
     for (u32 r = 0; r < R; ++r) {
         FriRound& fr = S.rounds[r];
         unsigned char seed[32];
         bool have_seed = false, speculating = false;
+        const double t_round = trace ? now_ms() : 0;
+        double t_launched = 0, t_absorbed = 0, t_root = 0;
         rp::Transcript::Speculation speculation;
         const bool fused = fr.length >= 2 && fr.length <= FRI_FUSED_MAX && !(r == 0 && S.round0_nodes);
         if (fused) {
@@ -205,10 +215,12 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
             const u64 seq = ++S.mailbox.seq;
             BFS_TRY(fri_round_fused_launch(pending, (u64*)fr.cw, fr.stride, fr.length, fr.nodes, stream, S.mailbox.dev, seq));
             pending.in = nullptr;
+            if (trace) t_launched = now_ms();
             if (r + 1 < R) {
                 if (r == 0) { ps.fiat_shamir(ps.objects.size(), seed, 32); have_seed = true; }
-                else { ps.speculate(speculation); speculating = true; }
+                else if (!looking) { ps.speculate(speculation); speculating = true; }
             }
+            if (trace) t_absorbed = now_ms();
             volatile u64* flag = S.mailbox.host + 8;
             u64 spins = 0;
             while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
@@ -235,10 +247,12 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
             // While the GPU hashes: the next challenge is SHAKE256 of the WHOLE transcript including this root (fri.py:112-120), tens
             // of KB -- as long as the tree kernels of the late rounds.  Everything in front of the root's 64 bytes is known already,
             // so the sponge absorbs it now and only the last block or two wait for the root.
+            if (trace) t_launched = now_ms();
             if (r + 1 < R) {
                 if (r == 0) { ps.fiat_shamir(ps.objects.size(), seed, 32); have_seed = true; }
-                else { ps.speculate(speculation); speculating = true; }
+                else if (!looking) { ps.speculate(speculation); speculating = true; }
             }
+            if (trace) t_absorbed = now_ms();
             volatile u64* flag = S.mailbox.host + 8;
             u64 spins = 0;
             while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
@@ -254,8 +268,13 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
             BFS_HIP(hipMemcpyAsync(fr.root, fr.nodes + 8, 64, hipMemcpyDeviceToHost, stream));
             BFS_HIP(hipStreamSynchronize(stream));
         }
+        if (trace) t_root = now_ms();
         if (speculating) ps.resolve(speculation, fr.root, seed, 32);          // the placeholder pushed by speculate() becomes the root
+        else if (r > 0 && looking) { ps.lookahead_next(look, fr.root, r + 1 < R ? seed : nullptr, 32); have_seed = r + 1 < R; }
         else if (r > 0) ps.objects.push_back(rp::mk_bytes(fr.root, 64));      // fri.py:112-113
+        if (trace)
+            fprintf(stderr, "fri round %2u  n %8llu  launch %6.1f us  absorb %6.1f us  wait %6.1f us  finish %6.1f us\n", r, (unsigned long long)fr.length,
+                    1e3 * (t_launched - t_round), 1e3 * (t_absorbed - t_launched), 1e3 * (t_root - t_absorbed), 1e3 * (now_ms() - t_root));
         if (r == R - 1) break;                                                // fri.py:116-117
         if (!speculating && !have_seed) ps.fiat_shamir(ps.objects.size(), seed, 32);   // fri.py:120
         Xfe alpha = rp::sample_xfe(seed, 32);

@@ -138,4 +138,27 @@ inline size_t shake256_absorb_blocks(const void* data, size_t limit, uint64_t st
     return done;
 }
 
+// the same over data[0, limit) with `patch_len` bytes at offset `patch_at` replaced (data itself is shared and stays as it is)
+inline size_t shake256_absorb_blocks_patched(const void* data, size_t limit, uint64_t state[25], size_t patch_at, const unsigned char* patch,
+                                             size_t patch_len) {
+    memset(state, 0, 25 * sizeof(uint64_t));
+    const size_t rate = 136;
+    const unsigned char* p = (const unsigned char*)data;
+    unsigned char block[136];
+    size_t done = 0;
+    while (done + rate <= limit) {
+        const unsigned char* src = p + done;
+        if (patch_len && patch_at < done + rate && patch_at + patch_len > done) {
+            memcpy(block, src, rate);
+            for (size_t i = 0; i < patch_len; ++i)
+                if (patch_at + i >= done && patch_at + i < done + rate) block[patch_at + i - done] = patch[i];
+            src = block;
+        }
+        for (size_t i = 0; i < rate / 8; ++i) { uint64_t w; memcpy(&w, src + 8 * i, 8); state[i] ^= w; }
+        keccak_f1600(state);
+        done += rate;
+    }
+    return done;
+}
+
 }  // namespace bfs

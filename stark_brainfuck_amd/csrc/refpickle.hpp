@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "gl.hpp"
+#include "helper_pool.hpp"
 #include "keccak.hpp"
 
 namespace bfs {
@@ -177,28 +178,59 @@ class Pickler {
         if (++stream_batch_ == BATCH) { op(0x65); stream_batch_ = 0; }   // APPENDS closes it after 1000 items
     }
     size_t stream_items() const { return stream_items_; }
+    size_t stream_size() const { return out_.size(); }
+    // the open form can be extended tentatively: stream_mark(), stream_item() of objects that are not part of the stream (yet),
+    // stream_bytes(), then stream_rollback(mark, those objects) -- Transcript::Lookahead pickles the NEXT rounds' streams that way
+    struct StreamMark { size_t size, frame, items, batch; std::string header; };
+    StreamMark stream_mark() const {
+        StreamMark m{out_.size(), frame_start_, stream_items_, stream_batch_, std::string()};
+        if (frame_start_ != NPOS) m.header = out_.substr(frame_start_, FRAME_HEADER);
+        return m;
+    }
+    void stream_rollback(const StreamMark& m, const std::vector<Ref>& tentative) {
+        for (const Ref& r : tentative) memo_.erase(r.get());       // (memo indices are handed out by size: the last ones go)
+        out_.resize(m.size);
+        if (m.frame != NPOS) out_.replace(m.frame, FRAME_HEADER, m.header);
+        frame_start_ = m.frame;
+        stream_items_ = m.items;
+        stream_batch_ = m.batch;
+    }
     // overwrite bytes of the open form (same offsets as in the last stream_bytes() result): a payload that was pickled as a
     // placeholder and has become known (Transcript::speculate / resolve)
     void stream_patch(size_t offset, const void* data, size_t len) { memcpy(&out_[offset], data, len); }
     std::string stream_bytes() {
+        std::string result;
+        stream_bytes_into(result);
+        return result;
+    }
+    void stream_bytes_into(std::string& result) {      // (a caller that keeps `result` around saves the allocation and its page faults)
+        stream_closed([&](const std::string& closed) { result.assign(closed); });
+    }
+    // bytes [from, end) of what stream_bytes() returns, and the nine bytes at `watch` in it (the header of a frame that is still open
+    // there depends on everything behind it)
+    void stream_tail_into(std::string& tail, size_t from, size_t watch, unsigned char watched[9]) {
+        stream_closed([&](const std::string& closed) {
+            tail.assign(closed, from < closed.size() ? from : closed.size(), std::string::npos);
+            for (size_t i = 0; i < FRAME_HEADER; ++i) watched[i] = watch + i < closed.size() ? (unsigned char)closed[watch + i] : 0;
+        });
+    }
+    // where the header of the frame lies that the next item goes into
+    size_t stream_open_frame() const { return frame_start_ != NPOS ? frame_start_ : out_.size(); }
+
+   private:
+    // run `use` on the finished pickle of the items so far, then reopen the stream for more items
+    template <class F>
+    void stream_closed(F&& use) {
         const size_t size = out_.size(), frame = frame_start_;
         std::string saved_header;
         if (frame != NPOS) saved_header = out_.substr(frame, FRAME_HEADER);
         if (stream_batch_ != 0) op(0x65);                      // APPENDS of the open batch
         op(0x2e);                                              // STOP
-        // after the two writes a frame is open in any case; remember where, in case it was opened by them
-        const size_t frame_now = frame_start_;
-        commit_frame();
-        std::string result = out_;
-        if (frame == NPOS) {                                   // the closing opcodes opened a frame of their own: drop all of it
-            out_.resize(size);
-        } else {
-            (void)frame_now;
-            out_.resize(size);
-            out_.replace(frame, FRAME_HEADER, saved_header);   // reopen the frame the items live in
-        }
+        commit_frame();                                        // (a frame is open in any case after the two writes)
+        use(out_);
+        out_.resize(size);                                     // (frame == NPOS: the closing opcodes opened a frame of their own, all of it goes)
+        if (frame != NPOS) out_.replace(frame, FRAME_HEADER, saved_header);   // reopen the frame the items live in
         frame_start_ = frame;
-        return result;
     }
 
    private:
@@ -472,6 +504,124 @@ struct Transcript {
         sp.active = true;
         return true;
     }
+    // The same idea for a RUN of digests (the commit phase of FRI pushes one root per round and asks for a challenge after each,
+    // fri.py:108-120): the pickles of "stream + k digests" for k = 1..count are all made up front with placeholder payloads, and
+    // helper threads absorb each one's blocks in front of the first placeholder (helper_pool.hpp) -- tens of KB per round that
+    // would otherwise be hashed on the proving thread between two kernel launches.  next() then pushes the real digest, fills the
+    // k payloads in and finishes the sponge over the last few hundred bytes.
+    struct Lookahead {
+        struct Job {
+            std::string tail;                        // the pickle of "stream + k digests" from offset `from` on
+            unsigned char watched[9];                // ... and its nine bytes at `watch` (the frame header in front depends on k)
+            const std::string* base = nullptr;
+            size_t from = 0, watch = 0;
+            uint64_t sponge[25];
+            std::atomic<int> done{0};
+        };
+        std::string base;                            // the whole pickle for k = 1: every job's prefix, up to the nine watched bytes
+        std::vector<std::unique_ptr<Job>> jobs;      // jobs[k - 1]: the stream followed by k digests
+        std::vector<size_t> holes;                   // offset of the k-th digest's payload, the same in every pickle that holds it
+        std::vector<std::string> digests;
+        size_t from = 0, base_objects = 0;
+        bool active = false;
+        void wait_all() {
+            for (auto& j : jobs)
+                while (!j->done.load(std::memory_order_acquire)) std::this_thread::yield();
+        }
+        // finished jobs (and the base) are kept per thread for the next proof: their strings keep their capacity
+        struct Spare { std::vector<std::unique_ptr<Job>> jobs; std::string base; };
+        static Spare& spare() { static thread_local Spare s; return s; }
+        static std::unique_ptr<Job> take() {
+            auto& s = spare().jobs;
+            if (s.empty()) return std::unique_ptr<Job>(new Job());
+            std::unique_ptr<Job> j = std::move(s.back());
+            s.pop_back();
+            j->done.store(0, std::memory_order_relaxed);
+            return j;
+        }
+        Lookahead() { base.swap(spare().base); }
+        ~Lookahead() {                               // the helpers read `base` and write into the jobs
+            wait_all();
+            for (auto& j : jobs)
+                if (spare().jobs.size() < 64) spare().jobs.push_back(std::move(j));
+            base.swap(spare().base);
+        }
+    };
+    static void lookahead_sentinel(size_t k, unsigned char out[64]) {
+        for (int i = 0; i < 64; ++i) out[i] = (unsigned char)(0xC3 ^ (i * 37) ^ (k * 101));
+    }
+    // false: nothing started (short stream, no helpers, or the pickles did not come out the expected shape) -- use speculate()
+    bool lookahead_begin(Lookahead& la, size_t count, size_t min_bytes = 4096) {
+        la.active = false;
+        if (count == 0 || objects.size() < 2) return false;
+        HelperPool* pool = HelperPool::get();
+        if (pool == nullptr) return false;
+        if (!streaming) { stream.stream_begin(); streaming = true; }
+        for (size_t i = stream.stream_items(); i < objects.size(); ++i) stream.stream_item(objects[i]);   // bring the open form up to date
+        if (stream.stream_size() < min_bytes) return false;
+        const Pickler::StreamMark mark = stream.stream_mark();
+        const size_t watch = stream.stream_open_frame();
+        std::vector<Ref> tentative;
+        bool ok = true;
+        for (size_t k = 1; k <= count && ok; ++k) {
+            unsigned char sentinel[64];
+            lookahead_sentinel(k, sentinel);
+            tentative.push_back(mk_bytes(sentinel, 64));
+            stream.stream_item(tentative.back());
+            std::unique_ptr<Lookahead::Job> job = Lookahead::take();
+            if (k == 1) {                            // the one whole copy; everything in front of the first payload's block is shared
+                stream.stream_bytes_into(la.base);
+                const size_t near = la.base.size() > 96 ? la.base.size() - 96 : 0;
+                const size_t at = la.base.find(std::string((const char*)sentinel, 64), near);
+                if (at == std::string::npos) { ok = false; break; }
+                la.holes.push_back(at);
+                la.from = at - at % 136;
+            }
+            stream.stream_tail_into(job->tail, la.from, watch, job->watched);
+            if (k > 1) {
+                const size_t near = job->tail.size() > 96 ? job->tail.size() - 96 : 0;
+                const size_t at = job->tail.find(std::string((const char*)sentinel, 64), near);
+                if (at == std::string::npos) { ok = false; break; }
+                la.holes.push_back(la.from + at);
+            }
+            for (size_t j = 1; j <= k && ok; ++j) {                           // the payloads sit where they sat
+                lookahead_sentinel(j, sentinel);
+                const size_t at = la.holes[j - 1] - la.from;
+                if (at + 64 > job->tail.size() || memcmp(&job->tail[at], sentinel, 64) != 0) ok = false;
+            }
+            job->base = &la.base;
+            job->from = la.from;
+            job->watch = watch;
+            la.jobs.push_back(std::move(job));
+        }
+        stream.stream_rollback(mark, tentative);
+        if (!ok) { la.jobs.clear(); la.holes.clear(); return false; }
+        std::vector<std::function<void()>> work;
+        for (auto& j : la.jobs) {
+            Lookahead::Job* job = j.get();
+            work.push_back([job] {
+                shake256_absorb_blocks_patched(job->base->data(), job->from, job->sponge, job->watch, job->watched, 9);
+                job->done.store(1, std::memory_order_release);
+            });
+        }
+        pool->submit(std::move(work));
+        la.base_objects = objects.size();
+        la.active = true;
+        return true;
+    }
+    // push the next digest; out != nullptr: the Fiat-Shamir bytes over the stream including it
+    void lookahead_next(Lookahead& la, const unsigned char digest[64], unsigned char* out, size_t num_bytes) {
+        objects.push_back(mk_bytes(digest, 64));
+        const size_t k = la.digests.size() + 1;
+        la.digests.emplace_back((const char*)digest, 64);
+        if (out == nullptr) return;
+        if (!la.active || k > la.jobs.size() || objects.size() != la.base_objects + k) { fiat_shamir(objects.size(), out, num_bytes); return; }
+        Lookahead::Job& job = *la.jobs[k - 1];
+        for (size_t j = 0; j < k; ++j) memcpy(&job.tail[la.holes[j] - la.from], la.digests[j].data(), 64);
+        while (!job.done.load(std::memory_order_acquire)) {}
+        shake256(job.tail.data(), job.tail.size(), out, num_bytes, job.sponge, 0);
+    }
+
     void resolve(Speculation& sp, const unsigned char digest[64], unsigned char* out, size_t num_bytes) {
         sp.node->data.assign((const char*)digest, 64);
         if (!sp.active) { fiat_shamir(objects.size(), out, num_bytes); return; }

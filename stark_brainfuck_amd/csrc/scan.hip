@@ -12,6 +12,8 @@
 // the trace columns are already in HBM for the low-degree extension, and the extension columns never visit the host.
 #include <string.h>
 
+#include <vector>
+
 #include "../../include/bfstark.h"
 #include "gl.hpp"
 #include "runtime.hpp"
@@ -33,6 +35,7 @@ struct ScanArgs {
     Xfe* block_c;
     Xfe* block_state;             // ... and, after the spine, the running value the block starts from; [gridDim.x] = terminal
     u64* terminal;                // optional device copy of the terminal (three words)
+    u32 kind, blocks;             // batched launches (scan_*_many_kernel): which scan this is, and how many workgroups it uses
 };
 
 struct Affine {
@@ -101,16 +104,20 @@ __device__ __forceinline__ Affine block_inclusive_scan(Affine mine, Affine* lds)
 }
 
 template <int KIND>
-__global__ void __launch_bounds__(256) scan_reduce_kernel(const ScanArgs a) {
-    __shared__ Affine lds[256];
+__device__ __forceinline__ void scan_reduce_body(const ScanArgs& a, Affine* lds) {
     const u64 first = ((u64)blockIdx.x * 256 + threadIdx.x) * a.items;
     const Affine total = block_inclusive_scan<KIND>(thread_aggregate<KIND>(a, first), lds);
     if (threadIdx.x == 255) { a.block_m[blockIdx.x] = total.m; a.block_c[blockIdx.x] = total.c; }
 }
 
 template <int KIND>
-__global__ void __launch_bounds__(256) scan_spine_kernel(const ScanArgs a, u32 blocks) {
+__global__ void __launch_bounds__(256) scan_reduce_kernel(const ScanArgs a) {
     __shared__ Affine lds[256];
+    scan_reduce_body<KIND>(a, lds);
+}
+
+template <int KIND>
+__device__ __forceinline__ void scan_spine_body(const ScanArgs& a, u32 blocks, Affine* lds) {
     const u32 t = threadIdx.x;
     Affine mine{Xfe{{1, 0, 0}}, Xfe{{0, 0, 0}}};
     if (t < blocks) { mine.m = a.block_m[t]; mine.c = a.block_c[t]; }
@@ -125,8 +132,13 @@ __global__ void __launch_bounds__(256) scan_spine_kernel(const ScanArgs a, u32 b
 }
 
 template <int KIND>
-__global__ void __launch_bounds__(256) scan_apply_kernel(const ScanArgs a) {
+__global__ void __launch_bounds__(256) scan_spine_kernel(const ScanArgs a, u32 blocks) {
     __shared__ Affine lds[256];
+    scan_spine_body<KIND>(a, blocks, lds);
+}
+
+template <int KIND>
+__device__ __forceinline__ void scan_apply_body(const ScanArgs& a, Affine* lds) {
     const u32 t = threadIdx.x;
     const u64 first = ((u64)blockIdx.x * 256 + t) * a.items;
     const Affine incl = block_inclusive_scan<KIND>(thread_aggregate<KIND>(a, first), lds);
@@ -144,6 +156,32 @@ __global__ void __launch_bounds__(256) scan_apply_kernel(const ScanArgs a) {
 }
 
 template <int KIND>
+__global__ void __launch_bounds__(256) scan_apply_kernel(const ScanArgs a) {
+    __shared__ Affine lds[256];
+    scan_apply_body<KIND>(a, lds);
+}
+
+// Several scans per launch (blockIdx.y = which one): the nine scans of a proof over short tables are nine chains of three tiny,
+// latency-bound kernels (10-25 us each: eight dependent compose steps per workgroup scan); side by side they cost as much as one.
+__global__ void __launch_bounds__(256) scan_reduce_many_kernel(const ScanArgs* args) {
+    __shared__ Affine lds[256];
+    const ScanArgs a = args[blockIdx.y];
+    if (blockIdx.x >= a.blocks) return;
+    if (a.kind == 0) scan_reduce_body<0>(a, lds); else scan_reduce_body<1>(a, lds);
+}
+__global__ void __launch_bounds__(256) scan_spine_many_kernel(const ScanArgs* args) {
+    __shared__ Affine lds[256];
+    const ScanArgs a = args[blockIdx.y];
+    if (a.kind == 0) scan_spine_body<0>(a, a.blocks, lds); else scan_spine_body<1>(a, a.blocks, lds);
+}
+__global__ void __launch_bounds__(256) scan_apply_many_kernel(const ScanArgs* args) {
+    __shared__ Affine lds[256];
+    const ScanArgs a = args[blockIdx.y];
+    if (blockIdx.x >= a.blocks) return;
+    if (a.kind == 0) scan_apply_body<0>(a, lds); else scan_apply_body<1>(a, lds);
+}
+
+template <int KIND>
 static int scan_launch(ScanArgs& a, u32 blocks, hipStream_t stream) {
     hipLaunchKernelGGL(scan_reduce_kernel<KIND>, dim3(blocks), dim3(256), 0, stream, a);
     hipLaunchKernelGGL(scan_spine_kernel<KIND>, dim3(1), dim3(256), 0, stream, a, blocks);
@@ -155,6 +193,52 @@ static int scan_launch(ScanArgs& a, u32 blocks, hipStream_t stream) {
 }  // namespace bfs
 
 using namespace bfs;
+
+static void scan_fill(ScanArgs& a, int kind, const u64* d_x1, const u64* d_x2, const u64* d_x3, u64 shift1, const unsigned char* d_mask, u64 n,
+                      const u64 constants[12], const u64 initial[3], int record_before, u64* d_out, u64 out_stride, u64* d_terminal) {
+    a = ScanArgs{};
+    a.x1 = d_x1; a.x2 = d_x2; a.x3 = d_x3; a.mask = d_mask; a.n = n; a.shift1 = d_x1 ? shift1 % n : 0;
+    for (int j = 0; j < 4; ++j) a.c[j] = Xfe{{constants[3 * j] % GL_P, constants[3 * j + 1] % GL_P, constants[3 * j + 2] % GL_P}};
+    a.initial = Xfe{{initial[0] % GL_P, initial[1] % GL_P, initial[2] % GL_P}};
+    a.record_before = record_before;
+    a.out = d_out; a.out_stride = out_stride; a.terminal = d_terminal;
+    u64 blocks = (n + 255) / 256;
+    if (blocks > 256) blocks = 256;
+    a.items = (n + blocks * 256 - 1) / (blocks * 256);
+    blocks = (n + a.items * 256 - 1) / (a.items * 256);          // no empty blocks at the end
+    a.blocks = (u32)blocks;
+    a.kind = (u32)kind;
+}
+
+extern "C" int bfs_xfe_scan_device_many(const bfs_scan_spec* specs, uint32_t count, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (count == 0) return BFS_OK;
+    if (count > 64) { set_error("bfs_xfe_scan_device_many: at most 64 scans per call"); return BFS_ERR_BAD_ARG; }
+    std::vector<ScanArgs> args(count);
+    const size_t per = (3 * 256 + 8) * sizeof(Xfe);
+    void* w = nullptr;
+    BFS_TRY(workspace(7, count * per + count * sizeof(ScanArgs) + 64, stream, &w));
+    u32 max_blocks = 0;
+    for (uint32_t k = 0; k < count; ++k) {
+        const bfs_scan_spec& sp = specs[k];
+        if (sp.kind != 0 && sp.kind != 1) { set_error("bfs_xfe_scan_device_many: kind must be 0 (product) or 1 (evaluation)"); return BFS_ERR_BAD_ARG; }
+        if (sp.n == 0 || sp.out_stride < sp.n) { set_error("bfs_xfe_scan_device_many: n >= 1 and out_stride >= n"); return BFS_ERR_BAD_ARG; }
+        scan_fill(args[k], sp.kind, sp.d_x1, sp.d_x2, sp.d_x3, sp.shift1, sp.d_mask, sp.n, sp.constants, sp.initial, sp.record_before, sp.d_out,
+                  sp.out_stride, sp.d_terminal);
+        args[k].block_m = (Xfe*)((char*)w + k * per);
+        args[k].block_c = args[k].block_m + 256;
+        args[k].block_state = args[k].block_c + 256;
+        if (args[k].blocks > max_blocks) max_blocks = args[k].blocks;
+    }
+    ScanArgs* d_args = (ScanArgs*)((char*)w + count * per);
+    BFS_HIP(hipMemcpyAsync(d_args, args.data(), count * sizeof(ScanArgs), hipMemcpyHostToDevice, stream));
+    hipLaunchKernelGGL(scan_reduce_many_kernel, dim3(max_blocks, count), dim3(256), 0, stream, (const ScanArgs*)d_args);
+    hipLaunchKernelGGL(scan_spine_many_kernel, dim3(1, count), dim3(256), 0, stream, (const ScanArgs*)d_args);
+    hipLaunchKernelGGL(scan_apply_many_kernel, dim3(max_blocks, count), dim3(256), 0, stream, (const ScanArgs*)d_args);
+    BFS_HIP(hipGetLastError());
+    BFS_HIP(hipStreamSynchronize(stream));            // `args` is pageable host memory the copy may still be reading
+    return BFS_OK;
+}
 
 extern "C" int bfs_xfe_scan_device(int kind, const uint64_t* d_x1, const uint64_t* d_x2, const uint64_t* d_x3, uint64_t shift1,
                                    const uint8_t* d_mask, uint64_t n, const uint64_t constants[12], const uint64_t initial[3],

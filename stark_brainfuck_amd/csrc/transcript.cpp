@@ -106,6 +106,19 @@ int bfs_ps_push_digest_fiat_shamir(void* ps, const uint8_t digest[64], uint8_t* 
     return BFS_OK;
 }
 
+// the same for a run of digests, the way bfs_fri_commit does it when the stream is long: the pickles of all `count` coming streams are
+// made first and helper threads absorb their prefixes (Transcript::Lookahead); out: count * num_bytes bytes
+int bfs_ps_push_digests_fiat_shamir(void* ps, const uint8_t* digests, size_t count, uint8_t* out, size_t num_bytes, int* used_lookahead) {
+    rp::Transcript::Lookahead look;
+    const bool on = T(ps)->lookahead_begin(look, count, 0);
+    if (used_lookahead) *used_lookahead = on ? 1 : 0;
+    for (size_t k = 0; k < count; ++k) {
+        if (on) T(ps)->lookahead_next(look, digests + 64 * k, out + num_bytes * k, num_bytes);
+        else bfs_ps_push_digest_fiat_shamir(ps, digests + 64 * k, out + num_bytes * k, num_bytes);
+    }
+    return BFS_OK;
+}
+
 int bfs_ps_obj_kind(void* ps, uint64_t handle) {
     Ref r = T(ps)->get(handle);
     if (!r) return -1;

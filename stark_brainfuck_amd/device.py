@@ -17,7 +17,7 @@ def current_stream():
         return int(_TORCH[0].cuda.current_stream().cuda_stream)
     try:
         import torch
-        if torch.cuda.is_available() and torch.cuda.is_initialized():
+        if torch.cuda.is_initialized():          # (a flag; is_available() probes the driver on every call)
             _TORCH.append(torch)
             return int(torch.cuda.current_stream().cuda_stream)
     except ImportError:

@@ -126,7 +126,7 @@ def extend_tables_device(tables, all_challenges, all_initials):
         _lib.check(lib.bfs_memcpy_h2d(d_masks.ptr, host.ctypes.data, host.size, stream))
     total = sum(len(specs) for _, specs in plans)
     d_terminals = DeviceBuffer(3 * max(total, 1))
-    mask_at, slot = 0, 0
+    mask_at, slot, batch_specs = 0, 0, []
     for t, specs in plans:
         h = t.height
         for k, sp in enumerate(specs):
@@ -137,10 +137,12 @@ def extend_tables_device(tables, all_challenges, all_initials):
                     mask_ptr = d_masks.ptr + mask_at
                     mask_at += h
                 flat = [v for c in sp["constants"] for v in c] + [0] * (12 - 3 * len(sp["constants"]))
-                _lib.check(lib.bfs_xfe_scan_device(sp["kind"], ptrs[0], ptrs[1], ptrs[2], sp.get("shift1", 0), mask_ptr, h,
-                                                   (_u64 * 12)(*flat), (_u64 * 3)(*sp["initial"]), 1 if sp["before"] else 0,
-                                                   t._ext_device.ptr + 8 * 3 * k * h, h, d_terminals.ptr + 24 * slot, None, stream))
+                batch_specs.append(_lib.ScanSpec(sp["kind"], 1 if sp["before"] else 0, ptrs[0], ptrs[1], ptrs[2], sp.get("shift1", 0),
+                                                 mask_ptr, h, (_u64 * 12)(*flat), (_u64 * 3)(*sp["initial"]),
+                                                 t._ext_device.ptr + 8 * 3 * k * h, h, d_terminals.ptr + 24 * slot))
             slot += 1
+    if batch_specs:          # every scan of the proof side by side: three launches
+        _lib.check(lib.bfs_xfe_scan_device_many((_lib.ScanSpec * len(batch_specs))(*batch_specs), len(batch_specs), stream))
     batch = GatherBatch()
     terminal_ticket = batch.add(d_terminals.ptr, 3 * max(total, 1), 1)
     read_tickets = {(t, k, row): batch.add(t._ext_device.ptr + 8 * (3 * k * t.height + row), 3, t.height)

@@ -207,6 +207,49 @@ def test_speculative_fiat_shamir_equals_hashing_afterwards(sb):
             assert out.raw == hashlib.shake_256(want).digest(32), (prefix, step)
 
 
+def test_lookahead_fiat_shamir_equals_hashing_afterwards(sb):
+    """what the FRI prover does behind a long transcript (Transcript::Lookahead): the pickles of the stream plus 1, 2, ... count
+    placeholder digests are made up front, helper threads absorb each one's SHAKE256 blocks in front of the first placeholder, the real
+    digests are filled in as they arrive.  Bytes and challenges must equal CPython's pickle + hashlib on the growing list -- also when
+    the run crosses the 64 KiB frame boundary or the 1000-item batch boundary of pickle protocol 4, and the stream must be usable as
+    before afterwards."""
+    import ctypes
+    import hashlib
+    import pickle
+    import random
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.ip import NativeTranscript
+    lib = _lib.load()
+    rng = random.Random(5)
+    took_the_lookahead_route = 0
+    # (466 objects of 137 bytes are 65 240 bytes of pickle: the fifth digest of the run takes the frame over 64 KiB, so the frame that is
+    # open when the run starts is closed in the middle of it)
+    for prefix, count, size in ((0, 3, None), (1, 3, None), (2, 5, None), (7, 20, None), (60, 14, None), (990, 25, None), (1100, 22, None),
+                                (470, 40, None), (466, 12, 137), (465, 9, 137), (467, 30, 137)):
+        t = NativeTranscript()
+        objects = []
+        for k in range(prefix):
+            obj = bytes(rng.randrange(256) for _ in range(size if size is not None else rng.choice((0, 5, 64, 136, 137))))
+            objects.append(obj)
+            t.push(obj)
+        for run in range(2):              # a second run on the same stream: the tentative items of the first left no trace
+            digests = bytes(rng.randrange(256) for _ in range(64 * count))
+            out = ctypes.create_string_buffer(32 * count)
+            used = ctypes.c_int(-1)
+            _lib.check(lib.bfs_ps_push_digests_fiat_shamir(t.handle, digests, count, out, 32, ctypes.byref(used)))
+            took_the_lookahead_route += used.value
+            for k in range(count):
+                objects.append(digests[64 * k:64 * k + 64])
+                want = pickle.dumps(objects, protocol=4)
+                assert out.raw[32 * k:32 * k + 32] == hashlib.shake_256(want).digest(32), (prefix, run, k)
+            assert t.serialize() == pickle.dumps(objects, protocol=4), (prefix, run)
+            extra = bytes(rng.randrange(256) for _ in range(33))
+            objects.append(extra)
+            t.push(extra)
+            assert t.serialize() == pickle.dumps(objects, protocol=4), (prefix, run)
+    assert took_the_lookahead_route >= 10          # (streams of fewer than two objects fall back)
+
+
 def test_fastlist_conversions_match_the_python_loops():
     """cpyext/fastlist.c: lists of element objects <-> uint64 buffers.  Same values, same object structure (trimmed coefficient
     lists, field references) -- checked through CPython's pickle of both results -- and the fallbacks for odd inputs."""

@@ -13,10 +13,16 @@ t1 = time.perf_counter()
 stark = BrainfuckStark(running_time, len(mm), program, inp, out)
 t2 = time.perf_counter()
 print("running time %d, memory rows %d, FRI domain 2^%d, setup %.3f s (vm %.3f s)" % (running_time, len(mm), stark.fri.domain.length.bit_length() - 1, t2 - t1, t1 - t0), flush=True)
-for rep in range(3):
+reps = int(os.environ.get("REPS", "3"))
+times = []
+for rep in range(reps):
     t = time.perf_counter()
     proof = stark.prove(program, pm, mm, im, inm, om)
     synchronize()
-    print("prove: %.3f s, proof %d bytes, sha256 %s" % (time.perf_counter() - t, len(proof), hashlib.sha256(proof).hexdigest()[:16]), flush=True)
-    if hasattr(stark, "timing"):
-        print("   ", {k: round(v, 4) for k, v in stark.timing.items()})
+    times.append(time.perf_counter() - t)
+    if rep < 3:
+        print("prove: %.2f ms, proof %d bytes, sha256 %s" % (times[-1] * 1e3, len(proof), hashlib.sha256(proof).hexdigest()[:16]), flush=True)
+        if hasattr(stark, "timing"):
+            print("   ", {k: round(v * 1e3, 3) for k, v in stark.timing.items()})
+times = sorted(times[1:]) or times
+print("median of %d: %.3f ms, best %.3f ms" % (len(times), times[len(times) // 2] * 1e3, times[0] * 1e3))

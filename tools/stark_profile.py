@@ -20,3 +20,4 @@ for s in starks:
 pr.disable()
 st = pstats.Stats(pr)
 st.sort_stats("tottime").print_stats(28)
+st.sort_stats("cumulative").print_stats(45)
