@@ -311,7 +311,7 @@ class BrainfuckStark:
         lap("base_tree")
 
         # challenges, initials, table extension, terminals (:181-192)
-        challenges = BrainfuckStark._sample_weights(11, proof_stream.prover_fiat_shamir())
+        challenges = tuple(BrainfuckStark._sample_weights(11, proof_stream.prover_fiat_shamir()))
         initials = [sample_ext(urandom(3 * 8)) for _ in self.permutation_arguments]
         extend_tables_device(self.tables, challenges, initials)       # prefix scans on the trace columns lde() left in HBM
         terminals = self.get_terminals()
@@ -496,7 +496,7 @@ class BrainfuckStark:
             return tuple(e.limbs()) if hasattr(e, "limbs") else (e.value % P, 0, 0)
 
         base_root = proof_stream.pull()
-        challenges = BrainfuckStark._sample_weights(11, proof_stream.verifier_fiat_shamir())
+        challenges = tuple(BrainfuckStark._sample_weights(11, proof_stream.verifier_fiat_shamir()))
         extension_root = proof_stream.pull()
         terminals = [limbs(proof_stream.pull()) for _ in range(5)]
 

@@ -34,6 +34,20 @@ def _val(x):
     return x.value if hasattr(x, "value") else int(x)
 
 
+_INVERSES = {}
+
+
+def _inv(v):
+    """1 / v mod p, remembered: a proof asks ~30 times for the inverses of the same five subgroup generators and heights, and a
+    modular exponentiation of Python integers is ~5 us"""
+    r = _INVERSES.get(v)
+    if r is None:
+        if len(_INVERSES) > 4096:
+            _INVERSES.clear()
+        r = _INVERSES[v] = pow(v, P - 2, P)
+    return r
+
+
 def sample_base(byte_array):
     """BaseField.sample (algebra.py:138-142)"""
     return int.from_bytes(bytes(byte_array), "big") % P
@@ -167,7 +181,7 @@ def zerofier_inverses(tables, domain):
     n = domain.length
     specs = [(0, 1)]
     for t in tables:
-        for spec in ((0, pow(t.omicron.value, P - 2, P)), (1, t.height.bit_length() - 1) if t.height else None):
+        for spec in ((0, _inv(t.omicron.value)), (1, t.height.bit_length() - 1) if t.height else None):
             if spec is not None and spec not in specs:
                 specs.append(spec)
     assert len(specs) <= 12
@@ -176,7 +190,7 @@ def zerofier_inverses(tables, domain):
                                          (ctypes.c_uint32 * len(specs))(*[s[0] for s in specs]), (_u64 * len(specs))(*[s[1] for s in specs]),
                                          out.ptr, stream))
     where = {spec: out.ptr + 8 * k * n for k, spec in enumerate(specs)}
-    per_table = {t: (where[(0, 1)], where[(0, pow(t.omicron.value, P - 2, P))],
+    per_table = {t: (where[(0, 1)], where[(0, _inv(t.omicron.value))],
                      where[(1, t.height.bit_length() - 1)] if t.height else None) for t in tables}
     return out, per_table
 
@@ -385,8 +399,8 @@ class Table:
         _lib.check(lib.bfs_memset(coeffs.ptr, 0, coeffs.nbytes, stream))
         d_in = columns if isinstance(columns, DeviceBuffer) else DeviceBuffer.from_numpy(columns.reshape(-1))
         self._last_input = d_in
-        omicron_inv = pow(self.omicron.value, P - 2, P)
-        raw_ntt(d_in.ptr, h, h, coeffs.ptr, h + 1, h.bit_length() - 1, ncol, omicron_inv, 1, pow(h, P - 2, P), stream)
+        omicron_inv = _inv(self.omicron.value)
+        raw_ntt(d_in.ptr, h, h, coeffs.ptr, h + 1, h.bit_length() - 1, ncol, omicron_inv, 1, _inv(h), stream)
         n_in = h
         self._coefficients = None
         if randomizers is not None:
@@ -473,7 +487,7 @@ class Table:
         tm = (_u64 * 15)(*[v for t in terminals for v in t])
         params = self.air_params(challenges)
         pr = (_u64 * 3)(*params[0]) if params else None
-        omicron_inv = pow(self.omicron.value, P - 2, P)
+        omicron_inv = _inv(self.omicron.value)
         _lib.check(lib.bfs_air_quotients(self.table_index, self.base_codewords.ptr, self.ext_codewords.ptr, out.ptr,
                                          n.bit_length() - 1, self.unit_distance(n), self.height, omicron_inv,
                                          domain.offset.value, domain.omega.value, ch, tm, pr, stream))
@@ -494,13 +508,14 @@ class Table:
         tm = (_u64 * 15)(*[v for t in terminals for v in t])
         params = self.air_params(challenges)
         pr = (_u64 * 3)(*params[0]) if params else None
-        omicron_inv = pow(self.omicron.value, P - 2, P)
+        omicron_inv = _inv(self.omicron.value)
         _lib.check(lib.bfs_air_combine(self.table_index, self.base_codewords.ptr, self.ext_codewords.ptr, n.bit_length() - 1,
                                        self.unit_distance(n), self.height, omicron_inv, domain.offset.value, domain.omega.value, ch, tm, pr,
                                        ws, randomizer.ptr if randomizer is not None else None,
                                        (_u64 * 3)(*randomizer_weight) if randomizer is not None else None, accumulator.ptr,
                                        (ctypes.c_void_p * 3)(*inverses) if inverses is not None else None, stream))
 
+    _challenge_analysis = (None, None, None, None)
     _generic_totals = {}      # (table, kind, which challenges / terminals / parameters are zero) -> total degrees per constraint
 
     def _constraint_total_degrees(self, kind, challenges, terminals, params):
@@ -517,9 +532,19 @@ class Table:
         brainfuck_stark.py:84-92, or small test values) always take the exact expansion."""
         md = self.interpolant_degree()
         params = self.air_params(challenges)
-        values = [tuple(v) for v in list(challenges) + list(terminals) + list(params)]
-        nonzero = [v for v in values if any(v)]
-        generic = len(set(nonzero)) == len(nonzero) and all(v[0] >> 32 or v[1] or v[2] for v in nonzero)
+        # (a proof asks fifteen times with the same challenges list: its part of the analysis is kept while that list is the argument)
+        # -- only for a tuple of tuples, which cannot change between the calls
+        seen = Table._challenge_analysis          # (one tuple, swapped whole: provers in other threads read a consistent one)
+        if seen[0] is not challenges or type(challenges) is not tuple or not all(type(v) is tuple for v in challenges):
+            ch_values = [tuple(v) for v in challenges]
+            ch_nonzero = [v for v in ch_values if any(v)]
+            seen = Table._challenge_analysis = (challenges, ch_values, set(ch_nonzero),
+                                                len(set(ch_nonzero)) == len(ch_nonzero) and all(v[0] >> 32 or v[1] or v[2] for v in ch_nonzero))
+        rest = [tuple(v) for v in list(terminals) + list(params)]
+        rest_nonzero = [v for v in rest if any(v)]
+        values = seen[1] + rest
+        generic = (seen[3] and len(set(rest_nonzero)) == len(rest_nonzero) and seen[2].isdisjoint(rest_nonzero)
+                   and all(v[0] >> 32 or v[1] or v[2] for v in rest_nonzero))
         if generic:
             key = (type(self).__name__, self.table_index, kind, tuple(any(v) for v in values))
             totals = Table._generic_totals.get(key)
