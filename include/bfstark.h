@@ -230,6 +230,10 @@ int bfs_merkle_build_rows_range(const bfs_row_column* columns, uint32_t ncols, u
                                 int salts_on_device, uint8_t* d_nodes, void* stream);
 int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n, const uint8_t* salts, int salts_on_device,
                           uint8_t* d_nodes, void* stream);
+/* bfs_merkle_build_rows_range that also hands back the root (SaltedMerkle.root(), salted_merkle.py:51-52: what the prover pushes
+ * next, brainfuck_stark.py:179, 198) in the read-back the call ends with anyway.  h_root may be NULL. */
+int bfs_merkle_build_rows_root(const bfs_row_column* columns, uint32_t ncols, uint64_t n, uint64_t limb_stride, const uint8_t* salts,
+                               int salts_on_device, uint8_t* d_nodes, uint8_t h_root[64], void* stream);
 /* nwords (a multiple of 8) pseudo-random words in HBM: 64-byte block j = BLAKE2b-512(seed || j).  For salts that never visit
  * the host (the reference draws os.urandom(24) per leaf, salted_merkle.py:25; the caller seeds this from os.urandom(32)). */
 int bfs_random_fill(const uint8_t seed[32], uint64_t* d_out, uint64_t nwords, void* stream);

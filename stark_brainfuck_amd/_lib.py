@@ -84,6 +84,7 @@ _SIGNATURES = {
     "bfs_stark_push_openings": (ci, [vp, vp, u32, ctypes.c_int32, vp, u32, ctypes.POINTER(u64), u32, u64, vp, vp, ci, vp, vp, ci, vp, u64, vp,
                                      ctypes.POINTER(u64), u32, ctypes.POINTER(u64), u32, ctypes.POINTER(u64), vp]),
     "bfs_merkle_build_rows_range": (ci, [vp, u32, u64, u64, vp, ci, vp, vp]),
+    "bfs_merkle_build_rows_root": (ci, [vp, u32, u64, u64, vp, ci, vp, vp, vp]),
     "bfs_random_fill": (ci, [ctypes.c_char_p, vp, u64, vp]),
     "bfs_xfe_sample_fill": (ci, [ctypes.c_char_p, vp, u64, u64, vp]),
     "bfs_xfe_fold": (ci, [vp, u64, vp, u64, u32, ctypes.POINTER(u64), u64, u64, vp]),

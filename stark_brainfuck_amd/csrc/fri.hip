@@ -53,23 +53,6 @@ __global__ void gather_requests_kernel(const GatherReq* req, u32 count, u64* out
     }
 }
 
-// pinned, device-visible staging for one gather call: a lease on a block of the pooled pinned-host allocator (runtime.cpp:
-// mutex-guarded, size classes, no hipHostMalloc / hipHostFree on the hot path).  One lease per call, so that concurrent provers
-// -- threads, or several devices driven by one process -- never share a staging buffer; the lease goes back when the call returns.
-struct PinnedLease {
-    void* host = nullptr;
-    void* dev = nullptr;
-    int get(size_t need) {
-        BFS_TRY(host_alloc(need < 4096 ? 4096 : need, &host));
-        BFS_HIP(hipHostGetDevicePointer(&dev, host, 0));
-        return BFS_OK;
-    }
-    ~PinnedLease() { if (host) (void)host_release(host); }
-    PinnedLease() = default;
-    PinnedLease(const PinnedLease&) = delete;
-    PinnedLease& operator=(const PinnedLease&) = delete;
-};
-
 // wall-clock breakdown of the last bfs_fri_commit / bfs_fri_query on this thread (ms): see bfs_fri_last_timing
 static thread_local double g_fri_timing[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 static inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }

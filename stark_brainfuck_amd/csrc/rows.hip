@@ -337,13 +337,29 @@ extern "C" int bfs_xfe_sample_fill(const uint8_t seed[32], uint64_t* d_out, uint
     return BFS_OK;
 }
 
+static int build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n, uint64_t limb_stride, const uint8_t* salts, int salts_on_device,
+                      uint8_t* d_nodes, uint8_t* h_root, void* stream_);
+
 extern "C" int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n, const uint8_t* salts, int salts_on_device,
                                      uint8_t* d_nodes, void* stream_) {
-    return bfs_merkle_build_rows_range(columns, ncols, n, n, salts, salts_on_device, d_nodes, stream_);
+    return build_rows(columns, ncols, n, n, salts, salts_on_device, d_nodes, nullptr, stream_);
 }
 
 extern "C" int bfs_merkle_build_rows_range(const bfs_row_column* columns, uint32_t ncols, uint64_t n, uint64_t limb_stride, const uint8_t* salts,
                                            int salts_on_device, uint8_t* d_nodes, void* stream_) {
+    return build_rows(columns, ncols, n, limb_stride, salts, salts_on_device, d_nodes, nullptr, stream_);
+}
+
+extern "C" int bfs_merkle_build_rows_root(const bfs_row_column* columns, uint32_t ncols, uint64_t n, uint64_t limb_stride, const uint8_t* salts,
+                                          int salts_on_device, uint8_t* d_nodes, uint8_t h_root[64], void* stream_) {
+    return build_rows(columns, ncols, n, limb_stride, salts, salts_on_device, d_nodes, h_root, stream_);
+}
+
+// A small proof spends as long around the leaf kernel as in it, so the host traffic is packed: the column description, the cleared
+// error words and the empty pattern set go up in ONE copy from a pinned block, the templates in another, and the error word comes back
+// together with the root (h_root given: the caller's next step is root(), brainfuck_stark.py:179).
+static int build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n, uint64_t limb_stride, const uint8_t* salts, int salts_on_device,
+                      uint8_t* d_nodes, uint8_t* h_root, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (limb_stride < n) { set_error("bfs_merkle_build_rows_range: limb_stride < n"); return BFS_ERR_BAD_ARG; }
     const uint8_t* h_salts = salts_on_device ? nullptr : salts;
@@ -359,24 +375,31 @@ extern "C" int bfs_merkle_build_rows_range(const bfs_row_column* columns, uint32
     const u64 npo2 = 1ull << depth;
 
     // device-side description of the columns, scratch for patterns / salts / flags
-    std::vector<const u64*> h_cols(ncols);
-    std::vector<u32> h_ext(ncols);
-    for (u32 c = 0; c < ncols; ++c) { h_cols[c] = columns[c].d_values; h_ext[c] = columns[c].is_ext ? 1u : 0u; }
     const size_t salt_words = h_salts ? (size_t)3 * n : 0;      // staging only for host salts
     const size_t set_bytes = PATTERN_SLOTS * sizeof(u64);
-    const size_t fixed_bytes = ncols * sizeof(u64*) + ncols * sizeof(u32) + 64 + set_bytes + salt_words * sizeof(u64) + 64;
+    const size_t cols_bytes = (ncols * sizeof(u64*) + 15) & ~(size_t)15, ext_bytes = (ncols * sizeof(u32) + 15) & ~(size_t)15;
+    const size_t head_bytes = cols_bytes + ext_bytes + 16 + set_bytes;       // what the one upload carries
+    const size_t fixed_bytes = head_bytes + salt_words * sizeof(u64) + 64;
     void* w = nullptr;
     BFS_TRY(workspace(5, fixed_bytes, stream, &w));
     char* base = (char*)w;
-    const u64** d_cols = (const u64**)base;                     base += ((ncols * sizeof(u64*) + 15) & ~(size_t)15);
-    u32* d_ext = (u32*)base;                                    base += ((ncols * sizeof(u32) + 15) & ~(size_t)15);
+    const u64** d_cols = (const u64**)base;                     base += cols_bytes;
+    u32* d_ext = (u32*)base;                                    base += ext_bytes;
     u32* d_err = (u32*)base;                                    base += 16;
     u64* d_set = (u64*)base;                                    base += set_bytes;
     u64* d_salts = (u64*)base;
-    BFS_HIP(hipMemcpyAsync(d_cols, h_cols.data(), ncols * sizeof(u64*), hipMemcpyHostToDevice, stream));
-    BFS_HIP(hipMemcpyAsync(d_ext, h_ext.data(), ncols * sizeof(u32), hipMemcpyHostToDevice, stream));
-    BFS_HIP(hipMemsetAsync(d_err, 0, 16, stream));
-    BFS_HIP(hipMemsetAsync(d_set, 0xFF, set_bytes, stream));
+    PinnedLease stage;
+    BFS_TRY(stage.get(head_bytes + 96));
+    {
+        char* h = (char*)stage.host;
+        memset(h, 0, cols_bytes + ext_bytes + 16);
+        for (u32 c = 0; c < ncols; ++c) {
+            ((const u64**)h)[c] = columns[c].d_values;
+            ((u32*)(h + cols_bytes))[c] = columns[c].is_ext ? 1u : 0u;
+        }
+        memset(h + cols_bytes + ext_bytes + 16, 0xFF, set_bytes);
+    }
+    BFS_HIP(hipMemcpyAsync(w, stage.host, head_bytes, hipMemcpyHostToDevice, stream));
     if (h_salts) BFS_TRY(copy_h2d(d_salts, h_salts, salt_words * sizeof(u64), stream));   // test mode: the reference's byte stream
 
     RowArgs a{};
@@ -389,10 +412,10 @@ extern "C" int bfs_merkle_build_rows_range(const bfs_row_column* columns, uint32
     // and unpinned by the runtime, and the unmapping stalls the next dispatches for ~25 ms (profiles/r01/README.md)
     hipLaunchKernelGGL(row_pattern_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, stream, a);
     BFS_HIP(hipGetLastError());
-    std::vector<u64> set(PATTERN_SLOTS + 2);
-    BFS_HIP(hipMemcpyAsync(set.data(), d_err, 16 + set_bytes, hipMemcpyDeviceToHost, stream));   // error words sit right before the set
+    const u64* set = (const u64*)((char*)stage.host + cols_bytes + ext_bytes);          // (the pinned block takes the answer too)
+    BFS_HIP(hipMemcpyAsync((void*)set, d_err, 16 + set_bytes, hipMemcpyDeviceToHost, stream));   // error words sit right before the set
     BFS_HIP(hipStreamSynchronize(stream));
-    if (((const u32*)set.data())[1]) { set_error("bfs_merkle_build_rows: more than %u distinct row patterns", PATTERN_SLOTS); return BFS_ERR_BAD_ARG; }
+    if (((const u32*)set)[1]) { set_error("bfs_merkle_build_rows: more than %u distinct row patterns", PATTERN_SLOTS); return BFS_ERR_BAD_ARG; }
     std::vector<u32> codes;
     for (u32 k = 0; k < PATTERN_SLOTS; ++k)
         if (set[2 + k] != ~0ull) codes.push_back((u32)set[2 + k]);
@@ -405,9 +428,12 @@ extern "C" int bfs_merkle_build_rows_range(const bfs_row_column* columns, uint32
     void* tw = nullptr;
     BFS_TRY(workspace(6, tbytes + sbytes + pbytes + 64, stream, &tw));
     char* tb = (char*)tw;
-    BFS_HIP(hipMemcpyAsync(tb, ht.templates.data(), tbytes, hipMemcpyHostToDevice, stream));
-    BFS_HIP(hipMemcpyAsync(tb + tbytes, ht.segs.data(), sbytes, hipMemcpyHostToDevice, stream));
-    BFS_HIP(hipMemcpyAsync(tb + tbytes + sbytes, ht.pool.data(), pbytes, hipMemcpyHostToDevice, stream));
+    PinnedLease tstage;
+    BFS_TRY(tstage.get(tbytes + sbytes + pbytes + 64));
+    memcpy(tstage.host, ht.templates.data(), tbytes);
+    memcpy((char*)tstage.host + tbytes, ht.segs.data(), sbytes);
+    memcpy((char*)tstage.host + tbytes + sbytes, ht.pool.data(), pbytes);
+    BFS_HIP(hipMemcpyAsync(tb, tstage.host, tbytes + sbytes + pbytes, hipMemcpyHostToDevice, stream));
     a.templates = (const RowTemplate*)tb;
     a.num_templates = (u32)ht.templates.size();
     a.segs = (const RowSeg*)(tb + tbytes);
@@ -417,9 +443,13 @@ extern "C" int bfs_merkle_build_rows_range(const bfs_row_column* columns, uint32
     hipLaunchKernelGGL(row_leaves_kernel, dim3((u32)((n + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0, stream, a);
     BFS_HIP(hipGetLastError());
     BFS_TRY(merkle_inner_launch((u64*)d_nodes, depth, n, stream, nullptr, 0));
-    u32 err = 0;
-    BFS_HIP(hipMemcpyAsync(&err, d_err, sizeof(u32), hipMemcpyDeviceToHost, stream));
+    // error word and root in one copy: nodes[1] is the root (heap order), digests of 8 words
+    char* back = (char*)stage.host;
+    BFS_HIP(hipMemcpyAsync(back, d_err, 16, hipMemcpyDeviceToHost, stream));
+    if (h_root != nullptr) BFS_HIP(hipMemcpyAsync(back + 16, (const u64*)d_nodes + 8, 64, hipMemcpyDeviceToHost, stream));
     BFS_HIP(hipStreamSynchronize(stream));
+    const u32 err = *(const u32*)back;
+    if (h_root != nullptr) memcpy(h_root, back + 16, 64);
     if (err) { set_error("bfs_merkle_build_rows: a row pattern without a template (internal)"); return BFS_ERR_BAD_ARG; }
     return BFS_OK;
 }

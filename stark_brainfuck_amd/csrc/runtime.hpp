@@ -72,4 +72,21 @@ int fri_round_fused_launch(const FriFoldArgs& fold, u64* d_cw, u64 cw_stride, u6
 int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_stride, u32 log_n, u32 batch, u64 root,
                u64 shift, u64 post_scale, hipStream_t stream);
 
+// pinned, device-visible staging for one gather call: a lease on a block of the pooled pinned-host allocator (runtime.cpp:
+// mutex-guarded, size classes, no hipHostMalloc / hipHostFree on the hot path).  One lease per call, so that concurrent provers
+// -- threads, or several devices driven by one process -- never share a staging buffer; the lease goes back when the call returns.
+struct PinnedLease {
+    void* host = nullptr;
+    void* dev = nullptr;
+    int get(size_t need) {
+        BFS_TRY(host_alloc(need < 4096 ? 4096 : need, &host));
+        BFS_HIP(hipHostGetDevicePointer(&dev, host, 0));
+        return BFS_OK;
+    }
+    ~PinnedLease() { if (host) (void)host_release(host); }
+    PinnedLease() = default;
+    PinnedLease(const PinnedLease&) = delete;
+    PinnedLease& operator=(const PinnedLease&) = delete;
+};
+
 }  // namespace bfs

@@ -91,7 +91,9 @@ class ZippedSaltedMerkle(SaltedMerkle):
             self._salts = DeviceBuffer(words)
             _lib.check(lib.bfs_random_fill(urandom(32), self._salts.ptr, words, stream))
             first = self._salts.ptr + 24 * salt_offset
-            _lib.check(lib.bfs_merkle_build_rows_range(cols, len(columns), n, limb_stride, first, 1, self._nodes.ptr, stream))
+            root = ctypes.create_string_buffer(64)
+            _lib.check(lib.bfs_merkle_build_rows_root(cols, len(columns), n, limb_stride, first, 1, self._nodes.ptr, root, stream))
+            self._root = root.raw              # (came back with the call's last read-back)
 
             cache = self._salt_cache = {}
             d_salts = self._salts           # the closure must not hold `self`: tree -> leafs -> closure -> tree would be a cycle
@@ -108,8 +110,10 @@ class ZippedSaltedMerkle(SaltedMerkle):
             assert len(salts) == 24 * n, "24 bytes of salt per leaf"
             keep = ctypes.create_string_buffer(salts, len(salts))
             self._salt_host = keep                   # bfs_stark_push_openings reads opened salts from here
-            _lib.check(lib.bfs_merkle_build_rows_range(cols, len(columns), n, limb_stride, ctypes.cast(keep, ctypes.c_void_p), 0,
-                                                       self._nodes.ptr, stream))
+            root = ctypes.create_string_buffer(64)
+            _lib.check(lib.bfs_merkle_build_rows_root(cols, len(columns), n, limb_stride, ctypes.cast(keep, ctypes.c_void_p), 0,
+                                                      self._nodes.ptr, root, stream))
+            self._root = root.raw
 
             def salt_of(i):
                 return salts[24 * i:24 * i + 24]
