@@ -159,6 +159,9 @@ uint64_t bfs_ps_obj_item(void* ps, uint64_t handle, size_t i);
 int bfs_ps_obj_get_bytes(void* ps, uint64_t handle, uint8_t* out, size_t capacity);
 int bfs_ps_obj_get_limbs(void* ps, uint64_t handle, uint64_t limbs[3]);
 /* BaseField.sample / ExtensionField.sample: big-endian bytes -> element        algebra.py:138-142, extension_field.py:100-111 */
+/* BrainfuckStark.sample_weights (brainfuck_stark.py:104-112): `count` extension elements, weight i = ExtensionField.sample of
+ * blake2b(randomness || i zero bytes); out: 3 * count limbs.  Host code (a proof draws ~170 of them). */
+int bfs_sample_weights(const uint8_t* randomness, size_t len, size_t count, uint64_t* out);
 uint64_t bfs_gl_sample(const uint8_t* bytes, size_t len);
 void bfs_xfe_sample(const uint8_t* bytes, size_t len, uint64_t out[3]);
 

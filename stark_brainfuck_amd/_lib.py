@@ -65,6 +65,7 @@ _SIGNATURES = {
     "bfs_ps_object_at": (u64, [vp, sz]),
     "bfs_ps_serialize": (ci, [vp, sz, vp, sz, ctypes.POINTER(sz)]),
     "bfs_ps_fiat_shamir": (ci, [vp, sz, vp, sz]),
+    "bfs_sample_weights": (ci, [ctypes.c_char_p, sz, sz, ctypes.POINTER(u64)]),
     "bfs_ps_push_digest_fiat_shamir": (ci, [vp, ctypes.c_char_p, vp, sz]),
     "bfs_ps_push_digests_fiat_shamir": (ci, [vp, ctypes.c_char_p, sz, vp, sz, ctypes.POINTER(ci)]),
     "bfs_ps_obj_dumps": (ci, [vp, u64, vp, sz, ctypes.POINTER(sz)]),

@@ -36,7 +36,7 @@ from .permutation_argument import PermutationArgument
 from .processor_table import ProcessorTable
 from .salted_merkle import SaltedMerkle, ZippedSaltedMerkle
 from .algebra import P_GOLDILOCKS
-from .table import extend_tables_device, sample_ext, sample_ext_many, zerofier_inverses
+from .table import extend_tables_device, lde_tables, sample_ext, sample_ext_many, zerofier_inverses
 from .univariate import Polynomial
 from .vm import VirtualMachine
 
@@ -104,6 +104,14 @@ class BrainfuckStark:
     def _sample_weights(number, randomness):
         """:104-112: weight i = ExtensionField.sample(blake2b(randomness + bytes(i)).digest()), i.e. the three 21-byte big-endian
         chunks of the digest mod p (extension_field.py:100-111; the 64th byte is not used).  One integer conversion per digest."""
+        if number > 4:             # natively (bfs_sample_weights): 157 digests and 471 reductions are ~150 us of a 4 ms proof in Python
+            import ctypes
+            lib = _lib.load()
+            raw = (ctypes.c_uint64 * (3 * number))()
+            randomness = bytes(randomness)
+            _lib.check(lib.bfs_sample_weights(randomness, len(randomness), number, raw))
+            flat = list(raw)
+            return [(flat[3 * i], flat[3 * i + 1], flat[3 * i + 2]) for i in range(number)]
         out, mask = [], (1 << 168) - 1
         for i in range(number):
             v = int.from_bytes(blake2b(randomness + bytes(i)).digest()[:63], "big")
@@ -279,8 +287,7 @@ class BrainfuckStark:
 
         lap("randomizer")
         # base codewords of all tables, one commitment to the zipped rows (:169-179)
-        for table in self.tables:
-            table.lde(domain)
+        lde_tables(self.tables, domain)
         base_degree_bounds = [t.interpolant_degree() for t in self.tables for _ in range(t.base_width)]
         lap("base_lde")
         f2 = BrainfuckStark.field
@@ -318,8 +325,7 @@ class BrainfuckStark:
         lap("extend")
 
         # extension codewords and their commitment (:194-201)
-        for table in self.tables:
-            table.ldex(domain, xf)
+        lde_tables(self.tables, domain, extension=True)
         extension_degree_bounds = [t.interpolant_degree() for t in self.tables for _ in range(t.full_width - t.base_width)]
         lap("ext_lde")
         num_ext_columns = sum(t.full_width - t.base_width for t in self.tables)

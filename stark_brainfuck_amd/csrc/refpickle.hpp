@@ -634,9 +634,16 @@ struct Transcript {
 
 // BaseField.sample (algebra.py:138-142): big-endian bytes -> integer mod p
 inline u64 sample_base(const unsigned char* b, size_t len) {
-    u128 acc = 0;
-    for (size_t i = 0; i < len; ++i) acc = ((acc << 8) | b[i]) % GL_P;
-    return (u64)acc;
+    // eight bytes at a time: acc <- acc * 2^64 + word, 2^64 = 2^32 - 1 (mod p)   (was one 128-bit division per byte)
+    u64 acc = 0;
+    size_t i = 0;
+    for (; i < len % 8; ++i) acc = (acc << 8) | b[i];
+    for (; i < len; i += 8) {
+        u64 w = 0;
+        for (int k = 0; k < 8; ++k) w = (w << 8) | b[i + k];
+        acc = gl_add(gl_mul(acc % GL_P, 0xFFFFFFFFULL), w % GL_P);
+    }
+    return acc % GL_P;
 }
 // ExtensionField.sample (extension_field.py:100-111): three chunks of len//3 bytes
 inline Xfe sample_xfe(const unsigned char* b, size_t len) {

@@ -13,6 +13,9 @@
 //      one 128-byte block buffer per lane in LDS, compressed whenever it fills.  The preimage never exists in memory.
 #include <algorithm>
 #include <map>
+#include <memory>
+#include <mutex>
+#include <string>
 #include <vector>
 
 #include "blake2b.hpp"
@@ -239,6 +242,9 @@ struct HostTemplates {
     std::vector<u64> pool;
 };
 
+static std::mutex g_template_mu;
+static std::map<std::string, std::shared_ptr<const HostTemplates>> g_template_cache;
+
 static void add_const(HostTemplates& ht, const std::string& bytes, size_t from, size_t to) {
     if (to <= from) return;
     RowSeg sg{SEG_CONST, (u32)ht.pool.size(), (u32)(to - from), 0};
@@ -421,9 +427,28 @@ static int build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n,
         if (set[2 + k] != ~0ull) codes.push_back((u32)set[2 + k]);
     std::sort(codes.begin(), codes.end());
 
-    // 2. one template per pattern
-    HostTemplates ht;
-    for (u32 code : codes) BFS_TRY(build_template(columns, ncols, code, salted, ht));
+    // 2. one template per pattern.  The same few patterns come back proof after proof (a pattern is the degree class of every
+    // extension element of the row: "all of degree 2" and a handful around all-zero columns), and making a template means pickling a
+    // row of sentinels -- ~30 us each: the finished sets are remembered per (column layout, patterns).
+    std::string key((const char*)&ncols, sizeof ncols);
+    for (u32 c = 0; c < ncols; ++c) { const int32_t d[2] = {columns[c].is_ext ? 1 : 0, columns[c].field_id}; key.append((const char*)d, sizeof d); }
+    key.push_back(salted ? 1 : 0);
+    key.append((const char*)codes.data(), codes.size() * sizeof(u32));
+    std::shared_ptr<const HostTemplates> cached;
+    {
+        std::lock_guard<std::mutex> lock(g_template_mu);
+        auto it = g_template_cache.find(key);
+        if (it != g_template_cache.end()) cached = it->second;
+    }
+    if (!cached) {
+        std::shared_ptr<HostTemplates> fresh(new HostTemplates());
+        for (u32 code : codes) BFS_TRY(build_template(columns, ncols, code, salted, *fresh));
+        std::lock_guard<std::mutex> lock(g_template_mu);
+        if (g_template_cache.size() >= 256) g_template_cache.clear();
+        g_template_cache[key] = fresh;
+        cached = fresh;
+    }
+    const HostTemplates& ht = *cached;
     const size_t tbytes = ht.templates.size() * sizeof(RowTemplate), sbytes = ht.segs.size() * sizeof(RowSeg), pbytes = ht.pool.size() * sizeof(u64);
     void* tw = nullptr;
     BFS_TRY(workspace(6, tbytes + sbytes + pbytes + 64, stream, &tw));

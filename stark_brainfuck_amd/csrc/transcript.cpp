@@ -1,6 +1,9 @@
 // transcript.cpp -- C ABI over rp::Transcript (proof stream / Fiat-Shamir, host side).
 // Declarations and reference citations: include/bfstark.h ("proof stream").
+#include <vector>
+
 #include "../../include/bfstark.h"
+#include "blake2b.hpp"
 #include "refpickle.hpp"
 #include "runtime.hpp"
 
@@ -151,6 +154,20 @@ int bfs_ps_obj_get_limbs(void* ps, uint64_t handle, uint64_t limbs[3]) {
     if (!r) return bad_handle(handle);
     if (r->kind == rp::K_INT) { limbs[0] = r->ival; limbs[1] = limbs[2] = 0; return BFS_OK; }
     for (int i = 0; i < 3; ++i) limbs[i] = r->limbs[i];
+    return BFS_OK;
+}
+
+/* BrainfuckStark.sample_weights (brainfuck_stark.py:104-112): weight i = ExtensionField.sample(blake2b(randomness + bytes(i)).digest()),
+ * bytes(i) being i zero bytes; out: 3 * count limbs */
+int bfs_sample_weights(const uint8_t* randomness, size_t len, size_t count, uint64_t* out) {
+    std::vector<unsigned char> msg(len + count, 0);
+    if (len) memcpy(msg.data(), randomness, len);
+    for (size_t i = 0; i < count; ++i) {
+        unsigned char digest[64];
+        blake2b_host(msg.data(), len + i, digest);
+        const Xfe x = rp::sample_xfe(digest, 64);          // three chunks of 64 // 3 = 21 bytes; the 64th byte is not used
+        for (int k = 0; k < 3; ++k) out[3 * i + k] = x.c[k];
+    }
     return BFS_OK;
 }
 

@@ -68,6 +68,27 @@ class DeviceBuffer:
             pass
 
 
+class DeviceView:
+    """`count` words starting `offset` words into a DeviceBuffer, which it keeps alive (the codewords of one table inside the buffer
+    a batched transform wrote for all tables)"""
+
+    def __init__(self, owner, offset, count):
+        self.owner, self.count, self.nbytes = owner, int(count), int(count) * 8
+        self.ptr = owner.ptr + 8 * int(offset)
+
+    def to_numpy(self, count=None, offset=0, stream=None):
+        count = self.count - offset if count is None else count
+        out = np.empty(count, dtype=np.uint64)
+        if count:
+            _lib.check(_lib.load().bfs_memcpy_d2h(out.ctypes.data, self.ptr + 8 * offset, count * 8,
+                                                  stream if stream is not None else current_stream()))
+        return out
+
+    def free(self):
+        """drop the share of the underlying buffer (which goes back to the pool with its last view)"""
+        self.owner, self.ptr = None, None
+
+
 class GatherBatch:
     """scattered reads collected first and fetched in ONE round trip: add() returns a ticket, run() gathers, words(ticket) gives
     that request's words.  (A proof opens ~10 rows of three trees; one gather per row and path costs ~30 us each.)"""

@@ -174,6 +174,75 @@ def extend_tables_device(tables, all_challenges, all_initials):
                         lambda k, row, t=t: tuple(int(v) for v in batch.words(read_tickets[(t, k, row)])))
 
 
+def lde_tables(tables, domain, extension=False):
+    """Table.lde (extension=False) or Table.ldex (True) of several tables with ONE transform onto the FRI domain: every table still
+    interpolates its own columns (its own subgroup), into a shared coefficient buffer, but the coset evaluation -- the same
+    N-point transform for all of them -- runs once over all columns (three launches instead of three per table; on short traces the
+    launches are the cost).  Randomizers are drawn table by table, column by column, as the separate calls draw them."""
+    lib, stream = _lib.load(), current_stream()
+    n = domain.length
+    log_n = n.bit_length() - 1
+    widths = [3 * (t.full_width - t.base_width) if extension else t.base_width for t in tables]
+    total, hmax = sum(widths), max(t.height for t in tables)
+    if total == 0 or hmax == 0:
+        for t in tables:
+            t.ldex(domain) if extension else t.lde(domain)
+        return
+    randomized = any(t.height and t.num_randomizers for t in tables)
+    stride = hmax + 1
+    n_in = hmax + 1 if randomized else hmax
+    assert n_in <= n, "interpolant does not fit the FRI domain"
+    coeffs = DeviceBuffer(total * stride)
+    _lib.check(lib.bfs_memset(coeffs.ptr, 0, coeffs.nbytes, stream))
+    out = DeviceBuffer(total * n)
+    omega, offset = domain.omega.value, domain.offset.value
+    at, inputs = 0, []
+    for t, w in zip(tables, widths):
+        h = t.height
+        d_in = None
+        if h and w:
+            if extension:
+                if getattr(t, "_ext_device", None) is not None:      # after extend_device(): already in HBM, (column, limb) planes
+                    d_in = t._ext_device
+                else:
+                    cols = staging_empty((w, h))
+                    np.concatenate(t.ext_columns, axis=0, out=cols)
+                    d_in = DeviceBuffer.from_numpy(cols.reshape(-1))
+            else:
+                d_in = DeviceBuffer.from_numpy(t.base_array().reshape(-1))
+            rand = None
+            if t.num_randomizers:
+                if extension:
+                    rand = [v for _ in range(w // 3) for v in sample_ext(urandom(3 * 8))]
+                else:
+                    rand = [sample_base(urandom(3 * 8)) for _ in range(w)]
+            mine = coeffs.ptr + 8 * at * stride
+            raw_ntt(d_in.ptr, h, h, mine, stride, h.bit_length() - 1, w, _inv(t.omicron.value), 1, _inv(h), stream)
+            if rand is not None:
+                _lib.check(lib.bfs_poly_randomize(mine, stride, h, w, omega, (_u64 * w)(*[int(v) for v in rand]), stream))
+        inputs.append(d_in)
+        at += w
+    raw_ntt(coeffs.ptr, n_in, stride, out.ptr, n, log_n, total, omega, offset, 1, stream)
+    masks = None
+    if extension:      # see Table.ext_sharing_moduli: a per-polynomial summary of the support
+        raw = (_u64 * total)()
+        _lib.check(lib.bfs_poly_support(coeffs.ptr, stride, n_in, total, raw, stream))
+        masks = [int(v) for v in raw]
+    from .device import DeviceView
+    at = 0
+    for t, w, d_in in zip(tables, widths, inputs):
+        view = DeviceView(out, at * n, w * n)
+        t._n = n
+        if extension:
+            t.ext_codewords = view
+            t._coefficients = masks[at:at + w] if t.height else None
+        else:
+            t.base_codewords = view
+            t._base_device = d_in          # the trace columns stay in HBM for extend_device()
+        t._last_input = None
+        at += w
+
+
 def zerofier_inverses(tables, domain):
     """bfs_zerofier_inverses for a set of tables: one kernel inverts every distinct zerofier denominator of the proof at every point.
     Returns (buffer, {table: (addr of 1/(x-1), addr of 1/(x - omicron^-1), addr of 1/(x^h - 1) or None)})."""
