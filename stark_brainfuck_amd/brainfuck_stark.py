@@ -101,7 +101,7 @@ class BrainfuckStark:
                 self.instruction_table.evaluation_terminal]
 
     @staticmethod
-    def _sample_weights(number, randomness):
+    def _sample_weights(number, randomness, as_array=False):
         """:104-112: weight i = ExtensionField.sample(blake2b(randomness + bytes(i)).digest()), i.e. the three 21-byte big-endian
         chunks of the digest mod p (extension_field.py:100-111; the 64th byte is not used).  One integer conversion per digest."""
         if number > 4:             # natively (bfs_sample_weights): 157 digests and 471 reductions are ~150 us of a 4 ms proof in Python
@@ -110,13 +110,15 @@ class BrainfuckStark:
             raw = (ctypes.c_uint64 * (3 * number))()
             randomness = bytes(randomness)
             _lib.check(lib.bfs_sample_weights(randomness, len(randomness), number, raw))
+            if as_array:           # (number, 3) uint64: the prover hands the weights on to the kernels as they are
+                return np.frombuffer(raw, dtype=np.uint64).reshape(number, 3)
             flat = list(raw)
             return [(flat[3 * i], flat[3 * i + 1], flat[3 * i + 2]) for i in range(number)]
         out, mask = [], (1 << 168) - 1
         for i in range(number):
             v = int.from_bytes(blake2b(randomness + bytes(i)).digest()[:63], "big")
             out.append(((v >> 336) % P_GOLDILOCKS, ((v >> 168) & mask) % P_GOLDILOCKS, (v & mask) % P_GOLDILOCKS))
-        return out
+        return np.array(out, dtype=np.uint64).reshape(number, 3) if as_array else out
 
     def sample_weights(self, number, randomness):
         """:111-112, as extension-field element objects"""
@@ -408,13 +410,20 @@ class BrainfuckStark:
         num_ext = sum(t.full_width - t.base_width for t in self.tables)
         num_quot = len(quotient_degree_bounds)
         weights_seed = proof_stream.prover_fiat_shamir()
-        weights = BrainfuckStark._sample_weights(1 + 2 * (num_base + num_ext + num_quot), weights_seed)
+        weight_array = BrainfuckStark._sample_weights(1 + 2 * (num_base + num_ext + num_quot), weights_seed, as_array=True)
+        weight0 = tuple(int(v) for v in weight_array[0])
 
         # terms in the order of the reference's `terms` list (:245-293): base, extension, quotient codewords; term s has the
-        # weights 1 + 2s, 2 + 2s and is shifted to the common degree bound
+        # weights 1 + 2s, 2 + 2s and is shifted to the common degree bound.  One row of seven words per term (bfs_comb_weight).
         bounds = base_degree_bounds + extension_degree_bounds + quotient_degree_bounds
-        assert 1 + 2 * len(bounds) == len(weights)
-        term = [(weights[1 + 2 * s], weights[2 + 2 * s], self.max_degree - bound) for s, bound in enumerate(bounds)]
+        assert 1 + 2 * len(bounds) == len(weight_array)
+        terms = np.empty((len(bounds), 7), dtype=np.uint64)
+        terms[:, 0:3] = weight_array[1::2]
+        terms[:, 3:6] = weight_array[2::2]
+        terms[:, 6] = [self.max_degree - bound for bound in bounds]
+
+        def term_of(s):
+            return tuple(int(v) for v in terms[s, 0:3]), tuple(int(v) for v in terms[s, 3:6]), int(terms[s, 6])
         combination = XArray.empty(n, xf)
         if self.keep_intermediates:
             sources = []
@@ -430,10 +439,11 @@ class BrainfuckStark:
             assert len(sources) == len(bounds)
             srcs = (_lib.CombSource * len(sources))()
             for s, (ptr, is_ext) in enumerate(sources):
-                srcs[s].ptr, srcs[s].is_ext, srcs[s].shift = ptr, is_ext, term[s][2]
-                srcs[s].wa = (_u64 * 3)(*term[s][0])
-                srcs[s].wb = (_u64 * 3)(*term[s][1])
-            _lib.check(lib.bfs_combination(srcs, len(sources), randomizer_codeword.ptr, (_u64 * 3)(*weights[0]), combination.ptr,
+                wa, wb, shift = term_of(s)
+                srcs[s].ptr, srcs[s].is_ext, srcs[s].shift = ptr, is_ext, shift
+                srcs[s].wa = (_u64 * 3)(*wa)
+                srcs[s].wb = (_u64 * 3)(*wb)
+            _lib.check(lib.bfs_combination(srcs, len(sources), randomizer_codeword.ptr, (_u64 * 3)(*weight0), combination.ptr,
                                            log_n, domain.offset.value, domain.omega.value, stream))
         else:
             inverse_buffer, inverses = zerofier_inverses(self.tables, domain)      # all zerofier denominators, one inversion per point
@@ -441,14 +451,14 @@ class BrainfuckStark:
             quot_at = num_base + num_ext
             for k, t in enumerate(self.tables):
                 bw, xw, nq = t.base_width, t.full_width - t.base_width, t.num_quotients()
-                mine = term[base_at:base_at + bw] + term[num_base + ext_at:num_base + ext_at + xw] + term[quot_at:quot_at + nq]
+                mine = np.concatenate([terms[base_at:base_at + bw], terms[num_base + ext_at:num_base + ext_at + xw], terms[quot_at:quot_at + nq]])
                 t.combine_into(domain, challenges, terminals, mine, combination,
-                               randomizer=randomizer_codeword if k == 0 else None, randomizer_weight=weights[0], inverses=inverses[t])
+                               randomizer=randomizer_codeword if k == 0 else None, randomizer_weight=weight0, inverses=inverses[t])
                 base_at, ext_at, quot_at = base_at + bw, ext_at + xw, quot_at + nq
             for pa in self.permutation_arguments:
-                pa.combine_into(domain, term[quot_at], combination, inv_x_minus_1=inverses[self.tables[0]][0])
+                pa.combine_into(domain, term_of(quot_at), combination, inv_x_minus_1=inverses[self.tables[0]][0])
                 quot_at += 1
-            assert quot_at == len(term)
+            assert quot_at == len(terms)
             inverse_buffer.free()
 
         if not self.keep_intermediates:

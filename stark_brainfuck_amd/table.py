@@ -570,9 +570,14 @@ class Table:
         lib, stream = _lib.load(), current_stream()
         n = domain.length
         assert len(weights) == self.full_width - self.base_width + self.base_width + self.num_quotients()
-        ws = (_lib.CombWeight * len(weights))()
-        for w, (wa, wb, shift) in zip(ws, weights):
-            w.wa, w.wb, w.shift = (_u64 * 3)(*wa), (_u64 * 3)(*wb), shift
+        if isinstance(weights, np.ndarray):          # rows of seven words = bfs_comb_weight, as the prover lays them out
+            weights = np.ascontiguousarray(weights, dtype=np.uint64)
+            assert weights.shape[1] == 7
+            ws = ctypes.c_void_p(weights.ctypes.data)
+        else:
+            ws = (_lib.CombWeight * len(weights))()
+            for w, (wa, wb, shift) in zip(ws, weights):
+                w.wa, w.wb, w.shift = (_u64 * 3)(*wa), (_u64 * 3)(*wb), shift
         ch = (_u64 * 33)(*[v for c in challenges for v in c])
         tm = (_u64 * 15)(*[v for t in terminals for v in t])
         params = self.air_params(challenges)
@@ -585,6 +590,7 @@ class Table:
                                        (ctypes.c_void_p * 3)(*inverses) if inverses is not None else None, stream))
 
     _challenge_analysis = (None, None, None, None)
+    _generic_bounds = {}      # ((table, kind, zero pattern), interpolant degree) -> the bounds themselves
     _generic_totals = {}      # (table, kind, which challenges / terminals / parameters are zero) -> total degrees per constraint
 
     def _constraint_total_degrees(self, kind, challenges, terminals, params):
@@ -616,12 +622,20 @@ class Table:
                    and all(v[0] >> 32 or v[1] or v[2] for v in rest_nonzero))
         if generic:
             key = (type(self).__name__, self.table_index, kind, tuple(any(v) for v in values))
+            bounds = Table._generic_bounds.get((key, md))
+            if bounds is not None:
+                return list(bounds)
             totals = Table._generic_totals.get(key)
             if totals is None:
                 totals = Table._generic_totals[key] = self._constraint_total_degrees(kind, challenges, terminals, params)
         else:
             totals = self._constraint_total_degrees(kind, challenges, terminals, params)
-        return [max([-1] + [t * md for t in ts]) for ts in totals]
+        bounds = [max([-1] + [t * md for t in ts]) for ts in totals]
+        if generic:
+            if len(Table._generic_bounds) > 4096:
+                Table._generic_bounds.clear()
+            Table._generic_bounds[(key, md)] = tuple(bounds)
+        return bounds
 
     def boundary_quotient_degree_bounds(self, challenges):
         return [b - 1 for b in self._degree_bounds("boundary", challenges, [air.X0] * 5)]
