@@ -760,6 +760,54 @@ def test_device_scan_matches_the_host_scan(sb, n):
 
 
 @pytest.mark.gpu
+def test_scans_side_by_side_match_the_host_scan(sb):
+    """bfs_xfe_scan_device_many: scans of different kinds, lengths (1 .. 70 000 rows: one workgroup up to the 256-workgroup cap with
+    several rows per thread), masks, shifts and recording modes in ONE call (blockIdx.y = scan), each against the sequential host
+    primitive; the bad-argument paths"""
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.device import DeviceBuffer, current_stream
+    from stark_brainfuck_amd.table import Table
+    lib, stream = _lib.load(), current_stream()
+    P = (1 << 64) - (1 << 32) + 1
+    rng = np.random.default_rng(77)
+    u64 = ctypes.c_uint64
+    plans = [(0, 3, True, True, 0, 1), (1, 1, False, False, 0, 2), (0, 2, True, False, 3, 255), (1, 3, True, True, 1, 256), (1, 1, True, False, 0, 257),
+             (0, 3, False, True, 0, 4096), (0, 1, True, False, 5, 65536), (1, 2, False, False, 0, 70000), (0, 3, True, True, 0, 1000)]
+    specs, keep, wants = [], [], []
+    for kind, ncols, use_mask, before, shift1, n in plans:
+        cols = rng.integers(0, P, (3, n), dtype=np.uint64)
+        cols[1, rng.integers(0, n, max(1, n // 7))] = 0
+        d_cols = DeviceBuffer.from_numpy(cols.reshape(-1))
+        mask = rng.integers(0, 4, n) != 0
+        d_mask = DeviceBuffer((n + 7) // 8)
+        m8 = np.ascontiguousarray(mask, dtype=np.uint8)
+        _lib.check(lib.bfs_memcpy_h2d(d_mask.ptr, m8.ctypes.data, n, stream))
+        constants = [tuple(int(v) for v in rng.integers(0, P, 3, dtype=np.uint64)) for _ in range(1 + ncols)]
+        initial = tuple(int(v) for v in rng.integers(0, P, 3, dtype=np.uint64))
+        host_cols = [cols[c] for c in range(ncols)]
+        shift1 %= n
+        if shift1:
+            host_cols[0] = np.roll(host_cols[0], -shift1)
+        wants.append(Table.scan(kind, host_cols, mask if use_mask else None, constants, initial, before))
+        out, d_terminal = DeviceBuffer(3 * n), DeviceBuffer(3)
+        ptrs = [d_cols.ptr + 8 * c * n for c in range(ncols)] + [None] * (3 - ncols)
+        flat = [v for c in constants for v in c] + [0] * (12 - 3 * len(constants))
+        specs.append(_lib.ScanSpec(kind, 1 if before else 0, ptrs[0], ptrs[1], ptrs[2], shift1, d_mask.ptr if use_mask else None, n,
+                                   (u64 * 12)(*flat), (u64 * 3)(*initial), out.ptr, n, d_terminal.ptr))
+        keep.append((d_cols, d_mask, out, d_terminal, n))
+    _lib.check(lib.bfs_xfe_scan_device_many((_lib.ScanSpec * len(specs))(*specs), len(specs), stream))
+    for plan, (_, _, out, d_terminal, n), (want, want_terminal) in zip(plans, keep, wants):
+        assert tuple(int(v) for v in d_terminal.to_numpy(3)) == want_terminal, plan
+        assert (out.to_numpy(3 * n).reshape(3, n) == want).all(), plan
+    assert lib.bfs_xfe_scan_device_many(None, 0, stream) == 0
+    bad = _lib.ScanSpec(2, 0, keep[0][0].ptr, None, None, 0, None, 1, (u64 * 12)(), (u64 * 3)(), keep[0][2].ptr, 1, None)
+    assert lib.bfs_xfe_scan_device_many((_lib.ScanSpec * 1)(bad), 1, stream) != 0 and b"kind" in lib.bfs_last_error()
+    empty = _lib.ScanSpec(0, 0, keep[0][0].ptr, None, None, 0, None, 0, (u64 * 12)(), (u64 * 3)(), keep[0][2].ptr, 1, None)
+    assert lib.bfs_xfe_scan_device_many((_lib.ScanSpec * 1)(empty), 1, stream) != 0
+    assert lib.bfs_xfe_scan_device_many((_lib.ScanSpec * 65)(*([specs[0]] * 65)), 65, stream) != 0
+
+
+@pytest.mark.gpu
 def test_memory_pools(sb):
     """bfs_malloc_async / bfs_free_async: a freed block is handed out again without going to the driver, the statistics add up,
     bfs_pool_trim gives the cache back, pinned staging arrays copy correctly, the stream-less pair keeps hipMalloc semantics"""

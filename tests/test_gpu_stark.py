@@ -222,3 +222,53 @@ def test_prove_from_plain_lists_of_elements(name, monkeypatch):
     stark = BrainfuckStark(running_time, len(matrices[1]), program, input_symbols, output_symbols)
     proof = stark.prove(program, *matrices)
     assert hashlib.sha256(proof).hexdigest() == g["proof_sha256"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("code, inputs", [("++>+++[<+>-]<.", ""), (",.,.", "ab"), ("+++[>+++[>++<-]<-]>>.", "")])
+def test_one_transform_for_all_tables_equals_one_per_table(code, inputs, monkeypatch):
+    """table.lde_tables (every table interpolated into its rows of one coefficient buffer, ONE coset transform over the columns of all
+    tables) against Table.lde / Table.ldex called table by table (table.py:112-148 of the reference does the latter): same
+    randomizers in the same order, so the codewords, the trace columns kept in HBM and the support summaries must be identical --
+    also for tables of height zero (no input / no output)."""
+    from stark_brainfuck_amd import table
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.table import extend_tables_device, lde_tables
+    from stark_brainfuck_amd.vm import VirtualMachine
+    program = VirtualMachine.compile(code)
+    running_time, input_symbols, output_symbols = VirtualMachine.run(program, input_data=list(inputs))
+    challenges = tuple((3 + 7 * k + (1 << 40), 5 + k + (1 << 33), 11 * k + (1 << 35)) for k in range(11))
+    initials = [(1 << 34, 3, 1 << 50), (1 << 41, 9, 1 << 36)]
+    results = []
+    for batched in (False, True):
+        monkeypatch.setattr(table, "urandom", Stream(b"lde-" + code.encode()))
+        matrices = VirtualMachine.simulate(program, input_data=list(input_symbols))
+        stark = BrainfuckStark(running_time, len(matrices[1]), program, input_symbols, output_symbols)
+        for t, m in zip(stark.tables, (matrices[0], matrices[2], matrices[1], matrices[3], matrices[4])):
+            t.matrix = m
+        for t in (stark.processor_table, stark.memory_table, stark.instruction_table, stark.input_table, stark.output_table):
+            t.pad()
+        domain, n = stark.fri.domain, stark.fri.domain.length
+        if batched:
+            lde_tables(stark.tables, domain)
+        else:
+            for t in stark.tables:
+                t.lde(domain)
+        base = [t.base_codewords.to_numpy(t.base_width * n) for t in stark.tables]
+        kept = [t._base_device.to_numpy() if t._base_device is not None else None for t in stark.tables]
+        extend_tables_device(stark.tables, challenges, initials)
+        if batched:
+            lde_tables(stark.tables, domain, extension=True)
+        else:
+            for t in stark.tables:
+                t.ldex(domain)
+        ext = [t.ext_codewords.to_numpy(3 * (t.full_width - t.base_width) * n) for t in stark.tables]
+        results.append((base, kept, ext, [t.ext_sharing_moduli(n) for t in stark.tables], [t.height for t in stark.tables]))
+    (base_a, kept_a, ext_a, moduli_a, heights), (base_b, kept_b, ext_b, moduli_b, _) = results
+    assert 0 in heights or inputs        # at least the input table is empty in the programs without input
+    for k in range(5):
+        assert np.array_equal(base_a[k], base_b[k]), k
+        assert np.array_equal(ext_a[k], ext_b[k]), k
+        assert (kept_a[k] is None) == (kept_b[k] is None) and (kept_a[k] is None or np.array_equal(kept_a[k], kept_b[k]))
+    assert moduli_a == moduli_b
+    assert any(a.any() for a in base_a) and any(a.any() for a in ext_a)
