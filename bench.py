@@ -379,12 +379,14 @@ def bench_stark(code=None, label="Hello World!"):
     matrices = VirtualMachine.simulate(program, input_data=inputs)
     trace_ms = (time.perf_counter() - t0) * 1e3
     times, timing, proof = [], None, None
-    for rep in range(4):
+    rep = 0
+    while rep < 4 or (rep < 24 and times[-1] < 0.008):       # a short proof is repeated more often: the median of 3 wobbled by 10 %
         stark = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs)
         t0 = time.perf_counter()
         proof = stark.prove(program, *matrices)
         times.append(time.perf_counter() - t0)
         timing = stark.timing
+        rep += 1
     t0 = time.perf_counter()
     ok = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs).verify(proof)
     verify_ms = (time.perf_counter() - t0) * 1e3
