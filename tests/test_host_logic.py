@@ -281,6 +281,45 @@ def test_lookahead_fiat_shamir_equals_hashing_afterwards(sb):
     assert took_the_lookahead_route >= 10          # (streams of fewer than two objects fall back)
 
 
+def test_helper_threads_are_restarted_in_a_forked_child(sb):
+    """the helper pool (csrc/helper_pool.hpp) belongs to the process that started it: a fork()ed child has the pool object but none
+    of its threads, and must start its own instead of waiting for jobs nobody runs"""
+    import ctypes
+    import hashlib
+    import os
+    import pickle
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.ip import NativeTranscript
+    lib = _lib.load()
+
+    def run(tag):
+        t = NativeTranscript()
+        objects = [bytes([k]) * 40 for k in range(200)]
+        for obj in objects:
+            t.push(obj)
+        digests = hashlib.shake_256(tag).digest(64 * 6)
+        out = ctypes.create_string_buffer(32 * 6)
+        used = ctypes.c_int(-1)
+        _lib.check(lib.bfs_ps_push_digests_fiat_shamir(t.handle, digests, 6, out, 32, ctypes.byref(used)))
+        for k in range(6):
+            objects.append(digests[64 * k:64 * k + 64])
+            if out.raw[32 * k:32 * k + 32] != hashlib.shake_256(pickle.dumps(objects, protocol=4)).digest(32):
+                return False
+        return used.value == 1
+
+    assert run(b"parent")
+    pid = os.fork()
+    if pid == 0:
+        code = 3
+        try:
+            code = 0 if run(b"child") else 1
+        finally:
+            os._exit(code)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
+    assert run(b"parent again")
+
+
 def test_fastlist_conversions_match_the_python_loops():
     """cpyext/fastlist.c: lists of element objects <-> uint64 buffers.  Same values, same object structure (trimmed coefficient
     lists, field references) -- checked through CPython's pickle of both results -- and the fallbacks for odd inputs."""
