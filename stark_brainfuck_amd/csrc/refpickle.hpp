@@ -139,6 +139,7 @@ class Pickler {
     std::string dumps(const Ref& root) {
         out_.clear();
         memo_.clear();
+        memo_next_ = 0;
         int_marks.clear();
         frame_start_ = NPOS;
         framing_ = false;
@@ -160,6 +161,7 @@ class Pickler {
     void stream_begin() {
         out_.clear();
         memo_.clear();
+        memo_next_ = 0;
         int_marks.clear();
         frame_start_ = NPOS;
         framing_ = false;
@@ -181,14 +183,15 @@ class Pickler {
     size_t stream_size() const { return out_.size(); }
     // the open form can be extended tentatively: stream_mark(), stream_item() of objects that are not part of the stream (yet),
     // stream_bytes(), then stream_rollback(mark, those objects) -- Transcript::Lookahead pickles the NEXT rounds' streams that way
-    struct StreamMark { size_t size, frame, items, batch; std::string header; };
+    struct StreamMark { size_t size, frame, items, batch; uint32_t memo_next; std::string header; };
     StreamMark stream_mark() const {
-        StreamMark m{out_.size(), frame_start_, stream_items_, stream_batch_, std::string()};
+        StreamMark m{out_.size(), frame_start_, stream_items_, stream_batch_, memo_next_, std::string()};
         if (frame_start_ != NPOS) m.header = out_.substr(frame_start_, FRAME_HEADER);
         return m;
     }
     void stream_rollback(const StreamMark& m, const std::vector<Ref>& tentative) {
-        for (const Ref& r : tentative) memo_.erase(r.get());       // (memo indices are handed out by size: the last ones go)
+        for (const Ref& r : tentative) memo_.erase(r.get());
+        memo_next_ = m.memo_next;
         out_.resize(m.size);
         if (m.frame != NPOS) out_.replace(m.frame, FRAME_HEADER, m.header);
         frame_start_ = m.frame;
@@ -240,7 +243,45 @@ class Pickler {
     static constexpr size_t NPOS = (size_t)-1;
     static constexpr size_t FRAME_HEADER = 9, FRAME_MIN = 4, FRAME_TARGET = 64 * 1024, BATCH = 1000;
     std::string out_;
-    std::unordered_map<const Node*, uint32_t> memo_;
+    // pickle's memo: object -> index.  Open addressing on the node address (a proof pickles ~10^4 nodes, and the node-per-entry
+    // std::unordered_map was most of the pickling time); inner objects of a compact element only advance the index counter.
+    struct PtrMap {
+        std::vector<const Node*> keys;
+        std::vector<uint32_t> vals;
+        size_t used = 0;                       // occupied slots including tombstones
+        static const Node* tomb() { return reinterpret_cast<const Node*>(uintptr_t(1)); }
+        void clear() { keys.clear(); vals.clear(); used = 0; }
+        size_t slot_of(const Node* k) const { return (size_t)(((uintptr_t)k * 0x9E3779B97F4A7C15ULL) >> 17) & (keys.size() - 1); }
+        bool find(const Node* k, uint32_t& v) const {
+            if (keys.empty()) return false;
+            for (size_t j = slot_of(k);; j = (j + 1) & (keys.size() - 1)) {
+                if (keys[j] == k) { v = vals[j]; return true; }
+                if (keys[j] == nullptr) return false;
+            }
+        }
+        void grow() {
+            std::vector<const Node*> k2(keys.empty() ? 1024 : 2 * keys.size(), nullptr);
+            std::vector<uint32_t> v2(k2.size(), 0);
+            keys.swap(k2); vals.swap(v2);
+            used = 0;
+            for (size_t i = 0; i < k2.size(); ++i)
+                if (k2[i] != nullptr && k2[i] != tomb()) put(k2[i], v2[i]);
+        }
+        void put(const Node* k, uint32_t v) {          // k is not in the map
+            if (2 * (used + 1) > keys.size()) grow();
+            size_t j = slot_of(k);
+            while (keys[j] != nullptr && keys[j] != tomb()) j = (j + 1) & (keys.size() - 1);
+            if (keys[j] == nullptr) ++used;
+            keys[j] = k; vals[j] = v;
+        }
+        void erase(const Node* k) {
+            if (keys.empty()) return;
+            for (size_t j = slot_of(k); keys[j] != nullptr; j = (j + 1) & (keys.size() - 1))
+                if (keys[j] == k) { keys[j] = tomb(); return; }
+        }
+    };
+    PtrMap memo_;
+    uint32_t memo_next_ = 0;
     size_t frame_start_ = NPOS;
     bool framing_ = false;
 
@@ -269,16 +310,13 @@ class Pickler {
         if (out_.size() - frame_start_ - FRAME_HEADER >= FRAME_TARGET) commit_frame();
     }
     void memo_put(const Node* n) {
-        uint32_t idx = (uint32_t)memo_.size();
-        memo_[n] = idx;
+        memo_.put(n, memo_next_++);
         op(0x94);  // MEMOIZE
     }
     void memo_skip() {   // an inner object of a compact element: takes a memo slot, can never be referenced again
-        uint32_t idx = (uint32_t)memo_.size();
-        memo_[reinterpret_cast<const Node*>(&dummy_) + 1 + idx] = idx;
+        ++memo_next_;
         op(0x94);
     }
-    char dummy_ = 0;
 
     // byte-for-byte what save() emits for World::xfe(limbs): instance -> dict{polynomial: instance(dict{coefficients:
     // [BaseFieldElement...]}), field: xfield}; inner objects only consume memo indices
@@ -350,8 +388,8 @@ class Pickler {
     void save(const Node* n) {
         opcode_boundary();
         if (n->kind == K_INT) { save_long(n->ival); return; }
-        auto it = memo_.find(n);
-        if (it != memo_.end()) { memo_get(it->second); return; }
+        uint32_t seen;
+        if (memo_.find(n, seen)) { memo_get(seen); return; }
         switch (n->kind) {
             case K_XFE: save_xfe(n); break;
             case K_BYTES: {
