@@ -656,7 +656,8 @@ struct Transcript {
         if (!la.active || k > la.jobs.size() || objects.size() != la.base_objects + k) { fiat_shamir(objects.size(), out, num_bytes); return; }
         Lookahead::Job& job = *la.jobs[k - 1];
         for (size_t j = 0; j < k; ++j) memcpy(&job.tail[la.holes[j] - la.from], la.digests[j].data(), 64);
-        while (!job.done.load(std::memory_order_acquire)) {}
+        for (unsigned spins = 0; !job.done.load(std::memory_order_acquire); ++spins)
+            if (spins > 4096) std::this_thread::yield();          // (a helper that lost its core to somebody else)
         shake256(job.tail.data(), job.tail.size(), out, num_bytes, job.sponge, 0);
     }
 
