@@ -590,6 +590,7 @@ class Table:
                                        (ctypes.c_void_p * 3)(*inverses) if inverses is not None else None, stream))
 
     _challenge_analysis = (None, None, None, None)
+    _exact_totals = {}        # (table, kind, the values themselves) -> total degrees per constraint
     _generic_bounds = {}      # ((table, kind, zero pattern), interpolant degree) -> the bounds themselves
     _generic_totals = {}      # (table, kind, which challenges / terminals / parameters are zero) -> total degrees per constraint
 
@@ -629,7 +630,14 @@ class Table:
             if totals is None:
                 totals = Table._generic_totals[key] = self._constraint_total_degrees(kind, challenges, terminals, params)
         else:
-            totals = self._constraint_total_degrees(kind, challenges, terminals, params)
+            # crafted values: the exact expansion, remembered per value tuple (the constructor asks with all-ones challenges every time
+            # a prover or verifier object is made: 2 ms of symbolic expansion)
+            exact_key = (type(self).__name__, self.table_index, kind, tuple(values))
+            totals = Table._exact_totals.get(exact_key)
+            if totals is None:
+                if len(Table._exact_totals) > 256:
+                    Table._exact_totals.clear()
+                totals = Table._exact_totals[exact_key] = self._constraint_total_degrees(kind, challenges, terminals, params)
         bounds = [max([-1] + [t * md for t in ts]) for ts in totals]
         if generic:
             if len(Table._generic_bounds) > 4096:

@@ -207,6 +207,50 @@ def test_speculative_fiat_shamir_equals_hashing_afterwards(sb):
             assert out.raw == hashlib.shake_256(want).digest(32), (prefix, step)
 
 
+def test_verifier_shortcuts_answer_like_the_polynomial_routines(sb):
+    """Fri.verify asks two polynomial questions (fri.py:253-259, 275-283) and answers them on integer residues: the degree of the
+    interpolant of the last codeword over its coset (fri._interpolant_degree) and whether three points lie on a line of degree exactly
+    one (fri._on_a_line).  Both against the Lagrange interpolation they replace (Polynomial.interpolate_domain, univariate.colinear's
+    general branch), on random and on degenerate inputs."""
+    import random
+    from stark_brainfuck_amd import fri as fri_module
+    from stark_brainfuck_amd.algebra import BaseField, BaseFieldElement
+    from stark_brainfuck_amd.extension_field import ExtensionField
+    from stark_brainfuck_amd.univariate import Polynomial
+    F, XF = BaseField.main(), ExtensionField.main()
+    p = F.p
+    rng = random.Random(19)
+
+    def xfe():
+        return XF.from_limbs([rng.randrange(p) for _ in range(3)])
+
+    for n in (1, 2, 4, 8, 16):
+        omega = F.primitive_nth_root(n) if n > 1 else BaseFieldElement(1, F)
+        offset = BaseFieldElement(rng.randrange(1, p), F)
+        domain = [XF.lift(offset * (omega ^ i)) for i in range(n)]
+        for degree in list(range(-1, n)):
+            poly = Polynomial([xfe() for _ in range(degree)] + ([xfe()] if degree >= 0 else []))      # leading coefficient non-zero w.h.p.
+            if degree >= 0 and poly.degree() != degree:
+                continue
+            values = poly.evaluate_domain(domain) if degree >= 0 else [XF.zero() for _ in range(n)]
+            assert Polynomial.interpolate_domain(domain, values).degree() == degree
+            assert fri_module._interpolant_degree(omega.value, [tuple(v.limbs()) for v in values]) == degree, (n, degree)
+    for case in range(200):
+        ax, bx = rng.randrange(p), rng.randrange(p)
+        cx = xfe()
+        slope, intercept = (XF.zero() if case % 7 == 0 else xfe()), xfe()
+        line = lambda x: slope * x + intercept
+        pa, pb, pc = XF.lift(BaseFieldElement(ax, F)), XF.lift(BaseFieldElement(bx, F)), cx
+        ya, yb, yc = line(pa), line(pb), line(pc)
+        if case % 3 == 0:
+            yc = yc + XF.one()                                   # off the line
+        want = Polynomial.interpolate_domain([pa, pb, pc], [ya, yb, yc]).degree() == 1
+        got = fri_module._on_a_line(ax, tuple(ya.limbs()), bx, tuple(yb.limbs()), tuple(cx.limbs()), tuple(yc.limbs()))
+        assert got is want, case
+    assert fri_module._on_a_line(5, (1, 0, 0), 5, (2, 0, 0), (9, 1, 0), (3, 0, 0)) is None          # coinciding abscissae
+    assert fri_module._on_a_line(5, (1, 0, 0), 6, (2, 0, 0), (5, 0, 0), (3, 0, 0)) is None
+
+
 def test_native_sampling_equals_the_reference_formulas(sb):
     """bfs_gl_sample = BaseField.sample (algebra.py:138-142: big-endian integer mod p) for every length the callers use and the edge
     values; bfs_sample_weights = BrainfuckStark.sample_weights (brainfuck_stark.py:114-115): ExtensionField.sample of
