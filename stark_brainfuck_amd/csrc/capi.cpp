@@ -47,7 +47,12 @@ int bfs_memset(void* d, int value, size_t bytes, void* stream) {
 }
 int bfs_stream_synchronize(void* stream) { BFS_HIP(hipStreamSynchronize((hipStream_t)stream)); return BFS_OK; }
 int bfs_stream_create(void** stream) { hipStream_t st; BFS_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); *stream = (void*)st; return BFS_OK; }
-int bfs_stream_destroy(void* stream) { BFS_HIP(hipStreamDestroy((hipStream_t)stream)); return BFS_OK; }
+int bfs_stream_destroy(void* stream) {
+    if (!stream) return BFS_OK;                  // the default stream is not ours to destroy
+    BFS_TRY(stream_retire((hipStream_t)stream));
+    BFS_HIP(hipStreamDestroy((hipStream_t)stream));
+    return BFS_OK;
+}
 int bfs_event_create(void** event) { hipEvent_t e; BFS_HIP(hipEventCreate(&e)); *event = (void*)e; return BFS_OK; }
 int bfs_event_destroy(void* event) { BFS_HIP(hipEventDestroy((hipEvent_t)event)); return BFS_OK; }
 int bfs_event_record(void* event, void* stream) { BFS_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream)); return BFS_OK; }

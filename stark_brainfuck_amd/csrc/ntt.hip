@@ -255,6 +255,12 @@ int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_str
     const u64 n = 1ull << log_n;
     if (n_in > n) { set_error("more coefficients (%llu) than the evaluation order (%llu)", (unsigned long long)n_in, (unsigned long long)n); return BFS_ERR_TOO_MANY_COEFFS; }
     if (batch == 0) return BFS_OK;
+    if (d_out == nullptr || (d_in == nullptr && n_in != 0)) { set_error("bfs_gl_ntt: null device pointer"); return BFS_ERR_BAD_ARG; }
+    if (batch > 1 && (out_stride < n || in_stride < n_in)) {
+        set_error("bfs_gl_ntt: transforms of a batch overlap (in_stride %llu < %llu coefficients or out_stride %llu < n = %llu)",
+                  (unsigned long long)in_stride, (unsigned long long)n_in, (unsigned long long)out_stride, (unsigned long long)n);
+        return BFS_ERR_BAD_ARG;
+    }
     if (batch > 65535) {
         // grid.y carries the batch index and is limited to 65535: larger batches go in slices (transforms are independent)
         for (u32 done = 0; done < batch;) {

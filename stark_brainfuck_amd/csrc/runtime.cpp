@@ -32,6 +32,25 @@ struct Scratch {
 std::mutex g_mu;
 std::map<std::tuple<int, hipStream_t, int>, Scratch> g_scratch;
 std::map<std::tuple<int, uint64_t, uint64_t, uint64_t>, const u64*> g_tables;
+// Tables are keyed by caller-supplied values (roots, coset shifts, post-scales), so a caller that sweeps arbitrary shifts would grow
+// the cache without bound.  At TABLE_CAP entries the cache starts over: the tables of the generation before LAST are freed (after a
+// device synchronisation), the current ones are retired -- a pointer handed out by a lookup therefore stays valid for at least
+// TABLE_CAP further insertions, far longer than the lookup-to-launch window of any caller.
+constexpr size_t TABLE_CAP = 4096;
+std::vector<std::pair<int, const u64*>> g_retired_tables;
+
+void retire_tables_locked() {
+    (void)hipDeviceSynchronize();
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (auto& t : g_retired_tables) {
+        if (hipSetDevice(t.first) == hipSuccess) { (void)hipDeviceSynchronize(); (void)hipFree((void*)t.second); }
+    }
+    (void)hipSetDevice(cur);
+    g_retired_tables.clear();
+    for (auto& kv : g_tables) g_retired_tables.emplace_back(std::get<0>(kv.first), kv.second);
+    g_tables.clear();
+}
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -251,6 +270,32 @@ int workspace(int slot, size_t bytes, hipStream_t stream, void** out) {
     return BFS_OK;
 }
 
+// bfs_stream_destroy: the stream's scratch buffers go back to the driver and pooled blocks that were released on it no longer
+// name it (a later stream may get the same handle value)
+int stream_retire(hipStream_t stream) {
+    BFS_HIP(hipStreamSynchronize(stream));
+    int dev = 0;
+    BFS_HIP(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lock(g_mu);
+        for (auto it = g_scratch.begin(); it != g_scratch.end();) {
+            if (std::get<0>(it->first) == dev && std::get<1>(it->first) == stream) {
+                if (it->second.ptr) (void)hipFree(it->second.ptr);
+                it = g_scratch.erase(it);
+            } else {
+                ++it;
+            }
+        }
+    }
+    for (Pool* pool : {&g_device_pool, &g_host_pool}) {
+        std::lock_guard<std::mutex> lock(pool->mu);
+        for (auto& kv : pool->free_lists)
+            for (Block& b : kv.second)
+                if (b.released_on == stream) b.released_on = NO_STREAM;     // synchronised above: nothing in flight on it
+    }
+    return BFS_OK;
+}
+
 bool cached_table_lookup(uint64_t a, uint64_t b, uint64_t c, const u64** d_out) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
@@ -271,9 +316,14 @@ int cached_table(uint64_t a, uint64_t b, uint64_t c, const u64* host, size_t cou
         *d_out = it->second;
         return BFS_OK;
     }
+    if (g_tables.size() >= TABLE_CAP) retire_tables_locked();
     void* d = nullptr;
     BFS_HIP(hipMalloc(&d, count * sizeof(u64)));
-    BFS_HIP(hipMemcpy(d, host, count * sizeof(u64), hipMemcpyHostToDevice));
+    if (hipMemcpy(d, host, count * sizeof(u64), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        set_error("upload of a %zu-entry table failed", count);
+        return BFS_ERR_HIP;
+    }
     g_tables[key] = (const u64*)d;
     *d_out = (const u64*)d;
     return BFS_OK;

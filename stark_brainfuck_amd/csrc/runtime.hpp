@@ -50,7 +50,10 @@ int host_release(void* ptr);
 int copy_h2d(void* d, const void* h, size_t bytes, hipStream_t stream);
 int copy_d2h(void* h, const void* d, size_t bytes, hipStream_t stream);
 
-// upload a host table once and keep it for the lifetime of the process (keyed by caller-chosen 128-bit key)
+// a stream is about to be destroyed: wait for it, free its scratch buffers, forget it in the pools
+int stream_retire(hipStream_t stream);
+
+// upload a host table once and keep it (keyed by caller-chosen values; the cache starts over after 4096 entries, runtime.cpp)
 int cached_table(uint64_t key_a, uint64_t key_b, uint64_t key_c, const u64* host, size_t count, const u64** d_out);
 bool cached_table_lookup(uint64_t key_a, uint64_t key_b, uint64_t key_c, const u64** d_out);
 
