@@ -893,3 +893,61 @@ def test_four_pass_plan_2p25(sb, oracle):
     assert (raw_ntt(sb, fwd, logn, oracle.inv(w), 1, oracle.inv(n)) == v).all()
     d = n // 4 + 3
     assert (raw_ntt(sb, v[:d], logn, w, 7, 1, n_in=d) == oracle.fast_coset_evaluate(v[:d], 7, w, n)).all()
+
+
+def test_c_abi_argument_checks_and_stream_lifetime(sb, oracle):
+    """bfs_gl_ntt refuses null pointers and batches whose transforms would overlap (BFS_ERR_BAD_ARG, nothing launched); a stream
+    made by bfs_stream_create carries a multi-pass transform (its scratch buffer is keyed by the stream), and destroying it gives
+    the scratch back and leaves the pools usable; the twiddle-table cache starts over after 4096 entries without disturbing
+    results (4200 distinct coset shifts at 2^6, the first one re-checked at the end)."""
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.device import DeviceBuffer, synchronize
+    lib = _lib.load()
+    BAD_ARG = 6
+    logn, n = 8, 256
+    w = lib.bfs_gl_primitive_root(logn)
+    v = oracle.felt_array(SEED, 0, 2 * n)
+    din, dout = DeviceBuffer.from_numpy(v), DeviceBuffer(2 * n)
+    assert lib.bfs_gl_ntt(None, n, n, dout.ptr, n, logn, 1, w, 1, 1, 0) == BAD_ARG and b"null" in lib.bfs_last_error()
+    assert lib.bfs_gl_ntt(din.ptr, n, n, None, n, logn, 1, w, 1, 1, 0) == BAD_ARG
+    assert lib.bfs_gl_ntt(din.ptr, n, n, dout.ptr, n - 1, logn, 2, w, 1, 1, 0) == BAD_ARG and b"overlap" in lib.bfs_last_error()
+    assert lib.bfs_gl_ntt(din.ptr, n, n - 1, dout.ptr, n, logn, 2, w, 1, 1, 0) == BAD_ARG
+    assert lib.bfs_gl_ntt(None, 0, 0, dout.ptr, n, logn, 1, w, 1, 1, 0) == 0          # no coefficients: the zero polynomial
+    synchronize(0)
+    assert not dout.to_numpy(n).any()
+    # a transform on a private stream (2^14: two passes, i.e. with a scratch buffer), then the stream goes away
+    logm, m = 14, 1 << 14
+    wm = lib.bfs_gl_primitive_root(logm)
+    x = oracle.felt_array(SEED + 5, 0, m)
+    want = oracle.ntt(wm, x)
+    for _ in range(3):
+        st = ctypes.c_void_p()
+        _lib.check(lib.bfs_stream_create(ctypes.byref(st)))
+        a, b = DeviceBuffer.from_numpy(x), DeviceBuffer(m)
+        _lib.check(lib.bfs_gl_ntt(a.ptr, m, m, b.ptr, m, logm, 1, wm, 1, 1, st))
+        _lib.check(lib.bfs_stream_synchronize(st))
+        assert (b.to_numpy() == want).all()
+        p = ctypes.c_void_p()
+        _lib.check(lib.bfs_malloc_async(ctypes.byref(p), 1 << 16, st))
+        _lib.check(lib.bfs_free_async(p, st))                   # cached with `st` as its release stream ...
+        _lib.check(lib.bfs_stream_destroy(st))                  # ... which must not be waited on after this
+        q = ctypes.c_void_p()
+        _lib.check(lib.bfs_malloc_async(ctypes.byref(q), 1 << 16, 0))
+        _lib.check(lib.bfs_free_async(q, 0))
+        a.free(); b.free()
+    assert lib.bfs_stream_destroy(None) == 0
+    # more distinct coset shifts than the table cache holds
+    k, logk = 64, 6
+    wk = lib.bfs_gl_primitive_root(logk)
+    y = oracle.felt_array(SEED + 6, 0, k)
+    src, dst = DeviceBuffer.from_numpy(y), DeviceBuffer(k)
+    first = None
+    for shift in list(range(2, 4202)) + [2]:
+        _lib.check(lib.bfs_gl_ntt(src.ptr, k, k, dst.ptr, k, logk, 1, wk, shift, 1, 0))
+        if shift in (2, 3000, 4201):
+            synchronize(0)
+            got = dst.to_numpy()
+            assert (got == oracle.ntt(wk, oracle.scale(shift, y))).all(), shift
+            if first is None:
+                first = got
+    assert (got == first).all()
