@@ -13,6 +13,7 @@ roots are all-gathered (shard.gather_roots over RCCL: the only collective of the
 Extra keys on the same JSON line:
     roofline      dominant kernel (the NTT tile kernel) vs the 8 TB/s HBM roofline, from HIP events on the kernel's stream
     cpu_baseline  the CPU oracle (oracle/gl_oracle.c, plain C port of ntt.py, 1 core) on a bounded sample, rank 0, N=1 only;
+                  cpu_baseline.python: the same algorithm in pure Python on boxed elements (the reference's cost model) at 2^14 / 2^16, timed live;
                   cpu_baseline.reference_python carries the reference's own CPython figure (measured in the build container)
     sustained     the same step back to back for the seconds the CPU baseline leg takes (second thread, untimed, N = 1): steady-state
                   clocks, and the GPU is busy while the host core is
@@ -435,7 +436,22 @@ def cpu_baseline(log_n):
         t0 = time.perf_counter()
         o.ntt(w, v)
         t += time.perf_counter() - t0
+    # north_star asks for the pure-Python CPU path timed on this box: the reference cannot travel, so its cost model does --
+    # oracle.ntt_python is ntt.py:4-23 on boxed elements (one object per value, arithmetic through the field object, per-index
+    # square-and-multiply powers), pinned on the reference's goldens; here in the build container it runs 2^14 in 1.49 s against
+    # 1.67 s for the reference itself (2^12: 0.30 s / 0.41 s).  Its rate falls with n (n log^2 n), so the size is part of the figure.
+    py = []
+    for lg in (14, 16):
+        m = 1 << lg
+        v = felt_array(SEED, 0, m).tolist()
+        wm = o.primitive_nth_root(m)
+        t0 = time.perf_counter()
+        o.ntt_python(wm, v)
+        dt = time.perf_counter() - t0
+        py.append({"log_n": lg, "seconds": round(dt, 3), "elements_per_s": round(m / dt, 1)})
     return {"value": n * sample_cols / t, "unit": "elements/s", "cores": 1, "kind": "port",
+            "python": {"kind": "port of ntt.py:4-23 on boxed elements, pure Python (oracle.ntt_python), 1 core, timed here", "runs": py,
+                       "build_container_check": "2^14: this port 1.49 s, the reference's ntt.py 1.67 s (same CPython 3.10.12)"},
             "sample": "%d column(s) of 2^%d elements, forward NTT, oracle/gl_oracle.c (gcc -O2), %.1f s" % (sample_cols, log_n, t),
             "host_cpus": os.cpu_count(),
             # the reference itself cannot travel to the GPU box; its own figure, measured in the build container (BASELINE.md section 2,

@@ -163,6 +163,62 @@ def intt(root, values):
     _check(_lib.glo_intt(root, _ptr(v), _ptr(out), v.size)); return out
 
 
+# ---- the reference's own cost model, for bench.py's cpu_baseline: ntt.py:4-23 on BOXED elements in pure Python ----
+# The reference cannot travel to the GPU box, so its CPU figure there is taken from this restatement: every field element is a
+# Python object holding an int and its field, every + and * goes through a method of the field object and allocates a new
+# element (algebra.py:12-19, 89-99), a power is square-and-multiply over the bits of the exponent (algebra.py:34-41), and the
+# transform is the recursive radix-2 of ntt.py:4-23 including its two asserts and the per-index power `primitive_root ^ i` --
+# the same operation count, allocation pattern and interpreter dispatch as the reference, on the same CPython.
+class _BoxedField:
+    def __init__(self, p):
+        self.p = p
+
+    def sum(self, a, b):
+        return _Boxed((a.value + b.value) % self.p, self)
+
+    def product(self, a, b):
+        return _Boxed((a.value * b.value) % self.p, self)
+
+
+class _Boxed:
+    def __init__(self, value, field):
+        self.value = value
+        self.field = field
+
+    def __add__(self, other):
+        return self.field.sum(self, other)
+
+    def __mul__(self, other):
+        return self.field.product(self, other)
+
+    def __xor__(self, e):                        # algebra.py:34-41
+        result, base = _Boxed(1, self.field), _Boxed(self.value, self.field)
+        for bit in reversed(range(len(bin(e)[2:]))):
+            result = result * result
+            if (e >> bit) & 1:
+                result = result * base
+        return result
+
+
+def _ntt_boxed(w, xs):
+    n = len(xs)
+    if n <= 1:
+        return xs
+    assert (w ^ n).value == 1, f"primitive root must be nth root of unity, where n is {n}"
+    assert (w ^ (n // 2)).value != 1, "primitive root is not primitive nth root of unity"
+    h = n // 2
+    w2 = w ^ 2
+    lo, hi = _ntt_boxed(w2, xs[::2]), _ntt_boxed(w2, xs[1::2])       # the reference transforms the odd half first; same values
+    return [lo[k % h] + (w ^ k) * hi[k % h] for k in range(n)]
+
+
+def ntt_python(root, values):
+    """ntt.py:4-23 in pure Python on boxed elements (see above); ints in, ints out"""
+    assert len(values) & (len(values) - 1) == 0, "cannot compute ntt of non-power-of-two sequence"
+    f = _BoxedField(P)
+    return [e.value for e in _ntt_boxed(_Boxed(int(root), f), [_Boxed(int(v), f) for v in values])]
+
+
 def scale(factor, coeffs):
     v = _arr(coeffs); out = np.empty_like(v)
     _lib.glo_scale(factor, _ptr(v), _ptr(out), v.size); return out

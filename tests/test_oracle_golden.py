@@ -77,6 +77,21 @@ def test_ntt20_if_present(oracle):
     assert sha_u64(oracle.intt(c["root"], v)) == c["sha_intt"]
 
 
+def test_pure_python_ntt_restatement(oracle):
+    """bench.py's `cpu_baseline.python` leg: the boxed-element restatement of ntt.py:4-23 gives the reference's outputs (goldens
+    2^0..2^10 produced by the reference itself) and the C oracle's at 2^11"""
+    for logn in range(0, 11):
+        c = load_golden("ntt.json")["cases"][str(logn)]
+        v = oracle.felt_array(SEED, 0, 1 << logn)
+        got = np.array(oracle.ntt_python(c["root"], v.tolist()), dtype=np.uint64)
+        assert sha_u64(got) == c["sha_ntt"], logn
+    w = oracle.primitive_nth_root(2048)
+    v = oracle.felt_array(SEED + 1, 0, 2048)
+    assert oracle.ntt_python(w, v.tolist()) == oracle.ntt(w, v).tolist()
+    with pytest.raises(AssertionError):
+        oracle.ntt_python(3, [1] * 8)
+
+
 def test_ntt_errors(oracle):
     w8 = oracle.primitive_nth_root(8)
     with pytest.raises(AssertionError, match="non-power-of-two"):
