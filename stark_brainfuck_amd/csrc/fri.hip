@@ -413,8 +413,9 @@ int fri_query(FriSession& S, rp::Transcript& ps, u32 t, u64* h_top, hipStream_t 
     }
     auto path_obj = [&](u32 r, u64 leaf) {
         std::vector<rp::Ref> items;
+        items.reserve(64 - (size_t)__builtin_clzll(S.rounds[r].length));
         for (u64 k = S.rounds[r].length | leaf; k > 1; k >>= 1) items.push_back(S.nodes[Key(r, k ^ 1)]);
-        return rp::mk_list(items);
+        return rp::mk_list(std::move(items));
     };
     // push in the reference's order: per layer, t leaf triples then the authentication paths (fri.py:147-156, 166-174)
     for (u32 i = 0; i < (u32)layer_idx.size(); ++i) {

@@ -41,13 +41,37 @@ struct Node {
     std::vector<Ref> items;  // LIST / TUPLE elements; DICT: k0 v0 k1 v1 ...; CLASS: module, qualname
     Ref cls, state;          // INSTANCE
     u64 limbs[3] = {0, 0, 0};  // R_XFE: value; R_BFE: limbs[0]
+    unsigned char* inl = nullptr;   // BYTES of exactly 64 bytes (digests: most nodes of a proof) live behind the node itself, see DigestNode
+    const char* bytes() const { return inl ? (const char*)inl : data.data(); }
+    size_t nbytes() const { return inl ? 64 : data.size(); }
+    void set_bytes(const void* p, size_t len) {
+        if (inl && len == 64) { memcpy(inl, p, 64); return; }
+        inl = nullptr;
+        data.assign((const char*)p, len);
+    }
+};
+// a 64-byte BYTES node in ONE allocation (node + payload) instead of two (node, std::string buffer): a FRI proof makes ~2 500 of them
+struct DigestNode : Node {
+    unsigned char payload[64];
 };
 
 inline Ref mk(Kind k) { Ref n = std::make_shared<Node>(); n->kind = k; return n; }
 inline Ref mk_int(u64 v) { Ref n = mk(K_INT); n->ival = v; return n; }
 inline Ref mk_str(const char* s) { Ref n = mk(K_STR); n->data = s; return n; }
-inline Ref mk_bytes(const void* p, size_t len) { Ref n = mk(K_BYTES); n->data.assign((const char*)p, len); return n; }
+inline Ref mk_bytes(const void* p, size_t len) {
+    if (len == 64) {
+        std::shared_ptr<DigestNode> d = std::make_shared<DigestNode>();
+        d->kind = K_BYTES;
+        d->inl = d->payload;
+        memcpy(d->payload, p, 64);
+        return d;
+    }
+    Ref n = mk(K_BYTES);
+    n->data.assign((const char*)p, len);
+    return n;
+}
 inline Ref mk_list(const std::vector<Ref>& it) { Ref n = mk(K_LIST); n->items = it; return n; }
+inline Ref mk_list(std::vector<Ref>&& it) { Ref n = mk(K_LIST); n->items = std::move(it); return n; }
 inline Ref mk_tuple(const std::vector<Ref>& it) { Ref n = mk(K_TUPLE); n->items = it; return n; }
 inline Ref mk_class(const Ref& module, const Ref& name) { Ref n = mk(K_CLASS); n->items = {module, name}; return n; }
 inline Ref mk_instance(const Ref& cls, const std::vector<Ref>& kv) {
@@ -393,10 +417,10 @@ class Pickler {
         switch (n->kind) {
             case K_XFE: save_xfe(n); break;
             case K_BYTES: {
-                size_t len = n->data.size();
+                size_t len = n->nbytes();
                 if (len < 256) { unsigned char h[2] = {0x43, (unsigned char)len}; write(h, 2); }
                 else { unsigned char h[5] = {0x42}; uint32_t l = (uint32_t)len; memcpy(h + 1, &l, 4); write(h, 5); }
-                write(n->data.data(), len);
+                write(n->bytes(), len);
                 memo_put(n);
                 break;
             }
@@ -662,7 +686,7 @@ struct Transcript {
     }
 
     void resolve(Speculation& sp, const unsigned char digest[64], unsigned char* out, size_t num_bytes) {
-        sp.node->data.assign((const char*)digest, 64);
+        sp.node->set_bytes(digest, 64);
         if (!sp.active) { fiat_shamir(objects.size(), out, num_bytes); return; }
         memcpy(&sp.bytes[sp.payload], digest, 64);
         stream.stream_patch(sp.payload, digest, 64);

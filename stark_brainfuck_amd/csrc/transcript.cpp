@@ -132,7 +132,7 @@ int bfs_ps_obj_kind(void* ps, uint64_t handle) {
 size_t bfs_ps_obj_len(void* ps, uint64_t handle) {
     Ref r = T(ps)->get(handle);
     if (!r) return 0;
-    return (r->kind == rp::K_BYTES || r->kind == rp::K_STR) ? r->data.size() : r->items.size();
+    return (r->kind == rp::K_BYTES || r->kind == rp::K_STR) ? r->nbytes() : r->items.size();
 }
 uint64_t bfs_ps_obj_item(void* ps, uint64_t handle, size_t i) {
     Transcript* t = T(ps);
@@ -145,8 +145,8 @@ uint64_t bfs_ps_obj_item(void* ps, uint64_t handle, size_t i) {
 }
 int bfs_ps_obj_get_bytes(void* ps, uint64_t handle, uint8_t* out, size_t capacity) {
     Ref r = T(ps)->get(handle);
-    if (!r || capacity < r->data.size()) return bad_handle(handle);
-    memcpy(out, r->data.data(), r->data.size());
+    if (!r || capacity < r->nbytes()) return bad_handle(handle);
+    memcpy(out, r->bytes(), r->nbytes());
     return BFS_OK;
 }
 int bfs_ps_obj_get_limbs(void* ps, uint64_t handle, uint64_t limbs[3]) {
