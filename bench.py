@@ -163,6 +163,7 @@ def main():
         finally:
             stop.set()
             worker.join()
+        cpu_line["python"] = cpu_baseline_python()
         sustained = {"seconds": count[1], "steps": count[0], "ms_per_step": count[1] / max(count[0], 1) * 1e3,
                      "elements_per_s": n * cols * count[0] / max(count[1], 1e-9),
                      "note": "untimed: the NTT step back to back from a second thread for as long as the CPU baseline leg runs"}
@@ -436,6 +437,20 @@ def cpu_baseline(log_n):
         t0 = time.perf_counter()
         o.ntt(w, v)
         t += time.perf_counter() - t0
+    return {"value": n * sample_cols / t, "unit": "elements/s", "cores": 1, "kind": "port",
+            "sample": "%d column(s) of 2^%d elements, forward NTT, oracle/gl_oracle.c (gcc -O2), %.1f s" % (sample_cols, log_n, t),
+            "host_cpus": os.cpu_count(),
+            # the reference itself cannot travel to the GPU box; its own figure, measured in the build container (BASELINE.md section 2,
+            # tests/golden/ntt20.json ref_seconds): CPython 3.10, 1 core, ntt.py on 2^20 elements in 242.7 s
+            "reference_python": {"value": 4320.0, "unit": "elements/s", "cores": 1,
+                                 "provenance": "BASELINE.md: /root/reference/code/ntt.py, n = 2^20, 242.7 s, CPython 3.10.12, build container (8-core host); "
+                                               "2^24 extrapolated there to ~2.6 k elements/s (1.8 h per column)"}}
+
+
+def cpu_baseline_python():
+    """the pure-Python CPU path, timed on this box (after the sustained GPU leg: a pure-Python loop holds the interpreter lock
+    that the thread feeding the GPU needs between its calls)."""
+    from oracle import ref_oracle as o
     # north_star asks for the pure-Python CPU path timed on this box: the reference cannot travel, so its cost model does --
     # oracle.ntt_python is ntt.py:4-23 on boxed elements (one object per value, arithmetic through the field object, per-index
     # square-and-multiply powers), pinned on the reference's goldens; here in the build container it runs 2^14 in 1.49 s against
@@ -449,16 +464,8 @@ def cpu_baseline(log_n):
         o.ntt_python(wm, v)
         dt = time.perf_counter() - t0
         py.append({"log_n": lg, "seconds": round(dt, 3), "elements_per_s": round(m / dt, 1)})
-    return {"value": n * sample_cols / t, "unit": "elements/s", "cores": 1, "kind": "port",
-            "python": {"kind": "port of ntt.py:4-23 on boxed elements, pure Python (oracle.ntt_python), 1 core, timed here", "runs": py,
-                       "build_container_check": "2^14: this port 1.49 s, the reference's ntt.py 1.67 s (same CPython 3.10.12)"},
-            "sample": "%d column(s) of 2^%d elements, forward NTT, oracle/gl_oracle.c (gcc -O2), %.1f s" % (sample_cols, log_n, t),
-            "host_cpus": os.cpu_count(),
-            # the reference itself cannot travel to the GPU box; its own figure, measured in the build container (BASELINE.md section 2,
-            # tests/golden/ntt20.json ref_seconds): CPython 3.10, 1 core, ntt.py on 2^20 elements in 242.7 s
-            "reference_python": {"value": 4320.0, "unit": "elements/s", "cores": 1,
-                                 "provenance": "BASELINE.md: /root/reference/code/ntt.py, n = 2^20, 242.7 s, CPython 3.10.12, build container (8-core host); "
-                                               "2^24 extrapolated there to ~2.6 k elements/s (1.8 h per column)"}}
+    return {"kind": "port of ntt.py:4-23 on boxed elements, pure Python (oracle.ntt_python), 1 core, timed here", "runs": py,
+            "build_container_check": "2^14: this port 1.49 s, the reference's ntt.py 1.67 s (same CPython 3.10.12)"}
 
 
 if __name__ == "__main__":
