@@ -286,7 +286,7 @@ def main():
                             "traffic": traffic, "traffic_source": tsrc,
                             "wasted_traffic_ratio": (traffic / bytes_per_launch) if traffic else None,
                             "valu_issue_frac": valu_frac,
-                            "kernel": "ntt_tile_kernel_split<4,4,0,4,MODE>", "launches_per_step": npass,
+                            "kernel": "ntt_tile_kernel_split<4,4,0,4,MODE,NT>" + ("(non-temporal data accesses)" if n * cols * 8 > (128 << 20) else ""), "launches_per_step": npass,
                             "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
                             "note": "three HBM passes move 3x the algorithmic bytes; the kernel is co-limited by integer VALU issue (DESIGN.md 4.1)"}
         if log_n == 24 and not args.no_single:

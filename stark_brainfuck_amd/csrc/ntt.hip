@@ -8,7 +8,7 @@ namespace bfs {
 // One workgroup per tile: T/16 threads hold 16 elements each.  LDS = tile (padded) + the stage-1 -> stage-2 twiddles.
 // (A persistent variant with next-tile prefetch and 16-byte paired-lane accesses was measured slower: the kernel is
 //  VALU-issue bound at the time and hardware workgroup turnover already overlaps HBM latency)
-template <int B1, int B2, int B3, int LOGC, int MODE>
+template <int B1, int B2, int B3, int LOGC, int MODE, bool NT>
 __global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a, const int early_loads) {
     extern __shared__ __attribute__((aligned(16))) u64 smem[];
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a, const i
         if (has_row && tid < (1u << Cfg::S)) rw0 = row[tid];
     }
     u64 x[16];
-    if (early) ntt_stage1_load<B1, B2, B3, LOGC, MODE>(a, tid, blockIdx.x, blockIdx.y, 0, x);
+    if (early) ntt_stage1_load<B1, B2, B3, LOGC, MODE, NT>(a, tid, blockIdx.x, blockIdx.y, 0, x);
     u64* rw = tw + Cfg::TW_WORDS;
     if (early) {
         if (TW_N && tid < TW_N) tw[tid] = tw0;
@@ -50,15 +50,15 @@ __global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a, const i
         for (u32 i = tid + (early ? blockDim.x : 0); i < (1u << Cfg::S); i += blockDim.x) rw[i] = row[i];
     const u64* rowtw = has_row ? rw : nullptr;
     if (Cfg::U >= 2 || has_row) __syncthreads();
-    if (!early) ntt_stage1_load<B1, B2, B3, LOGC, MODE>(a, tid, blockIdx.x, blockIdx.y, 0, x);
-    ntt_stage1_compute<B1, B2, B3, LOGC, MODE>(a, smem, tw, rowtw, threadIdx.x, blockIdx.x, blockIdx.y, 0, x);
+    if (!early) ntt_stage1_load<B1, B2, B3, LOGC, MODE, NT>(a, tid, blockIdx.x, blockIdx.y, 0, x);
+    ntt_stage1_compute<B1, B2, B3, LOGC, MODE, NT>(a, smem, tw, rowtw, threadIdx.x, blockIdx.x, blockIdx.y, 0, x);
     if constexpr (B2 > 0) {
         __syncthreads();
-        ntt_stage2<B1, B2, B3, LOGC, MODE>(a, smem, threadIdx.x, blockIdx.x, blockIdx.y);
+        ntt_stage2<B1, B2, B3, LOGC, MODE, NT>(a, smem, threadIdx.x, blockIdx.x, blockIdx.y);
     }
     if constexpr (B3 > 0) {
         __syncthreads();
-        ntt_stage3<B1, B2, B3, LOGC, MODE>(a, smem, threadIdx.x, blockIdx.x, blockIdx.y);
+        ntt_stage3<B1, B2, B3, LOGC, MODE, NT>(a, smem, threadIdx.x, blockIdx.x, blockIdx.y);
     }
 }
 
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a, const i
 // waiting -- for their loads, at a barrier -- idles: VALU issue was 82 % of the time.  A timing-only experiment (the same kernel
 // launched with less LDS than it indexes) put five or more workgroups per CU at 1.34 ms against 1.51 (profiles/r02).  The
 // price: 32 + 32 four-byte LDS accesses per thread instead of 16 + 16 eight-byte ones and two more barriers per tile.
-template <int B1, int B2, int B3, int LOGC, int MODE>
+template <int B1, int B2, int B3, int LOGC, int MODE, bool NT>
 __global__ void __launch_bounds__(256) ntt_tile_kernel_split(const PassArgs a) {
     static_assert(B1 == 4 && B2 > 0 && B3 == 0, "two register stages, 16 elements per thread");
     extern __shared__ __attribute__((aligned(16))) u64 smem[];
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__(256) ntt_tile_kernel_split(const PassArgs a) {
     if (tid < TW_N) tw0 = tab[(u64)tid << tw_shift];
     if (has_row && tid < (1u << Cfg::S)) rw0 = row[tid];
     u64 x[16];
-    ntt_stage1_load<B1, B2, B3, LOGC, MODE>(a, tid, blockIdx.x, blockIdx.y, 0, x);
+    ntt_stage1_load<B1, B2, B3, LOGC, MODE, NT>(a, tid, blockIdx.x, blockIdx.y, 0, x);
     u64* rw = tw + Cfg::TW_WORDS;
     if (tid < TW_N) tw[tid] = tw0;
     if (has_row && tid < (1u << Cfg::S)) rw[tid] = rw0;
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(256) ntt_tile_kernel_split(const PassArgs a) {
         u64 y[Q2];
         BFS_UNROLL
         for (int d = 0; d < Q2; ++d) y[d] = ((u64)tile[stage2_in_index<B1, B2, B3, LOGC, MODE>(tid, s, d)] << 32) | lo[s * Q2 + d];
-        ntt_stage2_from<B1, B2, B3, LOGC, MODE>(a, smem, tid, blockIdx.x, blockIdx.y, s, y);
+        ntt_stage2_from<B1, B2, B3, LOGC, MODE, NT>(a, smem, tid, blockIdx.x, blockIdx.y, s, y);
     }
 }
 
@@ -127,7 +127,10 @@ static int launch_tile_split(const PassArgs& a, u32 grid_x, u32 batch, hipStream
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     const size_t row_words = (MODE == PASS_COLUMN && a.tb.row != nullptr) ? (1u << Cfg::S) : 0;
     const size_t lds = ((Cfg::LDS_WORDS * 4 + 15) & ~15u) + (Cfg::TW_WORDS + row_words) * sizeof(u64);
-    hipLaunchKernelGGL((ntt_tile_kernel_split<B1, B2, B3, LOGC, MODE>), dim3(grid_x, batch), dim3(Cfg::W), lds, stream, a);
+    if (a.streaming)
+        hipLaunchKernelGGL((ntt_tile_kernel_split<B1, B2, B3, LOGC, MODE, true>), dim3(grid_x, batch), dim3(Cfg::W), lds, stream, a);
+    else
+        hipLaunchKernelGGL((ntt_tile_kernel_split<B1, B2, B3, LOGC, MODE, false>), dim3(grid_x, batch), dim3(Cfg::W), lds, stream, a);
     BFS_HIP(hipGetLastError());
     return BFS_OK;
 }
@@ -140,7 +143,10 @@ static int launch_tile(const PassArgs& a, u32 grid_x, u32 batch, hipStream_t str
     const size_t row_words = (MODE == PASS_COLUMN && a.tb.row != nullptr) ? (1u << Cfg::S) : 0;
     const size_t lds = (size_t)((B2 > 0 ? ((Cfg::LDS_WORDS + 1) & ~1) + Cfg::TW_WORDS : 0) + row_words) * sizeof(u64);
     static const int early = [] { const char* e = getenv("BFS_NTT_EARLY_LOADS"); return (e && e[0] == '0') ? 0 : 1; }();   // A/B switch
-    hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, LOGC, MODE>), dim3(grid_x, batch), dim3(Cfg::W), lds, stream, a, early);
+    if (a.streaming)
+        hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, LOGC, MODE, true>), dim3(grid_x, batch), dim3(Cfg::W), lds, stream, a, early);
+    else
+        hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, LOGC, MODE, false>), dim3(grid_x, batch), dim3(Cfg::W), lds, stream, a, early);
     BFS_HIP(hipGetLastError());
     return BFS_OK;
 }
@@ -189,6 +195,8 @@ static int dispatch_tile(const NttPlan& p, u32 t, const PassArgs& a, u32 grid_x,
     if (t + 1 == p.npass) return dispatch_multi<PASS_FINAL>(a, p.pass_bits[t], grid_x, batch, stream);
     return dispatch_multi<PASS_COLUMN>(a, p.pass_bits[t], grid_x, batch, stream);
 }
+
+constexpr u64 NTT_STREAMING_BYTES = 128ull << 20;     // one 2^24-point column (128 MiB) still runs out of the Infinity Cache, two do not
 
 enum { TBL_W_LO = 1, TBL_W_HI, TBL_T_IN, TBL_T_IN_LAST, TBL_S_LO, TBL_S_HI, TBL_ROW };
 
@@ -284,6 +292,10 @@ int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_str
     }
     NttTables tb;
     BFS_TRY(get_tables(p, root, shift, post_scale, tb));
+    // non-temporal data accesses once a buffer of the call no longer fits the Infinity Cache next to its neighbours (ntt_core.hpp);
+    // BFS_NTT_STREAMING=0 / 1 forces the choice (A/B)
+    static const int force_streaming = [] { const char* e = getenv("BFS_NTT_STREAMING"); return e ? atoi(e) : -1; }();
+    const u32 streaming = force_streaming >= 0 ? (u32)(force_streaming != 0) : (u32)((u64)n * batch * sizeof(u64) > NTT_STREAMING_BYTES);
     u64* ws = nullptr;
     if (p.npass > 1) {
         void* w = nullptr;
@@ -295,6 +307,7 @@ int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_str
         BFS_TRY(get_row_table(p, t, root, &tb.row));
         PassArgs a = ntt_pass_args(p, t, first ? d_in : ws, last ? d_out : ws, first ? in_stride : n, last ? out_stride : n,
                                    first ? n_in : n, tb, shift != 1, shift, post_scale);
+        a.streaming = streaming;
         u32 grid_x = (u32)((n >> p.pass_bits[t]) >> p.logC[t]);
         BFS_TRY(dispatch_tile(p, t, a, grid_x, batch, stream));
     }

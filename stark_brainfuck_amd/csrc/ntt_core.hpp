@@ -105,6 +105,26 @@ constexpr u32 cx_bitrev(u32 v, int bits) {
 template <int BITS>
 BFS_HD u32 perm_digit(int m, u32 uinv) { return (cx_bitrev((u32)m, BITS) * uinv) & ((1u << BITS) - 1); }
 
+// Streaming accesses.  Every element is read once and written once per pass, so when the data set is larger than the caches
+// nothing is gained by keeping it there: the NT = true instantiations mark the data loads and stores non-temporal (the twiddle
+// tables stay ordinary, cached reads).  8 x 2^24: 1.45 -> 1.41 ms, the memory-bound first pass 463 -> 437 us
+// (profiles/r02/ab_nontemporal.txt); a single 2^24 column, which lives in the 256 MiB Infinity Cache, is 2 % SLOWER with the
+// hint, so the launcher only uses it above NTT_STREAMING_BYTES per buffer (ntt.hip).
+template <bool NT>
+BFS_HD u64 ntt_ld(const u64* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+#endif
+    return *p;
+}
+template <bool NT>
+BFS_HD void ntt_st(u64* p, u64 v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (NT) { __builtin_nontemporal_store(v, p); return; }
+#endif
+    *p = v;
+}
+
 struct NttTables {
     const u64* w_lo;       // w^i,              i < 2^lo_bits
     const u64* w_hi;       // w^(i * 2^lo_bits), i < 2^(log_n - lo_bits)
@@ -140,6 +160,7 @@ struct PassArgs {
     u32 has_coset;       // pass 0: multiply input j by s^j
     u64 coset_delta;     // s^(stride of the stage-1 register index)
     u64 post_scale;      // multiplied in at the final store when the final pass has a single stage
+    u32 streaming;       // data loads / stores are non-temporal (the launcher picks the NT instantiation; kept here for the record)
     NttTables tb;
 };
 
@@ -236,7 +257,7 @@ BFS_HD TileGeom tile_geom(const PassArgs& a, u32 bid_x, u32 bid_y) {
 }
 
 // store the 2^BQ registers of the last stage.  klow = the already-final lower digits of k_pass, c = column
-template <typename Cfg, int LOGC, int MODE, int BQ>
+template <typename Cfg, int LOGC, int MODE, int BQ, bool NT = false>
 BFS_HD void final_store(const PassArgs& a, const TileGeom& g, const u64* x, u32 klow, int kshift, u32 c) {
     constexpr int Q = 1 << BQ;
     const bool scale = (Cfg::U == 1) && a.post_scale != 1;
@@ -255,7 +276,7 @@ BFS_HD void final_store(const PassArgs& a, const TileGeom& g, const u64* x, u32 
         if (x[m] != 0x123456789ULL) continue;
 #endif
         const u64 v = scale ? gl_mul(x[m], a.post_scale) : x[m];
-        tp[(u64)perm_digit<BQ>(m, a.uinv) << step_log] = v;
+        ntt_st<NT>(tp + ((u64)perm_digit<BQ>(m, a.uinv) << step_log), v);
     }
 }
 
@@ -287,7 +308,7 @@ BFS_HD Stage1Pos<B1, B2, B3, LOGC, MODE> stage1_pos(const PassArgs& a, const Til
     return p;
 }
 
-template <int B1, int B2, int B3, int LOGC, int MODE>
+template <int B1, int B2, int B3, int LOGC, int MODE, bool NT = false>
 BFS_HD void ntt_stage1_load(const PassArgs& a, u32 tid, u32 bid_x, u32 bid_y, int sub, u64* x) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     constexpr int Q = 1 << B1;
@@ -296,14 +317,14 @@ BFS_HD void ntt_stage1_load(const PassArgs& a, u32 tid, u32 bid_x, u32 bid_y, in
     const u64* tp = g.in + p.idx0;
     if (a.partial) {
         BFS_UNROLL
-        for (int d = 0; d < Q; ++d) x[d] = (p.idx0 + ((u64)d << p.step_log) < a.n_in) ? tp[(u64)d << p.step_log] : 0;
+        for (int d = 0; d < Q; ++d) x[d] = (p.idx0 + ((u64)d << p.step_log) < a.n_in) ? ntt_ld<NT>(tp + ((u64)d << p.step_log)) : 0;
     } else {
         BFS_UNROLL
         for (int d = 0; d < Q; ++d) {
 #ifdef BFS_ABL_NO_MEM
             x[d] = (p.idx0 + d) * 0x9E3779B97F4A7C15ULL >> 1;
 #else
-            x[d] = tp[(u64)d << p.step_log];
+            x[d] = ntt_ld<NT>(tp + ((u64)d << p.step_log));
 #endif
         }
     }
@@ -341,7 +362,7 @@ BFS_HD u32 stage2_in_index(u32 tid, int s, int d) {
 // stage 1 without the exchange: load-time twiddle, first radix and (U >= 2) the inner twiddle; x[m] is left holding the value
 // that stage1_out_index(m) receives.  U == 1: the values are final and are stored.
 // tw: dense inner-twiddle table for the stage 1 -> 2 exchange (2^(B1+B2) entries, in LDS on the GPU)
-template <int B1, int B2, int B3, int LOGC, int MODE>
+template <int B1, int B2, int B3, int LOGC, int MODE, bool NT = false>
 BFS_HD void ntt_stage1_values(const PassArgs& a, const u64* tw, const u64* rowtw, u32 tid, u32 bid_x, u32 bid_y, int sub, u64* x) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     constexpr int Q = 1 << B1;
@@ -377,7 +398,7 @@ BFS_HD void ntt_stage1_values(const PassArgs& a, const u64* tw, const u64* rowtw
     dif<Q>(x);
 #endif
     if constexpr (Cfg::U == 1) {
-        final_store<Cfg, LOGC, MODE, B1>(a, g, x, 0, 0, c);
+        final_store<Cfg, LOGC, MODE, B1, NT>(a, g, x, 0, 0, c);
     } else {
         const u32 i2 = o >> B3;
         BFS_UNROLL
@@ -395,10 +416,10 @@ BFS_HD void ntt_stage1_values(const PassArgs& a, const u64* tw, const u64* rowtw
     }
 }
 
-template <int B1, int B2, int B3, int LOGC, int MODE>
+template <int B1, int B2, int B3, int LOGC, int MODE, bool NT = false>
 BFS_HD void ntt_stage1_compute(const PassArgs& a, u64* smem, const u64* tw, const u64* rowtw, u32 tid, u32 bid_x, u32 bid_y, int sub, u64* x) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
-    ntt_stage1_values<B1, B2, B3, LOGC, MODE>(a, tw, rowtw, tid, bid_x, bid_y, sub, x);
+    ntt_stage1_values<B1, B2, B3, LOGC, MODE, NT>(a, tw, rowtw, tid, bid_x, bid_y, sub, x);
     if constexpr (Cfg::U >= 2) {
         BFS_UNROLL
         for (int m = 0; m < (1 << B1); ++m) smem[stage1_out_index<B1, B2, B3, LOGC, MODE>(a, tid, sub, m)] = x[m];
@@ -418,7 +439,7 @@ BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, const u64* tw, const u64* r
 
 // ---- stage 2: LDS read, second radix, (inner twiddle + LDS write) or final store
 // ntt_stage2_from: sub-group s of thread `tid` once its 2^B2 values are in x[] (however they got there)
-template <int B1, int B2, int B3, int LOGC, int MODE>
+template <int B1, int B2, int B3, int LOGC, int MODE, bool NT = false>
 BFS_HD void ntt_stage2_from(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid_y, int s, u64* x) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     if constexpr (B2 > 0) {
@@ -432,7 +453,7 @@ BFS_HD void ntt_stage2_from(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u3
         dif<Q>(x);
 #endif
         if constexpr (Cfg::U == 2) {
-            final_store<Cfg, LOGC, MODE, B2>(a, g, x, f1, B1, c);
+            final_store<Cfg, LOGC, MODE, B2, NT>(a, g, x, f1, B1, c);
         } else {
             const u64* tab = (MODE == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;
             BFS_UNROLL
@@ -446,7 +467,7 @@ BFS_HD void ntt_stage2_from(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u3
     }
 }
 
-template <int B1, int B2, int B3, int LOGC, int MODE>
+template <int B1, int B2, int B3, int LOGC, int MODE, bool NT = false>
 BFS_HD void ntt_stage2(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid_y) {
     if constexpr (B2 > 0) {
         constexpr int Q = 1 << B2, SG = 16 / Q;
@@ -455,13 +476,13 @@ BFS_HD void ntt_stage2(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid
             u64 x[Q];
             BFS_UNROLL
             for (int d = 0; d < Q; ++d) x[d] = smem[stage2_in_index<B1, B2, B3, LOGC, MODE>(tid, s, d)];
-            ntt_stage2_from<B1, B2, B3, LOGC, MODE>(a, smem, tid, bid_x, bid_y, s, x);
+            ntt_stage2_from<B1, B2, B3, LOGC, MODE, NT>(a, smem, tid, bid_x, bid_y, s, x);
         }
     }
 }
 
 // ---- stage 3: LDS read, third radix, final store
-template <int B1, int B2, int B3, int LOGC, int MODE>
+template <int B1, int B2, int B3, int LOGC, int MODE, bool NT = false>
 BFS_HD void ntt_stage3(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid_y) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     if constexpr (B3 > 0) {
@@ -477,7 +498,7 @@ BFS_HD void ntt_stage3(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid
             BFS_UNROLL
             for (int d = 0; d < Q; ++d) x[d] = smem[lds_addr<Cfg, LOGC>((f1 << Cfg::SH1) | (f2 << Cfg::SH2) | (u32)d, c)];
             dif<Q>(x);
-            final_store<Cfg, LOGC, MODE, B3>(a, g, x, f1 + (f2 << B1), B1 + B2, c);
+            final_store<Cfg, LOGC, MODE, B3, NT>(a, g, x, f1 + (f2 << B1), B1 + B2, c);
         }
     }
 }

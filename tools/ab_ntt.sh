@@ -7,7 +7,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for SPEC in "$@"; do
-  NAME=$(echo "$SPEC" | tr ',=' '__')
+  NAME=$(echo "$SPEC" | tr ',=/' '___')
   ( IFS=,; for kv in $SPEC; do export "$kv"; done
     python "$ROOT/tools/ntt_only.py" --steps 50 > "$OUT/plain_$NAME.json" 2>&1
     rocprofv3 --kernel-trace --output-format csv -d "$OUT/raw_$NAME" -o ntt -- python "$ROOT/tools/ntt_only.py" --steps 40 --no-check > /dev/null 2>&1
