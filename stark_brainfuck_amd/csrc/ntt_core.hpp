@@ -408,8 +408,9 @@ BFS_HD void ntt_stage1_values(const PassArgs& a, const u64* tw, const u64* rowtw
 #ifdef BFS_ABL_NO_INNER
             x[m] = x[m] + e;
 #else
-            // register 0 holds output digit 0: its twiddle is w^0, which is 1 unless n^-1 is folded into the table
-            const bool unit = (m == 0) && !(Cfg::U == 2 && MODE == PASS_FINAL);
+            // register 0 holds output digit 0: its twiddle is w^0, which is 1 unless a post-scale (n^-1 of intt) is folded into the
+            // table -- a wave-uniform question, so a forward transform skips that product in its VALU-bound last pass as well
+            const bool unit = (m == 0) && (!(Cfg::U == 2 && MODE == PASS_FINAL) || a.post_scale == 1);
             if (!unit) x[m] = gl_mul(x[m], tw[e]);
 #endif
         }
