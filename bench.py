@@ -158,15 +158,21 @@ def main():
             count[1] = time.perf_counter() - t0
         worker = threading.Thread(target=sustain)
         worker.start()
+        clock = {}
+        sampler = threading.Thread(target=lambda: clock.update(sample_clock_under_load(local_rank, delay_s=3.0) or {}))
+        sampler.start()
         try:
             cpu_line = cpu_baseline(log_n)
         finally:
+            sampler.join()
             stop.set()
             worker.join()
         cpu_line["python"] = cpu_baseline_python()
         sustained = {"seconds": count[1], "steps": count[0], "ms_per_step": count[1] / max(count[0], 1) * 1e3,
                      "elements_per_s": n * cols * count[0] / max(count[1], 1e-9),
                      "note": "untimed: the NTT step back to back from a second thread for as long as the CPU baseline leg runs"}
+        if clock:
+            sustained.update(clock)
     spin_t0, spin_steps = time.perf_counter(), 0
     while args.spinup_ms > 0 and (time.perf_counter() - spin_t0) * 1e3 < args.spinup_ms:
         step()
@@ -282,13 +288,22 @@ def main():
                 traffic = t["hbm_bytes_per_launch"]
                 tsrc = "static: profiles/ntt_traffic.json (%s)" % t.get("source", "rocprofv3 PMC")
                 valu_frac = t.get("valu_issue_frac")
+        sclk = (sustained or {}).get("sclk_mhz_under_load")
+        valu_frac_sustained = None
+        if valu_frac is not None and sclk:
+            # the PMC-derived fraction prices a wave64 VALU instruction at 4 cycles of the NOMINAL 2.4 GHz clock; under this load the
+            # package sits at its power limit and the shader clock is lower (profiles/r02/clock_under_load.txt)
+            valu_frac_sustained = t["valu_wave_instructions_per_step"] * 4.0 / 1024.0 / (sclk * 1e6) / (kern * 1e-3 / args.steps)
         line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                             "traffic": traffic, "traffic_source": tsrc,
                             "wasted_traffic_ratio": (traffic / bytes_per_launch) if traffic else None,
                             "valu_issue_frac": valu_frac,
+                            "valu_issue_frac_at_sustained_sclk": valu_frac_sustained,
                             "kernel": "ntt_tile_kernel_split<4,4,0,4,MODE,NT>" + ("(non-temporal data accesses)" if n * cols * 8 > (128 << 20) else ""), "launches_per_step": npass,
                             "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
-                            "note": "three HBM passes move 3x the algorithmic bytes; the kernel is co-limited by integer VALU issue (DESIGN.md 4.1)"}
+                            "note": "three HBM passes move 3x the algorithmic bytes; the step is bound by integer VALU issue at the shader clock the "
+                                    "1400 W package limit allows (sustained.sclk_mhz_under_load, one rocm-smi sample; the XCDs' clocks differ by a few "
+                                    "per cent, so the sustained-clock fraction can read slightly above 1) -- DESIGN.md 4.1"}
         if log_n == 24 and not args.no_single:
             line["single_column_2p24"] = bench_single_column(lib, _lib, d_in, d_out, n, log_n, root, stream)
         if not args.no_fri:
@@ -445,6 +460,30 @@ def cpu_baseline(log_n):
             "reference_python": {"value": 4320.0, "unit": "elements/s", "cores": 1,
                                  "provenance": "BASELINE.md: /root/reference/code/ntt.py, n = 2^20, 242.7 s, CPython 3.10.12, build container (8-core host); "
                                                "2^24 extrapolated there to ~2.6 k elements/s (1.8 h per column)"}}
+
+
+def sample_clock_under_load(gpu_index, delay_s=3.0):
+    """shader clock and package power as rocm-smi reports them `delay_s` into the sustained leg (best effort: None when rocm-smi is
+    missing or prints something else).  The 8 x 2^24 step runs the package into its power limit, and the clock that results --
+    not the nominal 2.4 GHz -- is what the VALU-issue bound of DESIGN.md 4.1 has to be priced at."""
+    import re
+    import subprocess
+    time.sleep(delay_s)
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower"], capture_output=True, text=True, timeout=20).stdout
+    except Exception:
+        return None
+    res = {}
+    m = re.search(r"GPU\[%d\]\s*:\s*sclk clock level: \d+: \((\d+)Mhz\)" % gpu_index, out)
+    if m:
+        res["sclk_mhz_under_load"] = int(m.group(1))
+    m = re.search(r"GPU\[%d\]\s*:\s*mclk clock level: \d+: \((\d+)Mhz\)" % gpu_index, out)
+    if m:
+        res["mclk_mhz_under_load"] = int(m.group(1))
+    m = re.search(r"GPU\[%d\]\s*:.*Power \(W\): ([0-9.]+)" % gpu_index, out)
+    if m:
+        res["package_power_w_under_load"] = float(m.group(1))
+    return res or None
 
 
 def cpu_baseline_python():
