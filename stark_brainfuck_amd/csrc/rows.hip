@@ -8,9 +8,10 @@
 //   1. a kernel computes every row's PATTERN (2 bits per extension column);
 //   2. the host builds one TEMPLATE per pattern that actually occurs (normally one or two) by running the generic pickle
 //      emitter (refpickle.hpp) on a row of sentinel values and cutting the result around the integer opcodes;
-//   3. the leaf kernel expands the template of each row -- constant segments from a small pool, integers encoded on the fly
-//      (BININT1/2, BININT, LONG1 as CPython's save_long), frame length patched in -- and feeds the bytes straight into BLAKE2b:
-//      one 128-byte block buffer per lane in LDS, compressed whenever it fills.  The preimage never exists in memory.
+//   3. the leaf kernel expands the template of each row -- the template is flattened on the host into steps of at most 8 preimage
+//      bytes (constant bytes carried in the step, integers encoded on the fly as BININT1/2, BININT or LONG1 like CPython's save_long,
+//      frame length patched in) which a wave walks in lockstep -- and feeds the bytes straight into BLAKE2b: a 24-word buffer per
+//      lane in LDS, compressed by the whole wave whenever the lane furthest ahead has filled it.  The preimage never exists in memory.
 #include <algorithm>
 #include <map>
 #include <memory>
@@ -28,44 +29,73 @@ namespace bfs {
 int merkle_inner_launch(u64* d_nodes, u32 depth, u64 n_leaves, hipStream_t stream, u64* root_out, u64 seq);
 
 constexpr int ROW_MAX_COLS = 32;
-enum { SEG_CONST = 0, SEG_INT = 1, SEG_FRAMELEN = 2, SEG_SALT = 3 };
+enum { SEG_CONST = 0, SEG_INT = 1, SEG_FRAMELEN = 2, SEG_SALT = 3, SEG_INT_HI = 4 };
 
+// host-side description of a template: constant byte runs (in a word pool) and the places where a row's integers go
 struct RowSeg {
     u32 kind;
     u32 a;      // CONST: word offset into the pool (segments start on a 64-bit word); INT: column
     u32 b;      // CONST: length in bytes; INT: limb
     u32 pad;
 };
+// what the kernel walks: the template flattened into steps of at most 8 preimage bytes each
+struct RowStep {
+    u32 kind;
+    u32 a;      // CONST: number of bytes (1..8); INT / INT_HI: column; SALT: word 0..2
+    u64 data;   // CONST: the bytes (zero padded); INT: limb | (column | limb << 8 of the integer ROW_PREFETCH places further on) << 8
+                //        | (index of this integer mod ROW_PREFETCH) << 24
+};
+// integers of a row are requested ROW_PREFETCH places ahead of where they are written (their loads go to HBM or the Infinity Cache:
+// 1-2 us, a few hundred instructions of encoding and hashing)
+constexpr u32 ROW_PREFETCH = 3, ROW_STEP_PAD = 4;
 struct RowTemplate {
-    u32 code, first_seg, num_segs, tuple_const_bytes, salt_bytes;
-    u32 pool_first, pool_words;      // the words of the pool its CONST segments point into
+    u32 code, first_step, num_steps, tuple_const_bytes, salt_bytes;
+    u32 first_int, num_ints;     // into RowArgs::ints: (column | limb << 8) of every integer of the row, in preimage order
     u32 pad;
 };
 struct RowArgs {
     const u64* const* columns;   // device array of column pointers
     const u32* is_ext;           // device array
     u32 ncols;
+    u32 n_ext;                   // extension columns among them ...
+    u32 ext_cols[4];             // ... and which they are, one byte each, in column order
     u64 n;                       // rows to hash
     u64 limb_stride;             // distance between the limb planes of an extension column (n, or the full column length when
                                  // the rows are a range of longer columns)
     const u64* salts;            // n x 3 words, or null
     const RowTemplate* templates;
     u32 num_templates;
-    const RowSeg* segs;
-    const u64* pool;
+    const RowStep* steps;
+    const u32* ints;
     u64* digests;                // n x 8 words
     u64* pattern_set;            // pattern kernel output: open-addressing set of the codes present (PATTERN_SLOTS entries, ~0 = empty)
     u32* error;                  // [0]: a row without a template, [1]: the pattern set overflowed
 };
 
+// 2 bits per extension column: how many coefficients its element of row i stores (trailing zero limbs are dropped).  The top limbs
+// of all extension columns are requested together (the column pointers come through the scalar unit, RowArgs::ext_cols lists the
+// columns): one memory latency for the common row whose top limbs are all non-zero, not one per column.
 __device__ __forceinline__ u32 row_pattern(const RowArgs& a, u64 i) {
-    u32 code = 0, shift = 0;
-    for (u32 c = 0; c < a.ncols; ++c) {
-        if (!a.is_ext[c]) continue;
-        const u64* p = a.columns[c];
-        const u32 k = p[2 * a.limb_stride + i] ? 3u : (p[a.limb_stride + i] ? 2u : (p[i] ? 1u : 0u));
-        code |= k << shift;
-        shift += 2;
+    typedef const u64* const __attribute__((address_space(4)))* Columns;
+    typedef const u64 __attribute__((address_space(1)))* Words;
+    const Columns columns = (Columns)a.columns;
+    u64 top[16];
+#pragma unroll
+    for (u32 j = 0; j < 16; ++j) {
+        top[j] = 1;
+        if (j < a.n_ext) top[j] = ((Words)columns[(a.ext_cols[j / 4] >> (8 * (j % 4))) & 0xFF])[2 * a.limb_stride + i];
+    }
+    u32 code = 0;
+#pragma unroll
+    for (u32 j = 0; j < 16; ++j) {
+        if (j < a.n_ext) {
+            u32 k = 3;
+            if (top[j] == 0) {
+                const Words p = (Words)columns[(a.ext_cols[j / 4] >> (8 * (j % 4))) & 0xFF];
+                k = p[a.limb_stride + i] ? 2u : (p[i] ? 1u : 0u);
+            }
+            code |= k << (2 * j);
+        }
     }
     return code;
 }
@@ -88,122 +118,205 @@ __global__ void row_pattern_kernel(const RowArgs a) {
     atomicOr(a.error + 1, 1u);
 }
 
-// One thread per row, 256 rows per workgroup.  The byte loop below is a chain of dependent loads (segment descriptor, then the
-// constant word or the column value it names): from global memory that chain, not BLAKE2b, set the pace (41 % of the VALU
-// floor).  Rows of a workgroup almost always share one template, so its descriptors and constants are staged in LDS once per
-// workgroup; a row with another pattern (or a template too large to stage) reads from global memory as before.
-constexpr u32 LEAF_THREADS = 256, STAGED_SEGS = 256, STAGED_WORDS = 512;
+// One thread per row, 256 rows per workgroup.  The rows of a wave (almost always) share one template, so the walk over the template is
+// WAVE-UNIFORM: segment descriptors and the constant words of the skeleton come through the scalar unit, the integers of a column are
+// one coalesced load per wave, and a lane's own work per 8 bytes of preimage is a funnel shift and an LDS store (the first version
+// kept a segment cursor per lane: 50-80 divergent VALU instructions per 8 bytes, 53 % of the BLAKE2b floor).  What differs between
+// lanes is only how many bytes their integers took, i.e. where in their block buffer they stand -- a few bytes of drift per block.  So
+// every lane has RING_WORDS (> 16) words of buffer, and the wave compresses TOGETHER when the lane that is furthest ahead has filled
+// its buffer: by then every lane holds a complete block unless the rows differ by more than 56 bytes, in which case the lanes behind
+// simply sit that compression out (still correct: block counters are per lane).  One compression site in the code (the final,
+// padded block goes through it as well), so the kernel stays inside the instruction cache.
+#ifndef BFS_ROW_UNROLL
+#define BFS_ROW_UNROLL 4
+#endif
+constexpr u32 LEAF_THREADS = 256, RING_WORDS = 24, ROW_UNROLL = BFS_ROW_UNROLL;
+// the template is read through the scalar unit: constant address space + wave-uniform index = s_load (the data was written by a
+// copy that completed before the launch, which is what the scalar cache needs)
+typedef const RowStep __attribute__((address_space(4)))* ConstSteps;
+typedef const u32 __attribute__((address_space(4)))* ConstInts;
+typedef const u64* const __attribute__((address_space(4)))* ConstColumns;
+typedef const u64 __attribute__((address_space(1)))* GlobalWords;
+__device__ __forceinline__ u32 uniform32(u32 x) { return (u32)__builtin_amdgcn_readfirstlane(x); }   // (the builtin returns a signed int)
+// a step that has to survive the compression site is kept in vector registers; reading it back through readfirstlane makes the
+// branches on its kind, and the loads that hang off it, scalar again
+__device__ __forceinline__ RowStep uniform_step(const RowStep& st) {
+    RowStep u;
+    u.kind = uniform32(st.kind);
+    u.a = uniform32(st.a);
+    u.data = ((u64)uniform32((u32)(st.data >> 32)) << 32) | (u64)uniform32((u32)st.data);
+    return u;
+}
 __global__ void __launch_bounds__(LEAF_THREADS) row_leaves_kernel(const RowArgs a) {
-    __shared__ u64 blk[16 * LEAF_THREADS];
-    __shared__ RowSeg s_segs[STAGED_SEGS];
-    __shared__ u64 s_pool[STAGED_WORDS];
+    __shared__ u64 blk[RING_WORDS * LEAF_THREADS];
     const u32 lane = threadIdx.x;
     const u64 i = (u64)blockIdx.x * LEAF_THREADS + lane;
-    const bool valid = i < a.n;
-    const u32 code = valid ? row_pattern(a, i) : 0u;
-    const RowTemplate* tp = nullptr;
+    if (i >= a.n) return;
+    const u32 code = row_pattern(a, i);
+    u32 mine = ~0u;
     for (u32 t = 0; t < a.num_templates; ++t)
-        if (a.templates[t].code == code) tp = a.templates + t;
-    // the template of the workgroup's first row is the staged one (the first row is always valid)
-    const u32 code0 = row_pattern(a, (u64)blockIdx.x * LEAF_THREADS);
-    const RowTemplate* staged = nullptr;
-    for (u32 t = 0; t < a.num_templates; ++t)
-        if (a.templates[t].code == code0) staged = a.templates + t;
-    if (staged && (staged->num_segs > STAGED_SEGS || staged->pool_words > STAGED_WORDS)) staged = nullptr;
-    if (staged) {
-        for (u32 k = lane; k < staged->num_segs; k += LEAF_THREADS) s_segs[k] = a.segs[staged->first_seg + k];
-        for (u32 k = lane; k < staged->pool_words; k += LEAF_THREADS) s_pool[k] = a.pool[staged->pool_first + k];
-    }
-    __syncthreads();
-    if (!valid) return;
-    if (tp == nullptr) { atomicOr(a.error, 1u); return; }
-    const bool cached = tp == staged;
-    const RowSeg* segs = a.segs + tp->first_seg;
-    const u32 pool_first = tp->pool_first;
-    auto segment = [&](u32 k) -> RowSeg { return cached ? s_segs[k] : segs[k]; };
-    auto constant = [&](u32 word) -> u64 { return cached ? s_pool[word - pool_first] : a.pool[word]; };
-    // pass 1: length of the tuple pickle = constant bytes + the integer opcodes of this row
-    u32 int_bytes = 0;
-    for (u32 s = 0; s < tp->num_segs; ++s) {
-        const RowSeg sg = segment(s);
-        if (sg.kind == SEG_INT) int_bytes += pickle_int_len(a.columns[sg.a][(u64)sg.b * a.limb_stride + i]);
-    }
-    const u32 tuple_len = tp->tuple_const_bytes + int_bytes;
-    const u32 total = tuple_len + tp->salt_bytes;
-    // pass 2: expand the template block by block.  Every lane fills its 128-byte block, then the wave compresses together:
-    // rows of one pattern differ only in the lengths of their integers, so the lanes drift apart by a few bytes -- with the
-    // compression inside the byte loop each lane would reach it in a different iteration and the wave would run the 2000
-    // instructions of a compression several times over with partial masks.
-    u64 h[8];
-    blake2b_init(h);
-    u64 acc = 0;            // funnel: pending bytes (< 8)
-    u32 fill = 0;
-    u32 s = 0, w = 0;       // current segment, word within it
-    const u32 nseg = tp->num_segs;
-    const u32 nblocks = total ? (total + 127) / 128 : 1;
-    for (u32 b = 0; b < nblocks; ++b) {
-        u32 wpos = 0;
-        while (wpos < 16 && s < nseg) {
-            const RowSeg sg = segment(s);
-            u64 data = 0;
-            u32 nb = 0;
-            if (sg.kind == SEG_CONST) {
-                data = constant(sg.a + w);
-                const u32 left = sg.b - 8 * w;
-                nb = left < 8 ? left : 8;
-                if (nb < 8) data &= (1ull << (8 * nb)) - 1;
-                if (8 * (w + 1) >= sg.b) { ++s; w = 0; } else ++w;
-            } else if (sg.kind == SEG_INT) {
-                const u64 v = a.columns[sg.a][(u64)sg.b * a.limb_stride + i];
-                u64 lo, hi = 0;
+        if (a.templates[t].code == code) mine = t;
+    if (mine == ~0u) { atomicOr(a.error, 1u); return; }
+    for (u32 t = 0; t < a.num_templates; ++t) {      // t is wave-uniform; lanes with another template wait their turn
+        if (mine != t) continue;
+        const RowTemplate* tp = a.templates + t;
+        // every lane here reads the same template: its fields go to scalar registers, and what hangs off them is read through the
+        // scalar unit
+        const u32 nsteps = uniform32(tp->num_steps), nints = uniform32(tp->num_ints);
+        const u32 tuple_const_bytes = uniform32(tp->tuple_const_bytes), salt_bytes = uniform32(tp->salt_bytes);
+        const ConstSteps steps = (ConstSteps)(a.steps + uniform32(tp->first_step));
+        const ConstInts ints = (ConstInts)(a.ints + uniform32(tp->first_int));
+        const ConstColumns columns = (ConstColumns)a.columns;
+        auto row_int = [&](u32 packed) -> u64 {
+#ifdef BFS_ROWS_ABL_NO_LOADS       // timing experiments only (tools/ab_rows.sh): wrong digests
+            return (u64)packed * 0x9E3779B97F4A7C15ULL + i;
+#endif
+            const GlobalWords col = (GlobalWords)columns[packed & 0xFF];
+            return col[(u64)((packed >> 8) & 0xFF) * a.limb_stride + i];
+        };
+        // pass 1: length of the tuple pickle = constant bytes + the integer opcodes of this row
+        u32 int_bytes = 0;
+#ifdef BFS_ROWS_ABL_NO_PASS1
+        int_bytes = 11 * nints;
+#else
+        {
+            u32 j = 0;
+            for (; j + 8 <= nints; j += 8) {         // eight loads in flight
+                u64 w[8];
+#pragma unroll
+                for (u32 q = 0; q < 8; ++q) w[q] = row_int(ints[j + q]);
+#pragma unroll
+                for (u32 q = 0; q < 8; ++q) int_bytes += pickle_int_len(w[q]);
+            }
+            for (; j < nints; ++j) int_bytes += pickle_int_len(row_int(ints[j]));
+        }
+#endif
+        const u32 tuple_len = tuple_const_bytes + int_bytes;
+        const u32 total = tuple_len + salt_bytes;
+        // pass 2: expand the template into the lane's buffer, compressing block-synchronously.  ROW_UNROLL steps per turn of the loop
+        // (the template is padded with empty steps): their descriptors are one scalar load, issued before the compression site.
+        u64 h[8];
+        blake2b_init(h);
+        u64 acc = 0;                // funnel: pending bytes (< 8)
+        u64 int_hi = 0;             // the integer being written: bytes 8.. of its opcode, and how many they are
+        u32 int_hi_bytes = 0;
+        // the next integers of the row, already requested; slot = integer index mod 3 (the step says which), so a slot is only ever
+        // touched by its own loads -- shifting values between registers would have to wait for loads still in flight
+        u64 r0 = 0, r1 = 0, r2 = 0;
+        if (nints) {
+            r0 = row_int(ints[0]);
+            r1 = row_int(ints[nints > 1 ? 1 : 0]);
+            r2 = row_int(ints[nints > 2 ? 2 : 0]);
+        }
+        u32 fill = 0, wpos = 0;     // bytes in acc; complete words in the buffer
+        u32 consumed = 0;           // bytes already compressed
+        u32 k = 0;                  // wave-uniform step counter
+        bool input_done = false, hashed_any = false;
+        auto take = [&](const RowStep& st) {
+            u64 data;
+            u32 nb;
+            if (st.kind == SEG_CONST) {
+                data = st.data;
+                nb = st.a;
+            } else if (st.kind == SEG_INT) {
+                const u32 slot = (u32)(st.data >> 24) & 0xFF, pf = (u32)(st.data >> 8) & 0xFFFF;
+                u64 v;
+                if (slot == 0) { v = r0; r0 = row_int(pf); }
+                else if (slot == 1) { v = r1; r1 = row_int(pf); }
+                else { v = r2; r2 = row_int(pf); }
                 u32 len;
-                if (v < (1ull << 8)) { lo = 0x4b | (v << 8); len = 2; }
-                else if (v < (1ull << 16)) { lo = 0x4d | (v << 8); len = 3; }
-                else if (v < (1ull << 31)) { lo = 0x4a | (v << 8); len = 5; }
-                else {
+                if (__all(v >= (1ull << 31))) {
+                    // field elements are almost never small: every lane writes a LONG1, no divergent branches
                     const u32 nn = (64 - (u32)__builtin_clzll(v)) / 8 + 1;
-                    lo = 0x8a | ((u64)nn << 8) | (v << 16);
-                    hi = v >> 48;
+                    data = 0x8a | ((u64)nn << 8) | (v << 16);
+                    int_hi = v >> 48;
                     len = 2 + nn;
+                } else {
+                    int_hi = 0;
+                    if (v < (1ull << 8)) { data = 0x4b | (v << 8); len = 2; }
+                    else if (v < (1ull << 16)) { data = 0x4d | (v << 8); len = 3; }
+                    else if (v < (1ull << 31)) { data = 0x4a | (v << 8); len = 5; }
+                    else {
+                        const u32 nn = (64 - (u32)__builtin_clzll(v)) / 8 + 1;
+                        data = 0x8a | ((u64)nn << 8) | (v << 16);
+                        int_hi = v >> 48;
+                        len = 2 + nn;
+                    }
                 }
-                if (w == 0) { data = lo; nb = len < 8 ? len : 8; if (len > 8) w = 1; else { ++s; } }
-                else { data = hi; nb = len - 8; ++s; w = 0; }
-            } else if (sg.kind == SEG_FRAMELEN) {
+                nb = len < 8 ? len : 8;
+                int_hi_bytes = len > 8 ? len - 8 : 0;
+            } else if (st.kind == SEG_INT_HI) {       // what did not fit into the first eight bytes of the integer's opcode
+                data = int_hi;
+                nb = int_hi_bytes;
+            } else if (st.kind == SEG_FRAMELEN) {
                 data = (u64)tuple_len - 11;
                 nb = 8;
-                ++s;
             } else {
-                data = a.salts[3 * i + w];
+                data = a.salts[3 * i + st.a];
                 nb = 8;
-                if (w == 2) { ++s; w = 0; } else ++w;
             }
-            // funnel the nb bytes into 64-bit words of the block buffer
+            // funnel the nb bytes into 64-bit words of the buffer (there is room: a lane that stood at RING_WORDS - ROW_UNROLL or
+            // beyond has just compressed)
             acc |= data << (8 * fill);
             const u32 nf = fill + nb;
             if (nf >= 8) {
                 blk[wpos * LEAF_THREADS + lane] = acc;
                 ++wpos;
-                acc = fill ? (data >> (8 * (8 - fill))) : 0;
+                acc = (data >> 1) >> (63 - 8 * fill);       // = data >> (64 - 8 fill), 0 for fill = 0
                 fill = nf - 8;
             } else {
                 fill = nf;
             }
-        }
-        if (wpos < 16 && fill) {      // end of the input: the pending bytes, zero padded
-            blk[wpos * LEAF_THREADS + lane] = acc;
-            ++wpos;
-            acc = 0;
-            fill = 0;
-        }
-        u64 m[16];
+        };
+        while (true) {
+            k = uniform32(k);       // (the same in every lane; the compiler cannot tell)
+            // ---- the compression site
+            bool want, last = false;
+            if (!input_done) {
+                want = __any(wpos >= RING_WORDS - ROW_UNROLL) && wpos >= 16 && consumed + 128 < total;
+            } else {
+                want = consumed < total || !hashed_any;
+                last = consumed + 128 >= total;
+                if (!__any(want)) break;
+            }
+            if (want) {
+                u64 m[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) m[j] = (u32)j < wpos ? blk[j * LEAF_THREADS + lane] : 0;
-        const bool last = b + 1 == nblocks;
-        blake2b_compress(h, m, last ? (u64)total : (u64)128 * (b + 1), last);
+                for (int j = 0; j < 16; ++j) m[j] = (u32)j < wpos ? blk[j * LEAF_THREADS + lane] : 0;
+#ifdef BFS_ROWS_ABL_NO_HASH
+#pragma unroll
+                for (int j = 0; j < 8; ++j) h[j] ^= m[j] + m[j + 8];
+#else
+                blake2b_compress(h, m, last ? (u64)total : (u64)consumed + 128, last);
+#endif
+                consumed += 128;
+                hashed_any = true;
+#pragma unroll
+                for (u32 j = 0; j < RING_WORDS - 16; ++j)
+                    if (16 + j < wpos) blk[j * LEAF_THREADS + lane] = blk[(16 + j) * LEAF_THREADS + lane];
+                wpos = wpos > 16 ? wpos - 16 : 0;
+            }
+            if (input_done) continue;
+            if (k < nsteps) {
+                // the descriptors of the next ROW_UNROLL steps: one scalar load, straight into scalar registers
+                RowStep st[ROW_UNROLL];
+#pragma unroll
+                for (u32 u = 0; u < ROW_UNROLL; ++u) { st[u].kind = steps[k + u].kind; st[u].a = steps[k + u].a; st[u].data = steps[k + u].data; }
+#pragma unroll
+                for (u32 u = 0; u < ROW_UNROLL; ++u) take(st[u]);
+                k += ROW_UNROLL;
+            } else {
+                if (fill) {                                     // end of the input: the pending bytes, zero padded
+                    blk[wpos * LEAF_THREADS + lane] = acc;
+                    ++wpos;
+                }
+                input_done = true;
+            }
+        }
+        u64* out = a.digests + i * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] = h[j];
     }
-    u64* out = a.digests + i * 8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) out[j] = h[j];
 }
 
 // Salts can also be made on the device: 64-byte block j of the stream is BLAKE2b-512(seed || j), seed = 32 bytes of os.urandom.
@@ -238,8 +351,10 @@ __global__ void xfe_sample_kernel(u64 s0, u64 s1, u64 s2, u64 s3, u64* out, u64 
 // ---- host: one template per pattern -------------------------------------------------------------------------------
 struct HostTemplates {
     std::vector<RowTemplate> templates;
-    std::vector<RowSeg> segs;
-    std::vector<u64> pool;
+    std::vector<RowStep> steps;      // what the kernel reads
+    std::vector<u32> ints;           // idem
+    std::vector<RowSeg> segs;        // scratch of build_template
+    std::vector<u64> pool;           // idem
 };
 
 static std::mutex g_template_mu;
@@ -282,8 +397,7 @@ static int build_template(const bfs_row_column* cols, u32 ncols, u32 code, bool 
     if (s.size() < 11 || (unsigned char)s[2] != 0x95) { set_error("row pickle without a frame"); return BFS_ERR_BAD_ARG; }
     RowTemplate t{};
     t.code = code;
-    t.first_seg = (u32)ht.segs.size();
-    t.pool_first = (u32)ht.pool.size();
+    const size_t first_seg = ht.segs.size();
     size_t pos = 0;
     u32 const_bytes = 0;
     auto flush = [&](size_t to) { add_const(ht, s, pos, to); const_bytes += (u32)(to - pos); pos = to; };
@@ -311,8 +425,30 @@ static int build_template(const bfs_row_column* cols, u32 ncols, u32 code, bool 
         add_const(ht, ss, at + 24, ss.size());
         t.salt_bytes = (u32)ss.size();
     }
-    t.num_segs = (u32)ht.segs.size() - t.first_seg;
-    t.pool_words = (u32)ht.pool.size() - t.pool_first;
+    // flatten: one step per (at most) 8 bytes of the preimage, constants carried in the step itself
+    t.first_step = (u32)ht.steps.size();
+    t.first_int = (u32)ht.ints.size();
+    for (size_t k = first_seg; k < ht.segs.size(); ++k)
+        if (ht.segs[k].kind == SEG_INT) ht.ints.push_back(ht.segs[k].a | (ht.segs[k].b << 8));
+    t.num_ints = (u32)ht.ints.size() - t.first_int;
+    u32 int_index = 0;
+    for (size_t k = first_seg; k < ht.segs.size(); ++k) {
+        const RowSeg& sg = ht.segs[k];
+        if (sg.kind == SEG_CONST) {
+            for (u32 w = 0; 8 * w < sg.b; ++w) ht.steps.push_back(RowStep{SEG_CONST, std::min<u32>(8u, sg.b - 8 * w), ht.pool[sg.a + w]});
+        } else if (sg.kind == SEG_INT) {
+            const u32 pf = ht.ints[t.first_int + std::min(int_index + ROW_PREFETCH, t.num_ints - 1)];    // what to request at this integer
+            ++int_index;
+            ht.steps.push_back(RowStep{SEG_INT, sg.a, (u64)sg.b | ((u64)pf << 8) | ((u64)((int_index - 1) % ROW_PREFETCH) << 24)});
+            ht.steps.push_back(RowStep{SEG_INT_HI, sg.a, sg.b});
+        } else if (sg.kind == SEG_FRAMELEN) {
+            ht.steps.push_back(RowStep{SEG_FRAMELEN, 0, 0});
+        } else {
+            for (u32 w = 0; w < 3; ++w) ht.steps.push_back(RowStep{SEG_SALT, w, 0});
+        }
+    }
+    while ((ht.steps.size() - t.first_step) % ROW_STEP_PAD) ht.steps.push_back(RowStep{SEG_CONST, 0, 0});   // the kernel takes several steps per turn
+    t.num_steps = (u32)ht.steps.size() - t.first_step;
     ht.templates.push_back(t);
     return BFS_OK;
 }
@@ -410,6 +546,8 @@ static int build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n,
 
     RowArgs a{};
     a.columns = d_cols; a.is_ext = d_ext; a.ncols = ncols; a.n = n; a.limb_stride = limb_stride;
+    for (u32 c = 0; c < ncols; ++c)
+        if (columns[c].is_ext) { a.ext_cols[a.n_ext / 4] |= c << (8 * (a.n_ext % 4)); ++a.n_ext; }
     a.salts = h_salts ? d_salts : (salted ? (const u64*)salts : nullptr);
     a.digests = (u64*)d_nodes + npo2 * 8;
     a.pattern_set = d_set; a.error = d_err;
@@ -449,20 +587,20 @@ static int build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n,
         cached = fresh;
     }
     const HostTemplates& ht = *cached;
-    const size_t tbytes = ht.templates.size() * sizeof(RowTemplate), sbytes = ht.segs.size() * sizeof(RowSeg), pbytes = ht.pool.size() * sizeof(u64);
+    const size_t tbytes = ht.templates.size() * sizeof(RowTemplate), sbytes = ht.steps.size() * sizeof(RowStep), ibytes = ht.ints.size() * sizeof(u32);
     void* tw = nullptr;
-    BFS_TRY(workspace(6, tbytes + sbytes + pbytes + 64, stream, &tw));
+    BFS_TRY(workspace(6, tbytes + sbytes + ibytes + 64, stream, &tw));
     char* tb = (char*)tw;
     PinnedLease tstage;
-    BFS_TRY(tstage.get(tbytes + sbytes + pbytes + 64));
+    BFS_TRY(tstage.get(tbytes + sbytes + ibytes + 64));
     memcpy(tstage.host, ht.templates.data(), tbytes);
-    memcpy((char*)tstage.host + tbytes, ht.segs.data(), sbytes);
-    memcpy((char*)tstage.host + tbytes + sbytes, ht.pool.data(), pbytes);
-    BFS_HIP(hipMemcpyAsync(tb, tstage.host, tbytes + sbytes + pbytes, hipMemcpyHostToDevice, stream));
+    memcpy((char*)tstage.host + tbytes, ht.steps.data(), sbytes);
+    memcpy((char*)tstage.host + tbytes + sbytes, ht.ints.data(), ibytes);
+    BFS_HIP(hipMemcpyAsync(tb, tstage.host, tbytes + sbytes + ibytes, hipMemcpyHostToDevice, stream));
     a.templates = (const RowTemplate*)tb;
     a.num_templates = (u32)ht.templates.size();
-    a.segs = (const RowSeg*)(tb + tbytes);
-    a.pool = (const u64*)(tb + tbytes + sbytes);
+    a.steps = (const RowStep*)(tb + tbytes);
+    a.ints = (const u32*)(tb + tbytes + sbytes);
 
     // 3. leaf digests, then the tree
     hipLaunchKernelGGL(row_leaves_kernel, dim3((u32)((n + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0, stream, a);

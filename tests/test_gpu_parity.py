@@ -690,8 +690,10 @@ def test_device_side_sampling_of_the_randomizer_polynomial(sb):
 @pytest.mark.parametrize("n,n_ext,n_base", [(1, 1, 0), (2, 0, 3), (3, 2, 2), (65, 16, 16), (1000, 2, 2)])
 def test_zipped_rows_edge_shapes(sb, oracle, n, n_ext, n_base):
     """row emitter on tiny, ragged (absent leaf slots) and wide inputs; 32 columns make the row pickle longer than 2.5 KB,
-    with memo back-references beyond index 255 (LONG_BINGET); the zeroed limbs put several patterns into one workgroup, so
-    rows whose template is not the one staged in LDS take the global-memory path of the leaf kernel"""
+    with memo back-references beyond index 255 (LONG_BINGET); the zeroed limbs put several patterns into one wave, so
+    the leaf kernel walks several templates per wave (lanes of another template wait their turn); the base columns hold
+    one-byte integers next to the 9-byte ones of the extension limbs, and the extension rows alternate between
+    coefficient counts, so the lanes of a wave drift apart in their block buffers"""
     from stark_brainfuck_amd import _lib
     from stark_brainfuck_amd.device import DeviceBuffer
     lib = _lib.load()
