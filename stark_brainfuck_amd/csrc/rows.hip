@@ -10,7 +10,7 @@
 //      emitter (refpickle.hpp) on a row of sentinel values and cutting the result around the integer opcodes;
 //   3. the leaf kernel expands the template of each row -- the template is flattened on the host into steps of at most 8 preimage
 //      bytes (constant bytes carried in the step, integers encoded on the fly as BININT1/2, BININT or LONG1 like CPython's save_long,
-//      frame length patched in) which a wave walks in lockstep -- and feeds the bytes straight into BLAKE2b: a 24-word buffer per
+//      frame length patched in) which a wave walks in lockstep -- and feeds the bytes straight into BLAKE2b: a 200-byte buffer per
 //      lane in LDS, compressed by the whole wave whenever the lane furthest ahead has filled it.  The preimage never exists in memory.
 #include <algorithm>
 #include <map>
@@ -22,6 +22,7 @@
 #include "blake2b.hpp"
 #include "leaf_encode.hpp"
 #include "refpickle.hpp"
+#include "rows_core.hpp"
 #include "runtime.hpp"
 
 namespace bfs {
@@ -29,7 +30,6 @@ namespace bfs {
 int merkle_inner_launch(u64* d_nodes, u32 depth, u64 n_leaves, hipStream_t stream, u64* root_out, u64 seq);
 
 constexpr int ROW_MAX_COLS = 32;
-enum { SEG_CONST = 0, SEG_INT = 1, SEG_FRAMELEN = 2, SEG_SALT = 3, SEG_INT_HI = 4 };
 
 // host-side description of a template: constant byte runs (in a word pool) and the places where a row's integers go
 struct RowSeg {
@@ -38,16 +38,7 @@ struct RowSeg {
     u32 b;      // CONST: length in bytes; INT: limb
     u32 pad;
 };
-// what the kernel walks: the template flattened into steps of at most 8 preimage bytes each
-struct RowStep {
-    u32 kind;
-    u32 a;      // CONST: number of bytes (1..8); INT / INT_HI: column; SALT: word 0..2
-    u64 data;   // CONST: the bytes (zero padded); INT: limb | (column | limb << 8 of the integer ROW_PREFETCH places further on) << 8
-                //        | (index of this integer mod ROW_PREFETCH) << 24
-};
-// integers of a row are requested ROW_PREFETCH places ahead of where they are written (their loads go to HBM or the Infinity Cache:
-// 1-2 us, a few hundred instructions of encoding and hashing)
-constexpr u32 ROW_PREFETCH = 3, ROW_STEP_PAD = 4;
+// (RowStep, the flattened form the kernel walks: rows_core.hpp)
 struct RowTemplate {
     u32 code, first_step, num_steps, tuple_const_bytes, salt_bytes;
     u32 first_int, num_ints;     // into RowArgs::ints: (column | limb << 8) of every integer of the row, in preimage order
@@ -119,18 +110,12 @@ __global__ void row_pattern_kernel(const RowArgs a) {
 }
 
 // One thread per row, 256 rows per workgroup.  The rows of a wave (almost always) share one template, so the walk over the template is
-// WAVE-UNIFORM: segment descriptors and the constant words of the skeleton come through the scalar unit, the integers of a column are
-// one coalesced load per wave, and a lane's own work per 8 bytes of preimage is a funnel shift and an LDS store (the first version
-// kept a segment cursor per lane: 50-80 divergent VALU instructions per 8 bytes, 53 % of the BLAKE2b floor).  What differs between
-// lanes is only how many bytes their integers took, i.e. where in their block buffer they stand -- a few bytes of drift per block.  So
-// every lane has RING_WORDS (> 16) words of buffer, and the wave compresses TOGETHER when the lane that is furthest ahead has filled
-// its buffer: by then every lane holds a complete block unless the rows differ by more than 56 bytes, in which case the lanes behind
-// simply sit that compression out (still correct: block counters are per lane).  One compression site in the code (the final,
-// padded block goes through it as well), so the kernel stays inside the instruction cache.
-#ifndef BFS_ROW_UNROLL
-#define BFS_ROW_UNROLL 4
-#endif
-constexpr u32 LEAF_THREADS = 256, RING_WORDS = 24, ROW_UNROLL = BFS_ROW_UNROLL;
+// WAVE-UNIFORM: step descriptors (with the constant bytes of the skeleton inside them) come through the scalar unit, the integers of
+// a column are one coalesced load per wave, and a lane's own work per step is one unaligned LDS store at its own byte position
+// (rows_core.hpp; the first version kept a segment cursor per lane: 50-80 divergent VALU instructions per 8 bytes, 53 % of the
+// BLAKE2b floor).  One compression site in the code (the final, padded block goes through it as well), so the kernel stays inside
+// the instruction cache.
+constexpr u32 LEAF_THREADS = 256;
 // the template is read through the scalar unit: constant address space + wave-uniform index = s_load (the data was written by a
 // copy that completed before the launch, which is what the scalar cache needs)
 typedef const RowStep __attribute__((address_space(4)))* ConstSteps;
@@ -138,18 +123,10 @@ typedef const u32 __attribute__((address_space(4)))* ConstInts;
 typedef const u64* const __attribute__((address_space(4)))* ConstColumns;
 typedef const u64 __attribute__((address_space(1)))* GlobalWords;
 __device__ __forceinline__ u32 uniform32(u32 x) { return (u32)__builtin_amdgcn_readfirstlane(x); }   // (the builtin returns a signed int)
-// a step that has to survive the compression site is kept in vector registers; reading it back through readfirstlane makes the
-// branches on its kind, and the loads that hang off it, scalar again
-__device__ __forceinline__ RowStep uniform_step(const RowStep& st) {
-    RowStep u;
-    u.kind = uniform32(st.kind);
-    u.a = uniform32(st.a);
-    u.data = ((u64)uniform32((u32)(st.data >> 32)) << 32) | (u64)uniform32((u32)st.data);
-    return u;
-}
 __global__ void __launch_bounds__(LEAF_THREADS) row_leaves_kernel(const RowArgs a) {
-    __shared__ u64 blk[RING_WORDS * LEAF_THREADS];
+    __shared__ __attribute__((aligned(16))) unsigned char blk[ROW_LANE_BYTES * LEAF_THREADS];
     const u32 lane = threadIdx.x;
+    unsigned char* const buf = blk + ROW_LANE_BYTES * lane;
     const u64 i = (u64)blockIdx.x * LEAF_THREADS + lane;
     if (i >= a.n) return;
     const u32 code = row_pattern(a, i);
@@ -192,12 +169,10 @@ __global__ void __launch_bounds__(LEAF_THREADS) row_leaves_kernel(const RowArgs 
         }
 #endif
         const u32 tuple_len = tuple_const_bytes + int_bytes;
-        const u32 total = tuple_len + salt_bytes;
         // pass 2: expand the template into the lane's buffer, compressing block-synchronously.  ROW_UNROLL steps per turn of the loop
-        // (the template is padded with empty steps): their descriptors are one scalar load, issued before the compression site.
-        u64 h[8];
-        blake2b_init(h);
-        u64 acc = 0;                // funnel: pending bytes (< 8)
+        // (the template is padded with empty steps): their descriptors are one scalar load.
+        RowLane st8;
+        row_lane_init(st8, tuple_len + salt_bytes);
         u64 int_hi = 0;             // the integer being written: bytes 8.. of its opcode, and how many they are
         u32 int_hi_bytes = 0;
         // the next integers of the row, already requested; slot = integer index mod 3 (the step says which), so a slot is only ever
@@ -208,10 +183,8 @@ __global__ void __launch_bounds__(LEAF_THREADS) row_leaves_kernel(const RowArgs 
             r1 = row_int(ints[nints > 1 ? 1 : 0]);
             r2 = row_int(ints[nints > 2 ? 2 : 0]);
         }
-        u32 fill = 0, wpos = 0;     // bytes in acc; complete words in the buffer
-        u32 consumed = 0;           // bytes already compressed
         u32 k = 0;                  // wave-uniform step counter
-        bool input_done = false, hashed_any = false;
+        bool input_done = false;
         auto take = [&](const RowStep& st) {
             u64 data;
             u32 nb;
@@ -225,24 +198,8 @@ __global__ void __launch_bounds__(LEAF_THREADS) row_leaves_kernel(const RowArgs 
                 else if (slot == 1) { v = r1; r1 = row_int(pf); }
                 else { v = r2; r2 = row_int(pf); }
                 u32 len;
-                if (__all(v >= (1ull << 31))) {
-                    // field elements are almost never small: every lane writes a LONG1, no divergent branches
-                    const u32 nn = (64 - (u32)__builtin_clzll(v)) / 8 + 1;
-                    data = 0x8a | ((u64)nn << 8) | (v << 16);
-                    int_hi = v >> 48;
-                    len = 2 + nn;
-                } else {
-                    int_hi = 0;
-                    if (v < (1ull << 8)) { data = 0x4b | (v << 8); len = 2; }
-                    else if (v < (1ull << 16)) { data = 0x4d | (v << 8); len = 3; }
-                    else if (v < (1ull << 31)) { data = 0x4a | (v << 8); len = 5; }
-                    else {
-                        const u32 nn = (64 - (u32)__builtin_clzll(v)) / 8 + 1;
-                        data = 0x8a | ((u64)nn << 8) | (v << 16);
-                        int_hi = v >> 48;
-                        len = 2 + nn;
-                    }
-                }
+                if (__all(v >= (1ull << 31))) row_long1_opcode(v, data, int_hi, len);   // field elements are almost never small: no divergent branches
+                else row_int_opcode(v, data, int_hi, len);
                 nb = len < 8 ? len : 8;
                 int_hi_bytes = len > 8 ? len - 8 : 0;
             } else if (st.kind == SEG_INT_HI) {       // what did not fit into the first eight bytes of the integer's opcode
@@ -255,47 +212,19 @@ __global__ void __launch_bounds__(LEAF_THREADS) row_leaves_kernel(const RowArgs 
                 data = a.salts[3 * i + st.a];
                 nb = 8;
             }
-            // funnel the nb bytes into 64-bit words of the buffer (there is room: a lane that stood at RING_WORDS - ROW_UNROLL or
-            // beyond has just compressed)
-            acc |= data << (8 * fill);
-            const u32 nf = fill + nb;
-            if (nf >= 8) {
-                blk[wpos * LEAF_THREADS + lane] = acc;
-                ++wpos;
-                acc = (data >> 1) >> (63 - 8 * fill);       // = data >> (64 - 8 fill), 0 for fill = 0
-                fill = nf - 8;
-            } else {
-                fill = nf;
-            }
+            row_lane_put(st8, buf, data, nb);
         };
         while (true) {
             k = uniform32(k);       // (the same in every lane; the compiler cannot tell)
             // ---- the compression site
-            bool want, last = false;
+            bool want;
             if (!input_done) {
-                want = __any(wpos >= RING_WORDS - ROW_UNROLL) && wpos >= 16 && consumed + 128 < total;
+                want = row_lane_wants_mid(st8, __any(row_lane_full(st8)));
             } else {
-                want = consumed < total || !hashed_any;
-                last = consumed + 128 >= total;
+                want = row_lane_wants_end(st8);
                 if (!__any(want)) break;
             }
-            if (want) {
-                u64 m[16];
-#pragma unroll
-                for (int j = 0; j < 16; ++j) m[j] = (u32)j < wpos ? blk[j * LEAF_THREADS + lane] : 0;
-#ifdef BFS_ROWS_ABL_NO_HASH
-#pragma unroll
-                for (int j = 0; j < 8; ++j) h[j] ^= m[j] + m[j + 8];
-#else
-                blake2b_compress(h, m, last ? (u64)total : (u64)consumed + 128, last);
-#endif
-                consumed += 128;
-                hashed_any = true;
-#pragma unroll
-                for (u32 j = 0; j < RING_WORDS - 16; ++j)
-                    if (16 + j < wpos) blk[j * LEAF_THREADS + lane] = blk[(16 + j) * LEAF_THREADS + lane];
-                wpos = wpos > 16 ? wpos - 16 : 0;
-            }
+            if (want) row_lane_compress(st8, buf, input_done);
             if (input_done) continue;
             if (k < nsteps) {
                 // the descriptors of the next ROW_UNROLL steps: one scalar load, straight into scalar registers
@@ -306,16 +235,13 @@ __global__ void __launch_bounds__(LEAF_THREADS) row_leaves_kernel(const RowArgs 
                 for (u32 u = 0; u < ROW_UNROLL; ++u) take(st[u]);
                 k += ROW_UNROLL;
             } else {
-                if (fill) {                                     // end of the input: the pending bytes, zero padded
-                    blk[wpos * LEAF_THREADS + lane] = acc;
-                    ++wpos;
-                }
+                row_lane_finish(st8, buf);
                 input_done = true;
             }
         }
         u64* out = a.digests + i * 8;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) out[j] = h[j];
+        for (int j = 0; j < 8; ++j) out[j] = st8.h[j];
     }
 }
 

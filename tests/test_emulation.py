@@ -20,7 +20,7 @@ u64, vp = ctypes.c_uint64, ctypes.c_void_p
 @pytest.fixture(scope="session")
 def emu():
     so = os.path.join(EMU_DIR, "libbfs_emu.so")
-    srcs = [os.path.join(EMU_DIR, f) for f in ("emu_ntt.cpp", "emu_merkle.cpp")]
+    srcs = [os.path.join(EMU_DIR, f) for f in ("emu_ntt.cpp", "emu_merkle.cpp", "emu_rows.cpp")]
     deps = srcs + [os.path.join(ROOT, "stark_brainfuck_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "stark_brainfuck_amd", "csrc")) if f.endswith(".hpp")]
     if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so] + srcs)
@@ -28,6 +28,8 @@ def emu():
     lib.emu_gl_ntt.argtypes = [vp, u64, u64, vp, u64, ctypes.c_uint32, ctypes.c_uint32, u64, u64, u64]
     lib.emu_plan.argtypes = [ctypes.c_uint32, u64, vp, vp, vp, vp]
     lib.emu_merkle_xfe.argtypes = [vp, u64, u64, vp]
+    u32 = ctypes.c_uint32
+    lib.emu_row_leaves.argtypes = [vp, vp, vp, u32, vp, u32, vp, u32, u32, u32, vp, vp]
     return lib
 
 
@@ -124,3 +126,93 @@ def test_merkle_bodies_match_reference_trees(emu, oracle):
         got = [nodes[i * 8:(i + 1) * 8].tobytes().hex() for i in range(2 * npo2)]
         for i in range(1, npo2 + n):
             assert got[i] == t["nodes"][i], (n, i)
+
+
+# ------------------------------------------------------------------ zipped-row leaf kernel: the per-lane state machine
+def _pickle_int(v):
+    """CPython's save_long for a non-negative int below 2^64 (what pickle protocol 4 writes for the reference's element values)"""
+    if v < 1 << 8:
+        return b"K" + bytes([v])
+    if v < 1 << 16:
+        return b"M" + v.to_bytes(2, "little")
+    if v < 1 << 31:
+        return b"J" + v.to_bytes(4, "little")
+    nn = v.bit_length() // 8 + 1
+    return b"\x8a" + bytes([nn]) + v.to_bytes(nn, "little")
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_row_lanes_walk_a_template_block_synchronously(emu, seed):
+    """csrc/rows_core.hpp on the host: 64 lanes walk a random flattened template (constant runs, integers of every opcode width,
+    frame length, salt) in lockstep, with unaligned 8-byte stores into 200-byte lane buffers full of stale bytes and wave-wide
+    compressions; every lane's digest must be BLAKE2b of the bytes a direct construction gives.  Value mixes: all nine-byte
+    integers (lanes drift by a byte or two), random widths, and alternating all-small / all-large rows (lanes whole blocks apart,
+    which sit compressions out); lengths that end on block boundaries occur along the way."""
+    import pickle
+    rng = np.random.default_rng(1000 + seed)
+    lanes, PAD = 64, 4
+    SEG_CONST, SEG_INT, SEG_FRAMELEN, SEG_SALT, SEG_INT_HI = 0, 1, 2, 3, 4
+    pieces = [("c", bytes(rng.integers(0, 256, 3, dtype=np.uint8))), ("f", None)]
+    nints = 0
+    for _ in range(int(rng.integers(1, 70))):
+        if rng.integers(0, 3) == 0:
+            pieces.append(("c", bytes(rng.integers(0, 256, int(rng.integers(1, 41)), dtype=np.uint8))))
+        else:
+            pieces.append(("i", nints))
+            nints += 1
+    salted = bool(seed % 2)
+    salt_pickle_pre, salt_pickle_post = b"\x80\x04\x95\x1c\x00\x00\x00\x00\x00\x00\x00C\x18", b"\x94."
+    assert pickle.dumps(bytes(24), protocol=4) == salt_pickle_pre + bytes(24) + salt_pickle_post
+    kinds, As, datas = [], [], []
+
+    def add_const(b):
+        for w in range(0, len(b), 8):
+            chunk = b[w:w + 8]
+            kinds.append(SEG_CONST); As.append(len(chunk)); datas.append(int.from_bytes(chunk, "little"))
+    const_bytes = 0
+    for kind, arg in pieces:
+        if kind == "c":
+            add_const(arg); const_bytes += len(arg)
+        elif kind == "f":
+            kinds.append(SEG_FRAMELEN); As.append(0); datas.append(0); const_bytes += 8
+        else:
+            kinds += [SEG_INT, SEG_INT_HI]; As += [arg, arg]; datas += [0, 0]
+    if salted:
+        add_const(salt_pickle_pre)
+        for w in range(3):
+            kinds.append(SEG_SALT); As.append(w); datas.append(0)
+        add_const(salt_pickle_post)
+    while len(kinds) % PAD:
+        kinds.append(SEG_CONST); As.append(0); datas.append(0)
+    P = (1 << 64) - (1 << 32) + 1
+    widths = [0, 255, 256, 65535, 65536, (1 << 31) - 1, 1 << 31, (1 << 40) - 1, 1 << 47, (1 << 48) + 9, (1 << 56) - 1, 1 << 56, (1 << 63) - 1, 1 << 63, P - 1]
+    mode = seed % 3
+    values = np.zeros((lanes, max(nints, 1)), dtype=np.uint64)
+    for l in range(lanes):
+        for j in range(nints):
+            if mode == 0:
+                values[l, j] = int(rng.integers(1 << 63, P, dtype=np.uint64))
+            elif mode == 1:
+                values[l, j] = widths[int(rng.integers(0, len(widths)))]
+            else:
+                values[l, j] = 5 if l % 2 else P - 1 - j
+    salts = rng.integers(0, 1 << 63, (lanes, 3), dtype=np.uint64)
+    k32 = np.array(kinds, dtype=np.uint32); a32 = np.array(As, dtype=np.uint32); d64 = np.array(datas, dtype=np.uint64)
+    out = np.zeros((lanes, 8), dtype=np.uint64)
+    skew = ctypes.c_uint32()
+    vals = np.ascontiguousarray(values[:, :nints]) if nints else np.zeros(1, dtype=np.uint64)
+    rc = emu.emu_row_leaves(k32.ctypes.data, a32.ctypes.data, d64.ctypes.data, len(kinds), vals.ctypes.data, nints, salts.ctypes.data,
+                            const_bytes, len(salt_pickle_pre) + 24 + len(salt_pickle_post) if salted else 0, lanes, out.ctypes.data, ctypes.byref(skew))
+    assert rc == 0, rc
+    for l in range(lanes):
+        ints = [_pickle_int(int(values[l, j])) for j in range(nints)]
+        tuple_len = const_bytes + sum(len(b) for b in ints)
+        pre = b""
+        for kind, arg in pieces:
+            pre += arg if kind == "c" else ((tuple_len - 11).to_bytes(8, "little") if kind == "f" else ints[arg])
+        assert len(pre) == tuple_len
+        if salted:
+            pre += salt_pickle_pre + salts[l].tobytes() + salt_pickle_post
+        assert out[l].tobytes() == hashlib.blake2b(pre).digest(), "lane %d, %d bytes" % (l, len(pre))
+    if mode == 2 and nints >= 8:
+        assert skew.value > 56, "the alternating rows should put lanes more than a buffer's slack apart"

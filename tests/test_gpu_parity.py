@@ -723,6 +723,52 @@ def test_zipped_rows_edge_shapes(sb, oracle, n, n_ext, n_base):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("salted", [True, False])
+def test_zipped_rows_lanes_far_apart(sb, oracle, salted):
+    """the leaf kernel compresses wave-synchronously: every lane has a 24-word block buffer and the wave compresses when the lane
+    furthest ahead has filled it.  Here neighbouring rows differ by up to 32 x 9 = 288 bytes of preimage (all integers one byte
+    long in one row, nine bytes in the next, mixed widths in others), so lanes are whole blocks apart, sit compressions out, and
+    finish with different numbers of blocks.  Every leaf digest is compared, not only the root."""
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.device import DeviceBuffer
+    lib = _lib.load()
+    P = (1 << 64) - (1 << 32) + 1
+    n, n_base = 333, 32
+    rng = np.random.default_rng(7)
+    widths = [0, 200, 60000, (1 << 31) - 1, 1 << 31, (1 << 40) + 5, (1 << 48) - 1, 1 << 55, (1 << 63) - 1, P - 1]
+    base = np.zeros((n_base, n), dtype=np.uint64)
+    for i in range(n):
+        kind = i % 4
+        for c in range(n_base):
+            if kind == 0:
+                base[c, i] = 7                                      # two bytes each
+            elif kind == 1:
+                base[c, i] = P - 1 - c                              # eleven bytes each
+            elif kind == 2:
+                base[c, i] = widths[(i + c) % len(widths)]
+            else:
+                base[c, i] = widths[int(rng.integers(0, len(widths)))] if c < (i % n_base) else 3
+    bufs = [DeviceBuffer.from_numpy(np.ascontiguousarray(base[c])) for c in range(n_base)]
+    rc = (_lib.RowColumn * n_base)()
+    for k, b in enumerate(bufs):
+        rc[k].d_values, rc[k].is_ext, rc[k].field_id = b.ptr, 0, 0
+    npo2 = 512
+    nodes = DeviceBuffer(2 * npo2 * 8)
+    salts = rng.integers(0, 256, 24 * n, dtype=np.uint8).tobytes()
+    keep = ctypes.create_string_buffer(salts, len(salts))
+    _lib.check(lib.bfs_merkle_build_rows(rc, n_base, n, ctypes.cast(keep, ctypes.c_void_p) if salted else None, 0, nodes.ptr, 0))
+    rows = [tuple(oracle.make_bfe(int(base[c, i])) for c in range(n_base)) for i in range(n)]
+    preimages = [oracle.salted_leaf_bytes(r, salts[24 * i:24 * i + 24]) if salted else oracle.dumps(r) for i, r in enumerate(rows)]
+    lengths = {len(p) for p in preimages}
+    assert max(lengths) - min(lengths) >= 280, "the rows should differ by more than two blocks of preimage"
+    ref = oracle.MerkleOracle(preimages)
+    got = nodes.to_numpy(8 * n, offset=8 * npo2).tobytes()
+    for i in range(n):
+        assert got[64 * i:64 * i + 64] == hashlib.blake2b(preimages[i]).digest(), "leaf %d (%d bytes)" % (i, len(preimages[i]))
+    assert nodes.to_numpy(8, offset=8).tobytes() == ref.root()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("n", [1, 5, 255, 256, 257, 4099, 70001, (1 << 17) + 3])
 def test_device_scan_matches_the_host_scan(sb, n):
     """bfs_xfe_scan_device (prefix scan of affine maps, csrc/scan.hip) against the sequential host primitive bfs_xfe_scan on the
