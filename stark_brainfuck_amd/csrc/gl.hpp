@@ -109,16 +109,33 @@ BFS_HD u64 gl_reduce96(u32 top, u64 lo) {
     return c3 ? (((u64)uhi << 32) | ulo) : (((u64)rhi << 32) | rlo);
 }
 
-// 64 x 64 -> 128 as four independent 32 x 32 products and a 5-instruction carry tree (no register shuffles)
+// 64 x 64 -> 128 in 8 instructions: the two middle products are added by the multiply-add itself (ah*bl + al*bh in ONE
+// v_mad_u64_u32, whose carry-out -- the 2^64 of that sum -- is picked up at once; C cannot ask for it), which leaves one add for
+// the low half and two add-with-carry steps for the high one.  (Four independent products and a carry tree were 10.)
 BFS_HD void gl_mul128(u64 a, u64 b, u64& hi, u64& lo) {
     const u32 al = (u32)a, ah = (u32)(a >> 32), bl = (u32)b, bh = (u32)(b >> 32);
-    const u64 A = (u64)al * bl, B = (u64)ah * bh, M1 = (u64)al * bh, M2 = (u64)ah * bl;
-    u32 c, k, k2, c3;
-    u32 mlo = __builtin_addc((u32)M1, (u32)M2, 0u, &c);
-    u32 mhi = __builtin_addc((u32)(M1 >> 32), (u32)(M2 >> 32), c, &k);
-    u32 l1 = __builtin_addc((u32)(A >> 32), mlo, 0u, &k2);
-    u32 h0 = __builtin_addc((u32)B, mhi, k2, &c3);
-    u32 h1 = (u32)(B >> 32) + k + c3;
+#ifdef BFS_ABL_MUL128_TREE        // A/B only: the four-independent-products form
+    {
+        const u64 A = (u64)al * bl, B = (u64)ah * bh, M1 = (u64)al * bh, M2 = (u64)ah * bl;
+        u32 c, k, k2, c3;
+        u32 mlo = __builtin_addc((u32)M1, (u32)M2, 0u, &c);
+        u32 mhi = __builtin_addc((u32)(M1 >> 32), (u32)(M2 >> 32), c, &k);
+        u32 l1 = __builtin_addc((u32)(A >> 32), mlo, 0u, &k2);
+        u32 h0 = __builtin_addc((u32)B, mhi, k2, &c3);
+        u32 h1 = (u32)(B >> 32) + k + c3;
+        lo = ((u64)l1 << 32) | (u32)A;
+        hi = ((u64)h1 << 32) | h0;
+        return;
+    }
+#endif
+    const u64 A = (u64)al * bl, B = (u64)ah * bh, M1 = (u64)al * bh;
+    u64 M;                                             // ah*bl + al*bh mod 2^64
+    u32 k;                                             // and its carry
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %4\n\ts_nop 1\n\tv_cndmask_b32 %1, 0, 1, vcc" : "=&v"(M), "=v"(k) : "v"(ah), "v"(bl), "v"(M1) : "vcc");
+    u32 k2, c3, c4;
+    u32 l1 = __builtin_addc((u32)(A >> 32), (u32)M, 0u, &k2);
+    u32 h0 = __builtin_addc((u32)B, (u32)(M >> 32), k2, &c3);
+    u32 h1 = __builtin_addc((u32)(B >> 32), k, c3, &c4);
     lo = ((u64)l1 << 32) | (u32)A;
     hi = ((u64)h1 << 32) | h0;
 }
