@@ -69,7 +69,7 @@ BFS_HD u32 gl_opaque_zero() {
 }
 
 // hi*2^64 + lo  ->  residue; CANON = false leaves the value in [0, 2^64) (fine as an operand of further multiplications).
-// 13 VALU instructions (17 as plain C): the multiply-add  hi_lo * (2^32 - 1) + t0  is ONE v_mad_u64_u32 whose carry-out is used
+// 11 VALU instructions (13 with add / add-with-carry pairs, 17 as plain C): the multiply-add  hi_lo * (2^32 - 1) + t0  is ONE v_mad_u64_u32 whose carry-out is used
 // directly -- C has no way to ask for that carry, and the compiler's version is mad + 64-bit add + 64-bit compare.
 template <bool CANON>
 BFS_HD u64 gl_reduce128_t(u64 hi, u64 lo) {
@@ -82,31 +82,49 @@ BFS_HD u64 gl_reduce128_t(u64 hi, u64 lo) {
     u32 t0lo = __builtin_subc(dlo, t, 0u, &b2);
     u32 t0hi = __builtin_subc(dhi, z, b2, &b3);
     u64 t0 = ((u64)t0hi << 32) | t0lo;
-    u64 r;                                             // + hi_lo * (2^32 - 1)  (2^64 = 2^32 - 1)
-    u32 m;                                             // 0xFFFFFFFF when that addition wrapped: + EPS (cannot wrap twice)
-    asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\ts_nop 1\n\tv_cndmask_b32 %1, 0, -1, vcc" : "=&v"(r), "=v"(m) : "v"(hl), "v"(t0) : "vcc");
-    u32 c2, c3;
-    u32 rlo = __builtin_addc((u32)r, m, 0u, &c2);
-    u32 rhi = __builtin_addc((u32)(r >> 32), z, c2, &c3);
-    if constexpr (!CANON) return ((u64)rhi << 32) | rlo;
-    // canonical form: r >= p  <=>  r + EPS carries out of 64 bits
-    u32 ulo = __builtin_addc(rlo, 0xFFFFFFFFu, 0u, &c2);
-    u32 uhi = __builtin_addc(rhi, z, c2, &c3);
-    return c3 ? (((u64)uhi << 32) | ulo) : (((u64)rhi << 32) | rlo);
+    // + hi_lo * (2^32 - 1)  (2^64 = 2^32 - 1): one multiply-add; when that addition wrapped, + EPS (cannot wrap twice), again as a
+    // multiply-add  r + mask * 1  on the register pair; and the canonical form (r >= p  <=>  r + EPS carries out of 64 bits) the same
+    // way: a multiply-add for the carry, the mask, a multiply-add that adds it.  Every step works on whole 64-bit pairs, so the
+    // sequence is 3 (+ 3) instructions where add / add-with-carry / select pairs were 4 (+ 4).
+    u64 r;
+#ifdef BFS_ABL_REDUCE_ADDC          // A/B only: the add-with-carry form
+    {
+        u32 m;
+        asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\ts_nop 1\n\tv_cndmask_b32 %1, 0, -1, vcc" : "=&v"(r), "=v"(m) : "v"(hl), "v"(t0) : "vcc");
+        u32 c2, c3;
+        u32 rlo = __builtin_addc((u32)r, m, 0u, &c2);
+        u32 rhi = __builtin_addc((u32)(r >> 32), z, c2, &c3);
+        if constexpr (!CANON) return ((u64)rhi << 32) | rlo;
+        u32 ulo = __builtin_addc(rlo, 0xFFFFFFFFu, 0u, &c2);
+        u32 uhi = __builtin_addc(rhi, z, c2, &c3);
+        return c3 ? (((u64)uhi << 32) | ulo) : (((u64)rhi << 32) | rlo);
+    }
+#endif
+    if constexpr (!CANON) {
+        u64 q;
+        u32 m;
+        asm("v_mad_u64_u32 %0, vcc, %3, -1, %4\n\ts_nop 1\n\tv_cndmask_b32 %2, 0, -1, vcc\n\tv_mad_u64_u32 %1, vcc, %2, 1, %0"
+            : "=&v"(q), "=&v"(r), "=&v"(m) : "v"(hl), "v"(t0) : "vcc");
+        return r;
+    } else {
+        u64 q, q1;
+        u32 m;
+        asm("v_mad_u64_u32 %0, vcc, %4, -1, %5\n\ts_nop 1\n\tv_cndmask_b32 %3, 0, -1, vcc\n\tv_mad_u64_u32 %1, vcc, %3, 1, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, -1, 1, %1\n\ts_nop 1\n\tv_cndmask_b32 %3, 0, -1, vcc\n\tv_mad_u64_u32 %2, vcc, %3, 1, %1"
+            : "=&v"(q), "=&v"(q1), "=&v"(r), "=&v"(m) : "v"(hl), "v"(t0) : "vcc");
+        return r;
+    }
 }
 BFS_HD u64 gl_reduce128(u64 hi, u64 lo) { return gl_reduce128_t<true>(hi, lo); }
 
 // lo + top * 2^64 for a 32-bit top  ->  canonical residue (x << r for r < 32 is such a 96-bit value): the tail of gl_reduce128_t
 BFS_HD u64 gl_reduce96(u32 top, u64 lo) {
-    const u32 z = gl_opaque_zero();
-    u64 r;
-    u32 m, c2, c3;
-    asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\ts_nop 1\n\tv_cndmask_b32 %1, 0, -1, vcc" : "=&v"(r), "=v"(m) : "v"(top), "v"(lo) : "vcc");
-    u32 rlo = __builtin_addc((u32)r, m, 0u, &c2);
-    u32 rhi = __builtin_addc((u32)(r >> 32), z, c2, &c3);
-    u32 ulo = __builtin_addc(rlo, 0xFFFFFFFFu, 0u, &c2);
-    u32 uhi = __builtin_addc(rhi, z, c2, &c3);
-    return c3 ? (((u64)uhi << 32) | ulo) : (((u64)rhi << 32) | rlo);
+    u64 q, q1, r;
+    u32 m;
+    asm("v_mad_u64_u32 %0, vcc, %4, -1, %5\n\ts_nop 1\n\tv_cndmask_b32 %3, 0, -1, vcc\n\tv_mad_u64_u32 %1, vcc, %3, 1, %0\n\t"
+        "v_mad_u64_u32 %0, vcc, -1, 1, %1\n\ts_nop 1\n\tv_cndmask_b32 %3, 0, -1, vcc\n\tv_mad_u64_u32 %2, vcc, %3, 1, %1"
+        : "=&v"(q), "=&v"(q1), "=&v"(r), "=&v"(m) : "v"(top), "v"(lo) : "vcc");
+    return r;
 }
 
 // 64 x 64 -> 128 in 8 instructions: the two middle products are added by the multiply-add itself (ah*bl + al*bh in ONE
