@@ -37,7 +37,12 @@ extern "C" int bfs_selftest_field(uint32_t log_count, uint64_t* mismatches) {
     const u64 n = 1ull << log_count;
     std::vector<u64> in(2 * n), got(ST_OPS * n);
     const u64 edges[] = {0, 1, 2, 3, 0xFFFFFFFFULL, 0x100000000ULL, 0x100000001ULL, GL_P - 1, GL_P - 2, GL_P - 3, 0xFFFFFFFF00000000ULL - 1,
-                         0xFFFFFFFEFFFFFFFFULL, 300, 44, 0xFFFFFFFE00000001ULL, 0x8000000000000000ULL};
+                         0xFFFFFFFEFFFFFFFFULL, 300, 44, 0xFFFFFFFE00000001ULL, 0x8000000000000000ULL,
+                         // products with 2 or 3 that fit 64 bits but are >= p: the reduction's value is only non-canonical in its last step
+                         // (one product in 2^32 lands there by chance)
+                         0x5555555555555555ULL, 0x7FFFFFFF80000001ULL, 0x7FFFFFFFFFFFFFFFULL, 0x55555555AAAAAAABULL,
+                         // ... and operands whose 96-bit shifts (mul_pow2 with K < 32) do the same
+                         0x000FFFFFFFF00001ULL, 0x000FFFFFFFFFFFFFULL};
     const u64 ne = sizeof(edges) / sizeof(edges[0]);
     u64 s = 3;
     auto rnd = [&]() { s += 0x9E3779B97F4A7C15ULL; u64 z = s; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; return (z ^ (z >> 31)) % GL_P; };
