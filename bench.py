@@ -75,6 +75,10 @@ def main():
     ap.add_argument("--no-check", action="store_true", help="skip the post-run round-trip check and root gather (PMC collection runs)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves -- the same one-process-per-GPU launch the driver uses
+        # (torch.distributed.run over 127.0.0.1); rank 0 of that job prints the JSON line on the stdout we share with it
+        raise SystemExit(self_launch(args.gpus))
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -113,9 +117,17 @@ def main():
             os.close(saved_stdout)
 
     from stark_brainfuck_amd import _lib, shard
-    from stark_brainfuck_amd.device import DeviceBuffer
+    from stark_brainfuck_amd.device import DeviceBuffer, DeviceView
     lib = _lib.load()
     _lib.check(lib.bfs_set_device(local_rank))
+    # who is in the job, as the collective backend itself sees it: world size from the process group and every rank's device
+    # (index + PCI bus id), all-gathered -- so the line shows N distinct GPUs behind N ranks, not N ranks on one device
+    ranks_seen, rank_devices = 1, [device_identity(torch, local_rank)]
+    if dist is not None:
+        ranks_seen = dist.get_world_size()
+        gathered = [None] * world
+        dist.all_gather_object(gathered, rank_devices[0])
+        rank_devices = gathered
 
     log_n = args.log_n
     n = 1 << log_n
@@ -205,18 +217,35 @@ def main():
     # ---- after the timed region: correctness guard + the one collective of the design (roots of all columns)
     from stark_brainfuck_amd.arrays import BaseArray
     from stark_brainfuck_amd.merkle import Merkle
-    if args.no_check:
-        world_roots = None
-    inv = DeviceBuffer(n) if not args.no_check else None
-    local_roots = {}
+    local_roots, column_sha, guard = {}, {}, None
     if not args.no_check:
-        _lib.check(lib.bfs_gl_ntt(d_out.ptr, n, n, inv.ptr, n, log_n, 1, lib.bfs_gl_inv(root), 1, lib.bfs_gl_inv(n), stream))
+        # every column of this rank, in full: (1) inverse transform of the whole batch == the input, (2) one SHA-256 per output
+        # column, compared with the oracle's known answers when the workload is the fixture's (2^24, tests/golden/ntt24_oracle.json:
+        # same seed, same columns), (3) a Merkle tree over the whole column (2^log_n leaves), whose root is what gets all-gathered
+        import hashlib
+        inv = DeviceBuffer(n * cols)
+        _lib.check(lib.bfs_gl_ntt(d_out.ptr, n, n, inv.ptr, n, log_n, cols, lib.bfs_gl_inv(root), 1, lib.bfs_gl_inv(n), stream))
         back = inv.to_numpy()
-        assert (back == host_in[:n]).all(), "intt(ntt(x)) != x on the bench data"
-        small = 1 << 12                                      # commit to a 4096-element prefix of each output column
+        assert (back == host_in).all(), "intt(ntt(x)) != x on the bench data"
+        del back, inv
+        known = None
+        gpath = os.path.join(ROOT, "tests", "golden", "ntt24_oracle.json")
+        if log_n == 24 and os.path.exists(gpath):
+            g = json.load(open(gpath))
+            if g.get("seed") == SEED and g.get("root") == root:
+                known = g["columns"]
+        checked = 0
         for j, c in enumerate(my_cols):
-            pref = BaseArray(DeviceBuffer.from_numpy(d_out.to_numpy(small, offset=j * n)), small)
-            local_roots[c] = Merkle(pref).root()
+            col = d_out.to_numpy(n, offset=j * n)
+            column_sha[c] = hashlib.sha256(np.ascontiguousarray(col, dtype="<u8").tobytes()).hexdigest()
+            if known is not None and c < len(known):
+                assert column_sha[c] == known[c]["output_sha256"], "column %d differs from the oracle's known answer" % c
+                checked += 1
+            tree = Merkle(BaseArray(DeviceView(d_out, j * n, n), n))       # leaves hashed where the transform left them
+            local_roots[c] = tree.root()
+            del tree, col
+        guard = {"columns_round_tripped": cols, "columns_sha256_vs_oracle_known_answers": checked,
+                 "merkle_leaves_per_column": n}
     world_roots = None
     if not args.no_check:
         # the one collective of the design: all-gather of the per-column roots (RCCL over xGMI when world > 1)
@@ -243,6 +272,8 @@ def main():
                    "log_n": log_n, "total_columns": total_cols, "columns_per_gpu": shard.columns_per_rank(total_cols, world),
                    "parallelism": "column c on rank c mod %d (shard.assign_columns), no data-path collective; roots all-gathered after the timed region" % world},
         "roots_sha256": __import__("hashlib").sha256(b"".join(world_roots)).hexdigest() if world_roots else None,
+        "guard": guard,
+        "rccl_ranks_seen": ranks_seen, "collective_backend": (backend if dist is not None else None), "rank_devices": rank_devices,
         "algorithmic_GBps": 16.0 * elems / elapsed / 1e9,
         "clock_spinup": {"ms": args.spinup_ms, "untimed_steps": spin_steps},
     }
@@ -325,6 +356,31 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def device_identity(torch, index):
+    try:
+        props = torch.cuda.get_device_properties(index)
+        bus = getattr(props, "pci_bus_id", None)
+        return {"device": index, "name": props.name, "pci_bus_id": bus, "uuid": str(getattr(props, "uuid", "")) or None}
+    except Exception:
+        return {"device": index}
+
+
+def self_launch(n_ranks):
+    """re-executes this command line under torch.distributed.run with one rank per GPU and returns its exit status"""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
 
 
 def bench_single_column(lib, _lib, d_in, d_out, n, log_n, root, stream, steps=200):

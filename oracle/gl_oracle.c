@@ -6,7 +6,7 @@
  * imports or calls anything in oracle/.
  *
  * Parity status: PINNED.  tests/test_oracle_golden.py checks every function here against the
- * fixtures in tests/golden/*.json, which were produced by running the reference itself
+ * fixtures in tests/golden/ (JSON), which were produced by running the reference itself
  * (tests/golden/gen_golden.py).
  *
  * Each function cites the reference file:line it restates (paths relative to /root/reference/code).

@@ -35,14 +35,31 @@ _LIB_PATH = os.path.join(_HERE, "libgl_oracle.so")
 PICKLE_PROTOCOL = 4               # the reference pickles with the interpreter default (3.8-3.13: 4)
 
 
-def build():
-    """compile oracle/gl_oracle.c -> oracle/libgl_oracle.so (gcc)."""
-    subprocess.check_call(["make", "-s", "-C", _HERE, "libgl_oracle.so"])
+def _source_key():
+    h = hashlib.sha256()
+    for name in ("gl_oracle.c", "Makefile"):
+        with open(os.path.join(_HERE, name), "rb") as fh:
+            h.update(name.encode() + b"\0" + hashlib.sha256(fh.read()).digest())
+    return h.hexdigest()
+
+
+def build(force=False):
+    """compile oracle/gl_oracle.c -> oracle/libgl_oracle.so (gcc, recipe: oracle/Makefile) unless the library was made
+    from exactly the present sources -- decided by a content hash kept beside it, not by file times."""
+    key = _source_key()
+    try:
+        current = os.path.exists(_LIB_PATH) and open(_LIB_PATH + ".key").read() == key
+    except OSError:
+        current = False
+    if force or not current:
+        subprocess.check_call(["make", "-s", "-B", "-C", _HERE, "libgl_oracle.so"])
+        with open(_LIB_PATH + ".key", "w") as fh:
+            fh.write(key)
+    return _LIB_PATH
 
 
 def _load():
-    if not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "gl_oracle.c")):
-        build()
+    build()
     lib = ctypes.CDLL(_LIB_PATH)
     u64, sz, vp = ctypes.c_uint64, ctypes.c_size_t, ctypes.c_void_p
     for name, res, args in [

@@ -5,7 +5,6 @@ never executes these paths on the CPU."""
 import ctypes
 import hashlib
 import os
-import subprocess
 
 import numpy as np
 import pytest
@@ -19,11 +18,10 @@ u64, vp = ctypes.c_uint64, ctypes.c_void_p
 
 @pytest.fixture(scope="session")
 def emu():
-    so = os.path.join(EMU_DIR, "libbfs_emu.so")
-    srcs = [os.path.join(EMU_DIR, f) for f in ("emu_ntt.cpp", "emu_merkle.cpp", "emu_rows.cpp")]
-    deps = srcs + [os.path.join(ROOT, "stark_brainfuck_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "stark_brainfuck_amd", "csrc")) if f.endswith(".hpp")]
-    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-o", so] + srcs)
+    import sys
+    sys.path.insert(0, EMU_DIR)
+    from build_emu import build_emulation
+    so = build_emulation()          # rebuilt whenever the CONTENT of a source or header differs from what the .so was made of
     lib = ctypes.CDLL(so)
     lib.emu_gl_ntt.argtypes = [vp, u64, u64, vp, u64, ctypes.c_uint32, ctypes.c_uint32, u64, u64, u64]
     lib.emu_plan.argtypes = [ctypes.c_uint32, u64, vp, vp, vp, vp]

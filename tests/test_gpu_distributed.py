@@ -259,3 +259,22 @@ def test_bench_with_two_ranks_on_one_gpu():
     assert line["stark_prove"]["verified"] is True
     assert line["stark_prove_cooperative"]["ranks"] == 2 and line["stark_prove_cooperative"]["verified"] is True
     assert line["roots_sha256"]
+
+
+def test_plain_bench_command_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (what a driver that reuses its N = 1 command line runs): bench.py starts
+    the two ranks itself under torch.distributed.run and rank 0's JSON line arrives on the caller's stdout.  Two ranks share this
+    box's one GPU and exchange over gloo (test hooks BFS_BENCH_BACKEND / BFS_BENCH_DEVICE)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--total-columns", "4",
+           "--log-n", "20", "--no-cpu", "--no-fri", "--spinup-ms", "0"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BFS_BENCH_BACKEND="gloo", BFS_BENCH_DEVICE="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2 and len(line["rank_devices"]) == 2
+    assert line["config"]["columns_per_gpu"] == [2, 2]
+    assert line["guard"]["columns_round_tripped"] == 2 and line["roots_sha256"]
