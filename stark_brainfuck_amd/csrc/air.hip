@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "air_generated.hpp"
+#include "lazy.hpp"
 #include "runtime.hpp"
 
 namespace bfs {
@@ -245,6 +246,47 @@ struct CombW {
     u64 shift;
 };
 
+// Round 3: the sum is taken as  sum_kind z_kind * [ sum_k wa_k v_k  +  sum_runs x^shift_run * sum_{k in run} wb_k v_k ]  with the
+// inner sums accumulated UNREDUCED (lazy.hpp: a weight is a 3 x 3 matrix of residues laid out by the host, the lanes only
+// multiply-accumulate into 64-bit columns) and x^shift applied once per run of terms that share it -- all columns of a table do
+// (their bound is the interpolant degree), and neighbouring quotients of one kind with the same generic degree do
+// (air_generated.hpp: *_Q_DEGREE).  The launcher compares the actual shifts and takes the GROUPED = false instantiation (every
+// term its own run) when a run's shifts differ, which crafted challenges can cause.  Per extension term that is 18 products of
+// 8 instructions where the reduced form spent 14 modular multiplications of 19 and 12 modular additions.
+template <int TABLE>
+struct CombineLayout {
+    typedef AirShape<TABLE> S;
+    static constexpr int NC = S::BW + S::XW, NQ = S::NB + S::NT + S::NZ, NTERM = NC + NQ;
+    static constexpr bool q_ext(int q) {
+        if constexpr (TABLE == 0) return airgen::PROCESSOR_Q_EXT[q];
+        else if constexpr (TABLE == 1) return airgen::INSTRUCTION_Q_EXT[q];
+        else if constexpr (TABLE == 2) return airgen::MEMORY_Q_EXT[q];
+        else if constexpr (TABLE == 3) return airgen::INPUT_Q_EXT[q];
+        else return airgen::OUTPUT_Q_EXT[q];
+    }
+    static constexpr int q_degree(int q) {
+        if constexpr (TABLE == 0) return airgen::PROCESSOR_Q_DEGREE[q];
+        else if constexpr (TABLE == 1) return airgen::INSTRUCTION_Q_DEGREE[q];
+        else if constexpr (TABLE == 2) return airgen::MEMORY_Q_DEGREE[q];
+        else if constexpr (TABLE == 3) return airgen::INPUT_Q_DEGREE[q];
+        else return airgen::OUTPUT_Q_DEGREE[q];
+    }
+    // term k: base columns, extension columns, quotients -- the order of the reference's `terms` list restricted to one table
+    static constexpr bool is_ext(int k) { return k < S::BW ? false : (k < NC ? true : q_ext(k - NC)); }
+    static constexpr int kind(int k) { return k < NC ? 0 : (k - NC < S::NB ? 1 : (k - NC < S::NB + S::NT ? 2 : 3)); }      // columns, boundary, transition, terminal
+    static constexpr bool continues_run(int k) {          // generic expectation: term k has the shift of term k - 1
+        if (k == 0 || kind(k) != kind(k - 1)) return false;
+        return kind(k) == 0 ? true : q_degree(k - NC) == q_degree(k - 1 - NC);
+    }
+    static constexpr int words(int k) { return 2 * (is_ext(k) ? LAZY_W_EXT : LAZY_W_BASE); }
+    static constexpr int offset(int k) {
+        int o = 0;
+        for (int j = 0; j < k; ++j) o += words(j);
+        return o;
+    }
+    static constexpr int NW = offset(NTERM);
+};
+
 template <int TABLE>
 struct AirCombineArgs {
     AirArgs a;
@@ -252,47 +294,73 @@ struct AirCombineArgs {
     Xfe w0;
     u64* acc;                // three limb planes of n
     const u64 *inv_boundary, *inv_terminal, *inv_transition;   // codewords of 1/(x - 1), 1/(x - omicron^-1), 1/(x^h - 1), or all null
-    CombW w[AirShape<TABLE>::BW + AirShape<TABLE>::XW + AirShape<TABLE>::NB + AirShape<TABLE>::NT + AirShape<TABLE>::NZ];
+    u64 offset_pow[CombineLayout<TABLE>::NTERM];               // offset^shift
+    u32 shift[CombineLayout<TABLE>::NTERM];
+    u64 w[CombineLayout<TABLE>::NW];                           // per term: wa then wb, 3 words each (base value) or 7 each (lazy.hpp)
 };
 
-struct ShiftPower {
-    const u64 *lo, *hi;
-    u32 lo_bits;
-    u64 i, mask;
-    // no caching of the last power across terms with equal shifts: the (uniform) branch it needs costs ~100 VGPRs in this kernel
-    __device__ __forceinline__ Xfe weight(const CombW& w) const {
-        const u64 value = gl_mul(w.offset_pow, tw_pow(lo, hi, lo_bits, (i * w.shift) & mask));
-        return xfe_add(w.wa, xfe_scale(w.wb, value));
-    }
-};
-
-// ... or weighted and added to the running sum.  The constraints arrive kind by kind (boundary, transition, terminal) and all
-// quotients of a kind share their zerofier inverse, so the weighted VALUES of a kind are summed first and the inverse is applied once.
-template <int TABLE>
+// The constraints arrive kind by kind (boundary, transition, terminal); all quotients of a kind share their zerofier inverse,
+// so the weighted VALUES of a kind are summed first and the inverse is applied once.
+template <int TABLE, bool GROUPED>
 struct CombineSink {
-    Xfe acc;
-    ShiftPower xp;
-    const CombW* w;          // the quotients' weights (kernel arguments)
+    typedef CombineLayout<TABLE> Lay;
+    const AirCombineArgs<TABLE>& A;
+    u64 i;
     Zerofiers z;
-    Xfe kind_sum;
-    template <int Q> __device__ __forceinline__ void close_kind() {
-        typedef AirShape<TABLE> S;
-        if constexpr (Q > 0 && (Q == S::NB || Q == S::NB + S::NT || Q == S::NB + S::NT + S::NZ)) {
-            acc = xfe_add(acc, xfe_scale(kind_sum, z.template of<TABLE, Q - 1>()));
-            kind_sum = Xfe{{0, 0, 0}};
+    Xfe acc, kind_sum;
+    LazyX sa, sb;            // sum of wa_k v_k over the kind so far; sum of wb_k v_k over the run so far
+
+    __device__ __forceinline__ u64 x_pow(int k) const {
+        const AirArgs& a = A.a;
+        return gl_mul(A.offset_pow[k], tw_pow(a.w_lo, a.w_hi, a.lo_bits, (i * A.shift[k]) & (a.n - 1)));
+    }
+    template <int K> __device__ __forceinline__ void close_run() {           // K: any term of the run that ends
+        kind_sum = xfe_add(kind_sum, xfe_scale(lazyx_reduce(sb), x_pow(K)));
+        sb = lazyx_zero();
+    }
+    template <int KIND> __device__ __forceinline__ void close_kind() {
+        kind_sum = xfe_add(kind_sum, lazyx_reduce(sa));
+        sa = lazyx_zero();
+        if constexpr (KIND == 0) acc = xfe_add(acc, kind_sum);
+        else acc = xfe_add(acc, xfe_scale(kind_sum, KIND == 1 ? z.boundary : (KIND == 2 ? z.transition : z.terminal)));
+        kind_sum = Xfe{{0, 0, 0}};
+    }
+    template <int K> __device__ __forceinline__ void open() {                // what ends where term K begins
+        if constexpr (K > 0) {
+            constexpr bool new_kind = Lay::kind(K) != Lay::kind(K - 1);
+            if constexpr (new_kind || !GROUPED || !Lay::continues_run(K)) close_run<K - 1>();
+            if constexpr (new_kind) close_kind<Lay::kind(K - 1)>();
         }
     }
-    template <int Q> __device__ __forceinline__ void put(const Xfe& v) {
-        close_kind<Q>();
-        kind_sum = xfe_add(kind_sum, xfe_mul(xp.weight(w[Q]), v));
+    template <int K> __device__ __forceinline__ void term_base(u64 v) {
+        static_assert(!Lay::is_ext(K), "layout and generated code disagree");
+        open<K>();
+        lazyx_mac_base(sa, A.w + Lay::offset(K), v);
+        lazyx_mac_base(sb, A.w + Lay::offset(K) + LAZY_W_BASE, v);
     }
-    template <int Q> __device__ __forceinline__ void put_base(u64 v) {
-        close_kind<Q>();
-        kind_sum = xfe_add(kind_sum, xfe_scale(xp.weight(w[Q]), v));
+    template <int K> __device__ __forceinline__ void term_ext(const Xfe& v) {
+        static_assert(Lay::is_ext(K), "layout and generated code disagree");
+        open<K>();
+        lazyx_mac_ext(sa, A.w + Lay::offset(K), v);
+        lazyx_mac_ext(sb, A.w + Lay::offset(K) + LAZY_W_EXT, v);
     }
+    __device__ __forceinline__ void finish() {
+        close_run<Lay::NTERM - 1>();
+        close_kind<Lay::kind(Lay::NTERM - 1)>();
+    }
+    // the generated code's interface
+    template <int Q> __device__ __forceinline__ void put(const Xfe& v) { term_ext<Lay::NC + Q>(v); }
+    template <int Q> __device__ __forceinline__ void put_base(u64 v) { term_base<Lay::NC + Q>(v); }
 };
 
-template <int TABLE>
+template <int TABLE, int C, class Sink>
+__device__ __forceinline__ void combine_columns(Sink& sink, const u64* bc, const Xfe* xc) {
+    typedef AirShape<TABLE> S;
+    if constexpr (C < S::BW) { sink.template term_base<C>(bc[C]); combine_columns<TABLE, C + 1>(sink, bc, xc); }
+    else if constexpr (C < S::BW + S::XW) { sink.template term_ext<C>(xc[C - S::BW]); combine_columns<TABLE, C + 1>(sink, bc, xc); }
+}
+
+template <int TABLE, bool GROUPED>
 __global__ void __launch_bounds__(256) air_combine_kernel(const AirCombineArgs<TABLE> A) {
     typedef AirShape<TABLE> S;
     const AirArgs& a = A.a;
@@ -311,19 +379,14 @@ __global__ void __launch_bounds__(256) air_combine_kernel(const AirCombineArgs<T
         Xfe acc;
         if (A.randomizer) acc = xfe_mul(A.w0, Xfe{{A.randomizer[i], A.randomizer[a.n + i], A.randomizer[2 * a.n + i]}});
         else acc = Xfe{{A.acc[i], A.acc[a.n + i], A.acc[2 * a.n + i]}};
-        ShiftPower xp;
-        xp.lo = a.w_lo; xp.hi = a.w_hi; xp.lo_bits = a.lo_bits; xp.i = i; xp.mask = a.n - 1;
-#pragma unroll
-        for (int c = 0; c < S::BW; ++c) acc = xfe_add(acc, xfe_scale(xp.weight(A.w[c]), bc[c]));
-#pragma unroll
-        for (int c = 0; c < S::XW; ++c) acc = xfe_add(acc, xfe_mul(xp.weight(A.w[S::BW + c]), xc[c]));
         const u64 x = gl_mul(a.offset, tw_pow(a.w_lo, a.w_hi, a.lo_bits, i));
-        CombineSink<TABLE> sink{acc, xp, A.w + S::BW + S::XW,
-                                A.inv_boundary ? Zerofiers(a, x, A.inv_boundary[i], A.inv_terminal[i], a.height != 0 ? A.inv_transition[i] : 0)
-                                               : Zerofiers(a, x),
-                                Xfe{{0, 0, 0}}};
+        CombineSink<TABLE, GROUPED> sink{A, i,
+                                         A.inv_boundary ? Zerofiers(a, x, A.inv_boundary[i], A.inv_terminal[i], a.height != 0 ? A.inv_transition[i] : 0)
+                                                        : Zerofiers(a, x),
+                                         acc, Xfe{{0, 0, 0}}, lazyx_zero(), lazyx_zero()};
+        combine_columns<TABLE, 0>(sink, bc, xc);
         air_eval<TABLE>(bc, bn, xc, xn, a, sink);
-        sink.template close_kind<S::NB + S::NT + S::NZ>();
+        sink.finish();
         A.acc[i] = sink.acc.c[0];
         A.acc[a.n + i] = sink.acc.c[1];
         A.acc[2 * a.n + i] = sink.acc.c[2];
@@ -492,7 +555,7 @@ static CombW comb_weight(const bfs_comb_weight& w, u64 offset) {
 template <int TABLE>
 static int air_combine_launch(const AirArgs& a, const bfs_comb_weight* h_weights, const uint64_t* d_randomizer, const uint64_t* h_w0,
                               uint64_t* d_acc, const uint64_t* const* d_inverses, hipStream_t stream) {
-    typedef AirShape<TABLE> S;
+    typedef CombineLayout<TABLE> Lay;
     AirCombineArgs<TABLE> A{};
     A.a = a;
     A.randomizer = d_randomizer;
@@ -501,13 +564,24 @@ static int air_combine_launch(const AirArgs& a, const bfs_comb_weight* h_weights
     if (d_inverses && d_inverses[0] && d_inverses[1] && (a.height == 0 || d_inverses[2])) {
         A.inv_boundary = d_inverses[0]; A.inv_terminal = d_inverses[1]; A.inv_transition = d_inverses[2];
     }
-    constexpr int count = S::BW + S::XW + S::NB + S::NT + S::NZ;
-    for (int k = 0; k < count; ++k) {
-        if (h_weights[k].shift >> 32) { set_error("bfs_air_combine: shift does not fit 32 bits"); return BFS_ERR_BAD_ARG; }
-        A.w[k] = comb_weight(h_weights[k], a.offset);
+    bool grouped = true;
+    for (int k = 0; k < Lay::NTERM; ++k) {
+        const bfs_comb_weight& w = h_weights[k];
+        if (w.shift >> 32) { set_error("bfs_air_combine: shift does not fit 32 bits"); return BFS_ERR_BAD_ARG; }
+        A.shift[k] = (u32)w.shift;
+        A.offset_pow[k] = (k > 0 && w.shift == h_weights[k - 1].shift) ? A.offset_pow[k - 1] : gl_pow(a.offset, w.shift);
+        if (Lay::continues_run(k) && w.shift != h_weights[k - 1].shift) grouped = false;     // not the generic degree pattern
+        u64* out = A.w + Lay::offset(k);
+        if (Lay::is_ext(k)) {
+            lazy_weight_matrix(xfe_from(w.wa), out);
+            lazy_weight_matrix(xfe_from(w.wb), out + LAZY_W_EXT);
+        } else {
+            for (int l = 0; l < 3; ++l) { out[l] = w.wa[l]; out[LAZY_W_BASE + l] = w.wb[l]; }
+        }
     }
     static_assert(sizeof(A) <= 4096, "kernel arguments");
-    hipLaunchKernelGGL(air_combine_kernel<TABLE>, dim3(grid_per_point(a.n)), dim3(256), 0, stream, A);
+    if (grouped) hipLaunchKernelGGL((air_combine_kernel<TABLE, true>), dim3(grid_per_point(a.n)), dim3(256), 0, stream, A);
+    else hipLaunchKernelGGL((air_combine_kernel<TABLE, false>), dim3(grid_per_point(a.n)), dim3(256), 0, stream, A);
     BFS_HIP(hipGetLastError());
     return BFS_OK;
 }
