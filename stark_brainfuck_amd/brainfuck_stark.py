@@ -19,6 +19,7 @@ import ctypes
 import numpy as np
 from hashlib import blake2b
 from os import urandom          # module-level on purpose: tests patch `brainfuck_stark.urandom` for determinism
+from .randomness import source as random_source
 
 from . import _lib, air
 from .algebra import BaseField, BaseFieldElement
@@ -280,11 +281,13 @@ class BrainfuckStark:
         # randomizer polynomial and codeword (:162-167)
         count = self.max_degree + 1
         import os
-        if urandom is os.urandom:        # production: coefficients expanded on the GPU from 32 bytes of the system's randomness
+        draw = random_source(urandom)    # the module's urandom, or this context's shared stream (randomness.override)
+        if draw is os.urandom or getattr(draw, "expand_on_device", False):
+            # production: coefficients expanded on the GPU from 32 bytes of the system's (or the ranks' shared) randomness
             randomizer_polynomial = XArray.empty(count, xf)
-            _lib.check(lib.bfs_xfe_sample_fill(urandom(32), randomizer_polynomial.ptr, count, count, stream))
+            _lib.check(lib.bfs_xfe_sample_fill(draw(32), randomizer_polynomial.ptr, count, count, stream))
         else:                            # a test replaced urandom: the reference's byte stream, `count` draws of 27 bytes
-            randomizer_polynomial = XArray.from_numpy(sample_ext_many(urandom(3 * 9 * count), count, 9), xf)
+            randomizer_polynomial = XArray.from_numpy(sample_ext_many(draw(3 * 9 * count), count, 9), xf)
         randomizer_codeword = domain.xevaluate(randomizer_polynomial, xf, as_array=True)
 
         lap("randomizer")
@@ -321,7 +324,7 @@ class BrainfuckStark:
 
         # challenges, initials, table extension, terminals (:181-192)
         challenges = tuple(BrainfuckStark._sample_weights(11, proof_stream.prover_fiat_shamir()))
-        initials = [sample_ext(urandom(3 * 8)) for _ in self.permutation_arguments]
+        initials = [sample_ext(draw(3 * 8)) for _ in self.permutation_arguments]
         extend_tables_device(self.tables, challenges, initials)       # prefix scans on the trace columns lde() left in HBM
         terminals = self.get_terminals()
         lap("extend")

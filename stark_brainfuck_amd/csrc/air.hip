@@ -6,6 +6,7 @@
 // Points of the FRI domain are x_i = offset * omega^i (fri.py:20-21); codewords are column-major: base column c at
 // base[c * n + i], extension column c as three limb planes at ext[(3 c + limb) * n + i].
 #include <algorithm>
+#include <cstddef>
 #include <vector>
 
 #include "air_generated.hpp"
@@ -287,6 +288,16 @@ struct CombineLayout {
     static constexpr int NW = offset(NTERM);
 };
 
+// Per-term data the lanes read: staged in LDS by the kernel.  As plain kernel arguments the compiler fetched all of it (~600 dwords for
+// the processor table) with scalar loads at the top of the kernel and spilled it to vector-register lanes at once: 709 v_writelane +
+// 715 v_readlane of 11 600 VALU instructions per thread (profiles/r03/ab_combine_lds_weights.txt).  LDS reads of a wave-uniform
+// address are broadcasts, and the compiler places them next to their use.
+template <int TABLE>
+struct CombineTerms {
+    u64 w[CombineLayout<TABLE>::NW];               // per term: wa then wb * offset^shift, 3 words each (base value) or 7 each (lazy.hpp)
+    u32 shift[(CombineLayout<TABLE>::NTERM + 1) & ~1];
+};
+
 template <int TABLE>
 struct AirCombineArgs {
     AirArgs a;
@@ -294,36 +305,34 @@ struct AirCombineArgs {
     Xfe w0;
     u64* acc;                // three limb planes of n
     const u64 *inv_boundary, *inv_terminal, *inv_transition;   // codewords of 1/(x - 1), 1/(x - omicron^-1), 1/(x^h - 1), or all null
-    u64 offset_pow[CombineLayout<TABLE>::NTERM];               // offset^shift
-    u32 shift[CombineLayout<TABLE>::NTERM];
-    u64 w[CombineLayout<TABLE>::NW];                           // per term: wa then wb, 3 words each (base value) or 7 each (lazy.hpp)
+    CombineTerms<TABLE> terms;
 };
 
 // The constraints arrive kind by kind (boundary, transition, terminal); all quotients of a kind share their zerofier inverse,
-// so the weighted VALUES of a kind are summed first and the inverse is applied once.
+// so the weighted VALUES of a kind are summed first and the inverse is applied once.  x^shift = offset^shift omega^(i shift): the
+// host folds offset^shift into wb, and the product of a run's sum with omega^(i shift) goes into the kind's unreduced sum as well.
 template <int TABLE, bool GROUPED>
 struct CombineSink {
     typedef CombineLayout<TABLE> Lay;
-    const AirCombineArgs<TABLE>& A;
+    const AirArgs& a;
+    const CombineTerms<TABLE>& T;   // in LDS
     u64 i;
     Zerofiers z;
-    Xfe acc, kind_sum;
-    LazyX sa, sb;            // sum of wa_k v_k over the kind so far; sum of wb_k v_k over the run so far
+    Xfe acc;
+    LazyX sa, sb;            // sum over the kind so far of wa_k v_k and of the closed runs' omega^(i shift) * sum; sum of wb_k v_k over the run so far
 
-    __device__ __forceinline__ u64 x_pow(int k) const {
-        const AirArgs& a = A.a;
-        return gl_mul(A.offset_pow[k], tw_pow(a.w_lo, a.w_hi, a.lo_bits, (i * A.shift[k]) & (a.n - 1)));
+    __device__ __forceinline__ u64 omega_pow(int k) const {
+        return tw_pow(a.w_lo, a.w_hi, a.lo_bits, (i * T.shift[k]) & (a.n - 1));
     }
     template <int K> __device__ __forceinline__ void close_run() {           // K: any term of the run that ends
-        kind_sum = xfe_add(kind_sum, xfe_scale(lazyx_reduce(sb), x_pow(K)));
+        lazyx_mac_scale(sa, lazyx_reduce(sb), omega_pow(K));
         sb = lazyx_zero();
     }
     template <int KIND> __device__ __forceinline__ void close_kind() {
-        kind_sum = xfe_add(kind_sum, lazyx_reduce(sa));
+        const Xfe kind_sum = lazyx_reduce(sa);
         sa = lazyx_zero();
         if constexpr (KIND == 0) acc = xfe_add(acc, kind_sum);
         else acc = xfe_add(acc, xfe_scale(kind_sum, KIND == 1 ? z.boundary : (KIND == 2 ? z.transition : z.terminal)));
-        kind_sum = Xfe{{0, 0, 0}};
     }
     template <int K> __device__ __forceinline__ void open() {                // what ends where term K begins
         if constexpr (K > 0) {
@@ -335,14 +344,14 @@ struct CombineSink {
     template <int K> __device__ __forceinline__ void term_base(u64 v) {
         static_assert(!Lay::is_ext(K), "layout and generated code disagree");
         open<K>();
-        lazyx_mac_base(sa, A.w + Lay::offset(K), v);
-        lazyx_mac_base(sb, A.w + Lay::offset(K) + LAZY_W_BASE, v);
+        lazyx_mac_base(sa, T.w + Lay::offset(K), v);
+        lazyx_mac_base(sb, T.w + Lay::offset(K) + LAZY_W_BASE, v);
     }
     template <int K> __device__ __forceinline__ void term_ext(const Xfe& v) {
         static_assert(Lay::is_ext(K), "layout and generated code disagree");
         open<K>();
-        lazyx_mac_ext(sa, A.w + Lay::offset(K), v);
-        lazyx_mac_ext(sb, A.w + Lay::offset(K) + LAZY_W_EXT, v);
+        lazyx_mac_ext(sa, T.w + Lay::offset(K), v);
+        lazyx_mac_ext(sb, T.w + Lay::offset(K) + LAZY_W_EXT, v);
     }
     __device__ __forceinline__ void finish() {
         close_run<Lay::NTERM - 1>();
@@ -360,9 +369,29 @@ __device__ __forceinline__ void combine_columns(Sink& sink, const u64* bc, const
     else if constexpr (C < S::BW + S::XW) { sink.template term_ext<C>(xc[C - S::BW]); combine_columns<TABLE, C + 1>(sink, bc, xc); }
 }
 
+// waves per SIMD asked of the register allocator: with the per-term data in LDS the scheduler otherwise pulls the reads far ahead of
+// their use and fills all 256 registers the block size allows (tables 1, 3, 4: 73-126 -> 250)
+#ifndef BFS_COMBINE_WAVES
+#define BFS_COMBINE_WAVES 2, 3, 4, 4, 4
+#endif
+constexpr int combine_waves(int table) {
+    constexpr int w[5] = {BFS_COMBINE_WAVES};
+    return w[table];
+}
 template <int TABLE, bool GROUPED>
-__global__ void __launch_bounds__(256) air_combine_kernel(const AirCombineArgs<TABLE> A) {
+__global__ void __launch_bounds__(256, combine_waves(TABLE)) air_combine_kernel(const AirCombineArgs<TABLE> A) {
     typedef AirShape<TABLE> S;
+    __shared__ CombineTerms<TABLE> T;
+    {
+        // the raw kernel-argument segment, read with a per-thread index (a vector load; indexing A itself at run time would make the
+        // compiler copy the whole struct to scratch)
+        const u64* karg = (const u64*)__builtin_amdgcn_kernarg_segment_ptr();
+        constexpr u32 first = offsetof(AirCombineArgs<TABLE>, terms) / 8, words = sizeof(CombineTerms<TABLE>) / 8;
+        static_assert(offsetof(AirCombineArgs<TABLE>, terms) % 8 == 0 && sizeof(CombineTerms<TABLE>) % 8 == 0, "staged as 64-bit words");
+        u64* dst = reinterpret_cast<u64*>(&T);
+        for (u32 k = threadIdx.x; k < words; k += 256) dst[k] = karg[first + k];
+    }
+    __syncthreads();
     const AirArgs& a = A.a;
     const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < a.n) {
@@ -380,10 +409,10 @@ __global__ void __launch_bounds__(256) air_combine_kernel(const AirCombineArgs<T
         if (A.randomizer) acc = xfe_mul(A.w0, Xfe{{A.randomizer[i], A.randomizer[a.n + i], A.randomizer[2 * a.n + i]}});
         else acc = Xfe{{A.acc[i], A.acc[a.n + i], A.acc[2 * a.n + i]}};
         const u64 x = gl_mul(a.offset, tw_pow(a.w_lo, a.w_hi, a.lo_bits, i));
-        CombineSink<TABLE, GROUPED> sink{A, i,
+        CombineSink<TABLE, GROUPED> sink{a, T, i,
                                          A.inv_boundary ? Zerofiers(a, x, A.inv_boundary[i], A.inv_terminal[i], a.height != 0 ? A.inv_transition[i] : 0)
                                                         : Zerofiers(a, x),
-                                         acc, Xfe{{0, 0, 0}}, lazyx_zero(), lazyx_zero()};
+                                         acc, lazyx_zero(), lazyx_zero()};
         combine_columns<TABLE, 0>(sink, bc, xc);
         air_eval<TABLE>(bc, bn, xc, xn, a, sink);
         sink.finish();
@@ -565,18 +594,20 @@ static int air_combine_launch(const AirArgs& a, const bfs_comb_weight* h_weights
         A.inv_boundary = d_inverses[0]; A.inv_terminal = d_inverses[1]; A.inv_transition = d_inverses[2];
     }
     bool grouped = true;
+    u64 offset_pow = 1;
     for (int k = 0; k < Lay::NTERM; ++k) {
         const bfs_comb_weight& w = h_weights[k];
         if (w.shift >> 32) { set_error("bfs_air_combine: shift does not fit 32 bits"); return BFS_ERR_BAD_ARG; }
-        A.shift[k] = (u32)w.shift;
-        A.offset_pow[k] = (k > 0 && w.shift == h_weights[k - 1].shift) ? A.offset_pow[k - 1] : gl_pow(a.offset, w.shift);
+        A.terms.shift[k] = (u32)w.shift;
+        offset_pow = (k > 0 && w.shift == h_weights[k - 1].shift) ? offset_pow : gl_pow(a.offset, w.shift);
         if (Lay::continues_run(k) && w.shift != h_weights[k - 1].shift) grouped = false;     // not the generic degree pattern
-        u64* out = A.w + Lay::offset(k);
+        u64* out = A.terms.w + Lay::offset(k);
+        const Xfe wb = xfe_scale(xfe_from(w.wb), offset_pow);                // x^shift = offset^shift * omega^(i shift)
         if (Lay::is_ext(k)) {
             lazy_weight_matrix(xfe_from(w.wa), out);
-            lazy_weight_matrix(xfe_from(w.wb), out + LAZY_W_EXT);
+            lazy_weight_matrix(wb, out + LAZY_W_EXT);
         } else {
-            for (int l = 0; l < 3; ++l) { out[l] = w.wa[l]; out[LAZY_W_BASE + l] = w.wb[l]; }
+            for (int l = 0; l < 3; ++l) { out[l] = w.wa[l]; out[LAZY_W_BASE + l] = wb.c[l]; }
         }
     }
     static_assert(sizeof(A) <= 4096, "kernel arguments");

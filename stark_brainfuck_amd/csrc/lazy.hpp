@@ -34,7 +34,23 @@ __device__ __forceinline__ void lazy_mac(LazyAcc& L, u64 a, u64 b) {
         : "+v"(L.c0), "+v"(L.c1), "+v"(L.c2), "+v"(L.t0), "+v"(L.t1), "+v"(L.t2), "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3)
         : "v"(a0), "v"(a1), "s"(b0), "s"(b1));
 }
+// the same with b in vector registers: a weight read from LDS (every lane reads the same word: a broadcast), or a per-lane factor
+__device__ __forceinline__ void lazy_mac_v(LazyAcc& L, u64 a, u64 b) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+    u64 k0, k1, k2, k3;
+    asm("v_mad_u64_u32 %0, %6, %10, %12, %0\n\t"
+        "v_mad_u64_u32 %1, %7, %10, %13, %1\n\t"
+        "v_mad_u64_u32 %2, %8, %11, %13, %2\n\t"
+        "v_mad_u64_u32 %1, %9, %11, %12, %1\n\t"
+        "v_addc_co_u32_e64 %3, %6, 0, %3, %6\n\t"
+        "v_addc_co_u32_e64 %4, %7, 0, %4, %7\n\t"
+        "v_addc_co_u32_e64 %5, %8, 0, %5, %8\n\t"
+        "v_addc_co_u32_e64 %4, %9, 0, %4, %9"
+        : "+v"(L.c0), "+v"(L.c1), "+v"(L.c2), "+v"(L.t0), "+v"(L.t1), "+v"(L.t2), "=&s"(k0), "=&s"(k1), "=&s"(k2), "=&s"(k3)
+        : "v"(a0), "v"(a1), "v"(b0), "v"(b1));
+}
 #else
+BFS_HD void lazy_mac_v(LazyAcc& L, u64 a, u64 b);
 BFS_HD void lazy_mac(LazyAcc& L, u64 a, u64 b) {
     const u64 a0 = (u32)a, a1 = a >> 32, b0 = (u32)b, b1 = b >> 32;
     u64 s;
@@ -43,6 +59,7 @@ BFS_HD void lazy_mac(LazyAcc& L, u64 a, u64 b) {
     s = L.c2 + a1 * b1; L.t2 += s < L.c2; L.c2 = s;
     s = L.c1 + a1 * b0; L.t1 += s < L.c1; L.c1 = s;
 }
+BFS_HD void lazy_mac_v(LazyAcc& L, u64 a, u64 b) { lazy_mac(L, a, b); }
 #endif
 
 // the canonical residue of  c0 + c1 2^32 + c2 2^64 + t0 2^64 + t1 2^96 + t2 2^128:  assembled as five 32-bit words W0..W4 plus
@@ -90,17 +107,24 @@ BFS_HD void lazy_weight_matrix(const Xfe& w, u64* out7) {
     out7[5] = gl_add(w.c[0], w.c[2]); out7[6] = gl_sub(w.c[1], w.c[2]);
 }
 // L += w * v for a base value v (w: 3 words) and for an extension value v (w: the 7 words above); `w` must be wave-uniform
+// (the weights are read from LDS -- see air.hip: as kernel arguments the compiler fetched all ~600 words up front and spilled them)
 template <class W>
 BFS_HD void lazyx_mac_base(LazyX& L, W w, u64 v) {
-    lazy_mac(L.r[0], v, w[0]);
-    lazy_mac(L.r[1], v, w[1]);
-    lazy_mac(L.r[2], v, w[2]);
+    lazy_mac_v(L.r[0], v, w[0]);
+    lazy_mac_v(L.r[1], v, w[1]);
+    lazy_mac_v(L.r[2], v, w[2]);
 }
 template <class W>
 BFS_HD void lazyx_mac_ext(LazyX& L, W w, const Xfe& v) {
-    lazy_mac(L.r[0], v.c[0], w[0]); lazy_mac(L.r[0], v.c[1], w[3]); lazy_mac(L.r[0], v.c[2], w[4]);
-    lazy_mac(L.r[1], v.c[0], w[1]); lazy_mac(L.r[1], v.c[1], w[5]); lazy_mac(L.r[1], v.c[2], w[6]);
-    lazy_mac(L.r[2], v.c[0], w[2]); lazy_mac(L.r[2], v.c[1], w[1]); lazy_mac(L.r[2], v.c[2], w[5]);
+    lazy_mac_v(L.r[0], v.c[0], w[0]); lazy_mac_v(L.r[0], v.c[1], w[3]); lazy_mac_v(L.r[0], v.c[2], w[4]);
+    lazy_mac_v(L.r[1], v.c[0], w[1]); lazy_mac_v(L.r[1], v.c[1], w[5]); lazy_mac_v(L.r[1], v.c[2], w[6]);
+    lazy_mac_v(L.r[2], v.c[0], w[2]); lazy_mac_v(L.r[2], v.c[1], w[1]); lazy_mac_v(L.r[2], v.c[2], w[5]);
+}
+// L += s * v for a per-lane base factor s and an extension value v
+BFS_HD void lazyx_mac_scale(LazyX& L, const Xfe& v, u64 s) {
+    lazy_mac_v(L.r[0], v.c[0], s);
+    lazy_mac_v(L.r[1], v.c[1], s);
+    lazy_mac_v(L.r[2], v.c[2], s);
 }
 
 }  // namespace bfs

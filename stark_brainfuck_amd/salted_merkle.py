@@ -5,6 +5,7 @@ two separate pickles concatenated (:32-35).  Preimages are assembled on the host
 import pickle
 from hashlib import blake2b
 from os import urandom          # module-level name on purpose: callers patch `salted_merkle.urandom` for determinism
+from .randomness import source as random_source
 
 import ctypes
 
@@ -19,7 +20,8 @@ class SaltedMerkle(Merkle):
         n = len(data_array)
         assert n & (n - 1) == 0 and n > 0, \
             f"in SaltedMerkle.__init__, next_power_of_two = {n} =/= 1 << self.depth"
-        leafs = [(element, urandom(24)) for element in data_array]
+        draw = random_source(urandom)
+        leafs = [(element, draw(24)) for element in data_array]
         t = NativeTranscript()
         preimages = [leaf_bytes(e, t) + pickle.dumps(s, protocol=4) for e, s in leafs]
         Merkle.__init__(self, preimages, _device_nodes=None)
@@ -85,11 +87,12 @@ class ZippedSaltedMerkle(SaltedMerkle):
         cols = (_lib.RowColumn * len(columns))()
         for c, (ptr, is_ext, field_id) in zip(cols, columns):
             c.d_values, c.is_ext, c.field_id = ptr, int(is_ext), field_id
-        if salts is None and (urandom is os.urandom or getattr(urandom, "expand_on_device", False)):
+        draw = random_source(urandom)
+        if salts is None and (draw is os.urandom or getattr(draw, "expand_on_device", False)):
             # one stream for all total_rows leaves, expanded from 32 bytes (every rank of a sharded commitment expands the same one)
             words = (3 * total_rows + 7) // 8 * 8
             self._salts = DeviceBuffer(words)
-            _lib.check(lib.bfs_random_fill(urandom(32), self._salts.ptr, words, stream))
+            _lib.check(lib.bfs_random_fill(draw(32), self._salts.ptr, words, stream))
             first = self._salts.ptr + 24 * salt_offset
             root = ctypes.create_string_buffer(64)
             _lib.check(lib.bfs_merkle_build_rows_root(cols, len(columns), n, limb_stride, first, 1, self._nodes.ptr, root, stream))
@@ -106,7 +109,7 @@ class ZippedSaltedMerkle(SaltedMerkle):
                 return cache[i]
         else:
             if salts is None:
-                salts = urandom(24 * total_rows)[24 * salt_offset:24 * (salt_offset + n)]   # the same bytes as one urandom(24) per leaf
+                salts = draw(24 * total_rows)[24 * salt_offset:24 * (salt_offset + n)]   # the same bytes as one urandom(24) per leaf
             assert len(salts) == 24 * n, "24 bytes of salt per leaf"
             keep = ctypes.create_string_buffer(salts, len(salts))
             self._salt_host = keep                   # bfs_stark_push_openings reads opened salts from here

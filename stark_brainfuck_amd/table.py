@@ -18,6 +18,7 @@ when `extend` (not `extend_device`) made them.
 """
 import ctypes
 from os import urandom          # module-level on purpose: tests patch `table.urandom` for determinism
+from .randomness import source as random_source
 
 import numpy as np
 
@@ -213,9 +214,9 @@ def lde_tables(tables, domain, extension=False):
             rand = None
             if t.num_randomizers:
                 if extension:
-                    rand = [v for _ in range(w // 3) for v in sample_ext(urandom(3 * 8))]
+                    rand = [v for _ in range(w // 3) for v in sample_ext(random_source(urandom)(3 * 8))]
                 else:
-                    rand = [sample_base(urandom(3 * 8)) for _ in range(w)]
+                    rand = [sample_base(random_source(urandom)(3 * 8)) for _ in range(w)]
             mine = coeffs.ptr + 8 * at * stride
             raw_ntt(d_in.ptr, h, h, mine, stride, h.bit_length() - 1, w, _inv(t.omicron.value), 1, _inv(h), stream)
             if rand is not None:
@@ -512,7 +513,7 @@ class Table:
         cols = self.base_array().reshape(self.base_width, self.height)
         rand = None
         if self.height != 0 and self.num_randomizers:
-            rand = [sample_base(urandom(3 * 8)) for _ in range(self.base_width)]
+            rand = [sample_base(random_source(urandom)(3 * 8)) for _ in range(self.base_width)]
         self._last_input = None
         self.base_codewords = self._extend_columns(domain, cols, rand)
         self._base_device = self._last_input          # the trace columns stay in HBM for extend_device()
@@ -532,7 +533,7 @@ class Table:
         if self.height != 0 and self.num_randomizers:
             rand = []
             for _ in range(width):
-                rand.extend(sample_ext(urandom(3 * 8)))
+                rand.extend(sample_ext(random_source(urandom)(3 * 8)))
         self.ext_codewords = self._extend_columns(domain, cols, rand, keep_coefficients=True)
         self._last_input = None
         return self.ext_codewords
