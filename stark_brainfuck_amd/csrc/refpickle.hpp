@@ -572,40 +572,69 @@ struct Transcript {
     // would otherwise be hashed on the proving thread between two kernel launches.  next() then pushes the real digest, fills the
     // k payloads in and finishes the sponge over the last few hundred bytes.
     struct Lookahead {
+        // A job is an offer to the helper threads, not a dependency on them: whoever gets to it first -- a helper, or the proving
+        // thread when it needs the result (or is tearing the look-ahead down) -- claims it with a compare-and-swap and does the
+        // work; the only wait left is for a helper that is already running the job.  The lambdas in the pool's queue share
+        // ownership of the job, so one that is dequeued late (after the proof) finds a claimed job in live memory and returns.
         struct Job {
             std::string tail;                        // the pickle of "stream + k digests" from offset `from` on
             unsigned char watched[9];                // ... and its nine bytes at `watch` (the frame header in front depends on k)
             const std::string* base = nullptr;
             size_t from = 0, watch = 0;
             uint64_t sponge[25];
-            std::atomic<int> done{0};
+            enum { PENDING = 0, RUNNING = 1, DONE = 2 };
+            std::atomic<int> state{PENDING};
+            bool by_helper = false;                  // the lambda in the pool's queue has been consumed (written before DONE is stored)
+            bool claim() {
+                int expected = PENDING;
+                return state.compare_exchange_strong(expected, RUNNING, std::memory_order_acq_rel);
+            }
+            void absorb() {
+                shake256_absorb_blocks_patched(base->data(), from, sponge, watch, watched, 9);
+            }
+            // the result is needed now: do it here unless a helper already has it in hand
+            void finish_here() {
+                if (claim()) {
+                    absorb();
+                    state.store(DONE, std::memory_order_release);
+                    return;
+                }
+                for (unsigned spins = 0; state.load(std::memory_order_acquire) != DONE; ++spins)
+                    if (spins > 4096) std::this_thread::yield();          // (a RUNNING helper that lost its core to somebody else)
+            }
+            // nobody needs the result any more: make sure no helper touches `base` from here on
+            void retire() {
+                if (claim()) { state.store(DONE, std::memory_order_release); return; }
+                while (state.load(std::memory_order_acquire) != DONE) std::this_thread::yield();
+            }
         };
         std::string base;                            // the whole pickle for k = 1: every job's prefix, up to the nine watched bytes
-        std::vector<std::unique_ptr<Job>> jobs;      // jobs[k - 1]: the stream followed by k digests
+        std::vector<std::shared_ptr<Job>> jobs;      // jobs[k - 1]: the stream followed by k digests
         std::vector<size_t> holes;                   // offset of the k-th digest's payload, the same in every pickle that holds it
         std::vector<std::string> digests;
         size_t from = 0, base_objects = 0;
         bool active = false;
         void wait_all() {
-            for (auto& j : jobs)
-                while (!j->done.load(std::memory_order_acquire)) std::this_thread::yield();
+            for (auto& j : jobs) j->retire();
         }
-        // finished jobs (and the base) are kept per thread for the next proof: their strings keep their capacity
-        struct Spare { std::vector<std::unique_ptr<Job>> jobs; std::string base; };
+        // finished jobs (and the base) are kept per thread for the next proof: their strings keep their capacity.  Only jobs whose
+        // queued lambda has run are recycled -- one that was finished here may still be referenced by a lambda waiting in the pool.
+        struct Spare { std::vector<std::shared_ptr<Job>> jobs; std::string base; };
         static Spare& spare() { static thread_local Spare s; return s; }
-        static std::unique_ptr<Job> take() {
+        static std::shared_ptr<Job> take() {
             auto& s = spare().jobs;
-            if (s.empty()) return std::unique_ptr<Job>(new Job());
-            std::unique_ptr<Job> j = std::move(s.back());
+            if (s.empty()) return std::make_shared<Job>();
+            std::shared_ptr<Job> j = std::move(s.back());
             s.pop_back();
-            j->done.store(0, std::memory_order_relaxed);
+            j->by_helper = false;
+            j->state.store(Job::PENDING, std::memory_order_relaxed);
             return j;
         }
         Lookahead() { base.swap(spare().base); }
         ~Lookahead() {                               // the helpers read `base` and write into the jobs
             wait_all();
             for (auto& j : jobs)
-                if (spare().jobs.size() < 64) spare().jobs.push_back(std::move(j));
+                if (j->by_helper && spare().jobs.size() < 64) spare().jobs.push_back(std::move(j));
             base.swap(spare().base);
         }
     };
@@ -630,7 +659,7 @@ struct Transcript {
             lookahead_sentinel(k, sentinel);
             tentative.push_back(mk_bytes(sentinel, 64));
             stream.stream_item(tentative.back());
-            std::unique_ptr<Lookahead::Job> job = Lookahead::take();
+            std::shared_ptr<Lookahead::Job> job = Lookahead::take();
             if (k == 1) {                            // the one whole copy; everything in front of the first payload's block is shared
                 stream.stream_bytes_into(la.base);
                 const size_t near = la.base.size() > 96 ? la.base.size() - 96 : 0;
@@ -660,10 +689,12 @@ struct Transcript {
         if (!ok) { la.jobs.clear(); la.holes.clear(); return false; }
         std::vector<std::function<void()>> work;
         for (auto& j : la.jobs) {
-            Lookahead::Job* job = j.get();
+            std::shared_ptr<Lookahead::Job> job = j;
             work.push_back([job] {
-                shake256_absorb_blocks_patched(job->base->data(), job->from, job->sponge, job->watch, job->watched, 9);
-                job->done.store(1, std::memory_order_release);
+                if (!job->claim()) return;           // the proving thread got there first (or the look-ahead is gone)
+                job->absorb();
+                job->by_helper = true;
+                job->state.store(Lookahead::Job::DONE, std::memory_order_release);
             });
         }
         pool->submit(std::move(work));
@@ -680,8 +711,7 @@ struct Transcript {
         if (!la.active || k > la.jobs.size() || objects.size() != la.base_objects + k) { fiat_shamir(objects.size(), out, num_bytes); return; }
         Lookahead::Job& job = *la.jobs[k - 1];
         for (size_t j = 0; j < k; ++j) memcpy(&job.tail[la.holes[j] - la.from], la.digests[j].data(), 64);
-        for (unsigned spins = 0; !job.done.load(std::memory_order_acquire); ++spins)
-            if (spins > 4096) std::this_thread::yield();          // (a helper that lost its core to somebody else)
+        job.finish_here();
         shake256(job.tail.data(), job.tail.size(), out, num_bytes, job.sponge, 0);
     }
 

@@ -62,22 +62,32 @@ def row_range(n, world_size, rank):
     return rank * m, m
 
 
-def exchange_rows(local_columns, planes, n, world_size, rank, group=None):
+def exchange_rows(local_columns, planes, n, world_size, rank, group=None, device=None):
     """the all-to-all row transpose.  local_columns: {global column c: int64 tensor (planes[c], n)} for the columns of this rank
     (CPU tensors under gloo, CUDA tensors under RCCL; uint64 values viewed as int64).  planes[c] = 1 for a base column, 3 for an
-    extension column (limb planes), for ALL columns.  Returns [tensor (planes[c], n / G) for c in all columns]: this rank's rows."""
+    extension column (limb planes), for ALL columns.  Returns [tensor (planes[c], n / G) for c in all columns]: this rank's rows.
+    device: where the exchange buffers live -- taken from the rank's own columns when it has any; a rank that owns NO column (fewer
+    columns than ranks) must say it (under RCCL the empty send buffer has to be a CUDA tensor like everybody else's)."""
     import torch
     import torch.distributed as dist
     num_columns = len(planes)
+    assert world_size >= 1 and world_size & (world_size - 1) == 0, "the number of ranks must be a power of two"
     mine = assign_columns(num_columns, world_size, rank)
     assert sorted(local_columns) == mine, "rank %d must supply exactly its own columns %r" % (rank, mine)
     first, m = row_range(n, world_size, rank)
     if world_size == 1:
         return [local_columns[c][:, first:first + m].contiguous() for c in range(num_columns)]
-    some = next(iter(local_columns.values())) if local_columns else torch.empty(0, dtype=torch.int64)
+    if mine:
+        device = next(iter(local_columns.values())).device if device is None else torch.device(device)
+        assert all(t.device == device for t in local_columns.values()), "all columns of a rank live on one device"
+    else:
+        if device is None:
+            assert dist.get_backend(group) != "nccl", "rank %d owns no column: pass device= (RCCL needs CUDA buffers on every rank)" % rank
+            device = torch.device("cpu")
+        device = torch.device(device)
     # to rank s: for each of my columns (ascending), its planes, rows of s
     send = torch.cat([local_columns[c][:, s * m:(s + 1) * m].reshape(-1) for s in range(world_size) for c in mine]) if mine \
-        else torch.empty(0, dtype=torch.int64, device=some.device)
+        else torch.empty(0, dtype=torch.int64, device=device)
     my_words = sum(planes[c] for c in mine) * m
     in_splits = [my_words] * world_size
     out_splits = [sum(planes[c] for c in assign_columns(num_columns, world_size, r)) * m for r in range(world_size)]
@@ -110,7 +120,7 @@ class ShardedZippedMerkle:
         self.n, self.world_size, self.rank, self.group = n, world_size, rank, group
         self.first, self.m = row_range(n, world_size, rank)
         assert world_size & (world_size - 1) == 0, "the top levels are a binary tree over the ranks"
-        self.rows = exchange_rows(local_columns, planes, n, world_size, rank, group) if rows is None else rows
+        self.rows = exchange_rows(local_columns, planes, n, world_size, rank, group, device=device) if rows is None else rows
         my_salts = None if salts is None else salts[24 * self.first:24 * (self.first + self.m)]
         self.subtree = build_subtree(self.rows, self.first, my_salts)
         mine = self.subtree.root()
@@ -269,15 +279,18 @@ class _SharedStream:
 
 
 class shared_randomness:
-    """context manager: inside it the prover modules draw their randomness from one stream shared by the ranks of `group`
-    (process-global: it replaces the module-level `urandom` of brainfuck_stark, table and salted_merkle for its duration)."""
+    """context manager: inside it the prover modules of THIS context (thread / task) draw their randomness from one stream shared by
+    the ranks of `group` (randomness.override: a context variable, so another prover thread of the same process keeps its own source
+    and the module-level `urandom` names are left alone).  On a clean exit the ranks compare how far each one read the stream: the
+    proofs can only agree if every rank drew the same bytes in the same order, and a divergence here would otherwise show up as
+    mismatched collectives later."""
 
     def __init__(self, world_size, rank, group=None, seed=None):
         self.world_size, self.rank, self.group, self.seed = world_size, rank, group, seed
 
     def __enter__(self):
         import os
-        from . import brainfuck_stark, salted_merkle, table
+        from . import randomness
         seed = self.seed
         if seed is None:
             box = [os.urandom(32) if self.rank == 0 else None]
@@ -285,13 +298,16 @@ class shared_randomness:
                 import torch.distributed as dist
                 dist.broadcast_object_list(box, src=0, group=self.group)
             seed = box[0]
-        stream = _SharedStream(seed)
-        self._saved = [(m, m.urandom) for m in (brainfuck_stark, salted_merkle, table)]
-        for m, _ in self._saved:
-            m.urandom = stream
-        return stream
+        self._stream = _SharedStream(seed)
+        self._override = randomness.override(self._stream)
+        self._override.__enter__()
+        return self._stream
 
-    def __exit__(self, *exc):
-        for m, f in self._saved:
-            m.urandom = f
+    def __exit__(self, exc_type, exc, tb):
+        self._override.__exit__(exc_type, exc, tb)
+        if exc_type is None and self.world_size > 1:
+            import torch.distributed as dist
+            positions = [None] * self.world_size
+            dist.all_gather_object(positions, self._stream._pos, group=self.group)
+            assert len(set(positions)) == 1, "the ranks read the shared random stream to different positions: %r" % (positions,)
         return False

@@ -68,6 +68,15 @@ class VirtualMachine:
     # the caller asks for another limit (`-[-]` counts down from p - 1 and a trace costs ~130 bytes per cycle natively,
     # several hundred as element objects).  = BFS_VM_DEFAULT_MAX_CYCLES of include/bfstark.h
     DEFAULT_MAX_CYCLES = 1 << 24
+    UNLIMITED = float("inf")        # max_cycles = VirtualMachine.UNLIMITED: run on like the reference does (no cap at all)
+
+    @staticmethod
+    def _cycle_limit(max_cycles):
+        """None and 0 mean DEFAULT_MAX_CYCLES (0 as in bfs_vm_trace_new); UNLIMITED or anything >= 2^64 - 1 means no limit"""
+        if max_cycles is None or max_cycles == 0:
+            return VirtualMachine.DEFAULT_MAX_CYCLES
+        assert max_cycles > 0, "max_cycles must be positive (0 / None: the default, VirtualMachine.UNLIMITED: none)"
+        return (1 << 64) - 1 if max_cycles >= (1 << 64) - 1 else int(max_cycles)
 
     @staticmethod
     def execute(brainfuck_code):
@@ -100,7 +109,7 @@ class VirtualMachine:
         """vm.py:107-165 -> (running_time, input_data, output_data).  Input symbols that are not supplied cannot be
         read from a terminal here: running out of input is an error.  max_cycles: see DEFAULT_MAX_CYCLES."""
         prog = VirtualMachine._words(program)
-        limit = VirtualMachine.DEFAULT_MAX_CYCLES if max_cycles is None else int(max_cycles)
+        limit = VirtualMachine._cycle_limit(max_cycles)
         ip, mp, memory = 0, 0, {}
         output_data, input_data, input_counter = [], list(input_data), 0
         running_time = 1
@@ -150,8 +159,7 @@ class VirtualMachine:
         symbols = [ord(c) if isinstance(c, str) else int(c) for c in input_data]
         inp = (ctypes.c_uint32 * max(len(symbols), 1))(*symbols)
         handle = ctypes.c_void_p()
-        limit = VirtualMachine.DEFAULT_MAX_CYCLES if max_cycles is None else int(max_cycles)
-        assert limit > 0, "max_cycles must be positive"
+        limit = VirtualMachine._cycle_limit(max_cycles)
         rc = lib.bfs_vm_trace_new(prog, len(words), inp, len(symbols), limit, ctypes.byref(handle))
         if rc:
             message = lib.bfs_last_error().decode("utf-8", "replace")

@@ -212,3 +212,38 @@ def test_exchange_rows_is_a_transpose_for_one_rank():
     out = shard.exchange_rows(cols, [3, 1, 1], 8, 1, 0)
     assert all((out[c] == cols[c]).all() for c in range(3))
     assert shard.row_range(16, 4, 3) == (12, 4)
+
+
+def _few_columns_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from stark_brainfuck_amd import shard
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    planes, n = [3, 1, 1], 16
+    full = {c: (torch.arange(planes[c] * n, dtype=torch.int64).reshape(planes[c], n) + 1000 * c) for c in range(3)}
+    mine = shard.assign_columns(3, world, rank)
+    rows = shard.exchange_rows({c: full[c] for c in mine}, planes, n, world, rank)     # rank 3 owns nothing and still takes part
+    first, m = shard.row_range(n, world, rank)
+    ok = all((rows[c] == full[c][:, first:first + m]).all() for c in range(3))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, bool(ok), len(mine)))
+
+
+def test_exchange_rows_with_a_rank_that_owns_no_column():
+    """fewer columns than ranks: the empty-handed rank's buffers live on the collective's device and the transpose is
+    still exact"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_few_columns_worker, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [g[1] for g in got] == [True] * 4 and [g[2] for g in got] == [1, 1, 1, 0]

@@ -433,3 +433,22 @@ def test_fastlist_conversions_match_the_python_loops():
     finally:
         gc.enable()
     assert min(t_c) * 1.5 < min(t_py), (t_c, t_py)
+
+
+def test_randomness_override_is_per_context_not_process_global():
+    """shard.shared_randomness: another prover thread inside the context keeps its own random source, and the
+    module-level `urandom` names -- which the reference's tests patch -- are not touched"""
+    import os
+    import threading
+    from stark_brainfuck_amd import brainfuck_stark, randomness, salted_merkle, shard, table
+    seen = {}
+    with shard.shared_randomness(1, 0, seed=b"s" * 32) as stream:
+        assert randomness.source(os.urandom) is stream
+        assert brainfuck_stark.urandom is os.urandom and table.urandom is os.urandom and salted_merkle.urandom is os.urandom
+        t = threading.Thread(target=lambda: seen.update(other=randomness.source(os.urandom)))
+        t.start(); t.join()
+        first = stream(16)
+    assert seen["other"] is os.urandom
+    assert randomness.source(os.urandom) is os.urandom
+    with shard.shared_randomness(1, 0, seed=b"s" * 32) as again:
+        assert again(16) == first and again(8) != first[:8]          # deterministic in the seed, and a stream, not a function of the count
