@@ -219,8 +219,26 @@ BFS_HD u64 gl_pow(u64 a, u64 e) {
     return acc;
 }
 
-// a^(p-2); inverse(0) = 0, which is also what the reference's xgcd-based inverse returns (algebra.py:101-103)
-BFS_HD u64 gl_inv(u64 a) { return gl_pow(a, GL_P - 2); }
+// a^(p-2); inverse(0) = 0, which is also what the reference's xgcd-based inverse returns (algebra.py:101-103).
+// p - 2 = 2^64 - 2^32 - 1 has 63 one bits, so square-and-multiply costs 64 + 62 products; with t_k = a^(2^k - 1)
+// (t_2k = t_k^(2^k) t_k) the exponent is (2^31 - 1) 2^33 + (2^32 - 1): 64 squarings and 10 multiplications.  Intermediate
+// squares are only ever multiplied again, so they stay in [0, 2^64) (gl_mul_lazy).
+BFS_HD u64 gl_sqr_times(u64 a, int times) {
+    for (int k = 0; k < times; ++k) a = gl_mul_lazy(a, a);
+    return a;
+}
+BFS_HD u64 gl_inv(u64 a) {
+    const u64 t2 = gl_mul_lazy(gl_sqr_times(a, 1), a);
+    const u64 t4 = gl_mul_lazy(gl_sqr_times(t2, 2), t2);
+    const u64 t8 = gl_mul_lazy(gl_sqr_times(t4, 4), t4);
+    const u64 t16 = gl_mul_lazy(gl_sqr_times(t8, 8), t8);
+    const u64 t24 = gl_mul_lazy(gl_sqr_times(t16, 8), t8);
+    const u64 t28 = gl_mul_lazy(gl_sqr_times(t24, 4), t4);
+    const u64 t30 = gl_mul_lazy(gl_sqr_times(t28, 2), t2);
+    const u64 t31 = gl_mul_lazy(gl_sqr_times(t30, 1), a);
+    const u64 t32 = gl_mul_lazy(gl_sqr_times(t31, 1), a);
+    return gl_mul(gl_sqr_times(t31, 33), t32);
+}
 
 // ---- cubic extension, X^3 = X - 1.  Limbs low degree first (c0, c1, c2). ----
 struct Xfe {

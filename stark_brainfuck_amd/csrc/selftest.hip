@@ -6,7 +6,7 @@
 
 namespace bfs {
 
-constexpr int ST_OPS = 32;
+constexpr int ST_OPS = 34;
 
 BFS_HD void selftest_ops(u64 a, u64 b, u64* o) {
     const u64 d = gl_sub(a, b), s = gl_add(a, b), m = gl_mul(a, b);
@@ -22,6 +22,7 @@ BFS_HD void selftest_ops(u64 a, u64 b, u64* o) {
     const Xfe x{{a, b, d}}, y{{s, m, a}};
     const Xfe z = xfe_mul(xfe_sub_base(xfe_add(x, y), 1ULL), xfe_base_sub(2ULL, xfe_scale(y, b)));
     o[29] = z.c[0]; o[30] = z.c[1]; o[31] = z.c[2];
+    o[32] = gl_inv(a); o[33] = gl_mul(gl_inv(d), d);          // the addition chain with non-canonical intermediate squares
 }
 
 __global__ void selftest_kernel(const u64* in, u64* out, u64 n) {
