@@ -325,7 +325,12 @@ def main():
             # the PMC-derived fraction prices a wave64 VALU instruction at 4 cycles of the NOMINAL 2.4 GHz clock; under this load the
             # package sits at its power limit and the shader clock is lower (profiles/r02/clock_under_load.txt)
             valu_frac_sustained = t["valu_wave_instructions_per_step"] * 4.0 / 1024.0 / (sclk * 1e6) / (kern * 1e-3 / args.steps)
-        line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        valu_obj = None
+        if traffic is not None:
+            valu_obj = valu_roofline(t["valu_wave_instructions_per_step"], kern * 1e-3 / args.steps, sclk,
+                                     "SQ_INSTS_VALU of the three launches of a step (static: profiles/ntt_traffic.json) over the HIP-event time of a step")
+        line["roofline"] = {"bound": "hbm", "bound_actual": "valu_int", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                            "valu": valu_obj,
                             "traffic": traffic, "traffic_source": tsrc,
                             "wasted_traffic_ratio": (traffic / bytes_per_launch) if traffic else None,
                             "valu_issue_frac": valu_frac,
@@ -342,10 +347,15 @@ def main():
             line["fri_prove"]["replicas"] = {"per_gpu_ms": [round(v, 4) for v in fri_all], "proofs_per_s": world / (max(fri_all) * 1e-3)}
             line["fri_prove_ms"] = max(fri_all)
             line["fri_prove_2p24"] = bench_fri(lib, _lib, stream, 22)
+            line["fri_prove"]["roofline"] = fri_roofline(line["fri_prove"], sclk)
+            line["fri_prove_2p24"]["roofline"] = fri_roofline(line["fri_prove_2p24"], sclk)
+            line["fri_prove_2p24"]["kernels"] = prover_kernel_table("fri24")
+            line["merkle_tree_2p24"] = bench_merkle_tree(lib, _lib, stream, 24, sclk)
         if not args.no_stark and not args.no_fri:
             line["stark_prove"] = stark_mine
             line["stark_prove"]["replicas"] = {"per_gpu_ms": [round(v, 4) for v in stark_all], "proofs_per_s": world / (max(stark_all) * 1e-3)}
             line["stark_prove_2p22"] = bench_stark("+" * 64 + "[>" + "+" * 64 + "[>++++<-]<-]+++.", "nested loops, 37 254 cycles")
+            line["stark_prove_2p22"]["roofline"] = stark_roofline(line["stark_prove_2p22"], sclk)
         if coop is not None:
             line["stark_prove_cooperative"] = coop
         if sustained is not None:
@@ -402,6 +412,92 @@ def bench_single_column(lib, _lib, d_in, d_out, n, log_n, root, stream, steps=20
     gbs = 16.0 * n / per / 1e6
     return {"ms": per, "elements_per_s": n / per * 1e3, "algorithmic_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "steps": steps,
             "note": "forward NTT of one column, batch 1, HIP events over %d back-to-back transforms" % steps}
+
+
+VALU_PER_COMPRESSION = 1983     # BLAKE2b-512 compression in VGPRs on gfx950: 801 xor + 576 funnel shifts + 575 64-bit adds + 31
+SIMDS = 1024                    # 256 CUs x 4
+NOMINAL_SCLK_MHZ = 2400
+
+
+def valu_roofline(wave_instructions, seconds, sclk_mhz=None, what=None):
+    """integer-VALU roofline of a piece of work: a wave64 VALU instruction occupies its SIMD for 4 cycles, so the chip retires at most
+    1024 SIMDs x sclk / 4 of them per second.  `achieved` = the work's ALGORITHMIC wave instructions / its time; peak at the nominal
+    2.4 GHz, and next to it at the clock sampled under sustained load (the package power limit lowers it)."""
+    achieved = wave_instructions / seconds / 1e9
+    peak = SIMDS * NOMINAL_SCLK_MHZ * 1e6 / 4 / 1e9
+    r = {"bound": "valu_int", "achieved": achieved, "peak": peak, "unit": "G wave-instructions/s", "frac": achieved / peak,
+         "algorithmic_wave_instructions": wave_instructions}
+    if sclk_mhz:
+        r["peak_at_sustained_sclk"] = SIMDS * sclk_mhz * 1e6 / 4 / 1e9
+        r["frac_at_sustained_sclk"] = achieved / r["peak_at_sustained_sclk"]
+        r["sclk_mhz"] = sclk_mhz
+    if what:
+        r["model"] = what
+    return r
+
+
+def fri_roofline(fri, sclk_mhz=None):
+    """Fri.prove is BLAKE2b: round r commits to N_r = N / 2^r extension elements -- 3 compressions per leaf behind the tabulated
+    first-block state (a 385..409-byte pickle is 4 blocks) and one per tree node -- so ~4 N_r compressions per round, 8 N in all;
+    the fold is 21 multiplications per element next to ~6000 instructions of hashing.  Timed over `breakdown_ms.rounds` (the commit
+    phase incl. its host round trips)."""
+    N, rounds = fri["N"], fri["rounds"]
+    compressions = sum(4 * (N >> r) - 1 for r in range(rounds))
+    r = valu_roofline(compressions * VALU_PER_COMPRESSION / 64.0, fri["breakdown_ms"]["rounds"] * 1e-3, sclk_mhz,
+                      "%d BLAKE2b compressions (3 per leaf + 1 per node over %d rounds) x %d VALU / 64 lanes, over breakdown_ms.rounds" % (compressions, rounds, VALU_PER_COMPRESSION))
+    r["compressions"] = compressions
+    r["hbm_frac"] = 376.0 * N / (fri["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    return r
+
+
+def bench_merkle_tree(lib, _lib, stream, log_n, sclk_mhz=None, steps=10):
+    """Merkle(codeword) over 2^log_n extension elements (merkle.py:8-41, the commitment of an FRI round) on its own, HIP events on the
+    kernels' stream: merkle_leaves_xfe_kernel + merkle_parents_kernel, the two kernels that are 90 % of Fri.prove at this size."""
+    from stark_brainfuck_amd.device import DeviceBuffer
+    n = 1 << log_n
+    limbs = DeviceBuffer.from_numpy(felt_array(SEED + 77, 0, 3 * n))
+    nodes = DeviceBuffer(2 * n * 8)
+
+    def one():
+        _lib.check(lib.bfs_merkle_build_xfe(limbs.ptr, n, n, nodes.ptr, stream))
+    for _ in range(3):
+        one()
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    lib.bfs_event_create(ctypes.byref(e0)); lib.bfs_event_create(ctypes.byref(e1))
+    lib.bfs_event_record(e0, stream)
+    for _ in range(steps):
+        one()
+    lib.bfs_event_record(e1, stream)
+    _lib.check(lib.bfs_stream_synchronize(stream))
+    ms = ctypes.c_float()
+    _lib.check(lib.bfs_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+    per = ms.value / steps
+    compressions = 4 * n - 1
+    r = valu_roofline(compressions * VALU_PER_COMPRESSION / 64.0, per * 1e-3, sclk_mhz,
+                      "(3 n leaf + n - 1 node) BLAKE2b compressions x %d VALU / 64 lanes; random leaves: every coefficient a 9-byte LONG1" % VALU_PER_COMPRESSION)
+    r["hbm_frac"] = (24.0 + 128.0) * n / (per * 1e-3) / 1e9 / HBM_PEAK_GBS
+    limbs.free(); nodes.free()
+    return {"ms": per, "leaves": n, "leaves_per_s": n / per * 1e3, "algorithmic_GBps": 152.0 * n / per / 1e6, "steps": steps, "roofline": r,
+            "note": "bfs_merkle_build_xfe, HIP events over %d back-to-back trees" % steps}
+
+
+def prover_kernel_table(workload):
+    """the tracked per-kernel evidence (profiles/prover_valu.json, made by tools/prof_prover.sh + tools/make_prover_valu.py from rocprofv3
+    --stats and --pmc runs): static, like roofline.traffic -- bench.py does not run a profiler"""
+    path = os.path.join(ROOT, "profiles", "prover_valu.json")
+    if not os.path.exists(path):
+        return None
+    w = json.load(open(path))["workloads"].get(workload)
+    if not w:
+        return None
+    rows = {}
+    for k, e in w["kernels"].items():
+        if e["total_ms"] / max(e["calls"], 1) < 0.02 and e["total_ms"] < 0.5:
+            continue
+        rows[k] = {f: (round(v, 4) if isinstance(v, float) else v) for f, v in e.items()
+                   if f in ("calls", "avg_us", "valu_wave_instructions_per_launch", "valu_issue_frac", "hbm_bytes_per_launch", "hbm_frac", "clock_hz_used")}
+    return {"source": "static: profiles/prover_valu.json (rocprofv3 --kernel-trace --stats; --pmc SQ_INSTS_VALU / GRBM_GUI_ACTIVE / FETCH_SIZE / "
+                      "WRITE_SIZE in separate passes; calls are over the 3 proofs (6 FRI runs) of the profiled command)", "kernels": rows}
 
 
 def bench_fri(lib, _lib, stream, log_d):
@@ -469,6 +565,34 @@ def bench_stark(code=None, label="Hello World!"):
             "breakdown_ms": {k: round(v * 1e3, 2) for k, v in timing.items()},
             "reference": "not runnable: > 12 h extrapolated from 361 s at N = 1024 (BASELINE.md); 757 s measured at N = 2048, 6 766 s at N = 16 384 (tests/golden/stark_*.json)",
             "note": "wall clock of prove() incl. host steps (padding, Fiat-Shamir, transcript); trace_ms = VirtualMachine.simulate (native), verify_ms = verify() on the host"}
+
+
+def stark_roofline(stark, sclk_mhz=None):
+    """the two stages that dominate a large proof against the integer-VALU roofline: the zipped-row commitments (row_leaves_kernel:
+    BLAKE2b over a pickled ROW per leaf) and the combination (air_combine_kernel<TABLE>: constraints + weighted sums at every point).
+    Their VALU instruction counts are the tracked PMC figures (static); the time is this run's stage time."""
+    tab = prover_kernel_table("stark22")
+    if tab is None:
+        return None
+    k = tab["kernels"]
+    b = stark["breakdown_ms"]
+
+    def stage(names, ms, what):
+        instr = 0.0
+        for kk, e in k.items():
+            if any(kk.startswith(name) for name in names) and "valu_wave_instructions_per_launch" in e:
+                instr += e["valu_wave_instructions_per_launch"] * e["calls"] / 3.0      # the profiled command runs three proofs
+        r = valu_roofline(instr, ms * 1e-3, sclk_mhz, what)
+        r["stage_ms"] = ms
+        return r
+    out = {"zipped_row_commitments": stage(["row_leaves_kernel", "row_pattern_kernel"], b["base_tree"] + b["ext_tree"],
+                                           "SQ_INSTS_VALU of row_leaves_kernel + row_pattern_kernel (2 launches each per proof; static) over base_tree + ext_tree of this run "
+                                           "(the stage also builds the 2 x 2^22 tree nodes above the leaves)"),
+           "combination": stage(["air_combine_kernel", "zerofier_inverses_kernel", "difference_combine_kernel"], b["combination"],
+                                "SQ_INSTS_VALU of the five air_combine_kernel<TABLE>, zerofier_inverses_kernel and difference_combine_kernel launches of a proof "
+                                "(static) over this run's combination stage"),
+           "kernels": tab}
+    return out
 
 
 def bench_stark_cooperative(world, rank, device, dist, torch):
