@@ -60,6 +60,20 @@ BFS_HD u64 gl_add(u64 a, u64 b) {
     return over ? (((u64)uhi << 32) | ulo) : (((u64)shi << 32) | slo);
 }
 
+// a + b for b canonical and ANY 64-bit a; the result is congruent to a + b and lies in [0, 2^64) but need not be canonical: fine
+// as the first operand of gl_add_lazy / gl_sub (the minuend), of mul_pow2 and of a multiplication -- never as a subtrahend, never
+// stored.  s = a + b; a carry means + 2^64 = + EPS, which cannot wrap again because s < p then.  5 instructions (gl_add: 6).
+BFS_HD u64 gl_add_lazy(u64 a, u64 b) {
+    u32 c1, c2, c3;
+    u32 slo = __builtin_addc((u32)a, (u32)b, 0u, &c1);
+    u32 shi = __builtin_addc((u32)(a >> 32), (u32)(b >> 32), c1, &c2);
+    u32 t = 0u - c2;                                   // EPS when the addition carried, else 0
+    u32 rlo = __builtin_addc(slo, t, 0u, &c3);
+    u32 rhi = shi + c3;
+    asm("" : "+v"(rhi));                               // (see gl_sub: keep the compiler from merging this carry into a consumer)
+    return ((u64)rhi << 32) | rlo;
+}
+
 // a VGPR holding 0 that the optimiser cannot see through: `x - 0 - borrow` written with it compiles to one v_subb_co_u32,
 // while a literal 0 makes hipcc materialise the borrow with v_cndmask first (one more instruction per carry step)
 BFS_HD u32 gl_opaque_zero() {
@@ -181,6 +195,12 @@ BFS_HD u64 gl_sub(u64 a, u64 b) {
     return a < b ? d - GL_EPS : d;  // borrow: add p (== subtract EPS in wrapped arithmetic)
 }
 
+// the device's lazy sum (any 64-bit a, canonical b; result in [0, 2^64), not necessarily canonical), bit for bit
+BFS_HD u64 gl_add_lazy(u64 a, u64 b) {
+    u64 s = a + b;
+    return s < a ? s + GL_EPS : s;
+}
+
 // reduce a 128-bit value hi*2^64 + lo.  2^64 = 2^32 - 1, 2^96 = -1 (mod p).
 BFS_HD u64 gl_reduce128(u64 hi, u64 lo) {
     u64 hi_hi = hi >> 32, hi_lo = hi & GL_EPS;
@@ -198,6 +218,8 @@ BFS_HD u64 gl_reduce96(u32 top, u64 lo) { return gl_reduce128((u64)top, lo); }
 #endif
 
 BFS_HD u64 gl_neg(u64 a) { return a ? GL_P - a : 0; }
+// any 64-bit value -> its canonical residue
+BFS_HD u64 gl_canon(u64 a) { return a >= GL_P ? a - GL_P : a; }
 
 #if !defined(__HIP_DEVICE_COMPILE__)
 BFS_HD u64 gl_mul(u64 a, u64 b) {

@@ -23,16 +23,12 @@ __global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a, const i
     const u32 tw_shift = a.tb.t_in_log - (B1 + B2);
     const bool early = early_loads != 0;
     const u32 tid = threadIdx.x;
-    bool has_row = false;
-    const u64* row = nullptr;
-    if constexpr (MODE == PASS_COLUMN) {
-        if (a.tb.row != nullptr) {
-            // this tile's row of the inter-pass twiddle table (one coalesced 2^S-entry read per workgroup)
-            const u64 K = a.pass_index ? digit_reverse((u64)(blockIdx.x >> a.lognl), a.pass_bits, 0, (int)a.pass_index - 1) : 0;
-            row = a.tb.row + (K << Cfg::S);
-            has_row = true;
-        }
-    }
+    // this tile's row of a product table (one coalesced 2^S-entry read per workgroup): factors of its input rows, or -- first pass of
+    // a balanced plan -- of its output rows; never both
+    const u64* lrow = tile_load_row<Cfg, MODE>(a, blockIdx.x);
+    const u64* srow_g = tile_store_row<Cfg, LOGC, MODE>(a, blockIdx.x);
+    const u64* row = lrow ? lrow : srow_g;
+    const bool has_row = row != nullptr;
     u64 tw0 = 0, rw0 = 0;
     if (early) {
         if (TW_N && tid < TW_N) tw0 = tab[(u64)tid << tw_shift];
@@ -48,17 +44,18 @@ __global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a, const i
     for (u32 i = tid + (early ? blockDim.x : 0); i < TW_N; i += blockDim.x) tw[i] = tab[(u64)i << tw_shift];
     if (has_row)
         for (u32 i = tid + (early ? blockDim.x : 0); i < (1u << Cfg::S); i += blockDim.x) rw[i] = row[i];
-    const u64* rowtw = has_row ? rw : nullptr;
+    const u64* rowtw = lrow ? rw : nullptr;
+    const u64* srow = srow_g && !lrow ? rw : nullptr;
     if (Cfg::U >= 2 || has_row) __syncthreads();
     if (!early) ntt_stage1_load<B1, B2, B3, LOGC, MODE, NT>(a, tid, blockIdx.x, blockIdx.y, 0, x);
-    ntt_stage1_compute<B1, B2, B3, LOGC, MODE, NT>(a, smem, tw, rowtw, threadIdx.x, blockIdx.x, blockIdx.y, 0, x);
+    ntt_stage1_compute<B1, B2, B3, LOGC, MODE, NT>(a, smem, tw, rowtw, threadIdx.x, blockIdx.x, blockIdx.y, 0, x, srow);
     if constexpr (B2 > 0) {
         __syncthreads();
-        ntt_stage2<B1, B2, B3, LOGC, MODE, NT>(a, smem, threadIdx.x, blockIdx.x, blockIdx.y);
+        ntt_stage2<B1, B2, B3, LOGC, MODE, NT>(a, smem, threadIdx.x, blockIdx.x, blockIdx.y, srow);
     }
     if constexpr (B3 > 0) {
         __syncthreads();
-        ntt_stage3<B1, B2, B3, LOGC, MODE, NT>(a, smem, threadIdx.x, blockIdx.x, blockIdx.y);
+        ntt_stage3<B1, B2, B3, LOGC, MODE, NT>(a, smem, threadIdx.x, blockIdx.x, blockIdx.y, srow);
     }
 }
 
@@ -80,15 +77,10 @@ __global__ void __launch_bounds__(256) ntt_tile_kernel_split(const PassArgs a) {
     const u64* tab = (MODE == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;      // U == 2: n^-1 folded into the last inner twiddle
     const u32 tw_shift = a.tb.t_in_log - (B1 + B2);
     const u32 tid = threadIdx.x;
-    bool has_row = false;
-    const u64* row = nullptr;
-    if constexpr (MODE == PASS_COLUMN) {
-        if (a.tb.row != nullptr) {
-            const u64 K = a.pass_index ? digit_reverse((u64)(blockIdx.x >> a.lognl), a.pass_bits, 0, (int)a.pass_index - 1) : 0;
-            row = a.tb.row + (K << Cfg::S);
-            has_row = true;
-        }
-    }
+    const u64* lrow = tile_load_row<Cfg, MODE>(a, blockIdx.x);
+    const u64* srow_g = tile_store_row<Cfg, LOGC, MODE>(a, blockIdx.x);
+    const u64* row = lrow ? lrow : srow_g;
+    const bool has_row = row != nullptr;
     // table entries first, then the data (see ntt_tile_kernel); W = 256 >= both table sizes
     u64 tw0 = 0, rw0 = 0;
     if (tid < TW_N) tw0 = tab[(u64)tid << tw_shift];
@@ -99,7 +91,8 @@ __global__ void __launch_bounds__(256) ntt_tile_kernel_split(const PassArgs a) {
     if (tid < TW_N) tw[tid] = tw0;
     if (has_row && tid < (1u << Cfg::S)) rw[tid] = rw0;
     __syncthreads();
-    ntt_stage1_values<B1, B2, B3, LOGC, MODE>(a, tw, has_row ? rw : nullptr, tid, blockIdx.x, blockIdx.y, 0, x);
+    const u64* srow = srow_g && !lrow ? rw : nullptr;
+    ntt_stage1_values<B1, B2, B3, LOGC, MODE>(a, tw, lrow ? rw : nullptr, tid, blockIdx.x, blockIdx.y, 0, x);
     constexpr int Q2 = 1 << B2, SG2 = 16 / Q2;
     BFS_UNROLL
     for (int m = 0; m < 16; ++m) tile[stage1_out_index<B1, B2, B3, LOGC, MODE>(a, tid, 0, m)] = (u32)x[m];
@@ -118,14 +111,14 @@ __global__ void __launch_bounds__(256) ntt_tile_kernel_split(const PassArgs a) {
         u64 y[Q2];
         BFS_UNROLL
         for (int d = 0; d < Q2; ++d) y[d] = ((u64)tile[stage2_in_index<B1, B2, B3, LOGC, MODE>(tid, s, d)] << 32) | lo[s * Q2 + d];
-        ntt_stage2_from<B1, B2, B3, LOGC, MODE, NT>(a, smem, tid, blockIdx.x, blockIdx.y, s, y);
+        ntt_stage2_from<B1, B2, B3, LOGC, MODE, NT>(a, smem, tid, blockIdx.x, blockIdx.y, s, y, srow);
     }
 }
 
 template <int B1, int B2, int B3, int LOGC, int MODE>
 static int launch_tile_split(const PassArgs& a, u32 grid_x, u32 batch, hipStream_t stream) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
-    const size_t row_words = (MODE == PASS_COLUMN && a.tb.row != nullptr) ? (1u << Cfg::S) : 0;
+    const size_t row_words = (a.tb.row != nullptr || a.tb.srow != nullptr) ? (1u << Cfg::S) : 0;
     const size_t lds = ((Cfg::LDS_WORDS * 4 + 15) & ~15u) + (Cfg::TW_WORDS + row_words) * sizeof(u64);
     if (a.streaming)
         hipLaunchKernelGGL((ntt_tile_kernel_split<B1, B2, B3, LOGC, MODE, true>), dim3(grid_x, batch), dim3(Cfg::W), lds, stream, a);
@@ -140,7 +133,7 @@ __global__ void ntt_small_kernel(const SmallArgs a) { ntt_small_body(a, threadId
 template <int B1, int B2, int B3, int LOGC, int MODE>
 static int launch_tile(const PassArgs& a, u32 grid_x, u32 batch, hipStream_t stream) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
-    const size_t row_words = (MODE == PASS_COLUMN && a.tb.row != nullptr) ? (1u << Cfg::S) : 0;
+    const size_t row_words = (a.tb.row != nullptr || a.tb.srow != nullptr) ? (1u << Cfg::S) : 0;
     const size_t lds = (size_t)((B2 > 0 ? ((Cfg::LDS_WORDS + 1) & ~1) + Cfg::TW_WORDS : 0) + row_words) * sizeof(u64);
     static const int early = [] { const char* e = getenv("BFS_NTT_EARLY_LOADS"); return (e && e[0] == '0') ? 0 : 1; }();   // A/B switch
     if (a.streaming)
@@ -200,24 +193,23 @@ constexpr u64 NTT_STREAMING_BYTES = 128ull << 20;     // one 2^24-point column (
 
 enum { TBL_W_LO = 1, TBL_W_HI, TBL_T_IN, TBL_T_IN_LAST, TBL_S_LO, TBL_S_HI, TBL_ROW };
 
-// row table of column pass t >= 1: row[K * 2^S + r] = w_{N_t}^(K r), N_t = 2^done <= 2^16 (512 KiB, L2 resident)
-static int get_row_table(const NttPlan& p, u32 t, u64 root, const u64** d_row) {
+// the product tables of pass t (ntt_row_specs): <= 2^16 entries each (512 KiB, L2 resident), cached per (omega, shape)
+static int get_row_tables(const NttPlan& p, u32 t, u64 root, const u64** d_row, const u64** d_srow) {
     *d_row = nullptr;
-    u32 done = 0;
-    for (u32 v = 0; v <= t; ++v) done += p.pass_bits[v];
-    if (t == 0 || t + 1 == p.npass || done > 16) return BFS_OK;
-    const u64 key = ((u64)p.log_n << 8) | TBL_ROW;
-    if (cached_table_lookup(root, key, t, d_row)) return BFS_OK;
-    const u32 S = p.pass_bits[t];
-    const u64 wN = gl_pow(root, 1ull << (p.log_n - done));
-    std::vector<u64> host((size_t)1 << done);
-    u64 wK = 1;                                  // w_N^K
-    for (u64 K = 0; K < (1ull << (done - S)); ++K) {
-        u64 v = 1;
-        for (u64 r = 0; r < (1ull << S); ++r) { host[(K << S) + r] = v; v = gl_mul(v, wK); }
-        wK = gl_mul(wK, wN);
+    *d_srow = nullptr;
+    NttRowSpec load, store;
+    ntt_row_specs(p, t, root, load, store);
+    for (int which = 0; which < 2; ++which) {
+        const NttRowSpec& sp = which ? store : load;
+        if (sp.omega == 0) continue;
+        const u64** out = which ? d_srow : d_row;
+        const u64 key = ((u64)sp.a_bits << 24) | ((u64)sp.b_bits << 16) | TBL_ROW;
+        if (cached_table_lookup(sp.omega, key, 0, out)) continue;
+        std::vector<u64> host;
+        ntt_product_table(sp.omega, sp.a_bits, sp.b_bits, host);
+        BFS_TRY(cached_table(sp.omega, key, 0, host.data(), host.size(), out));
     }
-    return cached_table(root, key, t, host.data(), host.size(), d_row);
+    return BFS_OK;
 }
 
 static int get_tables(const NttPlan& p, u64 root, u64 shift, u64 post_scale, NttTables& tb) {
@@ -304,7 +296,7 @@ int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_str
     }
     for (u32 t = 0; t < p.npass; ++t) {
         const bool first = t == 0, last = t + 1 == p.npass;
-        BFS_TRY(get_row_table(p, t, root, &tb.row));
+        BFS_TRY(get_row_tables(p, t, root, &tb.row, &tb.srow));
         PassArgs a = ntt_pass_args(p, t, first ? d_in : ws, last ? d_out : ws, first ? in_stride : n, last ? out_stride : n,
                                    first ? n_in : n, tb, shift != 1, shift, post_scale);
         a.streaming = streaming;

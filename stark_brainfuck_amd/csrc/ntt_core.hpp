@@ -73,24 +73,46 @@ BFS_HD u64 mul_pow2(u64 x) {
     }
 }
 
-// one level of the radix-Q decimation-in-frequency network, twiddle w_Q = 2^(192/Q)
-template <int Q, int I>
+// one level of the radix-Q decimation-in-frequency network, twiddle w_Q = 2^(192/Q).
+// LAZY (A/B switch BFS_NTT_LAZY_SUMS, profiles/r03/ab_lazy_minuend.txt): x[0] of a block is only ever the FIRST operand of the levels
+// below it (never a subtrahend), and gl_sub / mul_pow2 / a multiplication take any 64-bit value in that place -- so its sum may stay
+// unreduced in [0, 2^64) (gl_add_lazy: 5 instructions instead of 6): 15 of the 32 sums of a radix-16 block.  Every output that
+// descends from a lazy x[0] only through sums and untwiddled differences is then non-canonical as well, so only a block whose
+// outputs are all multiplied next (the first stage of a pass) can do this.
+template <int Q, int I, bool LAZY>
 BFS_HD void dif_level(u64* x) {
     if constexpr (I < Q / 2) {
         u64 a = x[I], b = x[I + Q / 2];
-        x[I] = gl_add(a, b);
+        if constexpr (LAZY && I == 0) x[I] = gl_add_lazy(a, b);
+        else x[I] = gl_add(a, b);
         x[I + Q / 2] = mul_pow2<(192 / Q) * I>(gl_sub(a, b));
-        dif_level<Q, I + 1>(x);
+        dif_level<Q, I + 1, LAZY>(x);
     }
 }
 
-// Q-point NTT with root 2^(192/Q); result for output index k is left in x[bitrev(k)]
-template <int Q>
+#ifdef BFS_NTT_LAZY_SUMS
+constexpr bool NTT_LAZY_SUMS = true;
+#else
+constexpr bool NTT_LAZY_SUMS = false;
+#endif
+
+// Q-point NTT with root 2^(192/Q); result for output index k is left in x[bitrev(k)].  LAZY: see dif_level (outputs in [0, 2^64))
+template <int Q, bool LAZY = false>
 BFS_HD void dif(u64* x) {
     if constexpr (Q >= 2) {
-        dif_level<Q, 0>(x);
-        dif<Q / 2>(x);
-        dif<Q / 2>(x + Q / 2);
+        dif_level<Q, 0, LAZY>(x);
+        dif<Q / 2, LAZY>(x);
+        dif<Q / 2, LAZY>(x + Q / 2);
+    }
+}
+
+// a layer of power-of-two twiddles with compile-time exponents (what a tile-uniform exponent costs after a uniform branch): register d
+// times 2^(3 d (V + 1) mod 96); 15 of 16 registers non-trivial.  Only used by the timing-only switch BFS_ABL_R64.
+template <int Q, int V, int D = 0>
+BFS_HD void pow2_layer(u64* x) {
+    if constexpr (D < Q) {
+        x[D] = mul_pow2<(3 * D * (V + 1) + (D ? 5 * V : 0)) % 96>(x[D]);
+        pow2_layer<Q, V, D + 1>(x);
     }
 }
 
@@ -134,7 +156,8 @@ struct NttTables {
     const u64* t_in_last;  // Omega^i * post_scale (used for the last inner twiddle of the final pass)
     const u64* s_lo;       // coset shift s: s^i, i < 2^lo_bits (null when no coset)
     const u64* s_hi;       // s^(i * 2^lo_bits)
-    const u64* row;        // column pass t >= 1 with N_t <= 2^16: row[K * 2^S + r] = w_{N_t}^(K r)  (null: use the chain)
+    const u64* row;        // load-time product table of this pass (null: chain / scalar / nothing): the tile's row K holds the factors of its 2^S rows
+    const u64* srow;       // store-time product table of pass 0 of a balanced plan (PassArgs::sched): the tile's row j_2 holds the factors of its 2^S outputs
 };
 
 enum { PASS_COLUMN = 0, PASS_FINAL = 1 };
@@ -161,6 +184,13 @@ struct PassArgs {
     u64 coset_delta;     // s^(stride of the stage-1 register index)
     u64 post_scale;      // multiplied in at the final store when the final pass has a single stage
     u32 streaming;       // data loads / stores are non-temporal (the launcher picks the NT instantiation; kept here for the record)
+    // Balanced twiddle schedule of a three-pass plan (ntt_plan.hpp, DESIGN.md 4.1 "round 3").  The inter-pass factor in front of pass 3
+    // splits, w_N^(j3 (k1 + n1 k2)) = w_N^(j3 k1) * w_{n2 n3}^(j3 k2), and each piece goes where it is cheap AND where there is room:
+    //   w_{n1 n2}^(j2 k1)  at pass 1's STORE (j2 is tile-uniform there: one row of a product table in LDS; that pass is memory-bound),
+    //   w_N^(j3 k1)        in pass 2 at load: k1 is tile-uniform, j3 is the thread's column, so ONE factor per thread (it commutes with
+    //                      the pass' transform, which runs over j2),
+    //   w_{n2 n3}^(j3 k2)  at pass 3's load from a tile-uniform row (k2) instead of a 31-product chain per thread.
+    u32 sched;
     NttTables tb;
 };
 
@@ -256,9 +286,30 @@ BFS_HD TileGeom tile_geom(const PassArgs& a, u32 bid_x, u32 bid_y) {
     return g;
 }
 
-// store the 2^BQ registers of the last stage.  klow = the already-final lower digits of k_pass, c = column
+// the row of the load-time product table that a tile stages in LDS (null: none): column pass -- row K = the digit-reversed previous
+// output digits; final pass of a balanced plan -- row k_2 (digit-reversed `mid`)
+template <typename Cfg, int MODE>
+BFS_HD const u64* tile_load_row(const PassArgs& a, u32 bid_x) {
+    if (a.tb.row == nullptr) return nullptr;
+    u64 K;
+    if constexpr (MODE == PASS_COLUMN) K = a.pass_index ? digit_reverse((u64)(bid_x >> a.lognl), a.pass_bits, 0, (int)a.pass_index - 1) : 0;
+    else K = a.mid_bits ? digit_reverse((u64)(bid_x >> a.logch), a.pass_bits, 1, (int)a.npass - 2) : 0;
+    return a.tb.row + (K << Cfg::S);
+}
+// ... and of the store-time table (pass 1 of a balanced plan): row j_2 = the tile's columns' next digit (the same for all of them)
+template <typename Cfg, int LOGC, int MODE>
+BFS_HD const u64* tile_store_row(const PassArgs& a, u32 bid_x) {
+    if constexpr (MODE != PASS_COLUMN) return nullptr;
+    if (a.tb.srow == nullptr) return nullptr;
+    const u64 c0 = (u64)(bid_x & ((1u << a.lognl) - 1)) << LOGC;
+    const u64 j2 = c0 >> (a.logL - pass_bits_of(a.pass_bits, (int)a.pass_index + 1));
+    return a.tb.srow + (j2 << Cfg::S);
+}
+
+// store the 2^BQ registers of the last stage.  klow = the already-final lower digits of k_pass, c = column;
+// srow (LDS, or null): the store-time factors of the tile's output rows
 template <typename Cfg, int LOGC, int MODE, int BQ, bool NT = false>
-BFS_HD void final_store(const PassArgs& a, const TileGeom& g, const u64* x, u32 klow, int kshift, u32 c) {
+BFS_HD void final_store(const PassArgs& a, const TileGeom& g, const u64* x, u32 klow, int kshift, u32 c, const u64* srow = nullptr) {
     constexpr int Q = 1 << BQ;
     const bool scale = (Cfg::U == 1) && a.post_scale != 1;
     u64* tp;          // per-thread base; the per-register offset below is wave-uniform
@@ -275,7 +326,8 @@ BFS_HD void final_store(const PassArgs& a, const TileGeom& g, const u64* x, u32 
 #ifdef BFS_ABL_NO_MEM
         if (x[m] != 0x123456789ULL) continue;
 #endif
-        const u64 v = scale ? gl_mul(x[m], a.post_scale) : x[m];
+        u64 v = scale ? gl_mul(x[m], a.post_scale) : x[m];
+        if (srow != nullptr) v = gl_mul(v, srow[klow + (perm_digit<BQ>(m, a.uinv) << kshift)]);      // (wave-uniform question)
         ntt_st<NT>(tp + ((u64)perm_digit<BQ>(m, a.uinv) << step_log), v);
     }
 }
@@ -363,7 +415,8 @@ BFS_HD u32 stage2_in_index(u32 tid, int s, int d) {
 // that stage1_out_index(m) receives.  U == 1: the values are final and are stored.
 // tw: dense inner-twiddle table for the stage 1 -> 2 exchange (2^(B1+B2) entries, in LDS on the GPU)
 template <int B1, int B2, int B3, int LOGC, int MODE, bool NT = false>
-BFS_HD void ntt_stage1_values(const PassArgs& a, const u64* tw, const u64* rowtw, u32 tid, u32 bid_x, u32 bid_y, int sub, u64* x) {
+BFS_HD void ntt_stage1_values(const PassArgs& a, const u64* tw, const u64* rowtw, u32 tid, u32 bid_x, u32 bid_y, int sub, u64* x,
+                              const u64* srow = nullptr) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     constexpr int Q = 1 << B1;
     const TileGeom g = tile_geom<Cfg, LOGC, MODE>(a, bid_x, bid_y);
@@ -371,10 +424,22 @@ BFS_HD void ntt_stage1_values(const PassArgs& a, const u64* tw, const u64* rowtw
     const Stage1Pos<B1, B2, B3, LOGC, MODE> p = stage1_pos<B1, B2, B3, LOGC, MODE>(a, g, tid, sub);
     const u32 o = p.o, c = p.c;
 #ifndef BFS_ABL_NO_CHAIN
-    if (MODE == PASS_COLUMN && rowtw != nullptr) {
-        // middle pass: the inter-pass twiddles of this tile are one row of a table (K is the same for the whole tile)
+    if (rowtw != nullptr) {
+        // the inter-pass twiddles of this tile are one row of a table (K is the same for the whole tile)
+#ifdef BFS_ABL_R64          // timing only (wrong results): see the inner twiddle below
+        pow2_layer<Q, 0>(x);
+#else
         BFS_UNROLL
         for (int d = 0; d < Q; ++d) x[d] = gl_mul(x[d], rowtw[((u32)d << Cfg::SH1) | o]);
+#endif
+    } else if (a.sched && a.pass_index > 0) {
+        // balanced plan, middle pass: w_N^(j3 k1) -- k1 belongs to the tile, j3 is this thread's column: one factor for all 16 rows
+        if constexpr (MODE == PASS_COLUMN) {
+            const u64 c0 = g.row0 & ((1ull << a.logL) - 1);
+            const u64 f = tw_pow(a.tb.w_lo, a.tb.w_hi, a.tb.lo_bits, (g.K * (c0 + c)) & nmask);
+            BFS_UNROLL
+            for (int d = 0; d < Q; ++d) x[d] = gl_mul(x[d], f);
+        }
     } else if (a.pass_index > 0 || a.has_coset) {
         // factor of row r = (d << SH1) | o is beta^r = gamma * delta^d: a geometric chain per thread
         u64 gam, del;
@@ -395,10 +460,10 @@ BFS_HD void ntt_stage1_values(const PassArgs& a, const u64* tw, const u64* rowtw
     }
 #endif
 #ifndef BFS_ABL_NO_DIF
-    dif<Q>(x);
+    dif<Q, (Cfg::U >= 2) && NTT_LAZY_SUMS>(x);        // U >= 2: every output is multiplied by an inner twiddle below (or reduced there)
 #endif
     if constexpr (Cfg::U == 1) {
-        final_store<Cfg, LOGC, MODE, B1, NT>(a, g, x, 0, 0, c);
+        final_store<Cfg, LOGC, MODE, B1, NT>(a, g, x, 0, 0, c, srow);
     } else {
         const u32 i2 = o >> B3;
         BFS_UNROLL
@@ -411,16 +476,30 @@ BFS_HD void ntt_stage1_values(const PassArgs& a, const u64* tw, const u64* rowtw
             // register 0 holds output digit 0: its twiddle is w^0, which is 1 unless a post-scale (n^-1 of intt) is folded into the
             // table -- a wave-uniform question, so a forward transform skips that product in its VALU-bound last pass as well
             const bool unit = (m == 0) && (!(Cfg::U == 2 && MODE == PASS_FINAL) || a.post_scale == 1);
+#ifdef BFS_ABL_R64
+            if (MODE == PASS_FINAL) { if (m == Q - 1) pow2_layer<Q, 3>(x); continue; }
+#endif
             if (!unit) x[m] = gl_mul(x[m], tw[e]);
+            else if constexpr (NTT_LAZY_SUMS) x[m] = gl_canon(x[m]);      // the one output that skips its (unit) product
 #endif
         }
+#ifdef BFS_ABL_R64
+        // TIMING-ONLY emulation of the 6-bit-digit plan (four radix-64 blocks whose internal 16 x 4 split has power-of-two twiddles with
+        // a tile-uniform exponent, three general twiddle layers at bits 6 / 12 / 18; profiles/r03/ab_radix64_emulation.txt): per pass the
+        // plan costs  pass 0: P + G,  pass 1: P + G,  pass 2: P + G(24-bit exponent) + P  where this code has  G | G(row) + G |
+        // G(chain) + G -- so pass 0 gets one more power-of-two layer here, pass 1's row-table product becomes one (above), and the last
+        // pass trades its inner product for two of them.  Results are wrong; the instruction stream is what is measured.
+        if (MODE == PASS_COLUMN && a.pass_index == 0) pow2_layer<Q, 1>(x);
+        if (MODE == PASS_FINAL) pow2_layer<Q, 2>(x);
+#endif
     }
 }
 
 template <int B1, int B2, int B3, int LOGC, int MODE, bool NT = false>
-BFS_HD void ntt_stage1_compute(const PassArgs& a, u64* smem, const u64* tw, const u64* rowtw, u32 tid, u32 bid_x, u32 bid_y, int sub, u64* x) {
+BFS_HD void ntt_stage1_compute(const PassArgs& a, u64* smem, const u64* tw, const u64* rowtw, u32 tid, u32 bid_x, u32 bid_y, int sub, u64* x,
+                               const u64* srow = nullptr) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
-    ntt_stage1_values<B1, B2, B3, LOGC, MODE, NT>(a, tw, rowtw, tid, bid_x, bid_y, sub, x);
+    ntt_stage1_values<B1, B2, B3, LOGC, MODE, NT>(a, tw, rowtw, tid, bid_x, bid_y, sub, x, srow);
     if constexpr (Cfg::U >= 2) {
         BFS_UNROLL
         for (int m = 0; m < (1 << B1); ++m) smem[stage1_out_index<B1, B2, B3, LOGC, MODE>(a, tid, sub, m)] = x[m];
@@ -428,20 +507,20 @@ BFS_HD void ntt_stage1_compute(const PassArgs& a, u64* smem, const u64* tw, cons
 }
 
 template <int B1, int B2, int B3, int LOGC, int MODE>
-BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, const u64* tw, const u64* rowtw, u32 tid, u32 bid_x, u32 bid_y) {
+BFS_HD void ntt_stage1(const PassArgs& a, u64* smem, const u64* tw, const u64* rowtw, u32 tid, u32 bid_x, u32 bid_y, const u64* srow = nullptr) {
     constexpr int Q = 1 << B1, SG = 16 / Q;
     BFS_UNROLL
     for (int s = 0; s < SG; ++s) {
         u64 x[Q];
         ntt_stage1_load<B1, B2, B3, LOGC, MODE>(a, tid, bid_x, bid_y, s, x);
-        ntt_stage1_compute<B1, B2, B3, LOGC, MODE>(a, smem, tw, rowtw, tid, bid_x, bid_y, s, x);
+        ntt_stage1_compute<B1, B2, B3, LOGC, MODE>(a, smem, tw, rowtw, tid, bid_x, bid_y, s, x, srow);
     }
 }
 
 // ---- stage 2: LDS read, second radix, (inner twiddle + LDS write) or final store
 // ntt_stage2_from: sub-group s of thread `tid` once its 2^B2 values are in x[] (however they got there)
 template <int B1, int B2, int B3, int LOGC, int MODE, bool NT = false>
-BFS_HD void ntt_stage2_from(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid_y, int s, u64* x) {
+BFS_HD void ntt_stage2_from(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid_y, int s, u64* x, const u64* srow = nullptr) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     if constexpr (B2 > 0) {
         constexpr int Q = 1 << B2;
@@ -454,7 +533,7 @@ BFS_HD void ntt_stage2_from(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u3
         dif<Q>(x);
 #endif
         if constexpr (Cfg::U == 2) {
-            final_store<Cfg, LOGC, MODE, B2, NT>(a, g, x, f1, B1, c);
+            final_store<Cfg, LOGC, MODE, B2, NT>(a, g, x, f1, B1, c, srow);
         } else {
             const u64* tab = (MODE == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;
             BFS_UNROLL
@@ -469,7 +548,7 @@ BFS_HD void ntt_stage2_from(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u3
 }
 
 template <int B1, int B2, int B3, int LOGC, int MODE, bool NT = false>
-BFS_HD void ntt_stage2(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid_y) {
+BFS_HD void ntt_stage2(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid_y, const u64* srow = nullptr) {
     if constexpr (B2 > 0) {
         constexpr int Q = 1 << B2, SG = 16 / Q;
         BFS_UNROLL
@@ -477,14 +556,14 @@ BFS_HD void ntt_stage2(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid
             u64 x[Q];
             BFS_UNROLL
             for (int d = 0; d < Q; ++d) x[d] = smem[stage2_in_index<B1, B2, B3, LOGC, MODE>(tid, s, d)];
-            ntt_stage2_from<B1, B2, B3, LOGC, MODE, NT>(a, smem, tid, bid_x, bid_y, s, x);
+            ntt_stage2_from<B1, B2, B3, LOGC, MODE, NT>(a, smem, tid, bid_x, bid_y, s, x, srow);
         }
     }
 }
 
 // ---- stage 3: LDS read, third radix, final store
 template <int B1, int B2, int B3, int LOGC, int MODE, bool NT = false>
-BFS_HD void ntt_stage3(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid_y) {
+BFS_HD void ntt_stage3(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid_y, const u64* srow = nullptr) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     if constexpr (B3 > 0) {
         constexpr int Q = 1 << B3, SG = 16 / Q;
@@ -499,7 +578,7 @@ BFS_HD void ntt_stage3(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u32 bid
             BFS_UNROLL
             for (int d = 0; d < Q; ++d) x[d] = smem[lds_addr<Cfg, LOGC>((f1 << Cfg::SH1) | (f2 << Cfg::SH2) | (u32)d, c)];
             dif<Q>(x);
-            final_store<Cfg, LOGC, MODE, B3, NT>(a, g, x, f1 + (f2 << B1), B1 + B2, c);
+            final_store<Cfg, LOGC, MODE, B3, NT>(a, g, x, f1 + (f2 << B1), B1 + B2, c, srow);
         }
     }
 }

@@ -3,6 +3,7 @@
 // Validation mirrors the reference's asserts: /root/reference/code/ntt.py:5-6 (power of two),
 // :13-14 (w^n == 1), :15-16 (w^(n/2) != 1).
 #pragma once
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/bfstark.h"
@@ -24,6 +25,7 @@ struct NttPlan {
     u32 uinv = 1;
     u32 lo_bits = 0;
     u32 t_in_log = 0;
+    u32 sched = 0;                    // 1: the balanced twiddle schedule of a three-pass plan (PassArgs::sched)
 };
 
 inline int ntt_check_root(u64 root, u32 log_n) {
@@ -46,6 +48,12 @@ inline u32 ntt_uinv(u64 root, u32 log_n) {
     for (u32 v = 1; v < 16; v += 2)
         if (((u * v) & 15) == 1) return v;
     return 1;
+}
+
+// tests: -1 = follow the environment (BFS_NTT_SCHEDULE), 0 / 1 = force the load-time / the balanced schedule
+inline int& ntt_schedule_override() {
+    static int v = -1;
+    return v;
 }
 
 inline bool ntt_make_plan(u32 log_n, u64 root, NttPlan& p) {
@@ -85,7 +93,47 @@ inline bool ntt_make_plan(u32 log_n, u64 root, NttPlan& p) {
     if (best_score == ~0u) return false;
     p.npass = m;
     for (u32 i = 0; i < m; ++i) { p.pass_bits[i] = best[i]; p.logC[i] = NTT_TILE_LOG - best[i]; }
+    // Balanced schedule (three passes): needs the first pass' tiles to sit inside one value of the next digit (C_1 <= n_3 ... the
+    // tile's columns l = j2 n3 + j3 then share j2), two-stage tiles everywhere, and product tables of at most 2^16 entries.
+    // BFS_NTT_SCHEDULE=0 keeps the load-time schedule (A/B, tools/ab_ntt.sh).
+    static const bool env_balanced = [] { const char* e = getenv("BFS_NTT_SCHEDULE"); return !(e && e[0] == '0'); }();
+    const bool balanced = ntt_schedule_override() < 0 ? env_balanced : ntt_schedule_override() != 0;
+    p.sched = (balanced && m == 3 && p.logC[0] <= best[2] && best[0] >= 5 && best[1] >= 5 && best[2] >= 5 && best[0] + best[1] <= 16 &&
+               best[1] + best[2] <= 16) ? 1 : 0;
     return true;
+}
+
+// product table: out[(a << b_bits) + b] = omega^(a b)
+inline void ntt_product_table(u64 omega, u32 a_bits, u32 b_bits, std::vector<u64>& out) {
+    out.resize((size_t)1 << (a_bits + b_bits));
+    u64 wa = 1;                                  // omega^a
+    for (u64 a = 0; a < (1ull << a_bits); ++a) {
+        u64 v = 1;
+        for (u64 b = 0; b < (1ull << b_bits); ++b) { out[(a << b_bits) + b] = v; v = gl_mul(v, wa); }
+        wa = gl_mul(wa, omega);
+    }
+}
+
+// The product tables pass t of a plan reads: `load` (NttTables::row: a tile multiplies its 2^S input rows by one row of it) and `store`
+// (NttTables::srow: ... its 2^S output rows).  omega = 0: no such table.
+struct NttRowSpec {
+    u64 omega = 0;
+    u32 a_bits = 0, b_bits = 0;
+};
+inline void ntt_row_specs(const NttPlan& p, u32 t, u64 root, NttRowSpec& load, NttRowSpec& store) {
+    load = NttRowSpec(); store = NttRowSpec();
+    if (p.npass < 2) return;
+    const bool last = t + 1 == p.npass;
+    if (p.sched) {
+        const u32 s0 = p.pass_bits[0], s1 = p.pass_bits[1], s2 = p.pass_bits[2];
+        if (t == 0) store = NttRowSpec{gl_pow(root, 1ull << s2), s1, s0};          // rows j2, entries k1:  w_{n1 n2}^(j2 k1)
+        if (t == 2) load = NttRowSpec{gl_pow(root, 1ull << s0), s1, s2};           // rows k2, entries j3:  w_{n2 n3}^(k2 j3)
+        return;
+    }
+    u32 done = 0;
+    for (u32 v = 0; v <= t; ++v) done += p.pass_bits[v];
+    if (t == 0 || last || done > 16) return;
+    load = NttRowSpec{gl_pow(root, 1ull << (p.log_n - done)), done - p.pass_bits[t], p.pass_bits[t]};     // rows K, entries r:  w_{N_t}^(K r)
 }
 
 // powers table helper: out[i] = base^i * scale
@@ -153,6 +201,7 @@ inline PassArgs ntt_pass_args(const NttPlan& p, u32 t, const u64* in, u64* out, 
         a.logch = a.n1_bits - p.logC[t];
     }
     a.uinv = p.uinv;
+    a.sched = p.sched;
     a.has_coset = (t == 0 && has_coset) ? 1 : 0;
     a.post_scale = final_pass ? post_scale : 1;
     a.tb = tb;

@@ -20,16 +20,17 @@ static void run_pass(const PassArgs& a, u32 grid_x, u32 batch) {
     if (B2 > 0) for (u32 i = 0; i < tw.size(); ++i) tw[i] = tab[(u64)i << (a.tb.t_in_log - (B1 + B2))];
     for (u32 by = 0; by < batch; ++by)
         for (u32 bx = 0; bx < grid_x; ++bx) {
-            const u64* rowtw = nullptr;
-            std::vector<u64> row;
-            if (MODE == PASS_COLUMN && a.tb.row != nullptr) {
-                const u64 K = a.pass_index ? digit_reverse((u64)(bx >> a.lognl), a.pass_bits, 0, (int)a.pass_index - 1) : 0;
-                row.assign(a.tb.row + (K << Cfg::S), a.tb.row + (K << Cfg::S) + (1u << Cfg::S));
-                rowtw = row.data();
-            }
-            for (u32 t = 0; t < (u32)Cfg::W; ++t) ntt_stage1<B1, B2, B3, LOGC, MODE>(a, smem.data(), tw.data(), rowtw, t, bx, by);
-            if (B2 > 0) for (u32 t = 0; t < (u32)Cfg::W; ++t) ntt_stage2<B1, B2, B3, LOGC, MODE>(a, smem.data(), t, bx, by);
-            if (B3 > 0) for (u32 t = 0; t < (u32)Cfg::W; ++t) ntt_stage3<B1, B2, B3, LOGC, MODE>(a, smem.data(), t, bx, by);
+            // the tile's row of the load-time / store-time product table, copied as the kernel copies it to LDS
+            std::vector<u64> row, srow_copy;
+            const u64* lrow = tile_load_row<Cfg, MODE>(a, bx);
+            const u64* srow_g = tile_store_row<Cfg, LOGC, MODE>(a, bx);
+            if (lrow) row.assign(lrow, lrow + (1u << Cfg::S));
+            if (srow_g) srow_copy.assign(srow_g, srow_g + (1u << Cfg::S));
+            const u64* rowtw = lrow ? row.data() : nullptr;
+            const u64* srow = srow_g && !lrow ? srow_copy.data() : nullptr;
+            for (u32 t = 0; t < (u32)Cfg::W; ++t) ntt_stage1<B1, B2, B3, LOGC, MODE>(a, smem.data(), tw.data(), rowtw, t, bx, by, srow);
+            if (B2 > 0) for (u32 t = 0; t < (u32)Cfg::W; ++t) ntt_stage2<B1, B2, B3, LOGC, MODE>(a, smem.data(), t, bx, by, srow);
+            if (B3 > 0) for (u32 t = 0; t < (u32)Cfg::W; ++t) ntt_stage3<B1, B2, B3, LOGC, MODE>(a, smem.data(), t, bx, by, srow);
         }
 }
 
@@ -80,30 +81,21 @@ extern "C" int emu_gl_ntt(const u64* in, u64 n_in, u64 in_stride, u64* out, u64 
     const bool coset = shift != 1;
     if (coset) ntt_build_coset_tables(p, shift, ct);
     NttTables tb{ht.w_lo.data(), ht.w_hi.data(), p.lo_bits, p.t_in_log, ht.t_in.data(), ht.t_in_last.data(),
-                 coset ? ct.s_lo.data() : nullptr, coset ? ct.s_hi.data() : nullptr, nullptr};
+                 coset ? ct.s_lo.data() : nullptr, coset ? ct.s_hi.data() : nullptr, nullptr, nullptr};
     std::vector<u64> ws;
     if (p.npass > 1) ws.resize((size_t)n * batch);
-    std::vector<std::vector<u64>> rows(p.npass);
+    std::vector<std::vector<u64>> rows(p.npass), srows(p.npass);
     for (u32 t = 0; t < p.npass; ++t) {
         const bool first = t == 0, last = t + 1 == p.npass;
         const u64* src = first ? in : ws.data();
         u64* dst = last ? out : ws.data();
         tb.row = nullptr;
+        tb.srow = nullptr;
         {
-            u32 done = 0;
-            for (u32 v = 0; v <= t; ++v) done += p.pass_bits[v];
-            if (t > 0 && !last && done <= 16) {
-                const u32 S = p.pass_bits[t];
-                const u64 wN = gl_pow(root, 1ull << (log_n - done));
-                rows[t].resize((size_t)1 << done);
-                u64 wK = 1;
-                for (u64 K = 0; K < (1ull << (done - S)); ++K) {
-                    u64 v = 1;
-                    for (u64 r = 0; r < (1ull << S); ++r) { rows[t][(K << S) + r] = v; v = gl_mul(v, wK); }
-                    wK = gl_mul(wK, wN);
-                }
-                tb.row = rows[t].data();
-            }
+            NttRowSpec load, store;
+            ntt_row_specs(p, t, root, load, store);
+            if (load.omega) { ntt_product_table(load.omega, load.a_bits, load.b_bits, rows[t]); tb.row = rows[t].data(); }
+            if (store.omega) { ntt_product_table(store.omega, store.a_bits, store.b_bits, srows[t]); tb.srow = srows[t].data(); }
         }
         PassArgs a = ntt_pass_args(p, t, src, dst, first ? in_stride : n, last ? out_stride : n, first ? n_in : n, tb,
                                    coset, shift, post_scale);
@@ -121,4 +113,12 @@ extern "C" int emu_plan(u32 log_n, u64 root, u32* npass, u32* bits, u32* logc, u
     *npass = p.npass; *uinv = p.uinv;
     for (int i = 0; i < 4; ++i) { bits[i] = p.pass_bits[i]; logc[i] = p.logC[i]; }
     return 0;
+}
+
+// the twiddle schedule of three-pass plans: -1 environment, 0 load-time, 1 balanced; returns what a plan for log_n then uses
+extern "C" int emu_set_schedule(int mode, u32 log_n, u64 root) {
+    ntt_schedule_override() = mode;
+    NttPlan p;
+    if (!ntt_make_plan(log_n, root, p)) return -1;
+    return (int)p.sched;
 }

@@ -24,6 +24,7 @@ def emu():
     so = build_emulation()          # rebuilt whenever the CONTENT of a source or header differs from what the .so was made of
     lib = ctypes.CDLL(so)
     lib.emu_gl_ntt.argtypes = [vp, u64, u64, vp, u64, ctypes.c_uint32, ctypes.c_uint32, u64, u64, u64]
+    lib.emu_set_schedule.argtypes = [ctypes.c_int, ctypes.c_uint32, u64]
     lib.emu_plan.argtypes = [ctypes.c_uint32, u64, vp, vp, vp, vp]
     lib.emu_merkle_xfe.argtypes = [vp, u64, u64, vp]
     u32 = ctypes.c_uint32
@@ -50,6 +51,30 @@ def test_tile_kernels_match_oracle(emu, oracle, logn):
     assert (emu_ntt(emu, v, logn, oracle.inv(w), 1, oracle.inv(n)) == oracle.intt(w, v)).all()
     d = max(1, n // 4)
     assert (emu_ntt(emu, v[:d], logn, w, 7, 1, n_in=d) == oracle.fast_coset_evaluate(v[:d], 7, w, n)).all()
+
+
+@pytest.mark.parametrize("logn", [17, 18, 19, 20])
+def test_three_pass_plans_under_both_twiddle_schedules(emu, oracle, logn):
+    """the balanced schedule (store-time row in pass 1, one factor per thread in pass 2, load-time row in pass 3) and the load-time
+    schedule (row table in pass 2, chain in pass 3) give the oracle's transform: forward, inverse with n^-1, coset with zero padding"""
+    n = 1 << logn
+    v = oracle.felt_array(SEED + logn, 0, n)
+    w = oracle.primitive_nth_root(n)
+    want = oracle.ntt(w, v)
+    want_inv = oracle.intt(w, v)
+    d = n // 4
+    want_coset = oracle.fast_coset_evaluate(v[:d], 7, w, n)
+    used = []
+    try:
+        for mode in (0, 1):
+            used.append(emu.emu_set_schedule(mode, logn, w))
+            assert (emu_ntt(emu, v, logn, w) == want).all(), mode
+            assert (emu_ntt(emu, v, logn, oracle.inv(w), 1, oracle.inv(n)) == want_inv).all(), mode
+            assert (emu_ntt(emu, v[:d], logn, w, 7, 1, n_in=d) == want_coset).all(), mode
+    finally:
+        emu.emu_set_schedule(-1, logn, w)
+    assert used[0] == 0
+    assert used[1] == 1 or logn == 17          # 2^17 = 6 + 6 + 5 (or 5 + 6 + 6): a first-pass tile spans two values of the next digit
 
 
 def test_tile_kernels_batch_and_other_roots(emu, oracle):

@@ -14,5 +14,10 @@ for SPEC in "$@"; do
     f=$(find "$OUT/raw_$NAME" -name "*kernel_trace.csv" | head -1)
     echo "== $SPEC"; tail -1 "$OUT/plain_$NAME.json"
     python "$ROOT/tools/per_pass.py" "$f" | tee "$OUT/per_pass_$NAME.txt"
-    rm -rf "$OUT/raw_$NAME" )
+    rm -rf "$OUT/raw_$NAME"
+    if [ "${PMC:-0}" = "1" ]; then       # VALU wave instructions per launch, in its own pass (kernel-trace only)
+      rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU --output-format csv -d "$OUT/pmc_$NAME" -o ntt -- python "$ROOT/tools/ntt_only.py" --steps 3 --warmup 1 --no-check > /dev/null 2>&1
+      find "$OUT/pmc_$NAME" -name "*counter_collection.csv" -exec python "$ROOT/tools/pmc_summary.py" {} \; | grep ntt_tile | sed 's/^/  /'
+      rm -rf "$OUT/pmc_$NAME"
+    fi )
 done
