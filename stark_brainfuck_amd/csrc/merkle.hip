@@ -10,18 +10,52 @@
 
 namespace bfs {
 
-constexpr int LEAF_THREADS = 64;  // one wavefront per workgroup: the staging area is 52 words x 64 lanes = 26 KiB
+constexpr int LEAF_THREADS = 64;  // one wavefront per workgroup
+
+// One wave hashes 64 leaves whose limbs it already holds (c0, c1, c2; `active` = the lane has a leaf) in the streaming form of
+// merkle_core.hpp: 21 words of LDS per lane = 10.5 KiB per wave instead of 18.  BFS_LEAF_STAGED (A/B, profiles/r03/ab_leaf_streaming.txt):
+// the staged form of rounds 1-2 (whole tail in LDS, then hashed).
+#ifdef BFS_LEAF_STAGED
+constexpr int LEAF_STAGE_WORDS = XFE_TAIL_MAX_WORDS * LEAF_THREADS;
+#else
+constexpr int LEAF_STAGE_WORDS = XFE_STREAM_WORDS * LEAF_THREADS;
+#endif
+
+__device__ __forceinline__ void xfe_leaf_staged_lane(u64 c0, u64 c1, u64 c2, u32 k, u64* stage, u32 stride, u64 h[8], const u64* midstates) {
+    const u32 body = xfe_leaf_body_len(k, c0, c1, c2);
+    const u64* ms = midstates + ((size_t)(k == 1 ? 0 : 1) * LEAF_MS_LEN + body) * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = ms[j];
+    LeafWriter w;
+    w.init(stage, stride);
+    encode_xfe_leaf_tail(w, k, c0, c1, c2);
+    blake2b_staged_tail(stage, stride, body + 11, h);
+}
+
+__device__ __forceinline__ void xfe_leaves_wave(u64 c0, u64 c1, u64 c2, bool active, u64* stage /* LEAF_STAGE_WORDS */, u64 h[8], const u64* midstates) {
+    const u32 lane = threadIdx.x;
+    const u32 k = active ? xfe_leaf_k(c0, c1, c2) : 0u;
+    if (active && k == 0) merkle_leaf_xfe_zero(h, midstates);
+#ifdef BFS_LEAF_STAGED
+    if (k != 0) xfe_leaf_staged_lane(c0, c1, c2, k, stage + lane, LEAF_THREADS, h, midstates);
+#else
+    // class by class (wave-uniform branches): a wave of random extension elements, or of lifted base-field elements, takes exactly one
+    // of the three; a mixed wave takes its classes in turn with the other lanes idle
+    if (__ballot(k == 3) != 0) { if (k == 3) merkle_leaf_xfe_stream<3>(c0, c1, c2, stage + lane, LEAF_THREADS, h, midstates); }
+    if (__ballot(k == 2) != 0) { if (k == 2) merkle_leaf_xfe_stream<2>(c0, c1, c2, stage + lane, LEAF_THREADS, h, midstates); }
+    if (__ballot(k == 1) != 0) { if (k == 1) merkle_leaf_xfe_stream<1>(c0, c1, c2, stage + lane, LEAF_THREADS, h, midstates); }
+#endif
+}
 
 __global__ void __launch_bounds__(LEAF_THREADS) merkle_leaves_xfe_kernel(const u64* limbs, u64 limb_stride, u64 n, u64* leaf_digests, const u64* midstates) {
-#ifdef BFS_LEAF_LDS_PAD
-    __shared__ u64 stage[(XFE_TAIL_MAX_WORDS + BFS_LEAF_LDS_PAD) * LEAF_THREADS];
-#else
-    __shared__ u64 stage[XFE_TAIL_MAX_WORDS * LEAF_THREADS];
-#endif
+    __shared__ u64 stage[LEAF_STAGE_WORDS];
     const u64 i = (u64)blockIdx.x * LEAF_THREADS + threadIdx.x;
-    if (i >= n) return;
+    const bool active = i < n;
+    u64 c0 = 0, c1 = 0, c2 = 0;
+    if (active) { c0 = limbs[i]; c1 = limbs[limb_stride + i]; c2 = limbs[2 * limb_stride + i]; }
     u64 d[8];
-    merkle_leaf_xfe_body(limbs, limb_stride, i, stage + threadIdx.x, LEAF_THREADS, d, midstates);
+    xfe_leaves_wave(c0, c1, c2, active, stage, d, midstates);
+    if (!active) return;
     u64* out = leaf_digests + i * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) out[j] = d[j];
@@ -30,10 +64,11 @@ __global__ void __launch_bounds__(LEAF_THREADS) merkle_leaves_xfe_kernel(const u
 // the same for a FRI round whose codeword does not exist yet: every thread first PRODUCES its element (the split-and-fold step of the
 // previous round, fri.py:127-128), stores it for the later openings and hashes it -- one launch and one pass over the codeword less
 __global__ void __launch_bounds__(LEAF_THREADS) merkle_leaves_xfe_fold_kernel(FriFoldArgs f, u64* cw, u64 cw_stride, u64 n, u64* leaf_digests, const u64* midstates) {
-    __shared__ u64 stage[XFE_TAIL_MAX_WORDS * LEAF_THREADS];
+    __shared__ u64 stage[LEAF_STAGE_WORDS];
     const u64 i = (u64)blockIdx.x * LEAF_THREADS + threadIdx.x;
-    if (i >= n) return;
-    {
+    const bool active = i < n;
+    u64 c0 = 0, c1 = 0, c2 = 0;
+    if (active) {
         const Xfe a{{f.in[i], f.in[f.in_stride + i], f.in[2 * f.in_stride + i]}};
         const Xfe b{{f.in[f.half + i], f.in[f.in_stride + f.half + i], f.in[2 * f.in_stride + f.half + i]}};
         const u64 sc = gl_mul(f.scal, tw_pow(f.winv_lo, f.winv_hi, f.lo_bits, i << f.round_shift));
@@ -43,12 +78,16 @@ __global__ void __launch_bounds__(LEAF_THREADS) merkle_leaves_xfe_fold_kernel(Fr
         const u64 x = (sum.c[0] >> 1) + ((sum.c[0] & 1) ? 0x7FFFFFFF80000001ULL : 0);      // / 2 mod p
         const u64 y = (sum.c[1] >> 1) + ((sum.c[1] & 1) ? 0x7FFFFFFF80000001ULL : 0);
         const u64 z = (sum.c[2] >> 1) + ((sum.c[2] & 1) ? 0x7FFFFFFF80000001ULL : 0);
-        cw[i] = gl_add(x, prod.c[0]);
-        cw[cw_stride + i] = gl_add(y, prod.c[1]);
-        cw[2 * cw_stride + i] = gl_add(z, prod.c[2]);
+        c0 = gl_add(x, prod.c[0]);
+        c1 = gl_add(y, prod.c[1]);
+        c2 = gl_add(z, prod.c[2]);
+        cw[i] = c0;
+        cw[cw_stride + i] = c1;
+        cw[2 * cw_stride + i] = c2;
     }
     u64 d[8];
-    merkle_leaf_xfe_body(cw, cw_stride, i, stage + threadIdx.x, LEAF_THREADS, d, midstates);     // reads back this thread's own stores
+    xfe_leaves_wave(c0, c1, c2, active, stage, d, midstates);
+    if (!active) return;
     u64* out = leaf_digests + i * 8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) out[j] = d[j];

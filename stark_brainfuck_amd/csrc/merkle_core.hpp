@@ -88,6 +88,88 @@ BFS_HD void merkle_leaf_xfe_body(const u64* limbs, u64 limb_stride, u64 i, u64* 
     for (int j = 0; j < 8; ++j) digest_out[j] = h[j];
 }
 
+// ---- the same leaf, streamed: the preimage is hashed block by block while it is being encoded ------------------------------------
+// merkle_leaf_xfe_body stages the whole tail (36 words per lane: 18 KiB per wave, two waves per SIMD).  Here a lane owns
+// XFE_STREAM_WORDS = 21 words: the first tail block is complete once a statically known prefix of the template has been written (the
+// three integers move a lane's position by at most 27 bytes), so ALL lanes compress it at the same place in the code, shift their <= 5
+// left-over words to the front and finish the encoding; the remaining one or two blocks follow as in the staged form.  The split
+// point depends on the class K (how many coefficients the element stores), so the wave-level caller (merkle.hip: xfe_leaves_wave)
+// runs the classes present in a wave one after the other -- exactly one for every codeword of random extension elements and for every
+// lifted base-field codeword.
+constexpr int XFE_STREAM_WORDS = 21;
+template <int K> struct XfeStreamSplit;      // bytes of the class' last constant segment written BEFORE the first compression
+template <> struct XfeStreamSplit<1> { static constexpr int BYTES = 96; };   // 41 + int + 96 = 139..148 >= 128
+template <> struct XfeStreamSplit<2> { static constexpr int BYTES = 24; };   // 42 + int + 58 + int + 24 = 128..146
+template <> struct XfeStreamSplit<3> { static constexpr int BYTES = 16; };   // 42 + int + 58 + int + 16 + int + 16 = 138..165 (21 words)
+
+template <int K>
+BFS_HD void merkle_leaf_xfe_stream(u64 c0, u64 c1, u64 c2, u64* stage, u32 stride, u64 h[8], const u64* midstates) {
+    static_assert(K >= 1 && K <= 3, "class");
+    constexpr int SPLIT = XfeStreamSplit<K>::BYTES;
+    static_assert(SPLIT % 8 == 0, "the constant segment is split between two words");
+    const u32 body = xfe_leaf_body_len((u32)K, c0, c1, c2);
+    const u32 total = body + 11;
+    const u64* ms = midstates + ((size_t)(K == 1 ? 0 : 1) * LEAF_MS_LEN + body) * 8;
+    BFS_UNROLL
+    for (int j = 0; j < 8; ++j) h[j] = ms[j];
+    LeafWriter w;
+    w.init(stage, stride);
+    const u64* post;
+    if constexpr (K == 1) {
+        w.put_const<tpl::XFE_PRE_B4_LEN>(tpl::XFE_PRE_B4);
+        w.put_int(c0);
+        post = tpl::XFE_POST1;
+    } else {
+        w.put_const<tpl::XFE_PRE_B3_LEN>(tpl::XFE_PRE_B3);
+        w.put_int(c0);
+        w.put_const<tpl::XFE_MID_A_LEN>(tpl::XFE_MID_A);
+        w.put_int(c1);
+        if constexpr (K == 2) {
+            post = tpl::XFE_POST2;
+        } else {
+            w.put_const<tpl::XFE_MID_B_LEN>(tpl::XFE_MID_B);
+            w.put_int(c2);
+            post = tpl::XFE_POST3;
+        }
+    }
+    constexpr int POST_LEN = K == 1 ? tpl::XFE_POST1_LEN : (K == 2 ? tpl::XFE_POST2_LEN : tpl::XFE_POST3_LEN);
+    w.put_const<SPLIT>(post);
+    // every lane holds at least 16 complete words now: bytes [128, 256) of the pickle, never the last block (totals are >= 345).
+    // ONE compression site for all blocks (a second inlined copy of the round function cost 76 VGPRs): the first turn of the loop
+    // takes those 16 words, shifts the <= 5 left-over words to the front and finishes the encoding; the later turns are the staged form.
+    const u32 nblk = (total + 127) / 128;           // 3 or 4
+    u32 first = 0, avail = 16;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma nounroll
+#endif
+    for (u32 b = 1; b < nblk; ++b) {
+        u64 m[16];
+        BFS_UNROLL
+        for (int j = 0; j < 16; ++j) {
+            const u32 wi = first + (u32)j;
+            m[j] = wi < avail ? stage[(size_t)wi * stride] : 0;
+        }
+        const bool last = (b + 1 == nblk);
+        blake2b_compress(h, m, last ? (u64)total : (u64)(b + 1) * 128, last);
+        if (b == 1) {
+            BFS_UNROLL
+            for (int j = 0; j < XFE_STREAM_WORDS - 16; ++j) stage[(size_t)j * stride] = stage[(size_t)(16 + j) * stride];
+            w.wpos -= 16;
+            w.put_const<POST_LEN - SPLIT>(post + SPLIT / 8);
+            w.finish();
+            avail = (total - 256 + 7) / 8;          // <= 20
+        } else {
+            first += 16;
+        }
+    }
+}
+
+// the zero element: a table lookup
+BFS_HD void merkle_leaf_xfe_zero(u64 h[8], const u64* midstates) {
+    BFS_UNROLL
+    for (int j = 0; j < 8; ++j) h[j] = midstates[(size_t)2 * LEAF_MS_LEN * 8 + j];
+}
+
 BFS_HD void merkle_leaf_bfe_body(const u64* values, u64 i, u64* stage, u32 stride, u64* digest_out) {
     LeafWriter w;
     w.init(stage, stride);

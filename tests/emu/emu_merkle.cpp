@@ -48,3 +48,20 @@ extern "C" void emu_merkle_xfe(const u64* limbs, u64 stride, u64 n, u64* nodes /
         present = 2 * count;
     }
 }
+
+// the streamed leaf (merkle_leaf_xfe_stream<K>) for every element of a codeword whose elements all share class K, and the staged form in
+// the half-wave layout (stride 32) the kernel falls back to for mixed waves: 64-byte digests out, -1 on an element of another class
+extern "C" int emu_xfe_leaf_stream(const u64* limbs, u64 stride, u64 n, int klass, u64* digests) {
+    std::vector<u64> stage(XFE_STREAM_WORDS * 64, 0xA5A5A5A5A5A5A5A5ULL), ms(LEAF_MS_WORDS);
+    leaf_midstates(ms.data());
+    for (u64 i = 0; i < n; ++i) {
+        const u64 c0 = limbs[i], c1 = limbs[stride + i], c2 = limbs[2 * stride + i];
+        if ((int)xfe_leaf_k(c0, c1, c2) != klass) return -1;
+        u64* st = stage.data() + (i % 64);
+        u64* h = digests + 8 * i;
+        if (klass == 1) merkle_leaf_xfe_stream<1>(c0, c1, c2, st, 64, h, ms.data());
+        else if (klass == 2) merkle_leaf_xfe_stream<2>(c0, c1, c2, st, 64, h, ms.data());
+        else merkle_leaf_xfe_stream<3>(c0, c1, c2, st, 64, h, ms.data());
+    }
+    return 0;
+}

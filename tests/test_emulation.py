@@ -27,6 +27,7 @@ def emu():
     lib.emu_set_schedule.argtypes = [ctypes.c_int, ctypes.c_uint32, u64]
     lib.emu_plan.argtypes = [ctypes.c_uint32, u64, vp, vp, vp, vp]
     lib.emu_merkle_xfe.argtypes = [vp, u64, u64, vp]
+    lib.emu_xfe_leaf_stream.argtypes = [vp, u64, u64, ctypes.c_int, vp]
     u32 = ctypes.c_uint32
     lib.emu_row_leaves.argtypes = [vp, vp, vp, u32, vp, u32, vp, u32, u32, u32, vp, vp]
     return lib
@@ -135,6 +136,31 @@ def test_hashes_match_hashlib(emu):
             o = ctypes.create_string_buffer(ol)
             emu.emu_shake256(data, ctypes.c_size_t(ln), o, ctypes.c_size_t(ol))
             assert o.raw == hashlib.shake_256(data).digest(ol)
+
+
+@pytest.mark.parametrize("klass", [1, 2, 3])
+def test_streamed_leaf_equals_hashlib_over_the_reference_pickle(emu, klass):
+    """merkle_leaf_xfe_stream<K> (first tail block compressed in the middle of the encoding, 21 words of staging per lane) against
+    BLAKE2b of the whole pickle -- the encoder itself is pinned on the reference's pickles above.  Coefficients of every pickle integer
+    length (2, 3, 5 and 3..11 bytes), so the lanes' positions at the split differ by the full 27 bytes; stale bytes in the staging area."""
+    rng = np.random.default_rng(40 + klass)
+    sizes = [1, 7, 8, 15, 16, 30, 31, 32, 33, 40, 47, 48, 55, 56, 57, 63, 64]
+
+    def value(bits):
+        v = int(rng.integers(1 << (bits - 1), (1 << bits) - 1, dtype=np.uint64)) if bits > 1 else 1
+        return v % ((1 << 64) - (1 << 32) + 1) or 1
+    n = 64 * 12
+    limbs = np.zeros((3, n), dtype=np.uint64)
+    for i in range(n):
+        for l in range(klass):
+            limbs[l, i] = value(sizes[int(rng.integers(0, len(sizes)))]) if (l == klass - 1 or rng.integers(0, 6)) else 0
+        assert limbs[klass - 1, i] != 0
+    digests = np.zeros(8 * n, dtype=np.uint64)
+    assert emu.emu_xfe_leaf_stream(limbs.ctypes.data, n, n, klass, digests.ctypes.data) == 0
+    for i in range(n):
+        buf = ctypes.create_string_buffer(424)
+        ln = emu.emu_xfe_leaf_pickle((u64 * 3)(*[int(limbs[l, i]) for l in range(3)]), buf)
+        assert digests[8 * i:8 * i + 8].tobytes() == hashlib.blake2b(buf.raw[:ln]).digest(), (klass, i, [int(limbs[l, i]) for l in range(3)])
 
 
 def test_merkle_bodies_match_reference_trees(emu, oracle):
