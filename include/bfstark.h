@@ -414,6 +414,22 @@ int bfs_difference_combine(const uint64_t* d_lhs, const uint64_t* d_rhs, uint32_
                            const bfs_comb_weight* h_weight, uint64_t* d_acc, const uint64_t* d_inv_x_minus_1, void* stream);
 int bfs_zerofier_inverses(uint32_t log_n, uint64_t offset, uint64_t omega, uint32_t count, const uint32_t* h_is_power, const uint64_t* h_values,
                           uint64_t* d_out, void* stream);
+/*
+ * The same three on a RANGE of the domain's points, rows [first_row, first_row + num_rows): every rank of a cooperative proof
+ * (BrainfuckStark.cooperate; brainfuck_stark.py:204-298 split by rows) holds all codewords and computes the pointwise stages for its own
+ * rows only -- a row's neighbour at unit_distance is read from the rank's own copy, so there is no halo to exchange -- and the ranks then
+ * all-gather the combination codeword.  d_out / d_acc are the FULL buffers (the range is written in place).
+ */
+int bfs_air_combine_rows(int table, const uint64_t* d_base, const uint64_t* d_ext, uint32_t log_n, uint64_t unit_distance, uint64_t height,
+                         uint64_t omicron_inv, uint64_t offset, uint64_t omega, const uint64_t* h_challenges, const uint64_t* h_terminals,
+                         const uint64_t* h_params, const bfs_comb_weight* h_weights, const uint64_t* d_randomizer,
+                         const uint64_t* h_randomizer_weight, uint64_t* d_acc, const uint64_t* const* d_zerofier_inverses, uint64_t first_row,
+                         uint64_t num_rows, void* stream);
+int bfs_difference_combine_rows(const uint64_t* d_lhs, const uint64_t* d_rhs, uint32_t log_n, uint64_t offset, uint64_t omega,
+                                const bfs_comb_weight* h_weight, uint64_t* d_acc, const uint64_t* d_inv_x_minus_1, uint64_t first_row,
+                                uint64_t num_rows, void* stream);
+int bfs_zerofier_inverses_rows(uint32_t log_n, uint64_t offset, uint64_t omega, uint32_t count, const uint32_t* h_is_power, const uint64_t* h_values,
+                               uint64_t* d_out, uint64_t first_row, uint64_t num_rows, void* stream);
 
 #ifdef __cplusplus
 }

@@ -449,20 +449,30 @@ class BrainfuckStark:
             _lib.check(lib.bfs_combination(srcs, len(sources), randomizer_codeword.ptr, (_u64 * 3)(*weight0), combination.ptr,
                                            log_n, domain.offset.value, domain.omega.value, stream))
         else:
-            inverse_buffer, inverses = zerofier_inverses(self.tables, domain)      # all zerofier denominators, one inversion per point
+            # a cooperative proof (cooperate()): the stage is pointwise, every rank holds all codewords (a row's neighbour at
+            # unit_distance comes from the rank's own copy), so each rank does its own rows and the ranks all-gather the combination
+            rows = None
+            if self._cooperation is not None:
+                from .shard import row_range
+                rows = row_range(n, self._cooperation[0], self._cooperation[1])
+            inverse_buffer, inverses = zerofier_inverses(self.tables, domain, rows=rows)      # all zerofier denominators, one inversion per point
             base_at = ext_at = 0
             quot_at = num_base + num_ext
             for k, t in enumerate(self.tables):
                 bw, xw, nq = t.base_width, t.full_width - t.base_width, t.num_quotients()
                 mine = np.concatenate([terms[base_at:base_at + bw], terms[num_base + ext_at:num_base + ext_at + xw], terms[quot_at:quot_at + nq]])
                 t.combine_into(domain, challenges, terminals, mine, combination,
-                               randomizer=randomizer_codeword if k == 0 else None, randomizer_weight=weight0, inverses=inverses[t])
+                               randomizer=randomizer_codeword if k == 0 else None, randomizer_weight=weight0, inverses=inverses[t], rows=rows)
                 base_at, ext_at, quot_at = base_at + bw, ext_at + xw, quot_at + nq
             for pa in self.permutation_arguments:
-                pa.combine_into(domain, term_of(quot_at), combination, inv_x_minus_1=inverses[self.tables[0]][0])
+                pa.combine_into(domain, term_of(quot_at), combination, inv_x_minus_1=inverses[self.tables[0]][0], rows=rows)
                 quot_at += 1
             assert quot_at == len(terms)
             inverse_buffer.free()
+            if rows is not None:
+                from .shard import all_gather_rows
+                world_size, rank, group, device = self._cooperation
+                all_gather_rows(combination.ptr, n, 3, combination.stride, world_size, rank, group=group, device=device, stream=stream)
 
         if not self.keep_intermediates:
             BrainfuckStark._release(randomizer_polynomial, *[buf for buf, _ in quotient_buffers])

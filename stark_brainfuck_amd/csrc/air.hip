@@ -89,6 +89,7 @@ struct AirArgs {
     const u64* ext;
     u64* out;
     u64 n;
+    u64 first, count;    // the points this launch works on: [first, first + count) of the domain (the whole domain, or a rank's rows)
     u64 unit_distance;
     u64 height;          // 0: the transition zerofier has no inverse and the reference multiplies by 0 (table.py:181-184)
     u32 log_height;
@@ -173,8 +174,8 @@ __global__ void __launch_bounds__(256) air_quotient_kernel(const AirArgs a) {
     typedef AirShape<TABLE> S;
     // one point per thread, no grid-stride loop: a loop would let the compiler hoist the (loop-invariant) challenges and weights out
     // of it into registers -- hundreds of them
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < a.n) {
+    const u64 i = a.first + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.first + a.count) {
         u64 j = i + a.unit_distance;
         if (j >= a.n) j -= a.n;
         u64 bc[S::BW], bn[S::BW];
@@ -203,9 +204,9 @@ struct ZerofierSpecs {
 };
 
 __global__ void __launch_bounds__(256) zerofier_inverses_kernel(ZerofierSpecs sp, u64* out, u64 n, u64 offset, const u64* w_lo, const u64* w_hi,
-                                                                u32 lo_bits) {
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+                                                                u32 lo_bits, u64 first, u64 count) {
+    const u64 i = first + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= first + count) return;
     const u64 x = gl_mul(offset, tw_pow(w_lo, w_hi, lo_bits, i));
     u64 v[12], prefix[12];
     u64 running = 1;
@@ -393,8 +394,8 @@ __global__ void __launch_bounds__(256, combine_waves(TABLE)) air_combine_kernel(
     }
     __syncthreads();
     const AirArgs& a = A.a;
-    const u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < a.n) {
+    const u64 i = a.first + (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.first + a.count) {
         u64 j = i + a.unit_distance;
         if (j >= a.n) j -= a.n;
         u64 bc[S::BW], bn[S::BW];
@@ -424,8 +425,8 @@ __global__ void __launch_bounds__(256, combine_waves(TABLE)) air_combine_kernel(
 
 // acc += (wa + wb x^shift) * (lhs - rhs) / (x - 1)      (the difference quotient of a permutation argument, folded the same way)
 __global__ void difference_combine_kernel(const u64* lhs, const u64* rhs, u64* acc, u64 n, u64 offset, const u64* w_lo, const u64* w_hi,
-                                          u32 lo_bits, CombW w, const u64* inv_x_minus_1) {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+                                          u32 lo_bits, CombW w, const u64* inv_x_minus_1, u64 first, u64 count) {
+    for (u64 i = first + (u64)blockIdx.x * blockDim.x + threadIdx.x; i < first + count; i += (u64)gridDim.x * blockDim.x) {
         const u64 z = inv_x_minus_1 ? inv_x_minus_1[i] : gl_inv(gl_sub(gl_mul(offset, tw_pow(w_lo, w_hi, lo_bits, i)), 1));
         const u64 xs = gl_mul(w.offset_pow, tw_pow(w_lo, w_hi, lo_bits, (i * w.shift) & (n - 1)));
         const Xfe weight = xfe_add(w.wa, xfe_scale(w.wb, xs));
@@ -546,6 +547,8 @@ static int fill_air_args(AirArgs& a, int table, const uint64_t* d_base, const ui
     a.omicron_inv = omicron_inv; a.offset = offset;
     BFS_TRY(ntt_power_tables(omega, log_n, &a.w_lo, &a.w_hi, &a.lo_bits));
     for (int i = 0; i < 11; ++i) a.ch[i] = xfe_from(h_challenges + 3 * i);
+    a.first = 0;
+    a.count = a.n;
     for (int i = 0; i < 5; ++i) a.tm[i] = xfe_from(h_terminals + 3 * i);
     a.pr[0] = h_params ? xfe_from(h_params) : Xfe{{1, 0, 0}};
     return BFS_OK;
@@ -611,23 +614,46 @@ static int air_combine_launch(const AirArgs& a, const bfs_comb_weight* h_weights
         }
     }
     static_assert(sizeof(A) <= 4096, "kernel arguments");
-    if (grouped) hipLaunchKernelGGL((air_combine_kernel<TABLE, true>), dim3(grid_per_point(a.n)), dim3(256), 0, stream, A);
-    else hipLaunchKernelGGL((air_combine_kernel<TABLE, false>), dim3(grid_per_point(a.n)), dim3(256), 0, stream, A);
+    if (grouped) hipLaunchKernelGGL((air_combine_kernel<TABLE, true>), dim3(grid_per_point(a.count)), dim3(256), 0, stream, A);
+    else hipLaunchKernelGGL((air_combine_kernel<TABLE, false>), dim3(grid_per_point(a.count)), dim3(256), 0, stream, A);
     BFS_HIP(hipGetLastError());
     return BFS_OK;
 }
 
 extern "C" {
 
+static int check_rows(const char* who, uint32_t log_n, uint64_t first_row, uint64_t num_rows) {
+    const u64 n = 1ull << log_n;
+    if (first_row > n || num_rows > n - first_row) {
+        set_error("%s: rows [%llu, %llu + %llu) are not inside the domain of %llu points", who, (unsigned long long)first_row,
+                  (unsigned long long)first_row, (unsigned long long)num_rows, (unsigned long long)n);
+        return BFS_ERR_BAD_ARG;
+    }
+    return BFS_OK;
+}
+
 int bfs_air_combine(int table, const uint64_t* d_base, const uint64_t* d_ext, uint32_t log_n, uint64_t unit_distance, uint64_t height,
                     uint64_t omicron_inv, uint64_t offset, uint64_t omega, const uint64_t* h_challenges, const uint64_t* h_terminals,
                     const uint64_t* h_params, const bfs_comb_weight* h_weights, const uint64_t* d_randomizer,
                     const uint64_t* h_randomizer_weight, uint64_t* d_acc, const uint64_t* const* d_zerofier_inverses, void* stream_) {
+    return bfs_air_combine_rows(table, d_base, d_ext, log_n, unit_distance, height, omicron_inv, offset, omega, h_challenges, h_terminals, h_params,
+                                h_weights, d_randomizer, h_randomizer_weight, d_acc, d_zerofier_inverses, 0, log_n > 32 ? 0 : 1ull << log_n, stream_);
+}
+
+int bfs_air_combine_rows(int table, const uint64_t* d_base, const uint64_t* d_ext, uint32_t log_n, uint64_t unit_distance, uint64_t height,
+                         uint64_t omicron_inv, uint64_t offset, uint64_t omega, const uint64_t* h_challenges, const uint64_t* h_terminals,
+                         const uint64_t* h_params, const bfs_comb_weight* h_weights, const uint64_t* d_randomizer,
+                         const uint64_t* h_randomizer_weight, uint64_t* d_acc, const uint64_t* const* d_zerofier_inverses, uint64_t first_row,
+                         uint64_t num_rows, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (log_n > 32) { set_error("bfs_air_combine: log_n"); return BFS_ERR_BAD_ARG; }
+    BFS_TRY(check_rows("bfs_air_combine_rows", log_n, first_row, num_rows));
+    if (num_rows == 0) return BFS_OK;
     AirArgs a{};
     BFS_TRY(fill_air_args(a, table, d_base, d_ext, log_n, unit_distance, height, omicron_inv, offset, omega, h_challenges, h_terminals,
                           h_params, "bfs_air_combine"));
+    a.first = first_row;
+    a.count = num_rows;
     switch (table) {
         case 0: return air_combine_launch<0>(a, h_weights, d_randomizer, h_randomizer_weight, d_acc, d_zerofier_inverses, stream);
         case 1: return air_combine_launch<1>(a, h_weights, d_randomizer, h_randomizer_weight, d_acc, d_zerofier_inverses, stream);
@@ -639,9 +665,16 @@ int bfs_air_combine(int table, const uint64_t* d_base, const uint64_t* d_ext, ui
 
 int bfs_zerofier_inverses(uint32_t log_n, uint64_t offset, uint64_t omega, uint32_t count, const uint32_t* h_is_power, const uint64_t* h_values,
                           uint64_t* d_out, void* stream_) {
+    return bfs_zerofier_inverses_rows(log_n, offset, omega, count, h_is_power, h_values, d_out, 0, log_n > 32 ? 0 : 1ull << log_n, stream_);
+}
+
+int bfs_zerofier_inverses_rows(uint32_t log_n, uint64_t offset, uint64_t omega, uint32_t count, const uint32_t* h_is_power, const uint64_t* h_values,
+                               uint64_t* d_out, uint64_t first_row, uint64_t num_rows, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (count == 0) return BFS_OK;
     if (count > 12 || log_n > 32) { set_error("bfs_zerofier_inverses: at most 12 denominators, log_n <= 32"); return BFS_ERR_BAD_ARG; }
+    BFS_TRY(check_rows("bfs_zerofier_inverses_rows", log_n, first_row, num_rows));
+    if (num_rows == 0) return BFS_OK;
     const u64 n = 1ull << log_n;
     ZerofierSpecs sp{};
     sp.count = count;
@@ -659,21 +692,31 @@ int bfs_zerofier_inverses(uint32_t log_n, uint64_t offset, uint64_t omega, uint3
     const u64 *lo, *hi;
     u32 lo_bits;
     BFS_TRY(ntt_power_tables(omega, log_n, &lo, &hi, &lo_bits));
-    hipLaunchKernelGGL(zerofier_inverses_kernel, dim3(grid_per_point(n)), dim3(256), 0, stream, sp, d_out, n, offset, lo, hi, lo_bits);
+    hipLaunchKernelGGL(zerofier_inverses_kernel, dim3(grid_per_point(num_rows)), dim3(256), 0, stream, sp, d_out, n, offset, lo, hi, lo_bits, first_row,
+                       num_rows);
     BFS_HIP(hipGetLastError());
     return BFS_OK;
 }
 
 int bfs_difference_combine(const uint64_t* d_lhs, const uint64_t* d_rhs, uint32_t log_n, uint64_t offset, uint64_t omega,
                            const bfs_comb_weight* h_weight, uint64_t* d_acc, const uint64_t* d_inv_x_minus_1, void* stream_) {
+    return bfs_difference_combine_rows(d_lhs, d_rhs, log_n, offset, omega, h_weight, d_acc, d_inv_x_minus_1, 0, log_n > 32 ? 0 : 1ull << log_n, stream_);
+}
+
+int bfs_difference_combine_rows(const uint64_t* d_lhs, const uint64_t* d_rhs, uint32_t log_n, uint64_t offset, uint64_t omega,
+                                const bfs_comb_weight* h_weight, uint64_t* d_acc, const uint64_t* d_inv_x_minus_1, uint64_t first_row,
+                                uint64_t num_rows, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    if (log_n > 32) { set_error("bfs_difference_combine: log_n"); return BFS_ERR_BAD_ARG; }
+    BFS_TRY(check_rows("bfs_difference_combine_rows", log_n, first_row, num_rows));
+    if (num_rows == 0) return BFS_OK;
     const u64 n = 1ull << log_n;
     if (h_weight->shift >> 32) { set_error("bfs_difference_combine: shift does not fit 32 bits"); return BFS_ERR_BAD_ARG; }
     const u64 *lo, *hi;
     u32 lo_bits;
     BFS_TRY(ntt_power_tables(omega, log_n, &lo, &hi, &lo_bits));
-    hipLaunchKernelGGL(difference_combine_kernel, dim3(grid_for(n)), dim3(256), 0, stream, d_lhs, d_rhs, d_acc, n, offset, lo, hi, lo_bits,
-                       comb_weight(*h_weight, offset), d_inv_x_minus_1);
+    hipLaunchKernelGGL(difference_combine_kernel, dim3(grid_for(num_rows)), dim3(256), 0, stream, d_lhs, d_rhs, d_acc, n, offset, lo, hi, lo_bits,
+                       comb_weight(*h_weight, offset), d_inv_x_minus_1, first_row, num_rows);
     BFS_HIP(hipGetLastError());
     return BFS_OK;
 }

@@ -22,16 +22,18 @@ class PermutationArgument:
                                                        n.bit_length() - 1, fri_domain.offset.value, fri_domain.omega.value, current_stream()))
         return out
 
-    def combine_into(self, fri_domain, weight, accumulator, inv_x_minus_1=None):
-        """bfs_difference_combine: accumulator += (wa + wb x^shift) * (lhs - rhs) / (x - 1) without writing the quotient codeword"""
+    def combine_into(self, fri_domain, weight, accumulator, inv_x_minus_1=None, rows=None):
+        """bfs_difference_combine: accumulator += (wa + wb x^shift) * (lhs - rhs) / (x - 1) without writing the quotient codeword;
+        rows = (first, count): only at those points of the domain"""
         n = fri_domain.length
+        first, count = (0, n) if rows is None else rows
         wa, wb, shift = weight
         w = _lib.CombWeight()
         w.wa, w.wb, w.shift = (ctypes.c_uint64 * 3)(*wa), (ctypes.c_uint64 * 3)(*wb), shift
         lt, rt = self.all_tables[self.lhs[0]], self.all_tables[self.rhs[0]]
-        _lib.check(_lib.load().bfs_difference_combine(lt.ext_codeword_ptr(self.lhs[1]), rt.ext_codeword_ptr(self.rhs[1]), n.bit_length() - 1,
-                                                      fri_domain.offset.value, fri_domain.omega.value, ctypes.byref(w), accumulator.ptr,
-                                                      inv_x_minus_1, current_stream()))
+        _lib.check(_lib.load().bfs_difference_combine_rows(lt.ext_codeword_ptr(self.lhs[1]), rt.ext_codeword_ptr(self.rhs[1]), n.bit_length() - 1,
+                                                           fri_domain.offset.value, fri_domain.omega.value, ctypes.byref(w), accumulator.ptr,
+                                                           inv_x_minus_1, first, count, current_stream()))
 
     def evaluate_difference(self, points):
         from .air import xsub

@@ -101,6 +101,48 @@ def exchange_rows(local_columns, planes, n, world_size, rank, group=None, device
     return out
 
 
+class _DeviceWords:
+    """a window of device memory (64-bit words) as an object torch.as_tensor can wrap without copying (__cuda_array_interface__)"""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<i8", "data": (int(ptr), False), "version": 2}
+
+
+def all_gather_rows(ptr, n, planes, stride, world_size, rank, group=None, device=None, stream=None, force_collective=False):
+    """every rank has filled rows [rank n/G, (rank+1) n/G) of `planes` planes of n words (`stride` words apart, first plane at device
+    address `ptr`); afterwards every rank holds all rows of all planes.  The one data-path collective of a cooperative proof: the
+    combination codeword before FRI (3 planes: 24 n bytes in all, (G-1)/G of them arriving over xGMI).  device given (RCCL): the
+    collective runs on the device buffers themselves; device None (gloo in the tests): through host copies."""
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    from .device import current_stream
+    first, m = row_range(n, world_size, rank)
+    if world_size == 1 and not force_collective:       # (force_collective: the single-rank RCCL test walks the device path)
+        return
+    lib = _lib.load()
+    stream = current_stream() if stream is None else stream
+    _lib.check(lib.bfs_stream_synchronize(stream))                 # the kernels that wrote this rank's rows
+    if device is not None:
+        for p in range(planes):
+            whole = torch.as_tensor(_DeviceWords(ptr + 8 * p * stride, n), device=device)
+            mine = whole[first:first + m].clone()                  # (the input of an all-gather must not alias its output)
+            dist.all_gather_into_tensor(whole, mine, group=group)
+        torch.cuda.synchronize()
+        return
+    import numpy as np
+    for p in range(planes):
+        mine = np.empty(m, dtype=np.uint64)
+        _lib.check(lib.bfs_memcpy_d2h(mine.ctypes.data, ptr + 8 * (p * stride + first), 8 * m, stream))
+        _lib.check(lib.bfs_stream_synchronize(stream))
+        send = torch.from_numpy(mine.view(np.int64))
+        recv = [torch.empty_like(send) for _ in range(world_size)]
+        dist.all_gather(recv, send, group=group)
+        whole = np.concatenate([r.numpy() for r in recv]).view(np.uint64)
+        _lib.check(lib.bfs_memcpy_h2d(ptr + 8 * p * stride, whole.ctypes.data, 8 * n, stream))
+        _lib.check(lib.bfs_stream_synchronize(stream))
+
+
 def _blake2b_pair(left, right):
     from hashlib import blake2b
     return blake2b(left + right).digest()

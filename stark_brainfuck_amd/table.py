@@ -244,11 +244,13 @@ def lde_tables(tables, domain, extension=False):
         at += w
 
 
-def zerofier_inverses(tables, domain):
+def zerofier_inverses(tables, domain, rows=None):
     """bfs_zerofier_inverses for a set of tables: one kernel inverts every distinct zerofier denominator of the proof at every point.
-    Returns (buffer, {table: (addr of 1/(x-1), addr of 1/(x - omicron^-1), addr of 1/(x^h - 1) or None)})."""
+    Returns (buffer, {table: (addr of 1/(x-1), addr of 1/(x - omicron^-1), addr of 1/(x^h - 1) or None)}).
+    rows = (first, count): only those points of the domain (a rank of a cooperative proof); the codewords are still n words long."""
     lib, stream = _lib.load(), current_stream()
     n = domain.length
+    first, count = (0, n) if rows is None else rows
     specs = [(0, 1)]
     for t in tables:
         for spec in ((0, _inv(t.omicron.value)), (1, t.height.bit_length() - 1) if t.height else None):
@@ -256,9 +258,9 @@ def zerofier_inverses(tables, domain):
                 specs.append(spec)
     assert len(specs) <= 12
     out = DeviceBuffer(len(specs) * n)
-    _lib.check(lib.bfs_zerofier_inverses(n.bit_length() - 1, domain.offset.value, domain.omega.value, len(specs),
-                                         (ctypes.c_uint32 * len(specs))(*[s[0] for s in specs]), (_u64 * len(specs))(*[s[1] for s in specs]),
-                                         out.ptr, stream))
+    _lib.check(lib.bfs_zerofier_inverses_rows(n.bit_length() - 1, domain.offset.value, domain.omega.value, len(specs),
+                                              (ctypes.c_uint32 * len(specs))(*[s[0] for s in specs]), (_u64 * len(specs))(*[s[1] for s in specs]),
+                                              out.ptr, first, count, stream))
     where = {spec: out.ptr + 8 * k * n for k, spec in enumerate(specs)}
     per_table = {t: (where[(0, 1)], where[(0, _inv(t.omicron.value))],
                      where[(1, t.height.bit_length() - 1)] if t.height else None) for t in tables}
@@ -563,13 +565,15 @@ class Table:
                                          domain.offset.value, domain.omega.value, ch, tm, pr, stream))
         return out
 
-    def combine_into(self, domain, challenges, terminals, weights, accumulator, randomizer=None, randomizer_weight=None, inverses=None):
+    def combine_into(self, domain, challenges, terminals, weights, accumulator, randomizer=None, randomizer_weight=None, inverses=None, rows=None):
         """bfs_air_combine: add this table's share of the non-linear combination -- its base columns, extension columns and
         quotients (in that order; weights: list of (wa, wb, shift)) -- to `accumulator` (XArray) without writing the quotient
         codewords.  randomizer (XArray) given: the accumulator is initialised to randomizer_weight * randomizer first.
-        inverses: device addresses of the codewords 1/(x - 1), 1/(x - omicron^-1), 1/(x^height - 1) (zerofier_inverses), or None."""
+        inverses: device addresses of the codewords 1/(x - 1), 1/(x - omicron^-1), 1/(x^height - 1) (zerofier_inverses), or None.
+        rows = (first, count): only those points (bfs_air_combine_rows)."""
         lib, stream = _lib.load(), current_stream()
         n = domain.length
+        first, count = (0, n) if rows is None else rows
         assert len(weights) == self.full_width - self.base_width + self.base_width + self.num_quotients()
         if isinstance(weights, np.ndarray):          # rows of seven words = bfs_comb_weight, as the prover lays them out
             weights = np.ascontiguousarray(weights, dtype=np.uint64)
@@ -584,11 +588,11 @@ class Table:
         params = self.air_params(challenges)
         pr = (_u64 * 3)(*params[0]) if params else None
         omicron_inv = _inv(self.omicron.value)
-        _lib.check(lib.bfs_air_combine(self.table_index, self.base_codewords.ptr, self.ext_codewords.ptr, n.bit_length() - 1,
-                                       self.unit_distance(n), self.height, omicron_inv, domain.offset.value, domain.omega.value, ch, tm, pr,
-                                       ws, randomizer.ptr if randomizer is not None else None,
-                                       (_u64 * 3)(*randomizer_weight) if randomizer is not None else None, accumulator.ptr,
-                                       (ctypes.c_void_p * 3)(*inverses) if inverses is not None else None, stream))
+        _lib.check(lib.bfs_air_combine_rows(self.table_index, self.base_codewords.ptr, self.ext_codewords.ptr, n.bit_length() - 1,
+                                            self.unit_distance(n), self.height, omicron_inv, domain.offset.value, domain.omega.value, ch, tm, pr,
+                                            ws, randomizer.ptr if randomizer is not None else None,
+                                            (_u64 * 3)(*randomizer_weight) if randomizer is not None else None, accumulator.ptr,
+                                            (ctypes.c_void_p * 3)(*inverses) if inverses is not None else None, first, count, stream))
 
     _challenge_analysis = (None, None, None, None)
     _exact_totals = {}        # (table, kind, the values themselves) -> total degrees per constraint

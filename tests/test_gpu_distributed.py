@@ -45,6 +45,34 @@ print("ok")
     assert res.returncode == 0 and "ok" in res.stdout, res.stdout + res.stderr
 
 
+def test_all_gather_rows_over_rccl_single_rank():
+    """shard.all_gather_rows on the library's own device memory wrapped as torch tensors (no copy), nccl (= RCCL) backend, world size 1:
+    the device path a cooperative proof takes with the combination codeword"""
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import torch, torch.distributed as dist
+from stark_brainfuck_amd import shard
+from stark_brainfuck_amd.device import DeviceBuffer
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+n, stride = 1 << 12, (1 << 12) + 8
+data = np.arange(3 * stride, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+buf = DeviceBuffer.from_numpy(data)
+view = torch.as_tensor(shard._DeviceWords(buf.ptr + 8 * stride, n), device=torch.device("cuda", 0))
+assert view.data_ptr() == buf.ptr + 8 * stride                       # a window, not a copy
+assert (view.cpu().numpy().view(np.uint64) == data[stride:stride + n]).all()
+shard.all_gather_rows(buf.ptr, n, 3, stride, 1, 0, device=torch.device("cuda", 0), force_collective=True)
+assert (buf.to_numpy() == data).all()                                # one rank: the gather is the identity, through the collective
+dist.barrier(); dist.destroy_process_group()
+print("ok")
+''' % ROOT
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout + res.stderr
+
+
 @pytest.mark.parametrize("scaling", ["strong", "weak"])
 def test_bench_under_torchrun_single_rank(scaling):
     """bench.py launched exactly as the driver launches N > 1 (torch.distributed.run, RCCL process group), with the one rank this
