@@ -72,6 +72,10 @@ def main():
     ap.add_argument("--cooperative", action="store_true",
                     help="N > 1: additionally time ONE BrainfuckStark.prove carried by all ranks together (BrainfuckStark.cooperate: every rank "
                          "hashes its range of the zipped rows; opt-in, the default legs run independent replicas)")
+    ap.add_argument("--no-cooperative", action="store_true",
+                    help="N > 1: do not time the cooperative proof at all (by default rank 0 runs it as a SEPARATE, time-limited job after "
+                         "the main measurement -- see guarded_cooperative -- unless --cooperative already ran it in-job)")
+    ap.add_argument("--coop-leg", action="store_true", help=argparse.SUPPRESS)     # internal: the separate job of guarded_cooperative
     ap.add_argument("--no-check", action="store_true", help="skip the post-run round-trip check and root gather (PMC collection runs)")
     args = ap.parse_args()
 
@@ -120,6 +124,15 @@ def main():
     from stark_brainfuck_amd.device import DeviceBuffer, DeviceView
     lib = _lib.load()
     _lib.check(lib.bfs_set_device(local_rank))
+    if args.coop_leg:
+        # the separate job of guarded_cooperative: nothing but the cooperative proof; rank 0 prints its own one-line JSON
+        coop = bench_stark_cooperative(world, rank, coll_device if backend == "nccl" else None, dist, torch) if dist is not None else None
+        if rank == 0:
+            print(json.dumps({"stark_prove_cooperative": coop}), flush=True)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     # who is in the job, as the collective backend itself sees it: world size from the process group and every rank's device
     # (index + PCI bus id), all-gathered -- so the line shows N distinct GPUs behind N ranks, not N ranks on one device
     ranks_seen, rank_devices = 1, [device_identity(torch, local_rank)]
@@ -362,10 +375,14 @@ def main():
             line["sustained"] = sustained
         if cpu_line is not None:
             line["cpu_baseline"] = cpu_line
-        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        if coop is None and world > 1 and (world & (world - 1)) == 0 and not args.no_cooperative and not args.no_stark and not args.no_fri:
+            del d_in, d_out
+            line["stark_prove_cooperative"] = guarded_cooperative(world)
+        print(json.dumps(line), flush=True)
 
 
 def device_identity(torch, index):
@@ -375,6 +392,40 @@ def device_identity(torch, index):
         return {"device": index, "name": props.name, "pci_bus_id": bus, "uuid": str(getattr(props, "uuid", "")) or None}
     except Exception:
         return {"device": index}
+
+
+def guarded_cooperative(n_ranks, limit_s=300):
+    """ONE proof carried by all GPUs together (BrainfuckStark.cooperate), timed in a job of its own: `bench.py --gpus N --coop-leg` under
+    torch.distributed.run, started by rank 0 after the main measurement is complete and its process group is gone, with a time limit.
+    It is the one leg whose collectives (row-range commitments, all-gather of the combination codeword over the library's device
+    memory) have never run across real xGMI links in development -- a failure or hang there must cost this entry, not the line."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK",
+                                                              "MASTER_ADDR", "MASTER_PORT") and not k.startswith("TORCHELASTIC")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(n_ranks), "--coop-leg"]
+    t0 = time.perf_counter()
+    try:
+        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        return {"error": "no result within %d s (job killed)" % limit_s, "ranks": n_ranks, "separate_job": True}
+    for l in reversed(res.stdout.splitlines()):
+        if l.startswith("{"):
+            try:
+                out = json.loads(l).get("stark_prove_cooperative")
+            except ValueError:
+                continue
+            if out:
+                out["separate_job"] = True
+                out["job_seconds"] = round(time.perf_counter() - t0, 1)
+                return out
+    return {"error": "exit status %d: %s" % (res.returncode, (res.stderr or res.stdout)[-400:]), "ranks": n_ranks, "separate_job": True}
 
 
 def self_launch(n_ranks):

@@ -290,9 +290,12 @@ int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_str
     const u32 streaming = force_streaming >= 0 ? (u32)(force_streaming != 0) : (u32)((u64)n * batch * sizeof(u64) > NTT_STREAMING_BYTES);
     u64* ws = nullptr;
     if (p.npass > 1) {
+        // BFS_NTT_WS_OFFSET (A/B, profiles/r03/ab_workspace_offset.txt): the intermediate buffer starts that many bytes into its
+        // allocation, so that a pass reading offset X of one buffer and writing offset X of the other meets different HBM banks
+        static const size_t ws_offset = [] { const char* e = getenv("BFS_NTT_WS_OFFSET"); return e ? (size_t)atoll(e) & ~(size_t)127 : (size_t)0; }();
         void* w = nullptr;
-        BFS_TRY(workspace(0, (size_t)n * batch * sizeof(u64), stream, &w));
-        ws = (u64*)w;
+        BFS_TRY(workspace(0, (size_t)n * batch * sizeof(u64) + ws_offset, stream, &w));
+        ws = (u64*)((char*)w + ws_offset);
     }
     for (u32 t = 0; t < p.npass; ++t) {
         const bool first = t == 0, last = t + 1 == p.npass;

@@ -291,10 +291,11 @@ def test_bench_with_two_ranks_on_one_gpu():
 
 def test_plain_bench_command_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it (what a driver that reuses its N = 1 command line runs): bench.py starts
-    the two ranks itself under torch.distributed.run and rank 0's JSON line arrives on the caller's stdout.  Two ranks share this
+    the two ranks itself under torch.distributed.run and rank 0's JSON line arrives on the caller's stdout; the cooperative proof runs as
+    bench.guarded_cooperative's separate job.  Two ranks share this
     box's one GPU and exchange over gloo (test hooks BFS_BENCH_BACKEND / BFS_BENCH_DEVICE)."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--total-columns", "4",
-           "--log-n", "20", "--no-cpu", "--no-fri", "--spinup-ms", "0"]
+           "--log-n", "20", "--no-cpu", "--spinup-ms", "0"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BFS_BENCH_BACKEND="gloo", BFS_BENCH_DEVICE="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
@@ -306,3 +307,6 @@ def test_plain_bench_command_launches_its_own_ranks():
     assert line["n_gpus"] == 2 and line["rccl_ranks_seen"] == 2 and len(line["rank_devices"]) == 2
     assert line["config"]["columns_per_gpu"] == [2, 2]
     assert line["guard"]["columns_round_tripped"] == 2 and line["roots_sha256"]
+    # ... and, with no flag asking for it, the cooperative proof as a separate time-limited job started by rank 0 afterwards
+    coop = line["stark_prove_cooperative"]
+    assert coop.get("separate_job") is True and coop.get("ranks") == 2 and coop.get("verified") is True, coop
