@@ -65,8 +65,13 @@ __global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a, const i
 // waiting -- for their loads, at a barrier -- idles: VALU issue was 82 % of the time.  A timing-only experiment (the same kernel
 // launched with less LDS than it indexes) put five or more workgroups per CU at 1.34 ms against 1.51 (profiles/r02).  The
 // price: 32 + 32 four-byte LDS accesses per thread instead of 16 + 16 eight-byte ones and two more barriers per tile.
+// six waves per SIMD asked of the register allocator (80 VGPRs): the store-time row of the balanced schedule took the column
+// instantiation from 78 to 82 registers, i.e. from six waves to five (the 5- and 6-bit digits would spill 20 bytes at 80: left as the compiler has them)
+#ifndef BFS_NTT_SPLIT_WAVES
+#define BFS_NTT_SPLIT_WAVES 6
+#endif
 template <int B1, int B2, int B3, int LOGC, int MODE, bool NT>
-__global__ void __launch_bounds__(256) ntt_tile_kernel_split(const PassArgs a) {
+__global__ void __launch_bounds__(256, B2 >= 3 ? BFS_NTT_SPLIT_WAVES : 0) ntt_tile_kernel_split(const PassArgs a) {
     static_assert(B1 == 4 && B2 > 0 && B3 == 0, "two register stages, 16 elements per thread");
     extern __shared__ __attribute__((aligned(16))) u64 smem[];
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;

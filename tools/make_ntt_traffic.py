@@ -11,6 +11,7 @@ import sys
 
 d = sys.argv[1]
 tl = sys.argv[2] if len(sys.argv) > 2 else "12"
+rnd = sys.argv[3] if len(sys.argv) > 3 else "r03"
 vals = {}
 for line in open(os.path.join(d, "ntt_only_pmc_tile%s.txt" % tl)):
     m = re.match(r"(.*) dispatches (\d+) (\{.*\})", line.strip())
@@ -26,7 +27,7 @@ valu_step = 2 * vals["SQ_INSTS_VALU"]["column"] + vals["SQ_INSTS_VALU"]["final"]
 ms = plain["ms_per_step"]
 out = {
     "log_n": 24, "columns": 8,
-    "kernel": "ntt_tile_kernel_split<4,4,0,4,MODE,NT=true> (2 column launches + 1 final launch per step)",
+    "kernel": "ntt_tile_kernel_split<4,4,0,4,MODE,NT=true> (2 column launches + 1 final launch per step; balanced twiddle schedule)",
     "FETCH_SIZE_KB": vals["FETCH_SIZE"], "WRITE_SIZE_KB": vals["WRITE_SIZE"],
     "correction": "gfx950: FETCH_SIZE reports 1/2 of streamed bytes (MI355X_MICROARCH.md, HBM) -> reads = 2*FETCH_SIZE*1024; WRITE_SIZE*1024 as is",
     "hbm_bytes_per_launch": (2 * col + fin) / 3, "hbm_bytes_per_launch_column": col, "hbm_bytes_per_launch_final": fin,
@@ -35,7 +36,14 @@ out = {
     "ms_per_step_of_the_same_run": ms,
     "valu_issue_frac": valu_step * 4 / (1024 * 2.4e9) / (ms * 1e-3),
     "SQ_LDS_BANK_CONFLICT": vals.get("SQ_LDS_BANK_CONFLICT"),
-    "source": "tools/prof_ntt.sh (rocprofv3 --pmc, one counter per pass, on `python tools/ntt_only.py`: the 8 x 2^24 NTT step alone); raw: profiles/r02/ntt_only_pmc.txt",
+    "source": "tools/prof_ntt.sh (rocprofv3 --pmc, one counter per pass, on `python tools/ntt_only.py`: the 8 x 2^24 NTT step alone); raw: profiles/%s/ntt_only_pmc.txt" % rnd,
 }
+import shutil
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.makedirs(os.path.join(root, "profiles", rnd), exist_ok=True)
+for src, dst in (("ntt_only_pmc_tile%s.txt" % tl, "ntt_only_pmc.txt"), ("ntt_only_kernel_stats_tile%s.csv" % tl, "ntt_only_kernel_stats.csv"),
+                 ("ntt_only_kernel_trace_tail_tile%s.csv" % tl, "ntt_only_kernel_trace_tail.csv"), ("plain_tile%s.json" % tl, "ntt_only_timing.json")):
+    if os.path.exists(os.path.join(d, src)):
+        shutil.copy(os.path.join(d, src), os.path.join(root, "profiles", rnd, dst))
 json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "ntt_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
