@@ -142,6 +142,7 @@ class BrainfuckStark:
     # ---- several GPUs on one proof (shard.RowShardedSaltedMerkle): every rank runs the polynomial stages on all columns and hashes
     # only its range of the zipped rows; set by cooperate() and used inside shard.shared_randomness()
     _cooperation = None
+    _row_windows = None      # tests: [(first, count), ...] tiling the FRI domain -- the combination stage runs window by window
 
     def cooperate(self, world_size, rank, group=None, device=None):
         """this prover is one of `world_size` identical provers (one per GPU) working on the SAME proof: the zipped commitments are
@@ -450,25 +451,32 @@ class BrainfuckStark:
                                            log_n, domain.offset.value, domain.omega.value, stream))
         else:
             # a cooperative proof (cooperate()): the stage is pointwise, every rank holds all codewords (a row's neighbour at
-            # unit_distance comes from the rank's own copy), so each rank does its own rows and the ranks all-gather the combination
+            # unit_distance comes from the rank's own copy), so each rank does its own rows and the ranks all-gather the combination.
+            # _row_windows (tests): the same row-window entry points on one GPU, the domain cut into arbitrary pieces.
             rows = None
             if self._cooperation is not None:
                 from .shard import row_range
                 rows = row_range(n, self._cooperation[0], self._cooperation[1])
-            inverse_buffer, inverses = zerofier_inverses(self.tables, domain, rows=rows)      # all zerofier denominators, one inversion per point
-            base_at = ext_at = 0
-            quot_at = num_base + num_ext
-            for k, t in enumerate(self.tables):
-                bw, xw, nq = t.base_width, t.full_width - t.base_width, t.num_quotients()
-                mine = np.concatenate([terms[base_at:base_at + bw], terms[num_base + ext_at:num_base + ext_at + xw], terms[quot_at:quot_at + nq]])
-                t.combine_into(domain, challenges, terminals, mine, combination,
-                               randomizer=randomizer_codeword if k == 0 else None, randomizer_weight=weight0, inverses=inverses[t], rows=rows)
-                base_at, ext_at, quot_at = base_at + bw, ext_at + xw, quot_at + nq
-            for pa in self.permutation_arguments:
-                pa.combine_into(domain, term_of(quot_at), combination, inv_x_minus_1=inverses[self.tables[0]][0], rows=rows)
-                quot_at += 1
-            assert quot_at == len(terms)
-            inverse_buffer.free()
+            windows = [rows]
+            if rows is None and self._row_windows is not None:
+                windows = list(self._row_windows)
+                ends = [first + count for first, count in windows]
+                assert [first for first, _ in windows] == [0] + ends[:-1] and ends[-1] == n, "the windows must tile the domain in order"
+            for window in windows:
+                inverse_buffer, inverses = zerofier_inverses(self.tables, domain, rows=window)      # all zerofier denominators, one inversion per point
+                base_at = ext_at = 0
+                quot_at = num_base + num_ext
+                for k, t in enumerate(self.tables):
+                    bw, xw, nq = t.base_width, t.full_width - t.base_width, t.num_quotients()
+                    mine = np.concatenate([terms[base_at:base_at + bw], terms[num_base + ext_at:num_base + ext_at + xw], terms[quot_at:quot_at + nq]])
+                    t.combine_into(domain, challenges, terminals, mine, combination,
+                                   randomizer=randomizer_codeword if k == 0 else None, randomizer_weight=weight0, inverses=inverses[t], rows=window)
+                    base_at, ext_at, quot_at = base_at + bw, ext_at + xw, quot_at + nq
+                for pa in self.permutation_arguments:
+                    pa.combine_into(domain, term_of(quot_at), combination, inv_x_minus_1=inverses[self.tables[0]][0], rows=window)
+                    quot_at += 1
+                assert quot_at == len(terms)
+                inverse_buffer.free()
             if rows is not None:
                 from .shard import all_gather_rows
                 world_size, rank, group, device = self._cooperation

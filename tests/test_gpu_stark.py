@@ -109,6 +109,30 @@ def test_production_path_writes_the_reference_proof(name, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["loop", "two_io"])
+def test_combination_by_row_windows_writes_the_reference_proof(name, monkeypatch):
+    """bfs_zerofier_inverses_rows / bfs_air_combine_rows / bfs_difference_combine_rows (a cooperative proof's share of the pointwise
+    stages) with the domain cut into ragged windows -- one point, an odd count, a piece that ends one short of the middle, the rest:
+    the accumulator must come out as from one launch over the whole domain, i.e. the proof is still the reference's"""
+    from stark_brainfuck_amd import brainfuck_stark, salted_merkle, table
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    g = json.load(open(os.path.join(GOLDEN, "stark_%s.json" % name)))
+    program = VirtualMachine.compile(g["program"])
+    running_time, input_symbols, output_symbols = VirtualMachine.run(program, input_data=list(g["input"]))
+    matrices = VirtualMachine.simulate(program, input_data=list(input_symbols))
+    stark = BrainfuckStark(running_time, len(matrices[1]), program, input_symbols, output_symbols)
+    n = stark.fri.domain.length
+    cuts = [0, 1, 258, n // 2 - 1, n]
+    stark._row_windows = [(a, b - a) for a, b in zip(cuts, cuts[1:])]
+    stream = Stream(name.encode())
+    for mod in (brainfuck_stark, salted_merkle, table):
+        monkeypatch.setattr(mod, "urandom", stream)
+    proof = stark.prove(program, *matrices)
+    assert len(proof) == g["proof_len"] and hashlib.sha256(proof).hexdigest() == g["proof_sha256"]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", NAMES)
 def test_verify_accepts_reference_proofs_and_rejects_tampering(name):
     """the verifier mirror (brainfuck_stark.py:343-579) on proofs written by the reference itself"""
