@@ -355,6 +355,7 @@ def main():
                                     "per cent, so the sustained-clock fraction can read slightly above 1) -- DESIGN.md 4.1"}
         if log_n == 24 and not args.no_single:
             line["single_column_2p24"] = bench_single_column(lib, _lib, d_in, d_out, n, log_n, root, stream)
+            line["pcie_inclusive_2p24"] = bench_pcie_inclusive(lib, _lib, d_in, d_out, n, log_n, root, stream)
         if not args.no_fri:
             line["fri_prove"] = mine
             line["fri_prove"]["replicas"] = {"per_gpu_ms": [round(v, 4) for v in fri_all], "proofs_per_s": world / (max(fri_all) * 1e-3)}
@@ -463,6 +464,27 @@ def bench_single_column(lib, _lib, d_in, d_out, n, log_n, root, stream, steps=20
     gbs = 16.0 * n / per / 1e6
     return {"ms": per, "elements_per_s": n / per * 1e3, "algorithmic_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "steps": steps,
             "note": "forward NTT of one column, batch 1, HIP events over %d back-to-back transforms" % steps}
+
+
+def bench_pcie_inclusive(lib, _lib, d_in, d_out, n, log_n, root, stream, reps=5):
+    """the same transform when the boundary hands over HOST buffers (never `value`, which is quoted with inputs resident in HBM): one
+    2^log_n column from pinned host memory to the GPU, transformed, and back into pinned host memory -- 16 bytes per element over PCIe
+    around 16 algorithmic bytes per element in HBM."""
+    from stark_brainfuck_amd.device import pinned_empty
+    h_in, h_out = pinned_empty(n), pinned_empty(n)
+    h_in[:] = felt_array(SEED + 5, 0, n)
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        _lib.check(lib.bfs_memcpy_h2d(d_in.ptr, h_in.ctypes.data, 8 * n, stream))
+        _lib.check(lib.bfs_gl_ntt(d_in.ptr, n, n, d_out.ptr, n, log_n, 1, root, 1, 1, stream))
+        _lib.check(lib.bfs_memcpy_d2h(h_out.ctypes.data, d_out.ptr, 8 * n, stream))
+        _lib.check(lib.bfs_stream_synchronize(stream))
+        times.append(time.perf_counter() - t0)
+    t = statistics.median(times[1:])
+    return {"ms": t * 1e3, "elements_per_s": n / t, "pcie_bytes": 16 * n, "pcie_GBps_if_the_transform_were_free": 16.0 * n / t / 1e9, "columns": 1,
+            "note": "pinned host -> HBM, forward NTT, HBM -> pinned host, one 2^%d column per call, serial (no overlap of copies and "
+                    "transform); pageable host memory goes through two pooled pinned bounce buffers at about half that copy rate" % log_n}
 
 
 VALU_PER_COMPRESSION = 1983     # BLAKE2b-512 compression in VGPRs on gfx950: 801 xor + 576 funnel shifts + 575 64-bit adds + 31 (DESIGN.md 4.2)
