@@ -412,10 +412,20 @@ def guarded_cooperative(n_ranks, limit_s=300):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(n_ranks), "--coop-leg"]
     t0 = time.perf_counter()
+    import signal
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
     try:
-        res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=limit_s)
+        out_text, err_text = proc.communicate(timeout=limit_s)
     except subprocess.TimeoutExpired:
+        try:
+            os.killpg(proc.pid, signal.SIGKILL)          # the launcher AND its ranks (its own session: nothing of ours is in that group)
+        except OSError:
+            pass
+        proc.communicate()
         return {"error": "no result within %d s (job killed)" % limit_s, "ranks": n_ranks, "separate_job": True}
+
+    class res:
+        stdout, stderr, returncode = out_text, err_text, proc.returncode
     for l in reversed(res.stdout.splitlines()):
         if l.startswith("{"):
             try:
