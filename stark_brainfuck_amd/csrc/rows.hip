@@ -123,7 +123,10 @@ typedef const u32 __attribute__((address_space(4)))* ConstInts;
 typedef const u64* const __attribute__((address_space(4)))* ConstColumns;
 typedef const u64 __attribute__((address_space(1)))* GlobalWords;
 __device__ __forceinline__ u32 uniform32(u32 x) { return (u32)__builtin_amdgcn_readfirstlane(x); }   // (the builtin returns a signed int)
-__global__ void __launch_bounds__(LEAF_THREADS) row_leaves_kernel(const RowArgs a) {
+#ifndef BFS_ROW_WAVES
+#define BFS_ROW_WAVES 4          // 128 VGPRs (20 bytes of scratch): with 38 KiB of LDS per workgroup the fourth wave per SIMD is there to be had
+#endif
+__global__ void __launch_bounds__(LEAF_THREADS, BFS_ROW_WAVES) row_leaves_kernel(const RowArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char blk[ROW_LANE_BYTES * LEAF_THREADS];
     const u32 lane = threadIdx.x;
     unsigned char* const buf = blk + ROW_LANE_BYTES * lane;

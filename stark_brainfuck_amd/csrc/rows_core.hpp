@@ -32,10 +32,18 @@ struct RowStep {
 // integers of a row are requested ROW_PREFETCH places ahead of where they are written; templates are padded to ROW_STEP_PAD steps
 constexpr u32 ROW_PREFETCH = 3, ROW_STEP_PAD = 4;
 #ifndef BFS_ROW_UNROLL
-#define BFS_ROW_UNROLL 4
+#define BFS_ROW_UNROLL 2
 #endif
 constexpr u32 ROW_UNROLL = BFS_ROW_UNROLL;              // steps per turn of the kernel's loop (one scalar load of their descriptors)
-constexpr u32 ROW_LANE_BYTES = 200;                     // 25 words; the odd word count keeps neighbouring lanes off the same LDS banks
+// Round 3 (profiles/r03/ab_rows_occupancy.txt): 152 bytes per lane (19 words; an odd word count keeps neighbouring lanes off the same LDS
+// banks) and two steps per turn instead of 200 and four: 38 KiB per 256-row workgroup, so FOUR workgroups fit a CU where three did.  A lane
+// is "full" 16 bytes before the end of its buffer, i.e. above 136: lanes that trail the wave's leader by more than 8 bytes sit that
+// compression out (the integers of a row of random field elements are 10 or 11 bytes each: ~13 bytes of spread over a 27-integer row),
+// which costs less than the fourth wave per SIMD brings: 2 x 2^22 rows 5.74 -> 5.30 ms.
+#ifndef BFS_ROW_LANE_BYTES
+#define BFS_ROW_LANE_BYTES 152
+#endif
+constexpr u32 ROW_LANE_BYTES = BFS_ROW_LANE_BYTES;
 static_assert(ROW_STEP_PAD % ROW_UNROLL == 0 && ROW_LANE_BYTES % 8 == 0 && ROW_LANE_BYTES - 8 * ROW_UNROLL >= 128,
               "a lane that must compress before the next ROW_UNROLL stores holds a complete block");
 

@@ -193,7 +193,7 @@ def _pickle_int(v):
 @pytest.mark.parametrize("seed", range(12))
 def test_row_lanes_walk_a_template_block_synchronously(emu, seed):
     """csrc/rows_core.hpp on the host: 64 lanes walk a random flattened template (constant runs, integers of every opcode width,
-    frame length, salt) in lockstep, with unaligned 8-byte stores into 200-byte lane buffers full of stale bytes and wave-wide
+    frame length, salt) in lockstep, with unaligned 8-byte stores into ROW_LANE_BYTES-byte lane buffers full of stale bytes and wave-wide
     compressions; every lane's digest must be BLAKE2b of the bytes a direct construction gives.  Value mixes: all nine-byte
     integers (lanes drift by a byte or two), random widths, and alternating all-small / all-large rows (lanes whole blocks apart,
     which sit compressions out); lengths that end on block boundaries occur along the way."""
