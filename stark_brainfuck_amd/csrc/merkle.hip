@@ -13,7 +13,7 @@ namespace bfs {
 constexpr int LEAF_THREADS = 64;  // one wavefront per workgroup
 
 // One wave hashes 64 leaves whose limbs it already holds (c0, c1, c2; `active` = the lane has a leaf) in the streaming form of
-// merkle_core.hpp: 21 words of LDS per lane = 10.5 KiB per wave instead of 18.  BFS_LEAF_STAGED (A/B, profiles/r03/ab_leaf_streaming.txt):
+// merkle_core.hpp: 20 words of LDS per lane = 10 KiB per wave instead of 18.  BFS_LEAF_STAGED (A/B, profiles/r03/ab_leaf_streaming.txt):
 // the staged form of rounds 1-2 (whole tail in LDS, then hashed).
 #ifdef BFS_LEAF_STAGED
 constexpr int LEAF_STAGE_WORDS = XFE_TAIL_MAX_WORDS * LEAF_THREADS;

@@ -90,17 +90,21 @@ BFS_HD void merkle_leaf_xfe_body(const u64* limbs, u64 limb_stride, u64 i, u64* 
 
 // ---- the same leaf, streamed: the preimage is hashed block by block while it is being encoded ------------------------------------
 // merkle_leaf_xfe_body stages the whole tail (36 words per lane: 18 KiB per wave, two waves per SIMD).  Here a lane owns
-// XFE_STREAM_WORDS = 21 words: the first tail block is complete once a statically known prefix of the template has been written (the
-// three integers move a lane's position by at most 27 bytes), so ALL lanes compress it at the same place in the code, shift their <= 5
+// XFE_STREAM_WORDS = 20 words: the first tail block is complete once a statically known prefix of the template has been written (the
+// three integers move a lane's position by at most 27 bytes), so ALL lanes compress it at the same place in the code, shift their <= 4
 // left-over words to the front and finish the encoding; the remaining one or two blocks follow as in the staged form.  The split
 // point depends on the class K (how many coefficients the element stores), so the wave-level caller (merkle.hip: xfe_leaves_wave)
 // runs the classes present in a wave one after the other -- exactly one for every codeword of random extension elements and for every
 // lifted base-field codeword.
+#ifdef BFS_LEAF_STREAM_21                     // A/B only: the first form (split 16 bytes into the last segment: up to 165 bytes before the first compression)
 constexpr int XFE_STREAM_WORDS = 21;
+#else
+constexpr int XFE_STREAM_WORDS = 20;         // 10 KiB per wave: sixteen waves per CU
+#endif
 template <int K> struct XfeStreamSplit;      // bytes of the class' last constant segment written BEFORE the first compression
 template <> struct XfeStreamSplit<1> { static constexpr int BYTES = 96; };   // 41 + int + 96 = 139..148 >= 128
 template <> struct XfeStreamSplit<2> { static constexpr int BYTES = 24; };   // 42 + int + 58 + int + 24 = 128..146
-template <> struct XfeStreamSplit<3> { static constexpr int BYTES = 16; };   // 42 + int + 58 + int + 16 + int + 16 = 138..165 (21 words)
+template <> struct XfeStreamSplit<3> { static constexpr int BYTES = XFE_STREAM_WORDS == 21 ? 16 : 8; };    // 42 + int + 58 + int + 16 + int + 8 = 130..157 (20 words); the rest of the tail is <= 20 words as well
 
 template <int K>
 BFS_HD void merkle_leaf_xfe_stream(u64 c0, u64 c1, u64 c2, u64* stage, u32 stride, u64 h[8], const u64* midstates) {

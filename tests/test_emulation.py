@@ -140,7 +140,7 @@ def test_hashes_match_hashlib(emu):
 
 @pytest.mark.parametrize("klass", [1, 2, 3])
 def test_streamed_leaf_equals_hashlib_over_the_reference_pickle(emu, klass):
-    """merkle_leaf_xfe_stream<K> (first tail block compressed in the middle of the encoding, 21 words of staging per lane) against
+    """merkle_leaf_xfe_stream<K> (first tail block compressed in the middle of the encoding, 20 words of staging per lane) against
     BLAKE2b of the whole pickle -- the encoder itself is pinned on the reference's pickles above.  Coefficients of every pickle integer
     length (2, 3, 5 and 3..11 bytes), so the lanes' positions at the split differ by the full 27 bytes; stale bytes in the staging area."""
     rng = np.random.default_rng(40 + klass)
