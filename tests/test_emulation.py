@@ -78,6 +78,21 @@ def test_three_pass_plans_under_both_twiddle_schedules(emu, oracle, logn):
     assert used[1] == 1 or logn == 17          # 2^17 = 6 + 6 + 5 (or 5 + 6 + 6): a first-pass tile spans two values of the next digit
 
 
+@pytest.mark.parametrize("logn", [4, 7, 10, 12, 13, 16, 18, 20])
+def test_zero_padded_inputs_of_every_shape(emu, oracle, logn):
+    """fast_coset_evaluate of few coefficients on a large domain (ntt.py:164-168; every trace column of the prover: h + 1 coefficients
+    on 64 h points): coefficient counts around n / 64, n / 16, n / 4 and n / 2, with and without the coset shift -- the first pass'
+    loads are predicated on n_in and everything above reads as zero."""
+    n = 1 << logn
+    w = oracle.primitive_nth_root(n)
+    counts = sorted({1, 2, max(1, n // 64), max(1, n // 64) + 1, n // 16, n // 16 + 1, n // 4 - 1, n // 4, n // 4 + 1, n // 2 + 3} & set(range(1, n + 1)))
+    v = oracle.felt_array(SEED + 3 * logn, 0, n)
+    for d in counts:
+        for shift in (1, 7):
+            want = oracle.fast_coset_evaluate(v[:d], shift, w, n)
+            assert (emu_ntt(emu, v[:d], logn, w, shift, 1, n_in=d) == want).all(), (logn, d, shift)
+
+
 def test_tile_kernels_batch_and_other_roots(emu, oracle):
     logn, n = 13, 1 << 13
     w = oracle.power(oracle.primitive_nth_root(n), 5)          # another primitive root (odd power)
