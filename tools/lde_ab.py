@@ -1,3 +1,5 @@
+"""Timing of the transforms the prover and FRI actually run: coset evaluations of few coefficients on a large domain (LDE) next to the
+full 8 x 2^24 step.   python tools/lde_ab.py"""
 import ctypes, os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np
@@ -18,7 +20,7 @@ def run(logn, n_in, cols, shift=7, steps=30):
     lib.bfs_event_record(e1, 0); _lib.check(lib.bfs_stream_synchronize(0))
     ms = ctypes.c_float(); lib.bfs_event_elapsed_ms(e0, e1, ctypes.byref(ms))
     return ms.value / steps
-print("prune", os.environ.get("BFS_NTT_PRUNE", "1"))
+print("zero-padded and full transforms, HIP events over 30 calls each (development tool; A/B via BFS_LIB_PATH or the NTT environment switches)")
 print("  LDE 16 cols 2^16+1 -> 2^22: %.3f ms" % run(22, (1 << 16) + 1, 16))
 print("  LDE 27 cols 2^16+1 -> 2^22: %.3f ms" % run(22, (1 << 16) + 1, 27))
 print("  xevaluate 3 x 2^22 -> 2^24: %.3f ms" % run(24, 1 << 22, 3))
