@@ -452,3 +452,24 @@ def test_randomness_override_is_per_context_not_process_global():
     assert randomness.source(os.urandom) is os.urandom
     with shard.shared_randomness(1, 0, seed=b"s" * 32) as again:
         assert again(16) == first and again(8) != first[:8]          # deterministic in the seed, and a stream, not a function of the count
+
+
+def test_row_window_entry_points_reject_windows_outside_the_domain():
+    """bfs_*_rows (the share of one rank of a cooperative proof): a window that does not lie inside the 2^log_n points is refused with
+    BFS_ERR_BAD_ARG before anything touches the device (so this runs without a GPU), and an empty window is a no-op"""
+    import ctypes
+    from stark_brainfuck_amd import _lib
+    lib = _lib.load()
+    u64 = ctypes.c_uint64
+    one = (ctypes.c_uint32 * 1)(0)
+    val = (u64 * 1)(1)
+    for first, count in ((17, 0), (16, 1), (0, 17), (8, 9), (1 << 63, 1 << 63)):
+        rc = lib.bfs_zerofier_inverses_rows(4, 7, 1, 1, one, val, None, first, count, None)
+        assert rc == 6, (first, count, rc)
+        assert b"not inside the domain" in lib.bfs_last_error()
+    w = _lib.CombWeight()
+    assert lib.bfs_difference_combine_rows(None, None, 4, 7, 1, ctypes.byref(w), None, None, 12, 5, None) == 6
+    assert lib.bfs_air_combine_rows(0, None, None, 4, 1, 0, 1, 7, 1, None, None, None, None, None, None, None, None, 3, 14, None) == 6
+    # an empty window inside the domain: nothing to do, no device needed
+    assert lib.bfs_zerofier_inverses_rows(4, 7, 1, 1, one, val, None, 16, 0, None) == 0
+    assert lib.bfs_difference_combine_rows(None, None, 4, 7, 1, ctypes.byref(w), None, None, 5, 0, None) == 0
