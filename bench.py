@@ -11,15 +11,22 @@ value = total field elements transformed per second over all ranks, timed over e
 synchronisation on both sides, max over ranks.  After the timed region every rank commits to its output columns and the 64-byte
 roots are all-gathered (shard.gather_roots over RCCL: the only collective of the design, never inside the timed region).
 Extra keys on the same JSON line:
-    roofline      dominant kernel (the NTT tile kernel) vs the 8 TB/s HBM roofline, from HIP events on the kernel's stream
+    roofline      dominant kernel (the NTT tile kernel) vs the 8 TB/s HBM roofline, from HIP events on the kernel's stream; bound_actual /
+                  roofline.valu: the integer-VALU roofline that actually binds (1024 SIMDs x sclk / 4 wave instructions per second)
     cpu_baseline  the CPU oracle (oracle/gl_oracle.c, plain C port of ntt.py, 1 core) on a bounded sample, rank 0, N=1 only;
                   cpu_baseline.python: the same algorithm in pure Python on boxed elements (the reference's cost model) at 2^14 / 2^16, timed live;
                   cpu_baseline.reference_python carries the reference's own CPython figure (measured in the build container)
     sustained     the same step back to back for the seconds the CPU baseline leg takes (second thread, untimed, N = 1): steady-state
                   clocks, and the GPU is busy while the host core is
     single_column_2p24  one 2^24-point column on its own (128 MiB: the transform north_star's target sentence is about)
+    pcie_inclusive_2p24  the same column from pinned host memory to the GPU, transformed and back (never `value`)
     fri_prove     Fri.prove on a random degree-2^18 codeword, expansion 4 (config 3), through the C ABI, median of 5;
-                  fri_prove_2p24: the same at N = 2^24 (degree 2^22)
+                  fri_prove_2p24: the same at N = 2^24 (degree 2^22); each with a VALU roofline from the BLAKE2b compression count
+    merkle_tree_2p24   Merkle(codeword) over 2^24 extension elements, HIP events (the two kernels that are 90 % of Fri.prove there)
+    stark_prove   BrainfuckStark.prove on Hello World (config 4) and on a 37 254-cycle program (FRI domain 2^22) with VALU rooflines
+                  of its two dominant stages and the tracked per-kernel table (profiles/prover_valu.json)
+    stark_prove_cooperative   N > 1: one proof carried by all ranks (rows of the commitments and of quotients + combination split),
+                  timed in a separate time-limited job started by rank 0 after the main measurement (--cooperative: in-job)
 Before the W warmup steps the device is spun up with untimed steps for --spinup-ms of wall time: after idle the
 first ~10 steps run ~10 % slower while the clocks ramp, and W is chosen by the caller.
 Nothing here reads /root/reference.
