@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN, golden_bytes, load_golden
+from conftest import GOLDEN, ROOT, golden_bytes, load_golden
 
 pytestmark = pytest.mark.gpu
 SEED = 0x5EED
@@ -941,6 +941,41 @@ def test_four_pass_plan_2p25(sb, oracle):
     assert (raw_ntt(sb, fwd, logn, oracle.inv(w), 1, oracle.inv(n)) == v).all()
     d = n // 4 + 3
     assert (raw_ntt(sb, v[:d], logn, w, 7, 1, n_in=d) == oracle.fast_coset_evaluate(v[:d], 7, w, n)).all()
+
+
+def test_three_pass_plans_with_the_load_time_twiddle_schedule():
+    """BFS_NTT_SCHEDULE=0 (the A/B switch of round 3: row table in the second pass, per-thread chain in the third -- the code that
+    four-pass plans still run in their middle and last passes) on three-pass sizes, in a process of its own because the switch is
+    read once: forward, inverse and zero-padded coset transforms against the oracle; the default (balanced) schedule is what every
+    other test of this file runs"""
+    import subprocess
+    import sys
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import numpy as np
+from oracle import ref_oracle as o
+from stark_brainfuck_amd import _lib
+from stark_brainfuck_amd.device import DeviceBuffer, synchronize
+lib = _lib.load()
+for logn in (17, 18, 20, 22):
+    n = 1 << logn
+    w = o.primitive_nth_root(n)
+    v = o.felt_array(0x5EED + logn, 0, n)
+    din, dout = DeviceBuffer.from_numpy(v), DeviceBuffer(n)
+    _lib.check(lib.bfs_gl_ntt(din.ptr, n, n, dout.ptr, n, logn, 1, w, 1, 1, 0)); synchronize(0)
+    fwd = dout.to_numpy()
+    assert (fwd == o.ntt(w, v)).all(), logn
+    _lib.check(lib.bfs_gl_ntt(dout.ptr, n, n, din.ptr, n, logn, 1, o.inv(w), 1, o.inv(n), 0)); synchronize(0)
+    assert (din.to_numpy() == v).all(), logn
+    d = n // 4 + 3
+    dc = DeviceBuffer.from_numpy(v[:d])
+    _lib.check(lib.bfs_gl_ntt(dc.ptr, d, d, dout.ptr, n, logn, 1, w, 7, 1, 0)); synchronize(0)
+    assert (dout.to_numpy() == o.fast_coset_evaluate(v[:d], 7, w, n)).all(), logn
+print("ok")
+''' % ROOT
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BFS_NTT_SCHEDULE="0"), capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
 
 
 def test_c_abi_argument_checks_and_stream_lifetime(sb, oracle):
