@@ -110,8 +110,19 @@ template <> struct AirShape<2> { static constexpr int BW = airgen::MEMORY_BASE_W
 template <> struct AirShape<3> { static constexpr int BW = airgen::INPUT_BASE_WIDTH, XW = airgen::INPUT_EXT_WIDTH, NB = airgen::INPUT_NUM_BOUNDARY, NT = airgen::INPUT_NUM_TRANSITION, NZ = airgen::INPUT_NUM_TERMINAL; };
 template <> struct AirShape<4> { static constexpr int BW = airgen::OUTPUT_BASE_WIDTH, XW = airgen::OUTPUT_EXT_WIDTH, NB = airgen::OUTPUT_NUM_BOUNDARY, NT = airgen::OUTPUT_NUM_TRANSITION, NZ = airgen::OUTPUT_NUM_TERMINAL; };
 
-template <int TABLE, class Sink>
-__device__ __forceinline__ void air_eval(const u64* bc, const u64* bn, const Xfe* xc, const Xfe* xn, const AirArgs& a, Sink& sink) {
+// the NEXT row of a thread kept in LDS ([value][thread], 64-bit words) and fetched where the constraint code uses it: 38 fewer live
+// registers in the processor table's combine kernel (A/B switch BFS_COMBINE_LDS_NEXT, profiles/r03/ab_combine_lds_next.txt)
+struct LdsNextBase {
+    const u64* p;
+    __device__ __forceinline__ u64 operator[](int k) const { return p[k * 256]; }
+};
+struct LdsNextExt {
+    const u64* p;
+    __device__ __forceinline__ Xfe operator[](int k) const { return Xfe{{p[(3 * k) * 256], p[(3 * k + 1) * 256], p[(3 * k + 2) * 256]}}; }
+};
+
+template <int TABLE, class Sink, class BN, class XN>
+__device__ __forceinline__ void air_eval(const u64* bc, BN bn, const Xfe* xc, XN xn, const AirArgs& a, Sink& sink) {
     if constexpr (TABLE == 0) airgen::air_processor(bc, bn, xc, xn, a.ch, a.tm, a.pr, sink);
     else if constexpr (TABLE == 1) airgen::air_instruction(bc, bn, xc, xn, a.ch, a.tm, a.pr, sink);
     else if constexpr (TABLE == 2) airgen::air_memory(bc, bn, xc, xn, a.ch, a.tm, a.pr, sink);
@@ -373,7 +384,10 @@ __device__ __forceinline__ void combine_columns(Sink& sink, const u64* bc, const
 // waves per SIMD asked of the register allocator: with the per-term data in LDS the scheduler otherwise pulls the reads far ahead of
 // their use and fills all 256 registers the block size allows (tables 1, 3, 4: 73-126 -> 250)
 #ifndef BFS_COMBINE_WAVES
-#define BFS_COMBINE_WAVES 2, 3, 4, 4, 4
+#define BFS_COMBINE_WAVES 3, 3, 4, 4, 4
+#endif
+#ifndef BFS_COMBINE_LDS_NEXT
+#define BFS_COMBINE_LDS_NEXT 1       // bit t: table t keeps its next row in LDS (LdsNextBase / LdsNextExt)
 #endif
 constexpr int combine_waves(int table) {
     constexpr int w[5] = {BFS_COMBINE_WAVES};
@@ -398,14 +412,24 @@ __global__ void __launch_bounds__(256, combine_waves(TABLE)) air_combine_kernel(
     if (i < a.first + a.count) {
         u64 j = i + a.unit_distance;
         if (j >= a.n) j -= a.n;
-        u64 bc[S::BW], bn[S::BW];
-        Xfe xc[S::XW], xn[S::XW];
+        constexpr bool LDS_NEXT = ((BFS_COMBINE_LDS_NEXT) >> TABLE) & 1;
+        __shared__ u64 next_row[LDS_NEXT ? (S::BW + 3 * S::XW) * 256 : 1];
+        u64 bc[S::BW], bn[LDS_NEXT ? 1 : S::BW];
+        Xfe xc[S::XW], xn[LDS_NEXT ? 1 : S::XW];
 #pragma unroll
-        for (int c = 0; c < S::BW; ++c) { bc[c] = a.base[(u64)c * a.n + i]; bn[c] = a.base[(u64)c * a.n + j]; }
+        for (int c = 0; c < S::BW; ++c) {
+            bc[c] = a.base[(u64)c * a.n + i];
+            if constexpr (LDS_NEXT) next_row[c * 256 + threadIdx.x] = a.base[(u64)c * a.n + j];
+            else bn[c] = a.base[(u64)c * a.n + j];
+        }
 #pragma unroll
         for (int c = 0; c < S::XW; ++c)
 #pragma unroll
-            for (int l = 0; l < 3; ++l) { xc[c].c[l] = a.ext[(u64)(3 * c + l) * a.n + i]; xn[c].c[l] = a.ext[(u64)(3 * c + l) * a.n + j]; }
+            for (int l = 0; l < 3; ++l) {
+                xc[c].c[l] = a.ext[(u64)(3 * c + l) * a.n + i];
+                if constexpr (LDS_NEXT) next_row[(S::BW + 3 * c + l) * 256 + threadIdx.x] = a.ext[(u64)(3 * c + l) * a.n + j];
+                else xn[c].c[l] = a.ext[(u64)(3 * c + l) * a.n + j];
+            }
         Xfe acc;
         if (A.randomizer) acc = xfe_mul(A.w0, Xfe{{A.randomizer[i], A.randomizer[a.n + i], A.randomizer[2 * a.n + i]}});
         else acc = Xfe{{A.acc[i], A.acc[a.n + i], A.acc[2 * a.n + i]}};
@@ -415,7 +439,8 @@ __global__ void __launch_bounds__(256, combine_waves(TABLE)) air_combine_kernel(
                                                         : Zerofiers(a, x),
                                          acc, lazyx_zero(), lazyx_zero()};
         combine_columns<TABLE, 0>(sink, bc, xc);
-        air_eval<TABLE>(bc, bn, xc, xn, a, sink);
+        if constexpr (LDS_NEXT) air_eval<TABLE>(bc, LdsNextBase{next_row + threadIdx.x}, xc, LdsNextExt{next_row + S::BW * 256 + threadIdx.x}, a, sink);
+        else air_eval<TABLE>(bc, (const u64*)bn, xc, (const Xfe*)xn, a, sink);
         sink.finish();
         A.acc[i] = sink.acc.c[0];
         A.acc[a.n + i] = sink.acc.c[1];
