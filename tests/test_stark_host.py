@@ -99,11 +99,11 @@ int main() {
     for (int i = 0; i < 5; ++i) for (int l = 0; l < 3; ++l) tm[i].c[l] = rd();
     for (int l = 0; l < 3; ++l) pr[0].c[l] = rd();
     Xfe out[32]; int n = 0;
-    if (table == 0) { airgen::air_processor(bc, bn, xc, xn, ch, tm, pr, out); n = 21; }
-    if (table == 1) { airgen::air_instruction(bc, bn, xc, xn, ch, tm, pr, out); n = 10; }
-    if (table == 2) { airgen::air_memory(bc, bn, xc, xn, ch, tm, pr, out); n = 11; }
-    if (table == 3) { airgen::air_input(bc, bn, xc, xn, ch, tm, pr, out); n = 3; }
-    if (table == 4) { airgen::air_output(bc, bn, xc, xn, ch, tm, pr, out); n = 3; }
+    if (table == 0) { airgen::air_processor_values(bc, bn, xc, xn, ch, tm, pr, out); n = 21; }
+    if (table == 1) { airgen::air_instruction_values(bc, bn, xc, xn, ch, tm, pr, out); n = 10; }
+    if (table == 2) { airgen::air_memory_values(bc, bn, xc, xn, ch, tm, pr, out); n = 11; }
+    if (table == 3) { airgen::air_input_values(bc, bn, xc, xn, ch, tm, pr, out); n = 3; }
+    if (table == 4) { airgen::air_output_values(bc, bn, xc, xn, ch, tm, pr, out); n = 3; }
     for (int i = 0; i < n; ++i) printf("%%llu %%llu %%llu\n", (unsigned long long)out[i].c[0], (unsigned long long)out[i].c[1], (unsigned long long)out[i].c[2]);
 }
 ''' % header)
