@@ -265,21 +265,14 @@ class BrainfuckStark:
         import time
         self.timing = {}
         mark = [time.perf_counter()]
-        for table, matrix in zip(self.tables, (processor_matrix, instruction_matrix, memory_matrix, input_matrix, output_matrix)):
-            table.matrix = matrix
-        for table in (self.processor_table, self.memory_table, self.instruction_table, self.input_table, self.output_table):
-            table.pad()                                                                      # :143-148
-        if proof_stream is None:
-            proof_stream = ProofStream()
-
         def lap(name):
             synchronize(stream)
             now = time.perf_counter()
             self.timing[name] = self.timing.get(name, 0.0) + now - mark[0]
             mark[0] = now
-        lap("pad")
 
-        # randomizer polynomial and codeword (:162-167)
+        # randomizer polynomial and codeword (:162-167) -- queued FIRST: padding (:143-148) is host work that draws no randomness, so the
+        # GPU expands and transforms the randomizer while the host pads (the order of the random draws is the reference's either way)
         count = self.max_degree + 1
         import os
         draw = random_source(urandom)    # the module's urandom, or this context's shared stream (randomness.override)
@@ -291,6 +284,13 @@ class BrainfuckStark:
             randomizer_polynomial = XArray.from_numpy(sample_ext_many(draw(3 * 9 * count), count, 9), xf)
         randomizer_codeword = domain.xevaluate(randomizer_polynomial, xf, as_array=True)
 
+        for table, matrix in zip(self.tables, (processor_matrix, instruction_matrix, memory_matrix, input_matrix, output_matrix)):
+            table.matrix = matrix
+        for table in (self.processor_table, self.memory_table, self.instruction_table, self.input_table, self.output_table):
+            table.pad()                                                                      # :143-148
+        if proof_stream is None:
+            proof_stream = ProofStream()
+        lap("pad")           # (includes the randomizer's GPU time where it outlasts the padding)
         lap("randomizer")
         # base codewords of all tables, one commitment to the zipped rows (:169-179)
         lde_tables(self.tables, domain)
@@ -333,6 +333,12 @@ class BrainfuckStark:
         # extension codewords and their commitment (:194-201)
         lde_tables(self.tables, domain, extension=True)
         extension_degree_bounds = [t.interpolant_degree() for t in self.tables for _ in range(t.full_width - t.base_width)]
+        early_quotient_bounds = None
+        if not self.keep_intermediates:
+            # the quotient degree bounds (:203-221) are host work on challenges and terminals: done here, while the GPU runs the coset
+            # transform of the extension columns that lde_tables has just queued
+            early_quotient_bounds = [b for table in self.tables for b in table.all_quotient_degree_bounds(challenges, terminals)]
+            early_quotient_bounds += [pa.quotient_degree_bound() for pa in self.permutation_arguments]
         lap("ext_lde")
         num_ext_columns = sum(t.full_width - t.base_width for t in self.tables)
         moduli = [m for t in self.tables for m in t.ext_sharing_moduli(n)]
@@ -378,14 +384,15 @@ class BrainfuckStark:
         # keep_intermediates (tests): the quotient codewords are written out and summed by bfs_combination, as the reference
         # does; otherwise they only ever exist in registers (bfs_air_combine below).  Same field elements either way.
         quotient_buffers, quotient_degree_bounds = [], []
-        for table in self.tables:
-            if self.keep_intermediates:
+        if early_quotient_bounds is not None:
+            quotient_degree_bounds = early_quotient_bounds
+        else:
+            for table in self.tables:
                 quotient_buffers.append((table.all_quotients(domain, None, challenges, terminals), table.num_quotients()))
-            quotient_degree_bounds += table.all_quotient_degree_bounds(challenges, terminals)
-        for pa in self.permutation_arguments:
-            if self.keep_intermediates:
+                quotient_degree_bounds += table.all_quotient_degree_bounds(challenges, terminals)
+            for pa in self.permutation_arguments:
                 quotient_buffers.append((pa.quotient(domain), 1))
-            quotient_degree_bounds.append(pa.quotient_degree_bound())
+                quotient_degree_bounds.append(pa.quotient_degree_bound())
 
         lap("quotients")
         # :223-224.  The input and output evaluations both start from ONE zero object (processor_table.py:340-347) and

@@ -223,12 +223,14 @@ def lde_tables(tables, domain, extension=False):
                 _lib.check(lib.bfs_poly_randomize(mine, stride, h, w, omega, (_u64 * w)(*[int(v) for v in rand]), stream))
         inputs.append(d_in)
         at += w
-    raw_ntt(coeffs.ptr, n_in, stride, out.ptr, n, log_n, total, omega, offset, 1, stream)
     masks = None
     if extension:      # see Table.ext_sharing_moduli: a per-polynomial summary of the support
+        # (read back BEFORE the big transform is queued: the read waits for what is in front of it on the stream, and the transform --
+        # most of this function's GPU time -- then runs while the caller goes on with host work)
         raw = (_u64 * total)()
         _lib.check(lib.bfs_poly_support(coeffs.ptr, stride, n_in, total, raw, stream))
         masks = [int(v) for v in raw]
+    raw_ntt(coeffs.ptr, n_in, stride, out.ptr, n, log_n, total, omega, offset, 1, stream)
     from .device import DeviceView
     at = 0
     for t, w, d_in in zip(tables, widths, inputs):
