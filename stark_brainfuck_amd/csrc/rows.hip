@@ -288,6 +288,7 @@ struct HostTemplates {
 
 static std::mutex g_template_mu;
 static std::map<std::string, std::shared_ptr<const HostTemplates>> g_template_cache;
+static std::map<std::string, std::vector<u32>> g_last_codes;      // column layout -> the row patterns its last commitment had
 
 static void add_const(HostTemplates& ht, const std::string& bytes, size_t from, size_t to) {
     if (to <= from) return;
@@ -481,67 +482,95 @@ static int build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n,
     a.digests = (u64*)d_nodes + npo2 * 8;
     a.pattern_set = d_set; a.error = d_err;
 
-    // 1. patterns present in this batch of rows: only the (small) set comes back -- a pageable n-word copy would be pinned
-    // and unpinned by the runtime, and the unmapping stalls the next dispatches for ~25 ms (profiles/r01/README.md)
-    hipLaunchKernelGGL(row_pattern_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, stream, a);
-    BFS_HIP(hipGetLastError());
-    const u64* set = (const u64*)((char*)stage.host + cols_bytes + ext_bytes);          // (the pinned block takes the answer too)
-    BFS_HIP(hipMemcpyAsync((void*)set, d_err, 16 + set_bytes, hipMemcpyDeviceToHost, stream));   // error words sit right before the set
-    BFS_HIP(hipStreamSynchronize(stream));
-    if (((const u32*)set)[1]) { set_error("bfs_merkle_build_rows: more than %u distinct row patterns", PATTERN_SLOTS); return BFS_ERR_BAD_ARG; }
-    std::vector<u32> codes;
-    for (u32 k = 0; k < PATTERN_SLOTS; ++k)
-        if (set[2 + k] != ~0ull) codes.push_back((u32)set[2 + k]);
-    std::sort(codes.begin(), codes.end());
+    // Which row patterns occur is a property of the data, but the same few come back proof after proof (a pattern is the degree class of
+    // every extension element of the row: "all of degree 2" and a handful around all-zero columns).  So the set found for this column
+    // layout LAST time is tried first: no pattern kernel, no read-back in the middle of the call.  The leaf kernel checks every row's
+    // pattern against the templates it was given and raises the error word for a row without one; then -- and the first time a layout
+    // is seen -- the patterns are collected (row_pattern_kernel) and the leaves hashed again.  BFS_ROWS_SPECULATE=0 always collects.
+    std::string layout((const char*)&ncols, sizeof ncols);
+    for (u32 c = 0; c < ncols; ++c) { const int32_t d[2] = {columns[c].is_ext ? 1 : 0, columns[c].field_id}; layout.append((const char*)d, sizeof d); }
+    layout.push_back(salted ? 1 : 0);
+    static const bool speculate = [] { const char* e = getenv("BFS_ROWS_SPECULATE"); return !(e && e[0] == '0'); }();
+    const u64* set = (const u64*)((char*)stage.host + cols_bytes + ext_bytes);          // (the pinned block takes the answers too)
+    char* back = (char*)stage.host + head_bytes;      // (behind the head block, which may have to go up a second time)
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        std::vector<u32> codes;
+        bool guessed = false;
+        if (attempt == 0 && speculate) {
+            std::lock_guard<std::mutex> lock(g_template_mu);
+            auto it = g_last_codes.find(layout);
+            if (it != g_last_codes.end()) { codes = it->second; guessed = true; }
+        }
+        if (!guessed) {
+            // 1. patterns present in this batch of rows: only the (small) set comes back -- a pageable n-word copy would be pinned
+            // and unpinned by the runtime, and the unmapping stalls the next dispatches for ~25 ms (profiles/r01/README.md)
+            if (attempt == 1) BFS_HIP(hipMemcpyAsync(w, stage.host, head_bytes, hipMemcpyHostToDevice, stream));     // cleared error words, empty set
+            hipLaunchKernelGGL(row_pattern_kernel, dim3((u32)((n + 255) / 256)), dim3(256), 0, stream, a);
+            BFS_HIP(hipGetLastError());
+            BFS_HIP(hipMemcpyAsync((void*)set, d_err, 16 + set_bytes, hipMemcpyDeviceToHost, stream));   // error words sit right before the set
+            BFS_HIP(hipStreamSynchronize(stream));
+            if (((const u32*)set)[1]) { set_error("bfs_merkle_build_rows: more than %u distinct row patterns", PATTERN_SLOTS); return BFS_ERR_BAD_ARG; }
+            for (u32 k = 0; k < PATTERN_SLOTS; ++k)
+                if (set[2 + k] != ~0ull) codes.push_back((u32)set[2 + k]);
+            std::sort(codes.begin(), codes.end());
+            std::lock_guard<std::mutex> lock(g_template_mu);
+            if (g_last_codes.size() >= 256) g_last_codes.clear();
+            g_last_codes[layout] = codes;
+        }
 
-    // 2. one template per pattern.  The same few patterns come back proof after proof (a pattern is the degree class of every
-    // extension element of the row: "all of degree 2" and a handful around all-zero columns), and making a template means pickling a
-    // row of sentinels -- ~30 us each: the finished sets are remembered per (column layout, patterns).
-    std::string key((const char*)&ncols, sizeof ncols);
-    for (u32 c = 0; c < ncols; ++c) { const int32_t d[2] = {columns[c].is_ext ? 1 : 0, columns[c].field_id}; key.append((const char*)d, sizeof d); }
-    key.push_back(salted ? 1 : 0);
-    key.append((const char*)codes.data(), codes.size() * sizeof(u32));
-    std::shared_ptr<const HostTemplates> cached;
-    {
-        std::lock_guard<std::mutex> lock(g_template_mu);
-        auto it = g_template_cache.find(key);
-        if (it != g_template_cache.end()) cached = it->second;
-    }
-    if (!cached) {
-        std::shared_ptr<HostTemplates> fresh(new HostTemplates());
-        for (u32 code : codes) BFS_TRY(build_template(columns, ncols, code, salted, *fresh));
-        std::lock_guard<std::mutex> lock(g_template_mu);
-        if (g_template_cache.size() >= 256) g_template_cache.clear();
-        g_template_cache[key] = fresh;
-        cached = fresh;
-    }
-    const HostTemplates& ht = *cached;
-    const size_t tbytes = ht.templates.size() * sizeof(RowTemplate), sbytes = ht.steps.size() * sizeof(RowStep), ibytes = ht.ints.size() * sizeof(u32);
-    void* tw = nullptr;
-    BFS_TRY(workspace(6, tbytes + sbytes + ibytes + 64, stream, &tw));
-    char* tb = (char*)tw;
-    PinnedLease tstage;
-    BFS_TRY(tstage.get(tbytes + sbytes + ibytes + 64));
-    memcpy(tstage.host, ht.templates.data(), tbytes);
-    memcpy((char*)tstage.host + tbytes, ht.steps.data(), sbytes);
-    memcpy((char*)tstage.host + tbytes + sbytes, ht.ints.data(), ibytes);
-    BFS_HIP(hipMemcpyAsync(tb, tstage.host, tbytes + sbytes + ibytes, hipMemcpyHostToDevice, stream));
-    a.templates = (const RowTemplate*)tb;
-    a.num_templates = (u32)ht.templates.size();
-    a.steps = (const RowStep*)(tb + tbytes);
-    a.ints = (const u32*)(tb + tbytes + sbytes);
+        // 2. one template per pattern.  Making a template means pickling a row of sentinels -- ~30 us each: the finished sets are
+        // remembered per (column layout, patterns).
+        std::string key = layout;
+        key.append((const char*)codes.data(), codes.size() * sizeof(u32));
+        std::shared_ptr<const HostTemplates> cached;
+        {
+            std::lock_guard<std::mutex> lock(g_template_mu);
+            auto it = g_template_cache.find(key);
+            if (it != g_template_cache.end()) cached = it->second;
+        }
+        if (!cached) {
+            std::shared_ptr<HostTemplates> fresh(new HostTemplates());
+            for (u32 code : codes) BFS_TRY(build_template(columns, ncols, code, salted, *fresh));
+            std::lock_guard<std::mutex> lock(g_template_mu);
+            if (g_template_cache.size() >= 256) g_template_cache.clear();
+            g_template_cache[key] = fresh;
+            cached = fresh;
+        }
+        const HostTemplates& ht = *cached;
+        const size_t tbytes = ht.templates.size() * sizeof(RowTemplate), sbytes = ht.steps.size() * sizeof(RowStep), ibytes = ht.ints.size() * sizeof(u32);
+        void* tw = nullptr;
+        BFS_TRY(workspace(6, tbytes + sbytes + ibytes + 64, stream, &tw));
+        char* tb = (char*)tw;
+        PinnedLease tstage;
+        BFS_TRY(tstage.get(tbytes + sbytes + ibytes + 64));
+        memcpy(tstage.host, ht.templates.data(), tbytes);
+        memcpy((char*)tstage.host + tbytes, ht.steps.data(), sbytes);
+        memcpy((char*)tstage.host + tbytes + sbytes, ht.ints.data(), ibytes);
+        BFS_HIP(hipMemcpyAsync(tb, tstage.host, tbytes + sbytes + ibytes, hipMemcpyHostToDevice, stream));
+        a.templates = (const RowTemplate*)tb;
+        a.num_templates = (u32)ht.templates.size();
+        a.steps = (const RowStep*)(tb + tbytes);
+        a.ints = (const u32*)(tb + tbytes + sbytes);
 
-    // 3. leaf digests, then the tree
-    hipLaunchKernelGGL(row_leaves_kernel, dim3((u32)((n + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0, stream, a);
-    BFS_HIP(hipGetLastError());
-    BFS_TRY(merkle_inner_launch((u64*)d_nodes, depth, n, stream, nullptr, 0));
-    // error word and root in one copy: nodes[1] is the root (heap order), digests of 8 words
-    char* back = (char*)stage.host;
-    BFS_HIP(hipMemcpyAsync(back, d_err, 16, hipMemcpyDeviceToHost, stream));
-    if (h_root != nullptr) BFS_HIP(hipMemcpyAsync(back + 16, (const u64*)d_nodes + 8, 64, hipMemcpyDeviceToHost, stream));
-    BFS_HIP(hipStreamSynchronize(stream));
-    const u32 err = *(const u32*)back;
-    if (h_root != nullptr) memcpy(h_root, back + 16, 64);
-    if (err) { set_error("bfs_merkle_build_rows: a row pattern without a template (internal)"); return BFS_ERR_BAD_ARG; }
-    return BFS_OK;
+        // 3. leaf digests, then the tree
+        hipLaunchKernelGGL(row_leaves_kernel, dim3((u32)((n + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0, stream, a);
+        BFS_HIP(hipGetLastError());
+        BFS_TRY(merkle_inner_launch((u64*)d_nodes, depth, n, stream, nullptr, 0));
+        // error word and root in one copy: nodes[1] is the root (heap order), digests of 8 words
+        BFS_HIP(hipMemcpyAsync(back, d_err, 16, hipMemcpyDeviceToHost, stream));
+        if (h_root != nullptr) BFS_HIP(hipMemcpyAsync(back + 16, (const u64*)d_nodes + 8, 64, hipMemcpyDeviceToHost, stream));
+        BFS_HIP(hipStreamSynchronize(stream));       // (tstage is released after this: the template copy has been consumed)
+        const u32 err = *(const u32*)back;
+        if (!err) {
+            if (h_root != nullptr) memcpy(h_root, back + 16, 64);
+            return BFS_OK;
+        }
+        if (!guessed) break;       // the patterns were collected from these very rows: a missing template is a bug
+        // a row with a pattern the remembered set does not have: collect and hash again (the head block -- column description, zeroed
+        // error words, empty set -- is still in the pinned stage; it goes up again in front of the pattern kernel)
+        memset((char*)stage.host + cols_bytes + ext_bytes, 0, 16);
+        memset((char*)stage.host + cols_bytes + ext_bytes + 16, 0xFF, set_bytes);
+    }
+    set_error("bfs_merkle_build_rows: a row pattern without a template (internal)");
+    return BFS_ERR_BAD_ARG;
 }

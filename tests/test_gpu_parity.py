@@ -687,6 +687,39 @@ def test_device_side_sampling_of_the_randomizer_polynomial(sb):
     assert (got < np.uint64(P)).all() and len(set(got.reshape(-1).tolist())) == 3 * count
 
 
+def test_zipped_rows_remembered_patterns_and_the_fallback(sb, oracle):
+    """bfs_merkle_build_rows tries the row patterns its column layout had LAST time before collecting them (no pattern kernel, no
+    read-back in the middle of the call) and hashes again when a row turns up without a template: three commitments of one layout --
+    all elements of full degree, then rows with zero and short elements (new patterns: the fallback), then full degree again (the
+    remembered set is now a superset) -- each against the oracle's pickles"""
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.device import DeviceBuffer
+    lib = _lib.load()
+    P = (1 << 64) - (1 << 32) + 1
+    n = 1 << 10
+    rng = np.random.default_rng(0xFA11)
+
+    def commit(ext, base):
+        bufs = [DeviceBuffer.from_numpy(np.ascontiguousarray(e).reshape(-1)) for e in ext] + [DeviceBuffer.from_numpy(b) for b in base]
+        rc = (_lib.RowColumn * len(bufs))()
+        for r, b, is_ext in zip(rc, bufs, [1] * len(ext) + [0] * len(base)):
+            r.d_values, r.is_ext, r.field_id = b.ptr, is_ext, 0
+        nodes = DeviceBuffer(2 * n * 8)
+        _lib.check(lib.bfs_merkle_build_rows(rc, len(bufs), n, None, 0, nodes.ptr, 0))
+        rows = [tuple([oracle.make_xfe([int(e[0, i]), int(e[1, i]), int(e[2, i])]) for e in ext] + [oracle.make_bfe(int(b[i])) for b in base]) for i in range(n)]
+        assert nodes.to_numpy(8, offset=8).tobytes() == oracle.MerkleOracle([oracle.dumps(r) for r in rows]).root()
+    full = lambda: rng.integers(1 << 40, P, (3, n), dtype=np.uint64)
+    base = [rng.integers(0, P, n, dtype=np.uint64) for _ in range(2)]
+    commit([full(), full()], base)
+    holes = full()
+    holes[:, 5] = 0                       # a zero element
+    holes[2, 100:140] = 0                 # two stored coefficients
+    holes[1:, 700] = 0                    # one
+    commit([full(), holes], base)
+    commit([full(), full()], base)
+    commit([holes, holes], base)
+
+
 @pytest.mark.parametrize("n,n_ext,n_base", [(1, 1, 0), (2, 0, 3), (3, 2, 2), (65, 16, 16), (1000, 2, 2)])
 def test_zipped_rows_edge_shapes(sb, oracle, n, n_ext, n_base):
     """row emitter on tiny, ragged (absent leaf slots) and wide inputs; 32 columns make the row pickle longer than 2.5 KB,
