@@ -341,6 +341,9 @@ int bfs_vm_trace_copy(void* trace, int which, uint64_t* out);
  */
 int bfs_xfe_scan(int kind, const uint64_t* x1, const uint64_t* x2, const uint64_t* x3, const uint8_t* mask, uint64_t n,
                  const uint64_t constants[12], const uint64_t initial[3], int record_before, uint64_t* out, uint64_t terminal[3]);
+/* host: rows x width words (row-major, rows src_stride words apart: the matrices VirtualMachine.simulate returns, vm.py:172-306) ->
+ * `width` columns of `rows` words each, dst_stride words apart: the column-major form Table.pad / Table.lde work on (table.py:95-136). */
+int bfs_host_transpose(const uint64_t* src, size_t rows, size_t src_stride, size_t width, uint64_t* dst, size_t dst_stride);
 /*
  * bfs_xfe_scan_device: the same primitive as a prefix scan on the GPU (csrc/scan.hip): the row updates are affine maps of the
  *     running value and compose associatively.  d_x1..d_x3 / d_mask are device pointers (n words / n bytes, NULL = absent),

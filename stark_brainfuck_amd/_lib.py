@@ -117,6 +117,7 @@ _SIGNATURES = {
                              ctypes.POINTER(u64), vp, ctypes.POINTER(vp), vp]),
     "bfs_difference_combine": (ci, [vp, vp, u32, u64, u64, vp, vp, vp, vp]),
     "bfs_zerofier_inverses": (ci, [u32, u64, u64, u32, ctypes.POINTER(u32), ctypes.POINTER(u64), vp, vp]),
+    "bfs_host_transpose": (ci, [vp, sz, sz, sz, vp, sz]),
     "bfs_air_combine_rows": (ci, [ci, vp, vp, u32, u64, u64, u64, u64, u64, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64), vp, vp,
                                   ctypes.POINTER(u64), vp, ctypes.POINTER(vp), u64, u64, vp]),
     "bfs_difference_combine_rows": (ci, [vp, vp, u32, u64, u64, vp, vp, vp, u64, u64, vp]),

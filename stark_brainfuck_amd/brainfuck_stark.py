@@ -37,7 +37,7 @@ from .permutation_argument import PermutationArgument
 from .processor_table import ProcessorTable
 from .salted_merkle import SaltedMerkle, ZippedSaltedMerkle
 from .algebra import P_GOLDILOCKS
-from .table import extend_tables_device, lde_tables, sample_ext, sample_ext_many, zerofier_inverses
+from .table import extend_tables_device, lde_tables, prepare_extension, sample_ext, sample_ext_many, zerofier_inverses
 from .univariate import Polynomial
 from .vm import VirtualMachine
 
@@ -295,6 +295,7 @@ class BrainfuckStark:
         # base codewords of all tables, one commitment to the zipped rows (:169-179)
         lde_tables(self.tables, domain)
         base_degree_bounds = [t.interpolant_degree() for t in self.tables for _ in range(t.base_width)]
+        prepared_extension = prepare_extension(self.tables)      # host work (row masks) behind the transform that has just been queued
         lap("base_lde")
         f2 = BrainfuckStark.field
 
@@ -326,7 +327,7 @@ class BrainfuckStark:
         # challenges, initials, table extension, terminals (:181-192)
         challenges = tuple(BrainfuckStark._sample_weights(11, proof_stream.prover_fiat_shamir()))
         initials = [sample_ext(draw(3 * 8)) for _ in self.permutation_arguments]
-        extend_tables_device(self.tables, challenges, initials)       # prefix scans on the trace columns lde() left in HBM
+        extend_tables_device(self.tables, challenges, initials, prepared=prepared_extension)   # prefix scans on the trace columns lde() left in HBM
         terminals = self.get_terminals()
         lap("extend")
 

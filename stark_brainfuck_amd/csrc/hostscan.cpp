@@ -37,3 +37,19 @@ extern "C" int bfs_xfe_scan(int kind, const uint64_t* x1, const uint64_t* x2, co
     terminal[0] = state.c[0]; terminal[1] = state.c[1]; terminal[2] = state.c[2];
     return BFS_OK;
 }
+
+// rows x width (row-major: the VM's matrices) -> width columns of `rows` words, dst_stride words apart (the layout the tables pad and
+// upload: table.py pads every column to a power of two in staging memory).  Blocked so that both sides stream.
+extern "C" int bfs_host_transpose(const uint64_t* src, size_t rows, size_t src_stride, size_t width, uint64_t* dst, size_t dst_stride) {
+    if (width > src_stride || rows > dst_stride) { set_error("bfs_host_transpose: width > src_stride or rows > dst_stride"); return BFS_ERR_BAD_ARG; }
+    constexpr size_t B = 64;
+    for (size_t r0 = 0; r0 < rows; r0 += B) {
+        const size_t r1 = r0 + B < rows ? r0 + B : rows;
+        for (size_t c = 0; c < width; ++c) {
+            uint64_t* d = dst + c * dst_stride;
+            const uint64_t* sp = src + c;
+            for (size_t r = r0; r < r1; ++r) d[r] = sp[r * src_stride];
+        }
+    }
+    return BFS_OK;
+}

@@ -14,8 +14,7 @@ class IOTable(Table):
         super().__init__(field, 1, 2, length, 0, generator, order)
 
     def pad(self):
-        m = self.base_array()
-        self.length = m.shape[1]
+        self.length, _ = self._rows_and_last()
         self._pad_to(np.zeros((1, self._padding_length(self.length)), dtype=np.uint64))
         self.height = len(self.matrix)
 

@@ -42,11 +42,10 @@ class MemoryTable(Table):
         return _matrix(rows, 4, field)
 
     def pad(self):
-        m = self.base_array()
-        k = self._padding_length(m.shape[1])
+        rows, last = self._rows_and_last()
+        k = self._padding_length(rows)
         pad = np.zeros((4, k), dtype=np.uint64)
         if k:
-            last = [int(v) for v in m[:, -1]]
             pad[0] = self._counting(last[0], k)                         # dummy rows: cycle counts up, pointer and value stay (:40-44)
             pad[1], pad[2], pad[3] = last[1], last[2], 1
         self._pad_to(pad)
@@ -54,7 +53,10 @@ class MemoryTable(Table):
     def _scans(self, all_challenges, all_initials):
         """memory_table.py:172-206"""
         a, b, c, d, e, f, alpha, beta, gamma, delta, eta = all_challenges
-        return [dict(kind=0, cols=[0, 1, 2], mask=self.base_array()[3] == 0, constants=[beta, d, e, f], initial=all_initials[1], before=True)]
+        return [dict(kind=0, cols=[0, 1, 2], mask=self._scan_masks()[0], constants=[beta, d, e, f], initial=all_initials[1], before=True)]
+
+    def _make_scan_masks(self):
+        return [self.base_array()[3] == 0]                  # dummy rows (the clock jumped) leave the product alone
 
     def _after_extend(self, terminals, all_challenges, read):
         self.permutation_terminal = terminals[0]

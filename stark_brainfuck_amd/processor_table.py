@@ -18,21 +18,23 @@ class ProcessorTable(Table):
         super().__init__(field, 7, 11, length, num_randomizers, generator, order)
 
     def pad(self):
-        m = self.base_array()
-        k = self._padding_length(m.shape[1])
-        last = [int(v) for v in m[:, -1]]
+        rows, last = self._rows_and_last()
+        k = self._padding_length(rows)
         pad = np.zeros((7, k), dtype=np.uint64)
         pad[0] = self._counting(last[0], k)                            # the cycle count keeps counting (processor_table.py:24-35)
         for col in (1, 4, 5, 6):                                       # instruction pointer, memory pointer / value / inverse stay
             pad[col] = last[col]
         self._pad_to(pad)
 
+    def _make_scan_masks(self):
+        ci = self.base_array()[2]
+        active = ci != 0                                                   # padding rows leave the products alone
+        return [active, active, ci == ord(","), ci == ord(".")]
+
     def _scans(self, all_challenges, all_initials):
         """the four extension columns as running products / evaluations (processor_table.py:329-427)"""
         a, b, c, d, e, f, alpha, beta, gamma, delta, eta = all_challenges
-        ci = self.base_array()[2]
-        active = ci != 0                                                   # padding rows leave the products alone
-        self._reads, self._writes = ci == ord(","), ci == ord(".")
+        active, _, self._reads, self._writes = self._scan_masks()
         one = (1, 0, 0)
         return [dict(kind=0, cols=[1, 2, 3], mask=active, constants=[alpha, a, b, c], initial=all_initials[0], before=True),
                 dict(kind=0, cols=[0, 4, 5], mask=active, constants=[beta, d, e, f], initial=all_initials[1], before=True),

@@ -119,12 +119,30 @@ def extend_all(tables, challenges, initials):
         future.result()
 
 
-def extend_tables_device(tables, all_challenges, all_initials):
+def prepare_extension(tables):
+    """the challenge-independent part of extend_tables_device -- row masks computed and queued for upload -- done ahead of time; returns
+    a token for extend_tables_device (or None when there is nothing to prepare)"""
+    lib, stream = _lib.load(), current_stream()
+    masks = []
+    for t in tables:
+        if t.height:
+            masks += [np.ascontiguousarray(m, dtype=np.uint8) for m in t._scan_masks() if m is not None]
+    if not masks:
+        return None
+    host = staging_empty(((sum(m.size for m in masks) + 7) // 8,)).view(np.uint8)
+    np.concatenate(masks, out=host[:sum(m.size for m in masks)])
+    d_masks = DeviceBuffer(host.size // 8)
+    _lib.check(lib.bfs_memcpy_h2d(d_masks.ptr, host.ctypes.data, host.size, stream))
+    return {"d_masks": d_masks, "host": host, "keys": [getattr(t, "_array_key", None) for t in tables]}
+
+
+def extend_tables_device(tables, all_challenges, all_initials, prepared=None):
     """Table.extend_device for several tables with ONE upload (all row masks), ONE read-back of the terminals and one gather for
     the values the tables look up afterwards -- a proof has nine scans over five tables, and every separate copy is a round trip."""
     from .device import GatherBatch
     lib, stream = _lib.load(), current_stream()
     plans, masks = [], []
+    use_prepared = prepared is not None and prepared["keys"] == [getattr(t, "_array_key", None) for t in tables]
     for t in tables:
         specs = t._scans(all_challenges, all_initials)
         assert len(specs) == t.full_width - t.base_width
@@ -132,10 +150,12 @@ def extend_tables_device(tables, all_challenges, all_initials):
         t._ext_device = DeviceBuffer(3 * len(specs) * t.height)
         assert t.height == 0 or t._base_device is not None, "extend_device() follows lde()"
         plans.append((t, specs))
-        if t.height:
+        if t.height and not use_prepared:
             masks += [np.ascontiguousarray(sp["mask"], dtype=np.uint8) for sp in specs if sp["mask"] is not None]
     d_masks = None
-    if masks:
+    if use_prepared:
+        d_masks = prepared["d_masks"]           # (same tables, same padded matrices: the masks are already on their way)
+    elif masks:
         host = np.concatenate(masks)
         d_masks = DeviceBuffer((host.size + 7) // 8)
         _lib.check(lib.bfs_memcpy_h2d(d_masks.ptr, host.ctypes.data, host.size, stream))
@@ -269,6 +289,21 @@ def zerofier_inverses(tables, domain, rows=None):
     return out, per_table
 
 
+def _columns_of(values, width, out=None, out_stride=None):
+    """the first `width` columns of a (rows, >= width) uint64 matrix as a (width, rows) array -- into `out` (rows out_stride apart)
+    when given.  Row-major C arrays (what the native VM returns) go through bfs_host_transpose: numpy's strided copy of the same
+    37 254 x 7 matrix takes three times as long, and padding is host time the GPU waits for."""
+    rows = values.shape[0]
+    if out is None:
+        out, out_stride = np.empty((width, rows), dtype=np.uint64), rows
+    if rows and width:
+        if values.dtype == np.uint64 and values.flags.c_contiguous and values.ndim == 2:
+            _lib.check(_lib.load().bfs_host_transpose(values.ctypes.data, rows, values.shape[1], width, out.ctypes.data, out_stride))
+        else:
+            out[:, :rows] = np.asarray(values[:, :width], dtype=np.uint64).T
+    return out
+
+
 def staging_empty(shape):
     """uint64 array for data on its way to HBM: pinned memory from the library's pool when there is a GPU, plain numpy otherwise"""
     if _POOLS.get("pinned", True):
@@ -359,7 +394,7 @@ class Table:
         if getattr(self, "_array_key", None) != key:
             values = getattr(self.matrix, "values", None)
             if values is not None:
-                arr = np.ascontiguousarray(values[:, :self.base_width].T, dtype=np.uint64)
+                arr = _columns_of(values, self.base_width)
             elif len(self.matrix):
                 arr = np.array([[_val(v) for v in row[:self.base_width]] for row in self.matrix], dtype=np.uint64).T.copy()
             else:
@@ -370,12 +405,42 @@ class Table:
     def base_rows(self):
         return self.base_array().T.tolist()
 
+    def _scan_masks(self):
+        """the row masks of this table's scans (None = every row), in the order of _scans(): they depend on the padded base columns
+        only, not on the challenges, so the prover computes and uploads them while the GPU is busy with the base columns' low-degree
+        extension (prepare_extension) instead of between the first commitment and the scans"""
+        key = getattr(self, "_array_key", None)
+        if getattr(self, "_mask_key", None) != key or key is None:
+            self._masks, self._mask_key = self._make_scan_masks(), key
+        return self._masks
+
+    def _make_scan_masks(self):
+        return [None] * (self.full_width - self.base_width)
+
+    def _rows_and_last(self):
+        """(number of rows, base values of the last row or None) without materialising the column-major array when the matrix
+        carries its values row-major (then _pad_to transposes straight into the padded staging array)"""
+        values = getattr(self.matrix, "values", None)
+        if values is not None and getattr(self, "_array_key", None) != (id(self.matrix), len(self.matrix)):
+            rows = values.shape[0]
+            return rows, ([int(v) for v in values[-1, :self.base_width]] if rows else None)
+        m = self.base_array()
+        return m.shape[1], ([int(v) for v in m[:, -1]] if m.shape[1] else None)
+
     def _pad_to(self, padding):
         """append `padding` (uint64 array, base_width x k) to the matrix"""
-        base = self.base_array()
-        arr = staging_empty((base.shape[0], base.shape[1] + padding.shape[1]))      # goes to HBM as it is (Table.lde)
-        arr[:, :base.shape[1]] = base
-        arr[:, base.shape[1]:] = padding
+        values = getattr(self.matrix, "values", None)
+        rows = len(self.matrix)
+        fresh = getattr(self, "_array_key", None) != (id(self.matrix), rows)
+        if values is not None and fresh and padding.shape[1]:
+            # straight from the VM's row-major matrix into the padded staging array: one pass instead of transpose + copy
+            arr = staging_empty((self.base_width, rows + padding.shape[1]))
+            _columns_of(values, self.base_width, out=arr, out_stride=arr.shape[1])
+        else:
+            base = self.base_array()
+            arr = staging_empty((base.shape[0], base.shape[1] + padding.shape[1]))      # goes to HBM as it is (Table.lde)
+            arr[:, :base.shape[1]] = base
+        arr[:, rows:] = padding
         self.matrix = _PaddedMatrix(self.matrix, arr, self.field)
         self._array, self._array_key = arr, (id(self.matrix), len(self.matrix))
 
