@@ -423,3 +423,64 @@ def test_runaway_programs_stop_at_the_cycle_limit():
     short = VirtualMachine.compile("+++[-]")
     assert len(VirtualMachine.simulate(short, max_cycles=0)[0]) == len(VirtualMachine.simulate(short, max_cycles=VirtualMachine.UNLIMITED)[0]) == 11
     assert VirtualMachine.run(short, max_cycles=0)[0] == VirtualMachine.run(short, max_cycles=VirtualMachine.UNLIMITED)[0]
+
+
+def _vm_golden():
+    return json.load(open(os.path.join(GOLDEN, "vm.json")))["programs"]
+
+
+def test_vm_pad_extend_against_the_reference_on_many_programs():
+    """tests/golden/vm.json (gen_vm_golden.py: the reference's VirtualMachine, Table.pad and Table.extend on 91 programs -- loops skipped
+    on a zero cell, cells and the memory pointer wrapping below zero, nested loops, input / output inside loops, empty tables, random
+    programs): compiled words, running time, output, the five trace matrices, the five padded tables, the five extended tables under
+    the fixture's challenges and initials, and the terminals.  vm.py:172-306, processor_table.py:24-31 / 359-427 and the other tables."""
+    import numpy as np
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    records = _vm_golden()
+    assert len(records) >= 90
+    checked = errors = 0
+    for g in records:
+        code, inp = g["program"], g["input"]
+        program = VirtualMachine.compile(code)
+        assert [w.value for w in program] == g["compiled_program"], code
+        if "run_error" in g:
+            # the reference's run() raises KeyError when `.` reads a cell nothing was ever written to (vm.py:148); so does the mirror
+            with pytest.raises(KeyError):
+                VirtualMachine.run(program, input_data=list(inp))
+            errors += 1
+            continue
+        running_time, inputs, outputs = VirtualMachine.run(program, input_data=list(inp))
+        assert running_time == g["running_time"] and "".join(outputs) == g["output"] and "".join(inputs) == g["input_symbols"], code
+        matrices = VirtualMachine.simulate(program, input_data=list(inputs))
+        assert [len(m) for m in matrices] == g["matrix_lengths"], code
+        assert [sha_rows(m) for m in matrices] == g["matrix_sha"], code
+        stark = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs)
+        assert stark.max_degree == g["max_degree"] and stark.fri.domain.length == g["fri_domain_length"], code
+        assert [t.height for t in stark.tables] == g["table_heights"], code
+        for table, matrix in zip(stark.tables, (matrices[0], matrices[2], matrices[1], matrices[3], matrices[4])):
+            table.matrix = matrix
+            table.pad()
+        padded = []
+        for table in stark.tables:
+            base = table.base_array()                                        # width x height
+            padded.append(hashlib.sha256(np.ascontiguousarray(base.T).astype("<u8").tobytes()).hexdigest())
+            assert base.shape[1] == g["padded_lengths"][len(padded) - 1], code
+        assert padded == g["padded_sha"], code
+        challenges = [tuple(c) for c in g["challenges"]]
+        initials = [tuple(c) for c in g["initials"]]
+        for table in stark.tables:
+            table.extend(challenges, initials)
+        for k, table in enumerate(stark.tables):
+            base = table.base_array()
+            height = base.shape[1]
+            width = table.base_width + len(table.ext_columns)
+            assert (width if height else 0) == g["extended_widths"][k], (code, k)
+            rows = np.zeros((height, width, 3), dtype="<u8")
+            rows[:, :table.base_width, 0] = base.T
+            for j, col in enumerate(table.ext_columns):
+                rows[:, table.base_width + j, :] = np.asarray(col, dtype=np.uint64).T
+            assert hashlib.sha256(rows.tobytes()).hexdigest() == g["extended_sha"][k], (code, type(table).__name__)
+        assert [list(t) for t in stark.get_terminals()] == g["terminals"], code
+        checked += 1
+    assert checked >= 75 and errors >= 5
