@@ -35,7 +35,47 @@ constexpr u64 GL_EPS = 0xFFFFFFFFULL;  // 2^64 mod p = 2^32 - 1
 // 64-bit compares / selects cost twice a 32-bit VALU op and hipcc recomputes carries with v_cmp_*_u64; the
 // __builtin_subc / __builtin_addc forms below compile to v_sub_co_u32 / v_subb_co_u32 carry chains instead
 // (5 VALU instructions for a canonical modular subtraction).
-BFS_HD u64 gl_sub(u64 a, u64 b) {
+// a - b in FOUR instructions (gl_sub4; a translation unit asks for it as its gl_sub with BFS_GL_SUB4 before including this header):
+// d = a - b with its borrow B kept in an SGPR pair; a borrow means + p = - EPS = + 1 - 2^32, so the low word becomes d_lo + B (an
+// add-with-carry whose carry-IN is B and whose carry-out C says d_lo was 0xFFFFFFFF) and the high word d_hi - (B and not C) (a
+// subtract-with-borrow whose borrow-in is that scalar combination).  hipcc keeps every carry in VCC and materialises the borrow as
+// a mask first (v_cndmask + v_sub_co + v_subb_co: five instructions, gl_sub5).  In the NTT tile kernels the asm form is 6.9 % fewer
+// VALU instructions per launch (profiles/r03/ab_sub4.txt); in the generated constraint code of air.hip its fixed register demands cost
+// the allocator more than the instruction saves (air_quotient_kernel<0>: 144 -> 243 VGPRs), so that unit keeps the compiler's form.
+BFS_HD u64 gl_sub4(u64 a, u64 b) {
+    u32 rlo, rhi;                                      // (the high word's register may be one of the inputs: they are all read by then)
+    u64 sb, sc;
+    asm("v_sub_co_u32 %0, vcc, %4, %6\n\t"
+        "s_nop 1\n\t"
+        "v_subb_co_u32 %1, %2, %5, %7, vcc\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %0, %3, %0, 0, %2\n\t"
+        "s_nop 1\n\t"
+        "s_andn2_b64 %2, %2, %3\n\t"
+        "v_subb_co_u32 %1, vcc, %1, 0, %2"
+        : "=&v"(rlo), "=v"(rhi), "=&s"(sb), "=&s"(sc)
+        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
+        : "vcc", "scc");                               // s_andn2_b64 sets SCC: undeclared, loops around the asm lost their exit condition
+    return ((u64)rhi << 32) | rlo;
+}
+// lo - hh (a 32-bit subtrahend, any 64-bit lo) the same way: the first step of the 128-bit reduction
+BFS_HD u64 gl_sub_word4(u64 lo, u32 hh) {
+    u32 rlo, rhi;
+    u64 sb, sc;
+    asm("v_sub_co_u32 %0, vcc, %4, %6\n\t"
+        "s_nop 1\n\t"
+        "v_subb_co_u32 %1, %2, %5, 0, vcc\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %0, %3, %0, 0, %2\n\t"
+        "s_nop 1\n\t"
+        "s_andn2_b64 %2, %2, %3\n\t"
+        "v_subb_co_u32 %1, vcc, %1, 0, %2"
+        : "=&v"(rlo), "=v"(rhi), "=&s"(sb), "=&s"(sc)
+        : "v"((u32)lo), "v"((u32)(lo >> 32)), "v"(hh)
+        : "vcc", "scc");
+    return ((u64)rhi << 32) | rlo;
+}
+BFS_HD u64 gl_sub5(u64 a, u64 b) {
     u32 bl, bh, b2;
     u32 dlo = __builtin_subc((u32)a, (u32)b, 0u, &bl);
     u32 dhi = __builtin_subc((u32)(a >> 32), (u32)(b >> 32), bl, &bh);
@@ -49,6 +89,13 @@ BFS_HD u64 gl_sub(u64 a, u64 b) {
     asm("" : "+v"(rhi));
     return ((u64)rhi << 32) | rlo;
 }
+#ifdef BFS_GL_SUB4
+constexpr bool GL_SUB4 = true;
+BFS_HD u64 gl_sub(u64 a, u64 b) { return gl_sub4(a, b); }
+#else
+constexpr bool GL_SUB4 = false;
+BFS_HD u64 gl_sub(u64 a, u64 b) { return gl_sub5(a, b); }
+#endif
 // a + b: s = a + b and u = s + EPS (= s - p mod 2^64) with both carries; a + b >= p  <=>  either addition carried
 BFS_HD u64 gl_add(u64 a, u64 b) {
     u32 c1, c2, c3, c4;
@@ -82,20 +129,52 @@ BFS_HD u32 gl_opaque_zero() {
     return z;
 }
 
+// base + w * 2^64 = base + w * EPS  ->  canonical residue, for ANY 64-bit base and 32-bit w: the tail of both reductions.
+// q = base + w * EPS mod 2^64 with carry C (one multiply-add).  C set: the value is q + EPS, which neither wraps nor reaches p
+// (q < w * EPS <= 2^64 - 2^33 + 1).  C clear: q may be >= p, i.e. the value is q + EPS mod 2^64 exactly when that addition carries (K).
+// MERGED: both cases are "+ EPS when C or K" -- a second multiply-add for K, the scalar OR of the two carries, one mask, one
+// multiply-add that adds it: 4 VALU instructions.  The separate form (wrap fix, then canonical form: carry, mask, add twice) is 6.
+template <bool MERGED>
+BFS_HD u64 gl_fold_word(u32 w, u64 base) {
+    if constexpr (MERGED) {
+        u64 q, r, sc;
+        u32 m;
+        asm("v_mad_u64_u32 %0, %3, %4, -1, %5\n\t"
+            "v_mad_u64_u32 %1, vcc, -1, 1, %0\n\t"
+            "s_or_b64 vcc, vcc, %3\n\t"
+            "v_cndmask_b32 %2, 0, -1, vcc\n\t"
+            "v_mad_u64_u32 %1, vcc, %2, 1, %0"
+            : "=&v"(q), "=&v"(r), "=&v"(m), "=&s"(sc) : "v"(w), "v"(base) : "vcc", "scc");
+        return r;
+    } else {
+        u64 q, q1, r;
+        u32 m;
+        asm("v_mad_u64_u32 %0, vcc, %4, -1, %5\n\ts_nop 1\n\tv_cndmask_b32 %3, 0, -1, vcc\n\tv_mad_u64_u32 %1, vcc, %3, 1, %0\n\t"
+            "v_mad_u64_u32 %0, vcc, -1, 1, %1\n\ts_nop 1\n\tv_cndmask_b32 %3, 0, -1, vcc\n\tv_mad_u64_u32 %2, vcc, %3, 1, %1"
+            : "=&v"(q), "=&v"(q1), "=&v"(r), "=&v"(m) : "v"(w), "v"(base) : "vcc");
+        return r;
+    }
+}
+
 // hi*2^64 + lo  ->  residue; CANON = false leaves the value in [0, 2^64) (fine as an operand of further multiplications).
 // 11 VALU instructions (13 with add / add-with-carry pairs, 17 as plain C): the multiply-add  hi_lo * (2^32 - 1) + t0  is ONE v_mad_u64_u32 whose carry-out is used
 // directly -- C has no way to ask for that carry, and the compiler's version is mad + 64-bit add + 64-bit compare.
-template <bool CANON>
+template <bool CANON, bool SUB4 = GL_SUB4>
 BFS_HD u64 gl_reduce128_t(u64 hi, u64 lo) {
-    const u32 z = gl_opaque_zero();
     u32 hh = (u32)(hi >> 32), hl = (u32)hi;
-    u32 bl, bh, b2, b3;
-    u32 dlo = __builtin_subc((u32)lo, hh, 0u, &bl);    // t0 = lo - hi_hi  (2^96 = -1)
-    u32 dhi = __builtin_subc((u32)(lo >> 32), z, bl, &bh);
-    u32 t = 0u - bh;
-    u32 t0lo = __builtin_subc(dlo, t, 0u, &b2);
-    u32 t0hi = __builtin_subc(dhi, z, b2, &b3);
-    u64 t0 = ((u64)t0hi << 32) | t0lo;
+    u64 t0;                                            // t0 = lo - hi_hi  (2^96 = -1)
+    if constexpr (SUB4) {
+        t0 = gl_sub_word4(lo, hh);
+    } else {
+        const u32 z = gl_opaque_zero();
+        u32 bl, bh, b2, b3;
+        u32 dlo = __builtin_subc((u32)lo, hh, 0u, &bl);
+        u32 dhi = __builtin_subc((u32)(lo >> 32), z, bl, &bh);
+        u32 t = 0u - bh;
+        u32 t0lo = __builtin_subc(dlo, t, 0u, &b2);
+        u32 t0hi = __builtin_subc(dhi, z, b2, &b3);
+        t0 = ((u64)t0hi << 32) | t0lo;
+    }
     // + hi_lo * (2^32 - 1)  (2^64 = 2^32 - 1): one multiply-add; when that addition wrapped, + EPS (cannot wrap twice), again as a
     // multiply-add  r + mask * 1  on the register pair; and the canonical form (r >= p  <=>  r + EPS carries out of 64 bits) the same
     // way: a multiply-add for the carry, the mask, a multiply-add that adds it.  Every step works on whole 64-bit pairs, so the
@@ -103,6 +182,7 @@ BFS_HD u64 gl_reduce128_t(u64 hi, u64 lo) {
     u64 r;
 #ifdef BFS_ABL_REDUCE_ADDC          // A/B only: the add-with-carry form
     {
+        const u32 z = gl_opaque_zero();
         u32 m;
         asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\ts_nop 1\n\tv_cndmask_b32 %1, 0, -1, vcc" : "=&v"(r), "=v"(m) : "v"(hl), "v"(t0) : "vcc");
         u32 c2, c3;
@@ -121,25 +201,13 @@ BFS_HD u64 gl_reduce128_t(u64 hi, u64 lo) {
             : "=&v"(q), "=&v"(r), "=&v"(m) : "v"(hl), "v"(t0) : "vcc");
         return r;
     } else {
-        u64 q, q1;
-        u32 m;
-        asm("v_mad_u64_u32 %0, vcc, %4, -1, %5\n\ts_nop 1\n\tv_cndmask_b32 %3, 0, -1, vcc\n\tv_mad_u64_u32 %1, vcc, %3, 1, %0\n\t"
-            "v_mad_u64_u32 %0, vcc, -1, 1, %1\n\ts_nop 1\n\tv_cndmask_b32 %3, 0, -1, vcc\n\tv_mad_u64_u32 %2, vcc, %3, 1, %1"
-            : "=&v"(q), "=&v"(q1), "=&v"(r), "=&v"(m) : "v"(hl), "v"(t0) : "vcc");
-        return r;
+        return gl_fold_word<SUB4>(hl, t0);
     }
 }
 BFS_HD u64 gl_reduce128(u64 hi, u64 lo) { return gl_reduce128_t<true>(hi, lo); }
 
 // lo + top * 2^64 for a 32-bit top  ->  canonical residue (x << r for r < 32 is such a 96-bit value): the tail of gl_reduce128_t
-BFS_HD u64 gl_reduce96(u32 top, u64 lo) {
-    u64 q, q1, r;
-    u32 m;
-    asm("v_mad_u64_u32 %0, vcc, %4, -1, %5\n\ts_nop 1\n\tv_cndmask_b32 %3, 0, -1, vcc\n\tv_mad_u64_u32 %1, vcc, %3, 1, %0\n\t"
-        "v_mad_u64_u32 %0, vcc, -1, 1, %1\n\ts_nop 1\n\tv_cndmask_b32 %3, 0, -1, vcc\n\tv_mad_u64_u32 %2, vcc, %3, 1, %1"
-        : "=&v"(q), "=&v"(q1), "=&v"(r), "=&v"(m) : "v"(top), "v"(lo) : "vcc");
-    return r;
-}
+BFS_HD u64 gl_reduce96(u32 top, u64 lo) { return gl_fold_word<GL_SUB4>(top, lo); }
 
 // 64 x 64 -> 128 in 8 instructions: the two middle products are added by the multiply-add itself (ah*bl + al*bh in ONE
 // v_mad_u64_u32, whose carry-out -- the 2^64 of that sum -- is picked up at once; C cannot ask for it), which leaves one add for
@@ -182,6 +250,12 @@ BFS_HD u64 gl_mul_lazy(u64 a, u64 b) {
     gl_mul128(a, b, hi, lo);
     return gl_reduce128_t<false>(hi, lo);
 }
+// the product through the OTHER form of the reduction's first step (selftest.hip: both forms are compared with the host on the device)
+BFS_HD u64 gl_mul_other_form(u64 a, u64 b) {
+    u64 hi, lo;
+    gl_mul128(a, b, hi, lo);
+    return gl_reduce128_t<true, !GL_SUB4>(hi, lo);
+}
 #else
 BFS_HD u64 gl_add(u64 a, u64 b) {
     u64 s = a + b;
@@ -194,6 +268,8 @@ BFS_HD u64 gl_sub(u64 a, u64 b) {
     u64 d = a - b;
     return a < b ? d - GL_EPS : d;  // borrow: add p (== subtract EPS in wrapped arithmetic)
 }
+BFS_HD u64 gl_sub4(u64 a, u64 b) { return gl_sub(a, b); }      // the device's two instruction sequences (selftest.hip compares both with this)
+BFS_HD u64 gl_sub5(u64 a, u64 b) { return gl_sub(a, b); }
 
 // the device's lazy sum (any 64-bit a, canonical b; result in [0, 2^64), not necessarily canonical), bit for bit
 BFS_HD u64 gl_add_lazy(u64 a, u64 b) {
@@ -227,6 +303,7 @@ BFS_HD u64 gl_mul(u64 a, u64 b) {
     return gl_reduce128((u64)(z >> 64), (u64)z);
 }
 BFS_HD u64 gl_mul_lazy(u64 a, u64 b) { return gl_mul(a, b); }
+BFS_HD u64 gl_mul_other_form(u64 a, u64 b) { return gl_mul(a, b); }
 #endif
 
 BFS_HD u64 gl_sqr(u64 a) { return gl_mul(a, a); }

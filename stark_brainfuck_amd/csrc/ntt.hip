@@ -1,6 +1,11 @@
 // ntt.hip -- gfx950 kernels and launcher for bfs_gl_ntt() (algorithm and reference citations: ntt_core.hpp)
 #include <cstdlib>
 
+// the four-instruction subtraction (gl.hpp: gl_sub4, explicit SGPR carries): 6.9 % fewer VALU instructions per launch of the tile kernels,
+// 8 x 2^24 1.345 -> 1.31 ms on one box (profiles/r03/ab_sub4.txt).  -DBFS_ABL_SUB5 keeps the compiler's five-instruction form for A/B.
+#ifndef BFS_ABL_SUB5
+#define BFS_GL_SUB4
+#endif
 #include "runtime.hpp"
 
 namespace bfs {

@@ -2,11 +2,12 @@
 // The same inline functions (gl.hpp, ntt_core.hpp) compile for both sides; the host side is plain 128-bit arithmetic.
 // It exists because hipcc (ROCm 7.2) miscompiled gl_add(gl_sub(a, b), 1) -- see gl_sub in gl.hpp -- and nothing but a
 // comparison on the device can notice that kind of error.  Called by tests/test_gpu_parity.py.
+#define BFS_GL_SUB4       // every operation below runs the four-instruction subtraction (gl.hpp); operations 34.. the other form
 #include "runtime.hpp"
 
 namespace bfs {
 
-constexpr int ST_OPS = 34;
+constexpr int ST_OPS = 42;
 
 BFS_HD void selftest_ops(u64 a, u64 b, u64* o) {
     const u64 d = gl_sub(a, b), s = gl_add(a, b), m = gl_mul(a, b);
@@ -23,6 +24,9 @@ BFS_HD void selftest_ops(u64 a, u64 b, u64* o) {
     const Xfe z = xfe_mul(xfe_sub_base(xfe_add(x, y), 1ULL), xfe_base_sub(2ULL, xfe_scale(y, b)));
     o[29] = z.c[0]; o[30] = z.c[1]; o[31] = z.c[2];
     o[32] = gl_inv(a); o[33] = gl_mul(gl_inv(d), d);          // the addition chain with non-canonical intermediate squares
+    // both instruction sequences of the subtraction and of the reduction's first step (gl_sub4 / gl_sub5, gl_reduce128_t<.., SUB4>)
+    o[34] = gl_sub5(a, b); o[35] = gl_sub5(gl_sub5(b, a), 2ULL); o[36] = gl_add(gl_sub5(a, b), 1ULL); o[37] = gl_sub4(gl_sub5(m, s), d);
+    o[38] = gl_sub4(b, a); o[39] = gl_add(gl_sub4(gl_sub4(a, b), b), 1ULL); o[40] = gl_mul_other_form(a, b); o[41] = gl_mul_other_form(gl_mul_other_form(d, s), m);
 }
 
 __global__ void selftest_kernel(const u64* in, u64* out, u64 n) {
