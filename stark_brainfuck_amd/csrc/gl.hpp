@@ -96,6 +96,12 @@ BFS_HD u64 gl_sub(u64 a, u64 b) { return gl_sub4(a, b); }
 constexpr bool GL_SUB4 = false;
 BFS_HD u64 gl_sub(u64 a, u64 b) { return gl_sub5(a, b); }
 #endif
+// the reductions' scalar-carry forms (gl_sub_word4 for lo - hi_hi, gl_fold_word<true> for the tail): everywhere unless a unit opts out
+#ifdef BFS_GL_REDUCE_SPLIT
+constexpr bool GL_REDUCE4 = false;
+#else
+constexpr bool GL_REDUCE4 = true;
+#endif
 // a + b: s = a + b and u = s + EPS (= s - p mod 2^64) with both carries; a + b >= p  <=>  either addition carried
 BFS_HD u64 gl_add(u64 a, u64 b) {
     u32 c1, c2, c3, c4;
@@ -159,7 +165,7 @@ BFS_HD u64 gl_fold_word(u32 w, u64 base) {
 // hi*2^64 + lo  ->  residue; CANON = false leaves the value in [0, 2^64) (fine as an operand of further multiplications).
 // 11 VALU instructions (13 with add / add-with-carry pairs, 17 as plain C): the multiply-add  hi_lo * (2^32 - 1) + t0  is ONE v_mad_u64_u32 whose carry-out is used
 // directly -- C has no way to ask for that carry, and the compiler's version is mad + 64-bit add + 64-bit compare.
-template <bool CANON, bool SUB4 = GL_SUB4>
+template <bool CANON, bool SUB4 = GL_REDUCE4>
 BFS_HD u64 gl_reduce128_t(u64 hi, u64 lo) {
     u32 hh = (u32)(hi >> 32), hl = (u32)hi;
     u64 t0;                                            // t0 = lo - hi_hi  (2^96 = -1)
@@ -207,7 +213,7 @@ BFS_HD u64 gl_reduce128_t(u64 hi, u64 lo) {
 BFS_HD u64 gl_reduce128(u64 hi, u64 lo) { return gl_reduce128_t<true>(hi, lo); }
 
 // lo + top * 2^64 for a 32-bit top  ->  canonical residue (x << r for r < 32 is such a 96-bit value): the tail of gl_reduce128_t
-BFS_HD u64 gl_reduce96(u32 top, u64 lo) { return gl_fold_word<GL_SUB4>(top, lo); }
+BFS_HD u64 gl_reduce96(u32 top, u64 lo) { return gl_fold_word<GL_REDUCE4>(top, lo); }
 
 // 64 x 64 -> 128 in 8 instructions: the two middle products are added by the multiply-add itself (ah*bl + al*bh in ONE
 // v_mad_u64_u32, whose carry-out -- the 2^64 of that sum -- is picked up at once; C cannot ask for it), which leaves one add for
@@ -239,7 +245,38 @@ BFS_HD void gl_mul128(u64 a, u64 b, u64& hi, u64& lo) {
     lo = ((u64)l1 << 32) | (u32)A;
     hi = ((u64)h1 << 32) | h0;
 }
+// Product and reduction in one piece: the carry K of the middle sum ah*bl + al*bh (weight 2^96 = -1) never becomes a register -- it stays
+// in the scalar pair the multiply-add wrote it to and enters the reduction's first subtraction  lo - hi_hi  as its borrow-IN
+// (gl_mul128 spends a v_cndmask on it and adds it into hi_hi).  hi_hi + K is the true top word, so nothing overflows.  15 instructions.
+BFS_HD u64 gl_mul_fused(u64 a, u64 b) {
+    const u32 al = (u32)a, ah = (u32)(a >> 32), bl = (u32)b, bh = (u32)(b >> 32);
+    const u64 A = (u64)al * bl, B = (u64)ah * bh, M1 = (u64)al * bh;
+    u64 M, sk;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=&v"(M), "=s"(sk) : "v"(ah), "v"(bl), "v"(M1));
+    u32 k2, c3, c4;
+    const u32 z = gl_opaque_zero();
+    u32 l1 = __builtin_addc((u32)(A >> 32), (u32)M, 0u, &k2);
+    u32 h0 = __builtin_addc((u32)B, (u32)(M >> 32), k2, &c3);
+    u32 h1 = __builtin_addc((u32)(B >> 32), z, c3, &c4);            // hi_hi without K
+    u32 rlo, rhi;
+    u64 sb, sc;
+    asm("v_subb_co_u32 %0, vcc, %4, %6, %7\n\t"                    // lo_lo - hi_hi - K
+        "s_nop 1\n\t"
+        "v_subb_co_u32 %1, %2, %5, 0, vcc\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %0, %3, %0, 0, %2\n\t"
+        "s_nop 1\n\t"
+        "s_andn2_b64 %2, %2, %3\n\t"
+        "v_subb_co_u32 %1, vcc, %1, 0, %2"
+        : "=&v"(rlo), "=&v"(rhi), "=&s"(sb), "=&s"(sc)
+        : "v"((u32)A), "v"(l1), "v"(h1), "s"(sk)
+        : "vcc", "scc");
+    return gl_fold_word<true>(h0, ((u64)rhi << 32) | rlo);
+}
 BFS_HD u64 gl_mul(u64 a, u64 b) {
+#ifndef BFS_ABL_MUL_UNFUSED
+    if constexpr (GL_REDUCE4) return gl_mul_fused(a, b);
+#endif
     u64 hi, lo;
     gl_mul128(a, b, hi, lo);
     return gl_reduce128_t<true>(hi, lo);
@@ -254,7 +291,7 @@ BFS_HD u64 gl_mul_lazy(u64 a, u64 b) {
 BFS_HD u64 gl_mul_other_form(u64 a, u64 b) {
     u64 hi, lo;
     gl_mul128(a, b, hi, lo);
-    return gl_reduce128_t<true, !GL_SUB4>(hi, lo);
+    return gl_reduce128_t<true, !GL_REDUCE4>(hi, lo);
 }
 #else
 BFS_HD u64 gl_add(u64 a, u64 b) {
