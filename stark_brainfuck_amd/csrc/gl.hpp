@@ -103,6 +103,23 @@ constexpr bool GL_REDUCE4 = false;
 constexpr bool GL_REDUCE4 = true;
 #endif
 // a + b: s = a + b and u = s + EPS (= s - p mod 2^64) with both carries; a + b >= p  <=>  either addition carried
+#if defined(BFS_GL_SUB4) && defined(BFS_ABL_ADD5)
+// A/B only (profiles/r03/ab_add5.txt): five instructions -- the sum's carry K in a scalar pair, K2 from ONE multiply-add s + EPS, the
+// scalar OR, a mask and a multiply-add that adds it (gl_fold_word's tail) -- against six with two selects
+BFS_HD u64 gl_add(u64 a, u64 b) {
+    u32 slo, shi, m;
+    u64 sk, r;
+    asm("v_add_co_u32 %0, vcc, %3, %5\n\ts_nop 1\n\tv_addc_co_u32 %1, %2, %4, %6, vcc"
+        : "=&v"(slo), "=v"(shi), "=s"(sk) : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)) : "vcc");
+    const u64 s = ((u64)shi << 32) | slo;
+    asm("v_mad_u64_u32 %0, vcc, -1, 1, %2\n\t"
+        "s_or_b64 vcc, vcc, %3\n\t"
+        "v_cndmask_b32 %1, 0, -1, vcc\n\t"
+        "v_mad_u64_u32 %0, vcc, %1, 1, %2"
+        : "=&v"(r), "=&v"(m) : "v"(s), "s"(sk) : "vcc", "scc");
+    return r;
+}
+#else
 BFS_HD u64 gl_add(u64 a, u64 b) {
     u32 c1, c2, c3, c4;
     u32 slo = __builtin_addc((u32)a, (u32)b, 0u, &c1);
@@ -112,6 +129,7 @@ BFS_HD u64 gl_add(u64 a, u64 b) {
     const bool over = (c2 | c4) != 0;
     return over ? (((u64)uhi << 32) | ulo) : (((u64)shi << 32) | slo);
 }
+#endif
 
 // a + b for b canonical and ANY 64-bit a; the result is congruent to a + b and lies in [0, 2^64) but need not be canonical: fine
 // as the first operand of gl_add_lazy / gl_sub (the minuend), of mul_pow2 and of a multiplication -- never as a subtrahend, never
