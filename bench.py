@@ -11,7 +11,8 @@ value = total field elements transformed per second over all ranks, timed over e
 synchronisation on both sides, max over ranks.  After the timed region every rank commits to its output columns and the 64-byte
 roots are all-gathered (shard.gather_roots over RCCL: the only collective of the design, never inside the timed region).
 Extra keys on the same JSON line:
-    roofline      dominant kernel (the NTT tile kernel) vs the 8 TB/s HBM roofline, from HIP events on the kernel's stream; bound_actual /
+    roofline      dominant kernel (the NTT tile kernel) vs the 8 TB/s HBM roofline, from HIP events on the kernel's stream; hbm_physical: the bytes
+                  really moved (3 passes) against the spec peak and the tile shape's copy roof; bound_actual /
                   roofline.valu: the integer-VALU roofline that actually binds (1024 SIMDs x sclk / 4 wave instructions per second)
     cpu_baseline  the CPU oracle (oracle/gl_oracle.c, plain C port of ntt.py, 1 core) on a bounded sample, rank 0, N=1 only;
                   cpu_baseline.python: the same algorithm in pure Python on boxed elements (the reference's cost model) at 2^14 / 2^16, timed live;
@@ -349,17 +350,28 @@ def main():
         if traffic is not None:
             valu_obj = valu_roofline(t["valu_wave_instructions_per_step"], kern * 1e-3 / args.steps, sclk,
                                      "SQ_INSTS_VALU of the three launches of a step (static: profiles/ntt_traffic.json) over the HIP-event time of a step")
-        line["roofline"] = {"bound": "hbm", "bound_actual": "valu_int", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                            "valu": valu_obj,
+        # the physical side of the same launches: bytes the memory system really moved (PMC, static) over the HIP-event launch time, against
+        # the spec peak and against what a kernel that only MOVES this tile shape reaches (tools/microbench/mem3.hip, profiles/r02)
+        COPY_ROOF_GBS = 5200.0
+        hbm_phys = None
+        if traffic is not None:
+            rate = traffic / avg_launch_s / 1e9
+            hbm_phys = {"achieved": rate, "unit": "GB/s", "frac_of_peak": rate / HBM_PEAK_GBS, "copy_roof_of_tile_shape": COPY_ROOF_GBS,
+                        "frac_of_copy_roof": rate / COPY_ROOF_GBS,
+                        "model": "HBM bytes per launch (static: profiles/ntt_traffic.json) over this run's average launch time; copy roof: "
+                                 "256 rows x 128-byte segments with non-temporal 8-byte accesses, profiles/r02/microbench_tile_copy_roof.txt"}
+        line["roofline"] = {"bound": "hbm", "bound_actual": "valu_int + hbm (three passes): co-limited", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                            "valu": valu_obj, "hbm_physical": hbm_phys,
                             "traffic": traffic, "traffic_source": tsrc,
                             "wasted_traffic_ratio": (traffic / bytes_per_launch) if traffic else None,
                             "valu_issue_frac": valu_frac,
                             "valu_issue_frac_at_sustained_sclk": valu_frac_sustained,
                             "kernel": "ntt_tile_kernel_split<4,4,0,4,MODE,NT>" + ("(non-temporal data accesses)" if n * cols * 8 > (128 << 20) else ""), "launches_per_step": npass,
                             "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
-                            "note": "three HBM passes move 3x the algorithmic bytes; the step is bound by integer VALU issue at the shader clock the "
-                                    "1400 W package limit allows (sustained.sclk_mhz_under_load, one rocm-smi sample; the XCDs' clocks differ by a few "
-                                    "per cent, so the sustained-clock fraction can read slightly above 1) -- DESIGN.md 4.1"}
+                            "note": "three HBM passes move 3x the algorithmic bytes; after the scalar-carry arithmetic (296 VALU instructions per element) "
+                                    "the step sits within a few per cent of BOTH roofs: integer VALU issue at the shader clock the 1400 W package limit "
+                                    "allows (roofline.valu; sustained.sclk_mhz_under_load is one rocm-smi sample and the XCDs' clocks differ by a few per "
+                                    "cent) and the copy roof of the passes' tile shape (roofline.hbm_physical) -- DESIGN.md 4.1"}
         if log_n == 24 and not args.no_single:
             line["single_column_2p24"] = bench_single_column(lib, _lib, d_in, d_out, n, log_n, root, stream)
             line["pcie_inclusive_2p24"] = bench_pcie_inclusive(lib, _lib, d_in, d_out, n, log_n, root, stream)
