@@ -1,7 +1,7 @@
 """Which buffers are slow?  (development tool)  The out-of-place passes of the 8 x 2^24 NTT step run at two speeds from one process to the
 next on the same box (pass 0 447 or 472-495 us, pass 2 412 or 450-478 us; the in-place pass is always 439-447).  This times the step for
 every ordered pair (input buffer, output buffer) out of K separately allocated 1 GiB buffers: if a BUFFER is slow, every pair that reads it
-(pass 0) or writes it (pass 2) is slow.   python tools/buffer_pairs.py [K] [ws-first] [two-ws]
+(pass 0) or writes it (pass 2) is slow.   python tools/buffer_pairs.py [K] [ws-first] [two-ws] [one-slab]
 (ws-first: the library's intermediate buffer is allocated before the K buffers; two-ws: the table once more on a second stream, i.e. with
 a second intermediate buffer.)  Findings: profiles/r03/buffer_placement.txt."""
 import ctypes, json, os, sys, time
@@ -18,7 +18,15 @@ if WS_FIRST:                                   # a first transform allocates the
     _lib.check(lib.bfs_gl_ntt(a.ptr, n, n, b.ptr, n, logn, cols, lib.bfs_gl_primitive_root(logn), 1, 1, 0))
     synchronize(0)
     print("first pair:", hex(a.ptr), hex(b.ptr), flush=True)
-bufs = [DeviceBuffer(n * cols) for _ in range(K)]
+if "one-slab" in sys.argv:                     # the K buffers are consecutive 1 GiB ranges of ONE allocation
+    slab = DeviceBuffer(n * cols * K)
+
+    class View:
+        def __init__(self, ptr):
+            self.ptr = ptr
+    bufs = [View(slab.ptr + i * n * cols * 8) for i in range(K)]
+else:
+    bufs = [DeviceBuffer(n * cols) for _ in range(K)]
 print("addresses:", [hex(b.ptr) for b in bufs], flush=True)
 v = (np.arange(n * cols, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) % np.uint64(0xFFFFFFFF00000001)
 for b in bufs:
