@@ -181,7 +181,8 @@ BFS_HD u64 gl_fold_word(u32 w, u64 base) {
 }
 
 // hi*2^64 + lo  ->  residue; CANON = false leaves the value in [0, 2^64) (fine as an operand of further multiplications).
-// 11 VALU instructions (13 with add / add-with-carry pairs, 17 as plain C): the multiply-add  hi_lo * (2^32 - 1) + t0  is ONE v_mad_u64_u32 whose carry-out is used
+// 8 VALU instructions in the scalar-carry forms (gl_sub_word4 + gl_fold_word<true>: 4 + 4; 11 in the split forms, 13 with add / add-with-carry pairs, 17 as
+// plain C): the multiply-add  hi_lo * (2^32 - 1) + t0  is ONE v_mad_u64_u32 whose carry-out is used
 // directly -- C has no way to ask for that carry, and the compiler's version is mad + 64-bit add + 64-bit compare.
 template <bool CANON, bool SUB4 = GL_REDUCE4>
 BFS_HD u64 gl_reduce128_t(u64 hi, u64 lo) {
