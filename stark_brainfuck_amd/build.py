@@ -103,7 +103,8 @@ def build_library(force=False, verbose=False, extra_flags=()):
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
-    compile_flags = [f for f in FLAGS if f != "-shared"] + list(extra_flags)
+    # -save-temps=obj leaves each unit's gfx950 listing next to its object (_build/*-gfx950.s): tools/isa_hazards.py scans what ships
+    compile_flags = [f for f in FLAGS if f != "-shared"] + ["-save-temps=obj"] + list(extra_flags)
     key = " ".join([hipcc] + compile_flags)
     jobs, objects = [], []
     for src in sources():

@@ -279,7 +279,11 @@ BFS_HD u64 gl_mul_fused(u64 a, u64 b) {
     u32 h1 = __builtin_addc((u32)(B >> 32), z, c3, &c4);            // hi_hi without K
     u32 rlo, rhi;
     u64 sb, sc;
-    asm("v_subb_co_u32 %0, vcc, %4, %6, %7\n\t"                    // lo_lo - hi_hi - K
+    // (s_nop 1 first: K was written by a VALU instruction in ANOTHER asm statement, and gfx950 wants two wait states between a VALU
+    //  write of an SGPR and a VALU read of it as a carry; the compiler cannot see either side, and for a constant operand it has been
+    //  seen to leave a single s_nop 0 between the two -- round-3 advice; tools/isa_hazards.py scans the shipped ISA for this)
+    asm("s_nop 1\n\t"
+        "v_subb_co_u32 %0, vcc, %4, %6, %7\n\t"                    // lo_lo - hi_hi - K
         "s_nop 1\n\t"
         "v_subb_co_u32 %1, %2, %5, 0, vcc\n\t"
         "s_nop 1\n\t"

@@ -2,19 +2,18 @@
 #include <cstdlib>
 
 // the four-instruction subtraction (gl.hpp: gl_sub4, explicit SGPR carries): 6.9 % fewer VALU instructions per launch of the tile kernels,
-// 8 x 2^24 1.345 -> 1.31 ms on one box (profiles/r03/ab_sub4.txt).  -DBFS_ABL_SUB5 keeps the compiler's five-instruction form for A/B.
-#ifndef BFS_ABL_SUB5
+// 8 x 2^24 1.345 -> 1.31 ms on one box (profiles/r03/ab_sub4.txt)
 #define BFS_GL_SUB4
-#endif
 #include "runtime.hpp"
 
 namespace bfs {
 
 // One workgroup per tile: T/16 threads hold 16 elements each.  LDS = tile (padded) + the stage-1 -> stage-2 twiddles.
-// (A persistent variant with next-tile prefetch and 16-byte paired-lane accesses was measured slower: the kernel is
-//  VALU-issue bound at the time and hardware workgroup turnover already overlaps HBM latency)
+// Used by single-pass plans (n <= 4096: up to three register stages) and by the single-stage (4-bit) digits of multi-pass plans.
+// (A persistent variant with next-tile prefetch and 16-byte paired-lane accesses was measured slower: hardware workgroup turnover
+//  already overlaps HBM latency)
 template <int B1, int B2, int B3, int LOGC, int MODE, bool NT>
-__global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a, const int early_loads) {
+__global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) u64 smem[];
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     u64* tw = smem + (B2 > 0 ? ((Cfg::LDS_WORDS + 1) & ~1) : 0);
@@ -24,35 +23,29 @@ __global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a, const i
     // front of the loads, a workgroup spent an L2 round trip and a half before its HBM loads were even issued.)
     static_assert(B1 == 4, "one sub-group of 16 elements per thread");
     constexpr u32 TW_N = Cfg::U >= 2 ? (1u << (B1 + B2)) : 0;
-    const u64* tab = (Cfg::U == 2 && MODE == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;   // n^-1 folded in when it is the last inner twiddle
+    const u64* tab = a.tw1;
     const u32 tw_shift = a.tb.t_in_log - (B1 + B2);
-    const bool early = early_loads != 0;
     const u32 tid = threadIdx.x;
-    // this tile's row of a product table (one coalesced 2^S-entry read per workgroup): factors of its input rows, or -- first pass of
-    // a balanced plan -- of its output rows; never both
-    const u64* lrow = tile_load_row<Cfg, MODE>(a, blockIdx.x);
+    // this tile's row of a product table (one coalesced 2^S-entry read per workgroup): factors of its input rows (last pass of a
+    // balanced plan) or of its output rows (first pass); never both
+    const u64* lrow = tile_load_row<Cfg, LOGC, MODE>(a, blockIdx.x);
     const u64* srow_g = tile_store_row<Cfg, LOGC, MODE>(a, blockIdx.x);
     const u64* row = lrow ? lrow : srow_g;
     const bool has_row = row != nullptr;
     u64 tw0 = 0, rw0 = 0;
-    if (early) {
-        if (TW_N && tid < TW_N) tw0 = tab[(u64)tid << tw_shift];
-        if (has_row && tid < (1u << Cfg::S)) rw0 = row[tid];
-    }
+    if (TW_N && tid < TW_N) tw0 = tab[(u64)tid << tw_shift];
+    if (has_row && tid < (1u << Cfg::S)) rw0 = row[tid];
     u64 x[16];
-    if (early) ntt_stage1_load<B1, B2, B3, LOGC, MODE, NT>(a, tid, blockIdx.x, blockIdx.y, 0, x);
+    ntt_stage1_load<B1, B2, B3, LOGC, MODE, NT>(a, tid, blockIdx.x, blockIdx.y, 0, x);
     u64* rw = tw + Cfg::TW_WORDS;
-    if (early) {
-        if (TW_N && tid < TW_N) tw[tid] = tw0;
-        if (has_row && tid < (1u << Cfg::S)) rw[tid] = rw0;
-    }
-    for (u32 i = tid + (early ? blockDim.x : 0); i < TW_N; i += blockDim.x) tw[i] = tab[(u64)i << tw_shift];
+    if (TW_N && tid < TW_N) tw[tid] = tw0;
+    if (has_row && tid < (1u << Cfg::S)) rw[tid] = rw0;
+    for (u32 i = tid + blockDim.x; i < TW_N; i += blockDim.x) tw[i] = tab[(u64)i << tw_shift];
     if (has_row)
-        for (u32 i = tid + (early ? blockDim.x : 0); i < (1u << Cfg::S); i += blockDim.x) rw[i] = row[i];
+        for (u32 i = tid + blockDim.x; i < (1u << Cfg::S); i += blockDim.x) rw[i] = row[i];
     const u64* rowtw = lrow ? rw : nullptr;
     const u64* srow = srow_g && !lrow ? rw : nullptr;
     if (Cfg::U >= 2 || has_row) __syncthreads();
-    if (!early) ntt_stage1_load<B1, B2, B3, LOGC, MODE, NT>(a, tid, blockIdx.x, blockIdx.y, 0, x);
     ntt_stage1_compute<B1, B2, B3, LOGC, MODE, NT>(a, smem, tw, rowtw, threadIdx.x, blockIdx.x, blockIdx.y, 0, x, srow);
     if constexpr (B2 > 0) {
         __syncthreads();
@@ -64,7 +57,7 @@ __global__ void __launch_bounds__(256) ntt_tile_kernel(const PassArgs a, const i
     }
 }
 
-// Two-stage tiles of multi-pass plans: the SAME kernel, but the stage 1 -> 2 exchange goes through LDS in two halves -- the low
+// Two-stage tiles of multi-pass plans: the stage 1 -> 2 exchange goes through LDS in two halves -- the low
 // 32-bit words of all 4096 values, then the high words -- so that the tile buffer is 17 KiB instead of 34 and a workgroup needs
 // 21.5 KiB of LDS instead of 39.  With 39 KiB four workgroups (4 waves per SIMD) fit a CU, and a SIMD whose four waves are all
 // waiting -- for their loads, at a barrier -- idles: VALU issue was 82 % of the time.  A timing-only experiment (the same kernel
@@ -84,10 +77,10 @@ __global__ void __launch_bounds__(256, B2 >= 3 ? BFS_NTT_SPLIT_WAVES : 0) ntt_ti
     u32* tile = (u32*)smem;
     u64* tw = (u64*)((char*)smem + TILE_BYTES);
     constexpr u32 TW_N = 1u << (B1 + B2);
-    const u64* tab = (MODE == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;      // U == 2: n^-1 folded into the last inner twiddle
+    const u64* tab = a.tw1;                                                  // n^-1 folded in when this is the last pass
     const u32 tw_shift = a.tb.t_in_log - (B1 + B2);
     const u32 tid = threadIdx.x;
-    const u64* lrow = tile_load_row<Cfg, MODE>(a, blockIdx.x);
+    const u64* lrow = tile_load_row<Cfg, LOGC, MODE>(a, blockIdx.x);
     const u64* srow_g = tile_store_row<Cfg, LOGC, MODE>(a, blockIdx.x);
     const u64* row = lrow ? lrow : srow_g;
     const bool has_row = row != nullptr;
@@ -145,11 +138,10 @@ static int launch_tile(const PassArgs& a, u32 grid_x, u32 batch, hipStream_t str
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     const size_t row_words = (a.tb.row != nullptr || a.tb.srow != nullptr) ? (1u << Cfg::S) : 0;
     const size_t lds = (size_t)((B2 > 0 ? ((Cfg::LDS_WORDS + 1) & ~1) + Cfg::TW_WORDS : 0) + row_words) * sizeof(u64);
-    static const int early = [] { const char* e = getenv("BFS_NTT_EARLY_LOADS"); return (e && e[0] == '0') ? 0 : 1; }();   // A/B switch
     if (a.streaming)
-        hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, LOGC, MODE, true>), dim3(grid_x, batch), dim3(Cfg::W), lds, stream, a, early);
+        hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, LOGC, MODE, true>), dim3(grid_x, batch), dim3(Cfg::W), lds, stream, a);
     else
-        hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, LOGC, MODE, false>), dim3(grid_x, batch), dim3(Cfg::W), lds, stream, a, early);
+        hipLaunchKernelGGL((ntt_tile_kernel<B1, B2, B3, LOGC, MODE, false>), dim3(grid_x, batch), dim3(Cfg::W), lds, stream, a);
     BFS_HIP(hipGetLastError());
     return BFS_OK;
 }
@@ -157,21 +149,12 @@ static int launch_tile(const PassArgs& a, u32 grid_x, u32 batch, hipStream_t str
 // multi-pass plans use 4096-element tiles (logC = 12 - S, S = 4..8); single-pass plans one column of 2^S rows (S = 4..12)
 template <int MODE>
 static int dispatch_multi(const PassArgs& a, u32 S, u32 grid_x, u32 batch, hipStream_t stream) {
-    static const bool split = [] { const char* e = getenv("BFS_NTT_SPLIT"); return !(e && e[0] == '0'); }();   // A/B switch (tools/ab_ntt.sh)
-    if (split) {
-        switch (S) {
-            case 5: return launch_tile_split<4, 1, 0, 7, MODE>(a, grid_x, batch, stream);
-            case 6: return launch_tile_split<4, 2, 0, 6, MODE>(a, grid_x, batch, stream);
-            case 7: return launch_tile_split<4, 3, 0, 5, MODE>(a, grid_x, batch, stream);
-            case 8: return launch_tile_split<4, 4, 0, 4, MODE>(a, grid_x, batch, stream);
-        }
-    }
     switch (S) {
         case 4: return launch_tile<4, 0, 0, 8, MODE>(a, grid_x, batch, stream);
-        case 5: return launch_tile<4, 1, 0, 7, MODE>(a, grid_x, batch, stream);
-        case 6: return launch_tile<4, 2, 0, 6, MODE>(a, grid_x, batch, stream);
-        case 7: return launch_tile<4, 3, 0, 5, MODE>(a, grid_x, batch, stream);
-        case 8: return launch_tile<4, 4, 0, 4, MODE>(a, grid_x, batch, stream);
+        case 5: return launch_tile_split<4, 1, 0, 7, MODE>(a, grid_x, batch, stream);
+        case 6: return launch_tile_split<4, 2, 0, 6, MODE>(a, grid_x, batch, stream);
+        case 7: return launch_tile_split<4, 3, 0, 5, MODE>(a, grid_x, batch, stream);
+        case 8: return launch_tile_split<4, 4, 0, 4, MODE>(a, grid_x, batch, stream);
     }
     set_error("internal: no tile kernel for a %u-bit digit of a multi-pass plan", S);
     return BFS_ERR_BAD_ARG;
@@ -179,15 +162,15 @@ static int dispatch_multi(const PassArgs& a, u32 S, u32 grid_x, u32 batch, hipSt
 
 static int dispatch_single(const PassArgs& a, u32 S, u32 batch, hipStream_t stream) {
     switch (S) {
-        case 4: return launch_tile<4, 0, 0, 0, PASS_FINAL>(a, 1, batch, stream);
-        case 5: return launch_tile<4, 1, 0, 0, PASS_FINAL>(a, 1, batch, stream);
-        case 6: return launch_tile<4, 2, 0, 0, PASS_FINAL>(a, 1, batch, stream);
-        case 7: return launch_tile<4, 3, 0, 0, PASS_FINAL>(a, 1, batch, stream);
-        case 8: return launch_tile<4, 4, 0, 0, PASS_FINAL>(a, 1, batch, stream);
-        case 9: return launch_tile<4, 4, 1, 0, PASS_FINAL>(a, 1, batch, stream);
-        case 10: return launch_tile<4, 4, 2, 0, PASS_FINAL>(a, 1, batch, stream);
-        case 11: return launch_tile<4, 4, 3, 0, PASS_FINAL>(a, 1, batch, stream);
-        case 12: return launch_tile<4, 4, 4, 0, PASS_FINAL>(a, 1, batch, stream);
+        case 4: return launch_tile<4, 0, 0, 0, PASS_SINGLE>(a, 1, batch, stream);
+        case 5: return launch_tile<4, 1, 0, 0, PASS_SINGLE>(a, 1, batch, stream);
+        case 6: return launch_tile<4, 2, 0, 0, PASS_SINGLE>(a, 1, batch, stream);
+        case 7: return launch_tile<4, 3, 0, 0, PASS_SINGLE>(a, 1, batch, stream);
+        case 8: return launch_tile<4, 4, 0, 0, PASS_SINGLE>(a, 1, batch, stream);
+        case 9: return launch_tile<4, 4, 1, 0, PASS_SINGLE>(a, 1, batch, stream);
+        case 10: return launch_tile<4, 4, 2, 0, PASS_SINGLE>(a, 1, batch, stream);
+        case 11: return launch_tile<4, 4, 3, 0, PASS_SINGLE>(a, 1, batch, stream);
+        case 12: return launch_tile<4, 4, 4, 0, PASS_SINGLE>(a, 1, batch, stream);
     }
     set_error("internal: no tile kernel for a %u-bit single-pass transform", S);
     return BFS_ERR_BAD_ARG;
@@ -195,7 +178,7 @@ static int dispatch_single(const PassArgs& a, u32 S, u32 batch, hipStream_t stre
 
 static int dispatch_tile(const NttPlan& p, u32 t, const PassArgs& a, u32 grid_x, u32 batch, hipStream_t stream) {
     if (p.npass == 1) return dispatch_single(a, p.pass_bits[0], batch, stream);
-    if (t + 1 == p.npass) return dispatch_multi<PASS_FINAL>(a, p.pass_bits[t], grid_x, batch, stream);
+    if (t == 0) return dispatch_multi<PASS_FIRST>(a, p.pass_bits[t], grid_x, batch, stream);
     return dispatch_multi<PASS_COLUMN>(a, p.pass_bits[t], grid_x, batch, stream);
 }
 
@@ -295,23 +278,34 @@ int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_str
     NttTables tb;
     BFS_TRY(get_tables(p, root, shift, post_scale, tb));
     // non-temporal data accesses once a buffer of the call no longer fits the Infinity Cache next to its neighbours (ntt_core.hpp);
-    // BFS_NTT_STREAMING=0 / 1 forces the choice (A/B)
+    // BFS_NTT_STREAMING=0 / 1 forces the choice (A/B, tools/ab_ntt.sh)
     static const int force_streaming = [] { const char* e = getenv("BFS_NTT_STREAMING"); return e ? atoi(e) : -1; }();
     const u32 streaming = force_streaming >= 0 ? (u32)(force_streaming != 0) : (u32)((u64)n * batch * sizeof(u64) > NTT_STREAMING_BYTES);
+    // Where the passes run.  Pass 0 transposes (it cannot run in place); every later pass rewrites the slots it read.  Separate
+    // input and output: in -> out, then in place on out -- no intermediate buffer.  Input and output overlapping (a transform "in
+    // place" for the caller): in -> intermediate, intermediate -> out in pass 1 (whose tiles touch one 2^(S_0+S_1)-element block
+    // each, so reading one buffer and writing another costs it nothing), then in place on out.
+    const u64* in_end = d_in + (u64)(batch - 1) * in_stride + n_in;
+    const u64* out_end = d_out + (u64)(batch - 1) * out_stride + n;
+    const bool overlap = p.npass > 1 && n_in != 0 && d_in < out_end && d_out < in_end;
     u64* ws = nullptr;
-    if (p.npass > 1) {
-        // BFS_NTT_WS_OFFSET (A/B, profiles/r03/ab_workspace_offset.txt): the intermediate buffer starts that many bytes into its
-        // allocation, so that a pass reading offset X of one buffer and writing offset X of the other meets different HBM banks
-        static const size_t ws_offset = [] { const char* e = getenv("BFS_NTT_WS_OFFSET"); return e ? (size_t)atoll(e) & ~(size_t)127 : (size_t)0; }();
+    if (overlap) {
         void* w = nullptr;
-        BFS_TRY(workspace(0, (size_t)n * batch * sizeof(u64) + ws_offset, stream, &w));
-        ws = (u64*)((char*)w + ws_offset);
+        BFS_TRY(workspace(0, (size_t)n * batch * sizeof(u64), stream, &w));
+        ws = (u64*)w;
     }
     for (u32 t = 0; t < p.npass; ++t) {
-        const bool first = t == 0, last = t + 1 == p.npass;
         BFS_TRY(get_row_tables(p, t, root, &tb.row, &tb.srow));
-        PassArgs a = ntt_pass_args(p, t, first ? d_in : ws, last ? d_out : ws, first ? in_stride : n, last ? out_stride : n,
-                                   first ? n_in : n, tb, shift != 1, shift, post_scale);
+        const u64* src = d_out;
+        u64* dst = d_out;
+        u64 src_stride = out_stride, dst_stride = out_stride;
+        if (t == 0) {
+            src = d_in; src_stride = in_stride;
+            if (overlap) { dst = ws; dst_stride = n; }
+        } else if (t == 1 && overlap) {
+            src = ws; src_stride = n;
+        }
+        PassArgs a = ntt_pass_args(p, t, src, dst, src_stride, dst_stride, t == 0 ? n_in : n, tb, shift != 1, shift, post_scale);
         a.streaming = streaming;
         u32 grid_x = (u32)((n >> p.pass_bits[t]) >> p.logC[t]);
         BFS_TRY(dispatch_tile(p, t, a, grid_x, batch, stream));

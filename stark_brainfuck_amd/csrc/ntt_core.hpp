@@ -6,11 +6,17 @@
 //   Polynomial.scale()  univariate.py:168-169     c_j * s^j, fused into the first pass' load (coset evaluation)
 //   zero padding of fast_coset_evaluate  ntt.py:164-168  fused: inputs j >= n_in read as 0, never materialised
 //
-// Algorithm (DESIGN.md "NTT"): n = n_1 * n_2 * ... * n_m (m <= 4 HBM passes, n_t = 2^S_t, S_t <= 12).
-// Pass t transforms digit t of the input index (most significant first).  After pass t the slot that held input
-// digit j_t holds output digit k_t, so after all passes slot (p_1|p_2|...|p_m) holds X[p_1 + n_1 p_2 + ...]; the
-// last pass writes straight to that natural-order index.  Between passes the element is multiplied by
-// w_{N_{t+1}}^(j_{t+1} * K_t) (N_t = n_1..n_t, K_t = k_1 + n_1 k_2 + ...), applied while pass t+1 loads.
+// Algorithm (DESIGN.md "NTT"): n = n_0 * n_1 * ... * n_{m-1} (m <= 4 HBM passes, n_t = 2^S_t, S_t <= 12), input index
+// j = (j_0 | j_1 | ... | j_{m-1}) with j_0 most significant, output index k = k_0 + n_0 k_1 + n_0 n_1 k_2 + ...
+// Pass 0 (PASS_FIRST) reads the column tiles of digit j_0 -- all n_0 rows x C adjacent values of l = (j_1|...|j_{m-1}) -- transforms
+// them into k_0 and writes the TRANSPOSED slot (j_{m-1} | ... | j_1 | k_0): C contiguous rows of n_0 elements.  Every later pass t
+// (PASS_COLUMN) then finds the slot layout (j_{m-1} | ... | j_{t+1} | j_t | k_{t-1} | ... | k_0), transforms digit j_t in its slot
+// (rows at stride n_0..n_{t-1}, C adjacent values of the finished low part K = k_0 + n_0 k_1 + ...) and leaves k_t there: after
+// the last pass the slot index IS the natural output index.  Only pass 0 reads one buffer and writes another; passes 1.. run in
+// place on the output, so a call with separate input and output needs no intermediate buffer at all (round 4; before, the LAST
+// pass did the transposition and both the first and the last pass were out of place through a library-owned buffer, whose
+// placement relative to the caller's buffers decided 10 % of the step: profiles/r03/buffer_placement.txt).
+// Before pass t transforms j_t the element is multiplied by w_{N_t}^(j_t * K) (N_t = n_0..n_t); K is the tile's COLUMN index.
 // Inside a pass the 2^S-point column transform is again split into <= 3 register stages of radix 2^B <= 16:
 // every thread holds 16 elements in VGPRs, runs a decimation-in-frequency network whose twiddles are powers
 // of two (any primitive 16th root of unity in this field is 2^(12u), u odd), multiplies by the inner twiddle
@@ -74,45 +80,25 @@ BFS_HD u64 mul_pow2(u64 x) {
 }
 
 // one level of the radix-Q decimation-in-frequency network, twiddle w_Q = 2^(192/Q).
-// LAZY (A/B switch BFS_NTT_LAZY_SUMS, profiles/r03/ab_lazy_minuend.txt): x[0] of a block is only ever the FIRST operand of the levels
-// below it (never a subtrahend), and gl_sub / mul_pow2 / a multiplication take any 64-bit value in that place -- so its sum may stay
-// unreduced in [0, 2^64) (gl_add_lazy: 5 instructions instead of 6): 15 of the 32 sums of a radix-16 block.  Every output that
-// descends from a lazy x[0] only through sums and untwiddled differences is then non-canonical as well, so only a block whose
-// outputs are all multiplied next (the first stage of a pass) can do this.
-template <int Q, int I, bool LAZY>
+// (Sums left unreduced where only the minuend role follows -- "lazy sums" -- were built and measured in round 3: more instructions,
+//  not fewer, once every non-canonical descendant is accounted for; profiles/r03/ab_ntt_three_experiments.txt.)
+template <int Q, int I>
 BFS_HD void dif_level(u64* x) {
     if constexpr (I < Q / 2) {
         u64 a = x[I], b = x[I + Q / 2];
-        if constexpr (LAZY && I == 0) x[I] = gl_add_lazy(a, b);
-        else x[I] = gl_add(a, b);
+        x[I] = gl_add(a, b);
         x[I + Q / 2] = mul_pow2<(192 / Q) * I>(gl_sub(a, b));
-        dif_level<Q, I + 1, LAZY>(x);
+        dif_level<Q, I + 1>(x);
     }
 }
 
-#ifdef BFS_NTT_LAZY_SUMS
-constexpr bool NTT_LAZY_SUMS = true;
-#else
-constexpr bool NTT_LAZY_SUMS = false;
-#endif
-
-// Q-point NTT with root 2^(192/Q); result for output index k is left in x[bitrev(k)].  LAZY: see dif_level (outputs in [0, 2^64))
-template <int Q, bool LAZY = false>
+// Q-point NTT with root 2^(192/Q); result for output index k is left in x[bitrev(k)]
+template <int Q>
 BFS_HD void dif(u64* x) {
     if constexpr (Q >= 2) {
-        dif_level<Q, 0, LAZY>(x);
-        dif<Q / 2, LAZY>(x);
-        dif<Q / 2, LAZY>(x + Q / 2);
-    }
-}
-
-// a layer of power-of-two twiddles with compile-time exponents (what a tile-uniform exponent costs after a uniform branch): register d
-// times 2^(3 d (V + 1) mod 96); 15 of 16 registers non-trivial.  Only used by the timing-only switch BFS_ABL_R64.
-template <int Q, int V, int D = 0>
-BFS_HD void pow2_layer(u64* x) {
-    if constexpr (D < Q) {
-        x[D] = mul_pow2<(3 * D * (V + 1) + (D ? 5 * V : 0)) % 96>(x[D]);
-        pow2_layer<Q, V, D + 1>(x);
+        dif_level<Q, 0>(x);
+        dif<Q / 2>(x);
+        dif<Q / 2>(x + Q / 2);
     }
 }
 
@@ -153,14 +139,17 @@ struct NttTables {
     u32 lo_bits;
     u32 t_in_log;          // inner table has 2^t_in_log entries: Omega^i, Omega = w^(n / 2^t_in_log)
     const u64* t_in;
-    const u64* t_in_last;  // Omega^i * post_scale (used for the last inner twiddle of the final pass)
+    const u64* t_in_last;  // Omega^i * post_scale (the last inner twiddle of the last pass: n^-1 of intt costs nothing)
     const u64* s_lo;       // coset shift s: s^i, i < 2^lo_bits (null when no coset)
     const u64* s_hi;       // s^(i * 2^lo_bits)
-    const u64* row;        // load-time product table of this pass (null: chain / scalar / nothing): the tile's row K holds the factors of its 2^S rows
-    const u64* srow;       // store-time product table of pass 0 of a balanced plan (PassArgs::sched): the tile's row j_2 holds the factors of its 2^S outputs
+    const u64* row;        // load-time product table of the last pass of a balanced plan: the tile's row k_1 holds the factors of its 2^S rows
+    const u64* srow;       // store-time product table of pass 0 of a balanced plan: the tile's row j_1 holds the factors of its 2^S outputs
 };
 
-enum { PASS_COLUMN = 0, PASS_FINAL = 1 };
+// PASS_SINGLE: the whole transform in one tile (n <= 4096, one column, natural order in and out)
+// PASS_FIRST:  pass 0 of a multi-pass plan: column tile in, transposed rows out
+// PASS_COLUMN: passes 1.. of a multi-pass plan: column tile in, the same slots out
+enum { PASS_COLUMN = 0, PASS_SINGLE = 1, PASS_FIRST = 2 };
 
 // everything a pass needs, precomputed on the host (ntt_plan.hpp) so that the kernel does no planning arithmetic
 struct PassArgs {
@@ -173,24 +162,29 @@ struct PassArgs {
     u32 pass_index;      // t, 0-based
     u32 npass;
     u32 pass_bits;       // S_v packed one byte per pass (no array: kernel-argument arrays indexed at run time go to scratch)
-    // column pass: element index = h * 2^(S+logL) + row * 2^logL + l ; a tile is all rows x C consecutive l
+    // column tiles (PASS_FIRST, PASS_COLUMN): element index = h * 2^(S+logL) + row * 2^logL + l ; a tile is all rows x C consecutive l.
+    // pass 0: logL = log n - S_0 (h = 0), l = the remaining input digits; pass t >= 1: logL = S_0 + .. + S_{t-1}, l = K = the finished
+    // output digits, h = the input digits still to come
     u32 logL;
     u32 lognl;           // log2(L / C): tiles per h
-    u32 tw_shift;        // K_prev -> exponent of w_n : kstep = (K << tw_shift) mod n
-    // final pass of a multi-pass plan: slot = (((p1 << mid_bits) + mid) << S) + row ; a tile is C consecutive p1 x all rows
-    u32 n1_bits, mid_bits, logch;
+    u32 tw_shift;        // pass t >= 1: w_{N_t} = w^(2^tw_shift), tw_shift = log n - logL - S_t
     u32 uinv;            // u^-1 mod 16 where w^(n/16) = 2^(12u)
     u32 has_coset;       // pass 0: multiply input j by s^j
     u64 coset_delta;     // s^(stride of the stage-1 register index)
-    u64 post_scale;      // multiplied in at the final store when the final pass has a single stage
+    u64 post_scale;      // last pass: n^-1 of intt (folded into tw_last below, or multiplied in at the store of a single-stage pass); else 1
     u32 streaming;       // data loads / stores are non-temporal (the launcher picks the NT instantiation; kept here for the record)
-    // Balanced twiddle schedule of a three-pass plan (ntt_plan.hpp, DESIGN.md 4.1 "round 3").  The inter-pass factor in front of pass 3
-    // splits, w_N^(j3 (k1 + n1 k2)) = w_N^(j3 k1) * w_{n2 n3}^(j3 k2), and each piece goes where it is cheap AND where there is room:
-    //   w_{n1 n2}^(j2 k1)  at pass 1's STORE (j2 is tile-uniform there: one row of a product table in LDS; that pass is memory-bound),
-    //   w_N^(j3 k1)        in pass 2 at load: k1 is tile-uniform, j3 is the thread's column, so ONE factor per thread (it commutes with
-    //                      the pass' transform, which runs over j2),
-    //   w_{n2 n3}^(j3 k2)  at pass 3's load from a tile-uniform row (k2) instead of a 31-product chain per thread.
+    // Balanced twiddle schedule of a three-pass plan (ntt_plan.hpp).  The factor in front of pass 2 splits,
+    // w_N^(j2 (k0 + n0 k1)) = w_N^(j2 k0) * w_{n1 n2}^(j2 k1), and each piece goes where one of its indices is tile-uniform AND where
+    // there is room:
+    //   w_{n0 n1}^(j1 k0)  at pass 0's STORE (j1 is tile-uniform there: one row of a product table in LDS),
+    //   w_N^(j2 k0)        in pass 1 at load: j2 is tile-uniform (the tile's h), k0 is the thread's column, so ONE factor per thread (it
+    //                      commutes with the pass' transform, which runs over j1),
+    //   w_{n1 n2}^(j2 k1)  at pass 2's load from a tile-uniform row (k1) of a product table.
+    // Without it (two- and four-pass plans) every pass t >= 1 multiplies row r of column K by w_{N_t}^(r K): a chain gamma * delta^d per thread.
     u32 sched;
+    u32 unit0;           // register 0 of stage 1 carries output digit 0, whose inner twiddle is w^0: skip that product unless tw1 has post_scale folded in
+    const u64* tw1;      // inner twiddle table after stage 1 (t_in, or t_in_last when that is the pass' last inner twiddle)
+    const u64* tw2;      // ... after stage 2 (three-stage tiles)
     NttTables tb;
 };
 
@@ -211,7 +205,7 @@ BFS_HD u32 mul24(u32 a, u32 b) {
 
 BFS_HD u32 pass_bits_of(u32 packed, int v) { return (packed >> (8 * v)) & 0xFFu; }
 
-// digit-reverse the slot digits p_first..p_last (p_first most significant in h) into K = p_first + n_first*(...)
+// reverse the digits p_first..p_last of h = (p_first | ... | p_last) (p_first most significant) into (p_last | ... | p_first)
 BFS_HD u64 digit_reverse(u64 h, u32 packed_bits, int first, int last) {
     u64 K = 0;
     bool any = false;
@@ -227,24 +221,35 @@ BFS_HD u64 digit_reverse(u64 h, u32 packed_bits, int first, int last) {
 
 template <int B1, int B2, int B3, int LOGC, int MODE>
 struct TileCfg {
+    static_assert(MODE != PASS_FIRST || B3 == 0, "multi-pass tiles have at most two register stages");
     static constexpr int S = B1 + B2 + B3;
     static constexpr int SH1 = B2 + B3, SH2 = B3;
     static constexpr int U = (B2 == 0) ? 1 : (B3 == 0 ? 2 : 3);
     static constexpr int T = (1 << S) << LOGC;           // elements per tile
     static constexpr int W = T / 16 ? T / 16 : 1;        // threads per tile
-    // LDS layout (bank-conflict analysis: ntt_plan.hpp / DESIGN.md):
-    //   column pass and single-column tiles: [row][col], + 2^PL words every 256
-    //   final pass of a multi-pass plan (lanes run along rows when loading): [col][row], + 1 word per column
-    static constexpr bool CMAJOR = (MODE == PASS_FINAL) && (LOGC > 0);
-    static constexpr int PL = (MODE == PASS_COLUMN) ? 4 : 1;
-    static constexpr int LDS_WORDS = CMAJOR ? (T + (1 << LOGC)) : (T + (((T - 1) >> 8) << PL) + (1 << PL));
+    // LDS layout of the exchange (bank-conflict analysis: ntt_plan.hpp / DESIGN.md):
+    //   PASS_COLUMN and PASS_SINGLE: [row][col], + 2^PL words every 256 (stage-1 and stage-2 lanes both run along the columns)
+    //   PASS_FIRST: stage-2 lanes run along the ROW digit f1 (so that the transposed store writes 128 contiguous bytes per 16
+    //               lanes) while stage-1 lanes run along the columns: a swizzled layout, lds_addr below; no padding
+    static constexpr bool SWZ = (MODE == PASS_FIRST);
+    static constexpr int PL = (MODE == PASS_SINGLE) ? 1 : 4;
+    static constexpr int LDS_WORDS = SWZ ? T : (T + (((T - 1) >> 8) << PL) + (1 << PL));
     static constexpr int TW_WORDS = (U >= 2) ? (1 << (B1 + B2)) : 0;   // stage-1 -> stage-2 twiddles kept in LDS
 };
 
+// word index of tile element (row r, column c).  PASS_FIRST (two stages, B1 = 4): r = (k1 << B2) | o where k1 is the digit stage 1
+// produced and o the digit stage 2 consumes; t1 = (o << LOGC) | c is the stage-1 thread that owns the element, and the word is
+//   16 t1 + ((k1 + t1 + (t1 >> 4)) & 15).
+// Stage-1 writes (lanes = consecutive t1, k1 fixed): 16 t1 steps a quarter of the 64 four-byte banks per lane and the rotation by
+// t1 + (t1 >> 4) spreads the 16 lanes of a quarter over its 16 banks -- conflict-free for 64 lanes x 4 bytes (split exchange) and
+// for 32 lanes x 8 bytes.  Stage-2 reads (lanes = f1 = k1 fastest, then c): 16 consecutive words per column, and the four (two)
+// columns of a wave (half-wave) differ in t1 mod 4 (mod 2), i.e. sit in different quarters (halves) of the banks -- conflict-free too.
 template <typename Cfg, int LOGC>
 BFS_HD u32 lds_addr(u32 r, u32 c) {
-    if constexpr (Cfg::CMAJOR) {
-        return (c << Cfg::S) + c + r;
+    if constexpr (Cfg::SWZ) {
+        const u32 k1 = r >> Cfg::SH1, o = r & ((1u << Cfg::SH1) - 1);
+        const u32 t1 = (o << LOGC) | c;
+        return (t1 << 4) + ((k1 + t1 + (t1 >> 4)) & 15u);
     } else {
         const u32 lin = (r << LOGC) + c;
         return lin + ((lin >> 8) << Cfg::PL);
@@ -255,9 +260,10 @@ BFS_HD u32 lds_addr(u32 r, u32 c) {
 struct TileGeom {
     const u64* in;    // transform base (+ batch)
     u64* out;
-    u64 row0;         // COLUMN: h*2^(S+logL) + c0 ; FINAL multi: ((c0 << mid_bits) + mid) << S ; single: 0
-    u64 kbase;        // COLUMN: exponent step of the inter-pass twiddle ; FINAL: c0 + (kmid << n1_bits)
-    u64 K;            // COLUMN: digit-reversed previous output digits (row of the twiddle table)
+    u64 row0;         // index of the tile's (row 0, column 0) element: h * 2^(S+logL) + c0 ; PASS_SINGLE: 0
+    u64 c0;           // the tile's first column (pass t >= 1: the first of its C values of K)
+    u64 h;            // the digits above the pass' own (pass 1 of a balanced plan: j_2)
+    u64 kbase;        // pass t >= 1: exponent of w that column c0's chain steps by per row: c0 << tw_shift
 };
 
 template <typename Cfg, int LOGC, int MODE>
@@ -265,45 +271,50 @@ BFS_HD TileGeom tile_geom(const PassArgs& a, u32 bid_x, u32 bid_y) {
     TileGeom g;
     g.in = a.in + (u64)bid_y * a.in_batch_stride;
     g.out = a.out + (u64)bid_y * a.out_batch_stride;
-    if constexpr (MODE == PASS_COLUMN) {
-        const u64 h = bid_x >> a.lognl;
-        const u64 c0 = (u64)(bid_x & ((1u << a.lognl) - 1)) << LOGC;
-        g.row0 = (h << (Cfg::S + a.logL)) + c0;
-        const u64 K = a.pass_index ? digit_reverse(h, a.pass_bits, 0, (int)a.pass_index - 1) : 0;
-        g.kbase = (K << a.tw_shift) & ((1ull << a.log_n) - 1);
-        g.K = K;
-    } else if (a.npass > 1) {
-        const u64 c0 = (u64)(bid_x & ((1u << a.logch) - 1)) << LOGC;
-        const u64 mid = bid_x >> a.logch;
-        g.row0 = ((c0 << a.mid_bits) + mid) << Cfg::S;
-        const u64 kmid = a.mid_bits ? digit_reverse(mid, a.pass_bits, 1, (int)a.npass - 2) : 0;
-        g.kbase = c0 + (kmid << a.n1_bits);
+    if constexpr (MODE != PASS_SINGLE) {
+        g.h = bid_x >> a.lognl;
+        g.c0 = (u64)(bid_x & ((1u << a.lognl) - 1)) << LOGC;
+        g.row0 = (g.h << (Cfg::S + a.logL)) + g.c0;
+        g.kbase = g.c0 << a.tw_shift;
     } else {
-        g.row0 = 0;
-        g.kbase = 0;
+        g.h = 0; g.c0 = 0; g.row0 = 0; g.kbase = 0;
     }
-    if constexpr (MODE != PASS_COLUMN) g.K = 0;
     return g;
 }
 
-// the row of the load-time product table that a tile stages in LDS (null: none): column pass -- row K = the digit-reversed previous
-// output digits; final pass of a balanced plan -- row k_2 (digit-reversed `mid`)
-template <typename Cfg, int MODE>
+// the row of the load-time product table that a tile stages in LDS (null: none): last pass of a balanced plan -- row k_1, the digit of
+// the tile's columns K = k_0 + n_0 k_1 above k_0 (the same for all C <= n_0 of them)
+template <typename Cfg, int LOGC, int MODE>
 BFS_HD const u64* tile_load_row(const PassArgs& a, u32 bid_x) {
+    if constexpr (MODE != PASS_COLUMN) return nullptr;
     if (a.tb.row == nullptr) return nullptr;
-    u64 K;
-    if constexpr (MODE == PASS_COLUMN) K = a.pass_index ? digit_reverse((u64)(bid_x >> a.lognl), a.pass_bits, 0, (int)a.pass_index - 1) : 0;
-    else K = a.mid_bits ? digit_reverse((u64)(bid_x >> a.logch), a.pass_bits, 1, (int)a.npass - 2) : 0;
-    return a.tb.row + (K << Cfg::S);
+    const u64 c0 = (u64)(bid_x & ((1u << a.lognl) - 1)) << LOGC;
+    return a.tb.row + ((c0 >> pass_bits_of(a.pass_bits, 0)) << Cfg::S);
 }
-// ... and of the store-time table (pass 1 of a balanced plan): row j_2 = the tile's columns' next digit (the same for all of them)
+// ... and of the store-time table (pass 0 of a balanced plan): row j_1 = the leading digit of the tile's columns l = (j_1 | j_2)
 template <typename Cfg, int LOGC, int MODE>
 BFS_HD const u64* tile_store_row(const PassArgs& a, u32 bid_x) {
-    if constexpr (MODE != PASS_COLUMN) return nullptr;
+    if constexpr (MODE != PASS_FIRST) return nullptr;
     if (a.tb.srow == nullptr) return nullptr;
     const u64 c0 = (u64)(bid_x & ((1u << a.lognl) - 1)) << LOGC;
-    const u64 j2 = c0 >> (a.logL - pass_bits_of(a.pass_bits, (int)a.pass_index + 1));
-    return a.tb.srow + (j2 << Cfg::S);
+    const u64 j1 = c0 >> (a.logL - pass_bits_of(a.pass_bits, 1));
+    return a.tb.srow + (j1 << Cfg::S);
+}
+
+// which tile element a thread of the LAST stage-2 (or stage-3) step holds: column c, f1 = the digit stage 1 produced, f3 = the digit
+// stage 3 will consume.  Lanes run along the columns, except in PASS_FIRST where they run along f1 (TileCfg)
+template <int B1, int B2, int B3, int LOGC, int MODE>
+BFS_HD void stage2_pos(u32 G, u32& c, u32& f1, u32& f3) {
+    if constexpr (MODE == PASS_FIRST) {
+        f1 = G & ((1u << B1) - 1);
+        c = (G >> B1) & ((1u << LOGC) - 1);
+        f3 = G >> (B1 + LOGC);
+    } else {
+        c = G & ((1u << LOGC) - 1);
+        const u32 rest = G >> LOGC;
+        f1 = rest & ((1u << B1) - 1);
+        f3 = rest >> B1;
+    }
 }
 
 // store the 2^BQ registers of the last stage.  klow = the already-final lower digits of k_pass, c = column;
@@ -317,15 +328,16 @@ BFS_HD void final_store(const PassArgs& a, const TileGeom& g, const u64* x, u32 
     if constexpr (MODE == PASS_COLUMN) {
         tp = g.out + g.row0 + ((u64)klow << a.logL) + c;
         step_log = (u32)kshift + a.logL;
+    } else if constexpr (MODE == PASS_FIRST) {
+        // slot (j_{m-1} | ... | j_1 | k_0): the row of column l = c0 + c starts at reverse(l) * n_0
+        tp = g.out + (digit_reverse(g.c0 + c, a.pass_bits, 1, (int)a.npass - 1) << Cfg::S) + klow;
+        step_log = (u32)kshift;
     } else {
-        tp = g.out + g.kbase + c + ((u64)klow << (a.log_n - Cfg::S));
-        step_log = (u32)kshift + (a.log_n - Cfg::S);
+        tp = g.out + klow;
+        step_log = (u32)kshift;
     }
     BFS_UNROLL
     for (int m = 0; m < Q; ++m) {
-#ifdef BFS_ABL_NO_MEM
-        if (x[m] != 0x123456789ULL) continue;
-#endif
         u64 v = scale ? gl_mul(x[m], a.post_scale) : x[m];
         if (srow != nullptr) v = gl_mul(v, srow[klow + (perm_digit<BQ>(m, a.uinv) << kshift)]);      // (wave-uniform question)
         ntt_st<NT>(tp + ((u64)perm_digit<BQ>(m, a.uinv) << step_log), v);
@@ -343,18 +355,25 @@ struct Stage1Pos {
     u64 idx0;         // index of element d = 0 inside the transform (also the n_in predicate and the coset exponent)
 };
 
+// (o, c) of stage-1 thread `tid`: o = the row bits below the stage's digit, c = column
+template <int B1, int B2, int B3, int LOGC, int MODE>
+BFS_HD void stage1_oc(u32 tid, int sub, u32& o, u32& c) {
+    typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
+    const u32 G = (u32)sub * Cfg::W + tid;
+    c = G & ((1u << LOGC) - 1);
+    o = G >> LOGC;
+}
+
 template <int B1, int B2, int B3, int LOGC, int MODE>
 BFS_HD Stage1Pos<B1, B2, B3, LOGC, MODE> stage1_pos(const PassArgs& a, const TileGeom& g, u32 tid, int sub) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
     Stage1Pos<B1, B2, B3, LOGC, MODE> p;
-    const u32 G = (u32)sub * Cfg::W + tid;
-    if constexpr (MODE == PASS_COLUMN) {
-        p.c = G & ((1u << LOGC) - 1); p.o = G >> LOGC;
+    stage1_oc<B1, B2, B3, LOGC, MODE>(tid, sub, p.o, p.c);
+    if constexpr (MODE != PASS_SINGLE) {
         p.idx0 = g.row0 + ((u64)p.o << a.logL) + p.c;
         p.step_log = Cfg::SH1 + a.logL;
     } else {
-        p.o = G & ((1u << Cfg::SH1) - 1); p.c = G >> Cfg::SH1;
-        p.idx0 = g.row0 + ((u64)p.c << (a.mid_bits + Cfg::S)) + p.o;
+        p.idx0 = p.o;
         p.step_log = Cfg::SH1;
     }
     return p;
@@ -372,27 +391,12 @@ BFS_HD void ntt_stage1_load(const PassArgs& a, u32 tid, u32 bid_x, u32 bid_y, in
         for (int d = 0; d < Q; ++d) x[d] = (p.idx0 + ((u64)d << p.step_log) < a.n_in) ? ntt_ld<NT>(tp + ((u64)d << p.step_log)) : 0;
     } else {
         BFS_UNROLL
-        for (int d = 0; d < Q; ++d) {
-#ifdef BFS_ABL_NO_MEM
-            x[d] = (p.idx0 + d) * 0x9E3779B97F4A7C15ULL >> 1;
-#else
-            x[d] = ntt_ld<NT>(tp + ((u64)d << p.step_log));
-#endif
-        }
+        for (int d = 0; d < Q; ++d) x[d] = ntt_ld<NT>(tp + ((u64)d << p.step_log));
     }
 }
 
-// (o, c) of stage-1 thread `tid`: o = the row bits below the stage's digit, c = column (stage1_pos without the tile geometry)
-template <int B1, int B2, int B3, int LOGC, int MODE>
-BFS_HD void stage1_oc(u32 tid, int sub, u32& o, u32& c) {
-    typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
-    const u32 G = (u32)sub * Cfg::W + tid;
-    if constexpr (MODE == PASS_COLUMN) { c = G & ((1u << LOGC) - 1); o = G >> LOGC; }
-    else { o = G & ((1u << Cfg::SH1) - 1); c = G >> Cfg::SH1; }
-}
-
 // The stage 1 -> 2 exchange: register m of stage-1 thread `tid` goes to tile word stage1_out_index, and register d of sub-group s
-// of stage-2 thread `tid` comes from stage2_in_index (word indices of the padded tile layout, lds_addr).
+// of stage-2 thread `tid` comes from stage2_in_index (word indices of the tile layout, lds_addr).
 template <int B1, int B2, int B3, int LOGC, int MODE>
 BFS_HD u32 stage1_out_index(const PassArgs& a, u32 tid, int sub, int m) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
@@ -404,16 +408,14 @@ BFS_HD u32 stage1_out_index(const PassArgs& a, u32 tid, int sub, int m) {
 template <int B1, int B2, int B3, int LOGC, int MODE>
 BFS_HD u32 stage2_in_index(u32 tid, int s, int d) {
     typedef TileCfg<B1, B2, B3, LOGC, MODE> Cfg;
-    const u32 G = (u32)s * Cfg::W + tid;
-    const u32 c = G & ((1u << LOGC) - 1);
-    const u32 rest = G >> LOGC;
-    const u32 f1 = rest & ((1u << B1) - 1), f3 = rest >> B1;
+    u32 c, f1, f3;
+    stage2_pos<B1, B2, B3, LOGC, MODE>((u32)s * Cfg::W + tid, c, f1, f3);
     return lds_addr<Cfg, LOGC>((f1 << Cfg::SH1) | ((u32)d << Cfg::SH2) | f3, c);
 }
 
 // stage 1 without the exchange: load-time twiddle, first radix and (U >= 2) the inner twiddle; x[m] is left holding the value
 // that stage1_out_index(m) receives.  U == 1: the values are final and are stored.
-// tw: dense inner-twiddle table for the stage 1 -> 2 exchange (2^(B1+B2) entries, in LDS on the GPU)
+// tw: dense inner-twiddle table for the stage 1 -> 2 exchange (2^(B1+B2) entries of a.tw1, in LDS on the GPU)
 template <int B1, int B2, int B3, int LOGC, int MODE, bool NT = false>
 BFS_HD void ntt_stage1_values(const PassArgs& a, const u64* tw, const u64* rowtw, u32 tid, u32 bid_x, u32 bid_y, int sub, u64* x,
                               const u64* srow = nullptr) {
@@ -423,28 +425,20 @@ BFS_HD void ntt_stage1_values(const PassArgs& a, const u64* tw, const u64* rowtw
     const u64 nmask = (1ull << a.log_n) - 1;
     const Stage1Pos<B1, B2, B3, LOGC, MODE> p = stage1_pos<B1, B2, B3, LOGC, MODE>(a, g, tid, sub);
     const u32 o = p.o, c = p.c;
-#ifndef BFS_ABL_NO_CHAIN
     if (rowtw != nullptr) {
-        // the inter-pass twiddles of this tile are one row of a table (K is the same for the whole tile)
-#ifdef BFS_ABL_R64          // timing only (wrong results): see the inner twiddle below
-        pow2_layer<Q, 0>(x);
-#else
+        // last pass of a balanced plan: the factors w_{n1 n2}^(j2 k1) of the tile's rows j2 are one row (k1) of a table
         BFS_UNROLL
         for (int d = 0; d < Q; ++d) x[d] = gl_mul(x[d], rowtw[((u32)d << Cfg::SH1) | o]);
-#endif
-    } else if (a.sched && a.pass_index > 0) {
-        // balanced plan, middle pass: w_N^(j3 k1) -- k1 belongs to the tile, j3 is this thread's column: one factor for all 16 rows
-        if constexpr (MODE == PASS_COLUMN) {
-            const u64 c0 = g.row0 & ((1ull << a.logL) - 1);
-            const u64 f = tw_pow(a.tb.w_lo, a.tb.w_hi, a.tb.lo_bits, (g.K * (c0 + c)) & nmask);
-            BFS_UNROLL
-            for (int d = 0; d < Q; ++d) x[d] = gl_mul(x[d], f);
-        }
+    } else if (a.sched && a.pass_index == 1) {
+        // balanced plan, middle pass: w_N^(j2 k0) -- j2 belongs to the tile, k0 is this thread's column: one factor for all 16 rows
+        const u64 f = tw_pow(a.tb.w_lo, a.tb.w_hi, a.tb.lo_bits, (g.h * (g.c0 + c)) & nmask);
+        BFS_UNROLL
+        for (int d = 0; d < Q; ++d) x[d] = gl_mul(x[d], f);
     } else if (a.pass_index > 0 || a.has_coset) {
         // factor of row r = (d << SH1) | o is beta^r = gamma * delta^d: a geometric chain per thread
         u64 gam, del;
         if (a.pass_index > 0) {
-            const u64 ks = (MODE == PASS_COLUMN) ? g.kbase : (g.kbase + c);
+            const u64 ks = g.kbase + ((u64)c << a.tw_shift);                 // w^ks = w_{N_t}^K for this thread's column K = c0 + c
             gam = tw_pow(a.tb.w_lo, a.tb.w_hi, a.tb.lo_bits, ((u64)o * ks) & nmask);
             del = tw_pow(a.tb.w_lo, a.tb.w_hi, a.tb.lo_bits, (ks << Cfg::SH1) & nmask);
         } else {
@@ -458,10 +452,7 @@ BFS_HD void ntt_stage1_values(const PassArgs& a, const u64* tw, const u64* rowtw
             if (d + 1 < Q) f = gl_mul_lazy(f, del);   // only ever multiplied again: no canonical form needed
         }
     }
-#endif
-#ifndef BFS_ABL_NO_DIF
-    dif<Q, (Cfg::U >= 2) && NTT_LAZY_SUMS>(x);        // U >= 2: every output is multiplied by an inner twiddle below (or reduced there)
-#endif
+    dif<Q>(x);
     if constexpr (Cfg::U == 1) {
         final_store<Cfg, LOGC, MODE, B1, NT>(a, g, x, 0, 0, c, srow);
     } else {
@@ -470,28 +461,11 @@ BFS_HD void ntt_stage1_values(const PassArgs& a, const u64* tw, const u64* rowtw
         for (int m = 0; m < Q; ++m) {
             const u32 k1 = perm_digit<B1>(m, a.uinv);                      // wave-uniform
             const u32 e = mul24(i2, k1) & ((1u << (B1 + B2)) - 1);         // exponent of w_M, M = 2^(B1+B2)
-#ifdef BFS_ABL_NO_INNER
-            x[m] = x[m] + e;
-#else
             // register 0 holds output digit 0: its twiddle is w^0, which is 1 unless a post-scale (n^-1 of intt) is folded into the
-            // table -- a wave-uniform question, so a forward transform skips that product in its VALU-bound last pass as well
-            const bool unit = (m == 0) && (!(Cfg::U == 2 && MODE == PASS_FINAL) || a.post_scale == 1);
-#ifdef BFS_ABL_R64
-            if (MODE == PASS_FINAL) { if (m == Q - 1) pow2_layer<Q, 3>(x); continue; }
-#endif
+            // table -- a wave-uniform question, so a forward transform skips that product
+            const bool unit = (m == 0) && a.unit0;
             if (!unit) x[m] = gl_mul(x[m], tw[e]);
-            else if constexpr (NTT_LAZY_SUMS) x[m] = gl_canon(x[m]);      // the one output that skips its (unit) product
-#endif
         }
-#ifdef BFS_ABL_R64
-        // TIMING-ONLY emulation of the 6-bit-digit plan (four radix-64 blocks whose internal 16 x 4 split has power-of-two twiddles with
-        // a tile-uniform exponent, three general twiddle layers at bits 6 / 12 / 18; profiles/r03/ab_radix64_emulation.txt): per pass the
-        // plan costs  pass 0: P + G,  pass 1: P + G,  pass 2: P + G(24-bit exponent) + P  where this code has  G | G(row) + G |
-        // G(chain) + G -- so pass 0 gets one more power-of-two layer here, pass 1's row-table product becomes one (above), and the last
-        // pass trades its inner product for two of them.  Results are wrong; the instruction stream is what is measured.
-        if (MODE == PASS_COLUMN && a.pass_index == 0) pow2_layer<Q, 1>(x);
-        if (MODE == PASS_FINAL) pow2_layer<Q, 2>(x);
-#endif
     }
 }
 
@@ -525,22 +499,17 @@ BFS_HD void ntt_stage2_from(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u3
     if constexpr (B2 > 0) {
         constexpr int Q = 1 << B2;
         const TileGeom g = tile_geom<Cfg, LOGC, MODE>(a, bid_x, bid_y);
-        const u32 G = (u32)s * Cfg::W + tid;
-        const u32 c = G & ((1u << LOGC) - 1);
-        const u32 rest = G >> LOGC;
-        const u32 f1 = rest & ((1u << B1) - 1), f3 = rest >> B1;
-#ifndef BFS_ABL_NO_DIF
+        u32 c, f1, f3;
+        stage2_pos<B1, B2, B3, LOGC, MODE>((u32)s * Cfg::W + tid, c, f1, f3);
         dif<Q>(x);
-#endif
         if constexpr (Cfg::U == 2) {
             final_store<Cfg, LOGC, MODE, B2, NT>(a, g, x, f1, B1, c, srow);
         } else {
-            const u64* tab = (MODE == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;
             BFS_UNROLL
             for (int m = 0; m < Q; ++m) {
                 const u32 k2 = perm_digit<B2>(m, a.uinv);
                 const u32 e = mul24(f3, f1 + (k2 << B1)) & ((1u << Cfg::S) - 1);
-                const u64 v = gl_mul(x[m], tab[(u64)e << (a.tb.t_in_log - Cfg::S)]);
+                const u64 v = gl_mul(x[m], a.tw2[(u64)e << (a.tb.t_in_log - Cfg::S)]);
                 smem[lds_addr<Cfg, LOGC>((f1 << Cfg::SH1) | (k2 << Cfg::SH2) | f3, c)] = v;
             }
         }

@@ -3,7 +3,6 @@
 // Validation mirrors the reference's asserts: /root/reference/code/ntt.py:5-6 (power of two),
 // :13-14 (w^n == 1), :15-16 (w^(n/2) != 1).
 #pragma once
-#include <cstdlib>
 #include <vector>
 
 #include "../../include/bfstark.h"
@@ -50,7 +49,8 @@ inline u32 ntt_uinv(u64 root, u32 log_n) {
     return 1;
 }
 
-// tests: -1 = follow the environment (BFS_NTT_SCHEDULE), 0 / 1 = force the load-time / the balanced schedule
+// tests: -1 = the planner's choice, 0 / 1 = force the chain / the balanced schedule where a plan allows it (tests/test_emulation.py
+// runs three-pass plans through both twiddle paths; the product never sets it)
 inline int& ntt_schedule_override() {
     static int v = -1;
     return v;
@@ -69,7 +69,7 @@ inline bool ntt_make_plan(u32 log_n, u64 root, NttPlan& p) {
     }
     u32 m = (log_n + NTT_MAX_PASS_BITS - 1) / NTT_MAX_PASS_BITS;
     if (m > 4) return false;
-    // enumerate splits S_0..S_{m-1} in [4,8]; keep tiles at 4096 elements; pick the most balanced feasible one
+    // enumerate splits S_0..S_{m-1} in [4,8]; tiles are 4096 elements (C_t = 2^(12 - S_t) columns); pick the most balanced feasible one
     u32 best[4] = {0, 0, 0, 0};
     u32 best_score = ~0u;
     u32 s[4];
@@ -79,27 +79,30 @@ inline bool ntt_make_plan(u32 log_n, u64 root, NttPlan& p) {
         u32 c = code, sum = 0, mx = 0, mn = 99;
         for (u32 i = 0; i < m; ++i) { s[i] = 4 + c % 5; c /= 5; sum += s[i]; mx = s[i] > mx ? s[i] : mx; mn = s[i] < mn ? s[i] : mn; }
         if (sum != log_n) continue;
+        // pass 0: its C_0 columns are values of l = (j_1|..|j_{m-1}) < n / n_0 -- always enough for log n > 12.
+        // pass t >= 1: its C_t columns are values of K < n_0 .. n_{t-1}
         bool ok = true;
-        u32 done = 0;
-        for (u32 t = 0; t + 1 < m && ok; ++t) {
+        u32 done = s[0];
+        for (u32 t = 1; t < m && ok; ++t) {
+            if (NTT_TILE_LOG - s[t] > done) ok = false;
             done += s[t];
-            if (NTT_TILE_LOG - s[t] > log_n - done) ok = false;  // C_t <= L_t
         }
-        if (NTT_TILE_LOG - s[m - 1] > s[0]) ok = false;          // final pass: C <= n_1
         if (!ok) continue;
-        u32 score = (mx - mn) * 16 + (8 - s[m - 1]);             // balanced first, then a long last digit
+        // balanced first; then (three passes) a split the balanced twiddle schedule accepts; then a long first digit (long rows in
+        // the transposed store)
+        const bool sched_ok = m == 3 && s[0] + s[2] >= NTT_TILE_LOG && s[0] >= 5 && s[1] >= 5 && s[2] >= 5;
+        u32 score = (mx - mn) * 32 + (m == 3 && !sched_ok ? 16 : 0) + (8 - s[0]);
         if (score < best_score) { best_score = score; for (u32 i = 0; i < m; ++i) best[i] = s[i]; }
     }
     if (best_score == ~0u) return false;
     p.npass = m;
     for (u32 i = 0; i < m; ++i) { p.pass_bits[i] = best[i]; p.logC[i] = NTT_TILE_LOG - best[i]; }
-    // Balanced schedule (three passes): needs the first pass' tiles to sit inside one value of the next digit (C_1 <= n_3 ... the
-    // tile's columns l = j2 n3 + j3 then share j2), two-stage tiles everywhere, and product tables of at most 2^16 entries.
-    // BFS_NTT_SCHEDULE=0 keeps the load-time schedule (A/B, tools/ab_ntt.sh).
-    static const bool env_balanced = [] { const char* e = getenv("BFS_NTT_SCHEDULE"); return !(e && e[0] == '0'); }();
-    const bool balanced = ntt_schedule_override() < 0 ? env_balanced : ntt_schedule_override() != 0;
-    p.sched = (balanced && m == 3 && p.logC[0] <= best[2] && best[0] >= 5 && best[1] >= 5 && best[2] >= 5 && best[0] + best[1] <= 16 &&
-               best[1] + best[2] <= 16) ? 1 : 0;
+    // Balanced schedule (three passes): pass 0's tile must sit inside one value of j_1 (C_0 <= n_2: its columns l = j_1 n_2 + j_2
+    // then share j_1) and the last pass' tile inside one value of k_1 (C_2 <= n_0) -- both say S_0 + S_2 >= 12 --, two-stage tiles
+    // everywhere, and product tables of at most 2^16 entries.
+    const bool can = m == 3 && best[0] + best[2] >= NTT_TILE_LOG && best[0] >= 5 && best[1] >= 5 && best[2] >= 5 &&
+                     best[0] + best[1] <= 16 && best[1] + best[2] <= 16;
+    p.sched = (can && ntt_schedule_override() != 0) ? 1 : 0;
     return true;
 }
 
@@ -114,26 +117,18 @@ inline void ntt_product_table(u64 omega, u32 a_bits, u32 b_bits, std::vector<u64
     }
 }
 
-// The product tables pass t of a plan reads: `load` (NttTables::row: a tile multiplies its 2^S input rows by one row of it) and `store`
-// (NttTables::srow: ... its 2^S output rows).  omega = 0: no such table.
+// The product tables pass t of a balanced plan reads: `store` (NttTables::srow, pass 0: a tile multiplies its 2^S_0 OUTPUT rows k_0 by
+// row j_1 of it) and `load` (NttTables::row, pass 2: ... its 2^S_2 INPUT rows j_2 by row k_1).  omega = 0: no such table.
 struct NttRowSpec {
     u64 omega = 0;
     u32 a_bits = 0, b_bits = 0;
 };
 inline void ntt_row_specs(const NttPlan& p, u32 t, u64 root, NttRowSpec& load, NttRowSpec& store) {
     load = NttRowSpec(); store = NttRowSpec();
-    if (p.npass < 2) return;
-    const bool last = t + 1 == p.npass;
-    if (p.sched) {
-        const u32 s0 = p.pass_bits[0], s1 = p.pass_bits[1], s2 = p.pass_bits[2];
-        if (t == 0) store = NttRowSpec{gl_pow(root, 1ull << s2), s1, s0};          // rows j2, entries k1:  w_{n1 n2}^(j2 k1)
-        if (t == 2) load = NttRowSpec{gl_pow(root, 1ull << s0), s1, s2};           // rows k2, entries j3:  w_{n2 n3}^(k2 j3)
-        return;
-    }
-    u32 done = 0;
-    for (u32 v = 0; v <= t; ++v) done += p.pass_bits[v];
-    if (t == 0 || last || done > 16) return;
-    load = NttRowSpec{gl_pow(root, 1ull << (p.log_n - done)), done - p.pass_bits[t], p.pass_bits[t]};     // rows K, entries r:  w_{N_t}^(K r)
+    if (!p.sched) return;
+    const u32 s0 = p.pass_bits[0], s1 = p.pass_bits[1], s2 = p.pass_bits[2];
+    if (t == 0) store = NttRowSpec{gl_pow(root, 1ull << s2), s1, s0};          // rows j1, entries k0:  w_{n0 n1}^(j1 k0)
+    if (t == 2) load = NttRowSpec{gl_pow(root, 1ull << s0), s1, s2};           // rows k1, entries j2:  w_{n1 n2}^(k1 j2)
 }
 
 // powers table helper: out[i] = base^i * scale
@@ -166,20 +161,19 @@ inline void ntt_build_coset_tables(const NttPlan& p, u64 shift, CosetHostTables&
     fill_powers(t.s_hi, 1ull << hi_bits, gl_pow(shift, 1ull << p.lo_bits), 1);
 }
 
-// LDS layout per pass (TileCfg in ntt_core.hpp), chosen so that both the stage-1 writes and the stage-2 reads of the tile
+// LDS layout per pass (TileCfg / lds_addr in ntt_core.hpp), chosen so that both the stage-1 writes and the stage-2 reads of the tile
 // are free of bank conflicts (ds_read_b64: 64 banks x 4 B per 32-lane group; ds_write_b64: 32 banks per 16-lane group):
 //   column pass  [row][col], +16 words every 256: stage-2 lanes (c = tid & 15, f1 = tid >> 4) of one 32-lane group then fall on
 //                disjoint bank halves (first version: +2 words -> 2-way conflicts on every read)
-//   final pass of a multi-pass plan: lanes run along the ROW index when loading (contiguous HBM rows), so the tile is kept
-//                [col][row] with +1 word per column: writes are consecutive, stage-2 reads (lanes along c) step 2 banks per lane
-//                (first version: [row][col] -> 16-way conflicts on every write, 73 % of LDS cycles, profiles/r01)
+//   first pass of a multi-pass plan: stage-2 lanes run along the output ROW digit (contiguous transposed stores) while stage-1 lanes
+//                run along the columns (coalesced loads): the swizzled layout of lds_addr
 //   single-pass plans (one column): +2 words every 256 rows
 
 // fill the per-pass kernel arguments (pointers are whatever address space the caller runs in)
 inline PassArgs ntt_pass_args(const NttPlan& p, u32 t, const u64* in, u64* out, u64 in_stride, u64 out_stride,
                               u64 n_in, const NttTables& tb, bool has_coset, u64 shift, u64 post_scale) {
     PassArgs a{};
-    const bool final_pass = (t + 1 == p.npass);
+    const bool last = (t + 1 == p.npass);
     const u32 S = p.pass_bits[t];
     a.in = in; a.out = out;
     a.in_batch_stride = in_stride; a.out_batch_stride = out_stride;
@@ -189,26 +183,29 @@ inline PassArgs ntt_pass_args(const NttPlan& p, u32 t, const u64* in, u64* out, 
     a.pass_index = t;
     a.npass = p.npass;
     a.pass_bits = p.pass_bits[0] | (p.pass_bits[1] << 8) | (p.pass_bits[2] << 16) | (p.pass_bits[3] << 24);
-    u32 done = 0;
-    for (u32 v = 0; v <= t; ++v) done += p.pass_bits[v];
-    if (!final_pass) {
-        a.logL = p.log_n - done;
+    if (p.npass > 1) {
+        if (t == 0) {
+            a.logL = p.log_n - S;
+        } else {
+            for (u32 v = 0; v < t; ++v) a.logL += p.pass_bits[v];
+            a.tw_shift = p.log_n - a.logL - S;
+        }
         a.lognl = a.logL - p.logC[t];
-        a.tw_shift = p.log_n - done;
-    } else if (p.npass > 1) {
-        a.n1_bits = p.pass_bits[0];
-        for (u32 v = 1; v + 1 < p.npass; ++v) a.mid_bits += p.pass_bits[v];
-        a.logch = a.n1_bits - p.logC[t];
     }
     a.uinv = p.uinv;
     a.sched = p.sched;
     a.has_coset = (t == 0 && has_coset) ? 1 : 0;
-    a.post_scale = final_pass ? post_scale : 1;
+    a.post_scale = last ? post_scale : 1;
     a.tb = tb;
+    // the inner twiddle tables: n^-1 of intt rides on the LAST inner twiddle of the last pass (a single-stage last pass multiplies at its store)
+    const u32 stages = S <= 4 ? 1 : (S <= 8 ? 2 : 3);
+    a.tw1 = (last && stages == 2) ? tb.t_in_last : tb.t_in;
+    a.tw2 = (last && stages == 3) ? tb.t_in_last : tb.t_in;
+    a.unit0 = (a.tw1 == tb.t_in || post_scale == 1) ? 1 : 0;
     if (a.has_coset) {
         u32 b1 = S < 4 ? S : 4;
         u32 sh1 = S - b1;
-        u64 stride = !final_pass ? ((1ull << (p.log_n - S)) << sh1) : (1ull << sh1);
+        u64 stride = p.npass > 1 ? ((1ull << (p.log_n - S)) << sh1) : (1ull << sh1);
         a.coset_delta = gl_pow(shift, stride);
     }
     return a;

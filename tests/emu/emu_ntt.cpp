@@ -16,13 +16,13 @@ static void run_pass(const PassArgs& a, u32 grid_x, u32 batch) {
     std::vector<u64> smem(Cfg::LDS_WORDS + 2);
     // dense stage-1 -> stage-2 twiddle table, as the kernel builds it in LDS
     std::vector<u64> tw(1u << (B1 + B2));
-    const u64* tab = (Cfg::U == 2 && MODE == PASS_FINAL) ? a.tb.t_in_last : a.tb.t_in;
+    const u64* tab = a.tw1;
     if (B2 > 0) for (u32 i = 0; i < tw.size(); ++i) tw[i] = tab[(u64)i << (a.tb.t_in_log - (B1 + B2))];
     for (u32 by = 0; by < batch; ++by)
         for (u32 bx = 0; bx < grid_x; ++bx) {
             // the tile's row of the load-time / store-time product table, copied as the kernel copies it to LDS
             std::vector<u64> row, srow_copy;
-            const u64* lrow = tile_load_row<Cfg, MODE>(a, bx);
+            const u64* lrow = tile_load_row<Cfg, LOGC, MODE>(a, bx);
             const u64* srow_g = tile_store_row<Cfg, LOGC, MODE>(a, bx);
             if (lrow) row.assign(lrow, lrow + (1u << Cfg::S));
             if (srow_g) srow_copy.assign(srow_g, srow_g + (1u << Cfg::S));
@@ -48,18 +48,21 @@ static void dispatch_multi(const PassArgs& a, u32 S, u32 grid_x, u32 batch) {
 
 static void dispatch_single(const PassArgs& a, u32 S, u32 batch) {
     switch (S) {
-        case 4: run_pass<4, 0, 0, 0, PASS_FINAL>(a, 1, batch); break;
-        case 5: run_pass<4, 1, 0, 0, PASS_FINAL>(a, 1, batch); break;
-        case 6: run_pass<4, 2, 0, 0, PASS_FINAL>(a, 1, batch); break;
-        case 7: run_pass<4, 3, 0, 0, PASS_FINAL>(a, 1, batch); break;
-        case 8: run_pass<4, 4, 0, 0, PASS_FINAL>(a, 1, batch); break;
-        case 9: run_pass<4, 4, 1, 0, PASS_FINAL>(a, 1, batch); break;
-        case 10: run_pass<4, 4, 2, 0, PASS_FINAL>(a, 1, batch); break;
-        case 11: run_pass<4, 4, 3, 0, PASS_FINAL>(a, 1, batch); break;
-        case 12: run_pass<4, 4, 4, 0, PASS_FINAL>(a, 1, batch); break;
+        case 4: run_pass<4, 0, 0, 0, PASS_SINGLE>(a, 1, batch); break;
+        case 5: run_pass<4, 1, 0, 0, PASS_SINGLE>(a, 1, batch); break;
+        case 6: run_pass<4, 2, 0, 0, PASS_SINGLE>(a, 1, batch); break;
+        case 7: run_pass<4, 3, 0, 0, PASS_SINGLE>(a, 1, batch); break;
+        case 8: run_pass<4, 4, 0, 0, PASS_SINGLE>(a, 1, batch); break;
+        case 9: run_pass<4, 4, 1, 0, PASS_SINGLE>(a, 1, batch); break;
+        case 10: run_pass<4, 4, 2, 0, PASS_SINGLE>(a, 1, batch); break;
+        case 11: run_pass<4, 4, 3, 0, PASS_SINGLE>(a, 1, batch); break;
+        case 12: run_pass<4, 4, 4, 0, PASS_SINGLE>(a, 1, batch); break;
         default: abort();
     }
 }
+
+static int emu_force_ws = 0;
+extern "C" void emu_set_force_ws(int v) { emu_force_ws = v; }
 
 extern "C" int emu_gl_ntt(const u64* in, u64 n_in, u64 in_stride, u64* out, u64 out_stride, u32 log_n, u32 batch,
                           u64 root, u64 shift, u64 post_scale) {
@@ -82,13 +85,24 @@ extern "C" int emu_gl_ntt(const u64* in, u64 n_in, u64 in_stride, u64* out, u64 
     if (coset) ntt_build_coset_tables(p, shift, ct);
     NttTables tb{ht.w_lo.data(), ht.w_hi.data(), p.lo_bits, p.t_in_log, ht.t_in.data(), ht.t_in_last.data(),
                  coset ? ct.s_lo.data() : nullptr, coset ? ct.s_hi.data() : nullptr, nullptr, nullptr};
+    // the product's buffer flow (ntt.hip: ntt_launch): pass 0 in -> out, later passes in place on out; overlapping in / out go through
+    // an intermediate buffer in passes 0 and 1.  `force_ws` lets a test take that route with separate buffers too.
+    const u64* in_end = in + (u64)(batch - 1) * in_stride + n_in;
+    const u64* out_end = out + (u64)(batch - 1) * out_stride + n;
+    const bool overlap = p.npass > 1 && n_in != 0 && ((in < out_end && out < in_end) || emu_force_ws);
     std::vector<u64> ws;
-    if (p.npass > 1) ws.resize((size_t)n * batch);
+    if (overlap) ws.resize((size_t)n * batch);
     std::vector<std::vector<u64>> rows(p.npass), srows(p.npass);
     for (u32 t = 0; t < p.npass; ++t) {
-        const bool first = t == 0, last = t + 1 == p.npass;
-        const u64* src = first ? in : ws.data();
-        u64* dst = last ? out : ws.data();
+        const u64* src = out;
+        u64* dst = out;
+        u64 src_stride = out_stride, dst_stride = out_stride;
+        if (t == 0) {
+            src = in; src_stride = in_stride;
+            if (overlap) { dst = ws.data(); dst_stride = n; }
+        } else if (t == 1 && overlap) {
+            src = ws.data(); src_stride = n;
+        }
         tb.row = nullptr;
         tb.srow = nullptr;
         {
@@ -97,11 +111,10 @@ extern "C" int emu_gl_ntt(const u64* in, u64 n_in, u64 in_stride, u64* out, u64 
             if (load.omega) { ntt_product_table(load.omega, load.a_bits, load.b_bits, rows[t]); tb.row = rows[t].data(); }
             if (store.omega) { ntt_product_table(store.omega, store.a_bits, store.b_bits, srows[t]); tb.srow = srows[t].data(); }
         }
-        PassArgs a = ntt_pass_args(p, t, src, dst, first ? in_stride : n, last ? out_stride : n, first ? n_in : n, tb,
-                                   coset, shift, post_scale);
+        PassArgs a = ntt_pass_args(p, t, src, dst, src_stride, dst_stride, t == 0 ? n_in : n, tb, coset, shift, post_scale);
         u32 grid_x = (u32)((n >> p.pass_bits[t]) >> p.logC[t]);
         if (p.npass == 1) dispatch_single(a, p.pass_bits[0], batch);
-        else if (last) dispatch_multi<PASS_FINAL>(a, p.pass_bits[t], grid_x, batch);
+        else if (t == 0) dispatch_multi<PASS_FIRST>(a, p.pass_bits[t], grid_x, batch);
         else dispatch_multi<PASS_COLUMN>(a, p.pass_bits[t], grid_x, batch);
     }
     return 0;

@@ -25,6 +25,7 @@ def emu():
     lib = ctypes.CDLL(so)
     lib.emu_gl_ntt.argtypes = [vp, u64, u64, vp, u64, ctypes.c_uint32, ctypes.c_uint32, u64, u64, u64]
     lib.emu_set_schedule.argtypes = [ctypes.c_int, ctypes.c_uint32, u64]
+    lib.emu_set_force_ws.argtypes = [ctypes.c_int]
     lib.emu_plan.argtypes = [ctypes.c_uint32, u64, vp, vp, vp, vp]
     lib.emu_merkle_xfe.argtypes = [vp, u64, u64, vp]
     lib.emu_xfe_leaf_stream.argtypes = [vp, u64, u64, ctypes.c_int, vp]
@@ -91,6 +92,42 @@ def test_zero_padded_inputs_of_every_shape(emu, oracle, logn):
         for shift in (1, 7):
             want = oracle.fast_coset_evaluate(v[:d], shift, w, n)
             assert (emu_ntt(emu, v[:d], logn, w, shift, 1, n_in=d) == want).all(), (logn, d, shift)
+
+
+@pytest.mark.parametrize("logn", [13, 16, 17, 20])
+def test_multi_pass_buffer_flow(emu, oracle, logn):
+    """round 4: pass 0 transposes from the input into the output and every later pass runs in place there; when input and output
+    overlap (a caller transforming in place) passes 0 and 1 go through the intermediate buffer instead.  Same values either way, for
+    a batch whose transforms are spaced wider than n on both sides."""
+    n = 1 << logn
+    w = oracle.primitive_nth_root(n)
+    batch, in_stride, out_stride = 2, n + 24, n + 8
+    src = np.zeros(in_stride * batch, dtype=np.uint64)
+    cols = [oracle.felt_array(SEED + 77 + b, 0, n) for b in range(batch)]
+    for b in range(batch):
+        src[b * in_stride:b * in_stride + n] = cols[b]
+    want = [oracle.ntt(w, c) for c in cols]
+
+    def run(buf_in, buf_out, stride_in, stride_out):
+        rc = emu.emu_gl_ntt(buf_in.ctypes.data, n, stride_in, buf_out.ctypes.data, stride_out, logn, batch, w, 1, 1)
+        assert rc == 0
+
+    out = np.zeros(out_stride * batch, dtype=np.uint64)
+    run(src, out, in_stride, out_stride)                          # separate buffers: no intermediate buffer
+    for b in range(batch):
+        assert (out[b * out_stride:b * out_stride + n] == want[b]).all()
+        assert not out[b * out_stride + n:(b + 1) * out_stride].any()          # nothing written between the transforms
+    emu.emu_set_force_ws(1)
+    try:
+        out2 = np.zeros(out_stride * batch, dtype=np.uint64)
+        run(src, out2, in_stride, out_stride)                     # the overlapping-buffers route, forced
+        assert (out2 == out).all()
+    finally:
+        emu.emu_set_force_ws(0)
+    inplace = src.copy()
+    run(inplace, inplace, in_stride, in_stride)                   # in == out
+    for b in range(batch):
+        assert (inplace[b * in_stride:b * in_stride + n] == want[b]).all()
 
 
 def test_tile_kernels_batch_and_other_roots(emu, oracle):

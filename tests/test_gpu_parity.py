@@ -50,7 +50,7 @@ def raw_ntt(sb, v, logn, root, shift=1, scale=1, n_in=None, batch=1):
 
 
 # ------------------------------------------------------------------------------------------------ NTT
-@pytest.mark.parametrize("logn", list(range(0, 21)))
+@pytest.mark.parametrize("logn", list(range(0, 24)))
 def test_ntt_intt_coset_vs_oracle(sb, oracle, logn):
     n = 1 << logn
     v = oracle.felt_array(SEED, 0, n)
@@ -976,39 +976,41 @@ def test_four_pass_plan_2p25(sb, oracle):
     assert (raw_ntt(sb, v[:d], logn, w, 7, 1, n_in=d) == oracle.fast_coset_evaluate(v[:d], 7, w, n)).all()
 
 
-def test_three_pass_plans_with_the_load_time_twiddle_schedule():
-    """BFS_NTT_SCHEDULE=0 (the A/B switch of round 3: row table in the second pass, per-thread chain in the third -- the code that
-    four-pass plans still run in their middle and last passes) on three-pass sizes, in a process of its own because the switch is
-    read once: forward, inverse and zero-padded coset transforms against the oracle; the default (balanced) schedule is what every
-    other test of this file runs"""
-    import subprocess
-    import sys
-    code = r'''
-import sys
-sys.path.insert(0, %r)
-import numpy as np
-from oracle import ref_oracle as o
-from stark_brainfuck_amd import _lib
-from stark_brainfuck_amd.device import DeviceBuffer, synchronize
-lib = _lib.load()
-for logn in (17, 18, 20, 22):
+@pytest.mark.parametrize("logn", [13, 16, 17, 20, 22])
+def test_multi_pass_buffer_flow(sb, oracle, logn):
+    """Pass 0 of a multi-pass plan transposes from the input into the output and every later pass runs in place there (no
+    intermediate buffer); when input and output overlap -- a caller transforming in place, or an output that starts inside the
+    input -- passes 0 and 1 go through the library's intermediate buffer.  Same values on every route, for a batch whose
+    transforms are spaced wider than n, and nothing is written between the transforms of a batch."""
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.device import DeviceBuffer, synchronize
+    lib = _lib.load()
     n = 1 << logn
-    w = o.primitive_nth_root(n)
-    v = o.felt_array(0x5EED + logn, 0, n)
-    din, dout = DeviceBuffer.from_numpy(v), DeviceBuffer(n)
-    _lib.check(lib.bfs_gl_ntt(din.ptr, n, n, dout.ptr, n, logn, 1, w, 1, 1, 0)); synchronize(0)
-    fwd = dout.to_numpy()
-    assert (fwd == o.ntt(w, v)).all(), logn
-    _lib.check(lib.bfs_gl_ntt(dout.ptr, n, n, din.ptr, n, logn, 1, o.inv(w), 1, o.inv(n), 0)); synchronize(0)
-    assert (din.to_numpy() == v).all(), logn
-    d = n // 4 + 3
-    dc = DeviceBuffer.from_numpy(v[:d])
-    _lib.check(lib.bfs_gl_ntt(dc.ptr, d, d, dout.ptr, n, logn, 1, w, 7, 1, 0)); synchronize(0)
-    assert (dout.to_numpy() == o.fast_coset_evaluate(v[:d], 7, w, n)).all(), logn
-print("ok")
-''' % ROOT
-    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, BFS_NTT_SCHEDULE="0"), capture_output=True, text=True, timeout=900)
-    assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+    w = oracle.primitive_nth_root(n)
+    batch, in_stride, out_stride = 2, n + 24, n + 8
+    cols = [oracle.felt_array(SEED + 77 + b, 0, n) for b in range(batch)]
+    want = [oracle.ntt(w, c) for c in cols]
+    src = np.zeros(in_stride * batch, dtype=np.uint64)
+    for b in range(batch):
+        src[b * in_stride:b * in_stride + n] = cols[b]
+    marker = np.uint64(0xDEADBEEFCAFEF00D)
+    din = DeviceBuffer.from_numpy(src)
+    dout = DeviceBuffer.from_numpy(np.full(out_stride * batch, marker, dtype=np.uint64))
+    _lib.check(lib.bfs_gl_ntt(din.ptr, n, in_stride, dout.ptr, out_stride, logn, batch, w, 1, 1, 0)); synchronize(0)
+    out = dout.to_numpy()
+    for b in range(batch):
+        assert (out[b * out_stride:b * out_stride + n] == want[b]).all()
+        assert (out[b * out_stride + n:(b + 1) * out_stride] == marker).all()
+    assert (din.to_numpy() == src).all()                                               # the input is left alone
+    _lib.check(lib.bfs_gl_ntt(din.ptr, n, in_stride, din.ptr, in_stride, logn, batch, w, 1, 1, 0)); synchronize(0)      # in == out
+    got = din.to_numpy()
+    for b in range(batch):
+        assert (got[b * in_stride:b * in_stride + n] == want[b]).all()
+    # an output that starts inside the input (one transform, zero-padded coset evaluation of n / 4 coefficients)
+    d = n // 4
+    buf = DeviceBuffer.from_numpy(np.concatenate([cols[0][:d], np.zeros(n, dtype=np.uint64)]))
+    _lib.check(lib.bfs_gl_ntt(buf.ptr, d, d, buf.ptr + 8 * (d // 2), n, logn, 1, w, 7, 1, 0)); synchronize(0)
+    assert (buf.to_numpy()[d // 2:d // 2 + n] == oracle.fast_coset_evaluate(cols[0][:d], 7, w, n)).all()
 
 
 def test_c_abi_argument_checks_and_stream_lifetime(sb, oracle):
