@@ -239,8 +239,8 @@ struct TileCfg {
 
 // word index of tile element (row r, column c).  PASS_FIRST (two stages, B1 = 4): r = (k1 << B2) | o where k1 is the digit stage 1
 // produced and o the digit stage 2 consumes; t1 = (o << LOGC) | c is the stage-1 thread that owns the element, and the word is
-//   16 t1 + ((k1 + t1 + (t1 >> 4)) & 15).
-// Stage-1 writes (lanes = consecutive t1, k1 fixed): 16 t1 steps a quarter of the 64 four-byte banks per lane and the rotation by
+//   16 t1 + (k1 xor ((t1 + (t1 >> 4)) & 15))        (one v_xad_u32 per access: k1 is a wave-uniform scalar in stage 1).
+// Stage-1 writes (lanes = consecutive t1, k1 fixed): 16 t1 steps a quarter of the 64 four-byte banks per lane and the permutation by
 // t1 + (t1 >> 4) spreads the 16 lanes of a quarter over its 16 banks -- conflict-free for 64 lanes x 4 bytes (split exchange) and
 // for 32 lanes x 8 bytes.  Stage-2 reads (lanes = f1 = k1 fastest, then c): 16 consecutive words per column, and the four (two)
 // columns of a wave (half-wave) differ in t1 mod 4 (mod 2), i.e. sit in different quarters (halves) of the banks -- conflict-free too.
@@ -249,7 +249,7 @@ BFS_HD u32 lds_addr(u32 r, u32 c) {
     if constexpr (Cfg::SWZ) {
         const u32 k1 = r >> Cfg::SH1, o = r & ((1u << Cfg::SH1) - 1);
         const u32 t1 = (o << LOGC) | c;
-        return (t1 << 4) + ((k1 + t1 + (t1 >> 4)) & 15u);
+        return (t1 << 4) + (k1 ^ ((t1 + (t1 >> 4)) & 15u));
     } else {
         const u32 lin = (r << LOGC) + c;
         return lin + ((lin >> 8) << Cfg::PL);

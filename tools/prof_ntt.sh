@@ -10,7 +10,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for TL in $TILES; do
-  export BFS_NTT_TILE_LOG=$TL
+  : # (one tile size since round 2; the loop variable only names the output files)
   python "$ROOT/tools/ntt_only.py" --steps 30 > "$OUT/plain_tile$TL.json" 2>&1
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/raw$TL" -o ntt -- python "$ROOT/tools/ntt_only.py" --steps 30 > "$OUT/rocprof_stdout_tile$TL.log" 2>&1
   find "$OUT/raw$TL" -name "*kernel_stats.csv" -exec cp {} "$OUT/ntt_only_kernel_stats_tile$TL.csv" \;
