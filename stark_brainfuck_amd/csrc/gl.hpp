@@ -97,29 +97,8 @@ constexpr bool GL_SUB4 = false;
 BFS_HD u64 gl_sub(u64 a, u64 b) { return gl_sub5(a, b); }
 #endif
 // the reductions' scalar-carry forms (gl_sub_word4 for lo - hi_hi, gl_fold_word<true> for the tail): everywhere unless a unit opts out
-#ifdef BFS_GL_REDUCE_SPLIT
-constexpr bool GL_REDUCE4 = false;
-#else
 constexpr bool GL_REDUCE4 = true;
-#endif
 // a + b: s = a + b and u = s + EPS (= s - p mod 2^64) with both carries; a + b >= p  <=>  either addition carried
-#if defined(BFS_GL_SUB4) && defined(BFS_ABL_ADD5)
-// A/B only (profiles/r03/ab_add5.txt): five instructions -- the sum's carry K in a scalar pair, K2 from ONE multiply-add s + EPS, the
-// scalar OR, a mask and a multiply-add that adds it (gl_fold_word's tail) -- against six with two selects
-BFS_HD u64 gl_add(u64 a, u64 b) {
-    u32 slo, shi, m;
-    u64 sk, r;
-    asm("v_add_co_u32 %0, vcc, %3, %5\n\ts_nop 1\n\tv_addc_co_u32 %1, %2, %4, %6, vcc"
-        : "=&v"(slo), "=v"(shi), "=s"(sk) : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32)) : "vcc");
-    const u64 s = ((u64)shi << 32) | slo;
-    asm("v_mad_u64_u32 %0, vcc, -1, 1, %2\n\t"
-        "s_or_b64 vcc, vcc, %3\n\t"
-        "v_cndmask_b32 %1, 0, -1, vcc\n\t"
-        "v_mad_u64_u32 %0, vcc, %1, 1, %2"
-        : "=&v"(r), "=&v"(m) : "v"(s), "s"(sk) : "vcc", "scc");
-    return r;
-}
-#else
 BFS_HD u64 gl_add(u64 a, u64 b) {
     u32 c1, c2, c3, c4;
     u32 slo = __builtin_addc((u32)a, (u32)b, 0u, &c1);
@@ -128,21 +107,6 @@ BFS_HD u64 gl_add(u64 a, u64 b) {
     u32 uhi = __builtin_addc(shi, 0u, c3, &c4);
     const bool over = (c2 | c4) != 0;
     return over ? (((u64)uhi << 32) | ulo) : (((u64)shi << 32) | slo);
-}
-#endif
-
-// a + b for b canonical and ANY 64-bit a; the result is congruent to a + b and lies in [0, 2^64) but need not be canonical: fine
-// as the first operand of gl_add_lazy / gl_sub (the minuend), of mul_pow2 and of a multiplication -- never as a subtrahend, never
-// stored.  s = a + b; a carry means + 2^64 = + EPS, which cannot wrap again because s < p then.  5 instructions (gl_add: 6).
-BFS_HD u64 gl_add_lazy(u64 a, u64 b) {
-    u32 c1, c2, c3;
-    u32 slo = __builtin_addc((u32)a, (u32)b, 0u, &c1);
-    u32 shi = __builtin_addc((u32)(a >> 32), (u32)(b >> 32), c1, &c2);
-    u32 t = 0u - c2;                                   // EPS when the addition carried, else 0
-    u32 rlo = __builtin_addc(slo, t, 0u, &c3);
-    u32 rhi = shi + c3;
-    asm("" : "+v"(rhi));                               // (see gl_sub: keep the compiler from merging this carry into a consumer)
-    return ((u64)rhi << 32) | rlo;
 }
 
 // a VGPR holding 0 that the optimiser cannot see through: `x - 0 - borrow` written with it compiles to one v_subb_co_u32,
@@ -205,20 +169,6 @@ BFS_HD u64 gl_reduce128_t(u64 hi, u64 lo) {
     // way: a multiply-add for the carry, the mask, a multiply-add that adds it.  Every step works on whole 64-bit pairs, so the
     // sequence is 3 (+ 3) instructions where add / add-with-carry / select pairs were 4 (+ 4).
     u64 r;
-#ifdef BFS_ABL_REDUCE_ADDC          // A/B only: the add-with-carry form
-    {
-        const u32 z = gl_opaque_zero();
-        u32 m;
-        asm("v_mad_u64_u32 %0, vcc, %2, -1, %3\n\ts_nop 1\n\tv_cndmask_b32 %1, 0, -1, vcc" : "=&v"(r), "=v"(m) : "v"(hl), "v"(t0) : "vcc");
-        u32 c2, c3;
-        u32 rlo = __builtin_addc((u32)r, m, 0u, &c2);
-        u32 rhi = __builtin_addc((u32)(r >> 32), z, c2, &c3);
-        if constexpr (!CANON) return ((u64)rhi << 32) | rlo;
-        u32 ulo = __builtin_addc(rlo, 0xFFFFFFFFu, 0u, &c2);
-        u32 uhi = __builtin_addc(rhi, z, c2, &c3);
-        return c3 ? (((u64)uhi << 32) | ulo) : (((u64)rhi << 32) | rlo);
-    }
-#endif
     if constexpr (!CANON) {
         u64 q;
         u32 m;
@@ -239,20 +189,6 @@ BFS_HD u64 gl_reduce96(u32 top, u64 lo) { return gl_fold_word<GL_REDUCE4>(top, l
 // the low half and two add-with-carry steps for the high one.  (Four independent products and a carry tree were 10.)
 BFS_HD void gl_mul128(u64 a, u64 b, u64& hi, u64& lo) {
     const u32 al = (u32)a, ah = (u32)(a >> 32), bl = (u32)b, bh = (u32)(b >> 32);
-#ifdef BFS_ABL_MUL128_TREE        // A/B only: the four-independent-products form
-    {
-        const u64 A = (u64)al * bl, B = (u64)ah * bh, M1 = (u64)al * bh, M2 = (u64)ah * bl;
-        u32 c, k, k2, c3;
-        u32 mlo = __builtin_addc((u32)M1, (u32)M2, 0u, &c);
-        u32 mhi = __builtin_addc((u32)(M1 >> 32), (u32)(M2 >> 32), c, &k);
-        u32 l1 = __builtin_addc((u32)(A >> 32), mlo, 0u, &k2);
-        u32 h0 = __builtin_addc((u32)B, mhi, k2, &c3);
-        u32 h1 = (u32)(B >> 32) + k + c3;
-        lo = ((u64)l1 << 32) | (u32)A;
-        hi = ((u64)h1 << 32) | h0;
-        return;
-    }
-#endif
     const u64 A = (u64)al * bl, B = (u64)ah * bh, M1 = (u64)al * bh;
     u64 M;                                             // ah*bl + al*bh mod 2^64
     u32 k;                                             // and its carry
@@ -297,9 +233,7 @@ BFS_HD u64 gl_mul_fused(u64 a, u64 b) {
     return gl_fold_word<true>(h0, ((u64)rhi << 32) | rlo);
 }
 BFS_HD u64 gl_mul(u64 a, u64 b) {
-#ifndef BFS_ABL_MUL_UNFUSED
     if constexpr (GL_REDUCE4) return gl_mul_fused(a, b);
-#endif
     u64 hi, lo;
     gl_mul128(a, b, hi, lo);
     return gl_reduce128_t<true>(hi, lo);
@@ -330,12 +264,6 @@ BFS_HD u64 gl_sub(u64 a, u64 b) {
 }
 BFS_HD u64 gl_sub4(u64 a, u64 b) { return gl_sub(a, b); }      // the device's two instruction sequences (selftest.hip compares both with this)
 BFS_HD u64 gl_sub5(u64 a, u64 b) { return gl_sub(a, b); }
-
-// the device's lazy sum (any 64-bit a, canonical b; result in [0, 2^64), not necessarily canonical), bit for bit
-BFS_HD u64 gl_add_lazy(u64 a, u64 b) {
-    u64 s = a + b;
-    return s < a ? s + GL_EPS : s;
-}
 
 // reduce a 128-bit value hi*2^64 + lo.  2^64 = 2^32 - 1, 2^96 = -1 (mod p).
 BFS_HD u64 gl_reduce128(u64 hi, u64 lo) {

@@ -148,17 +148,11 @@ __global__ void __launch_bounds__(LEAF_THREADS, BFS_ROW_WAVES) row_leaves_kernel
         const ConstInts ints = (ConstInts)(a.ints + uniform32(tp->first_int));
         const ConstColumns columns = (ConstColumns)a.columns;
         auto row_int = [&](u32 packed) -> u64 {
-#ifdef BFS_ROWS_ABL_NO_LOADS       // timing experiments only (tools/ab_rows.sh): wrong digests
-            return (u64)packed * 0x9E3779B97F4A7C15ULL + i;
-#endif
             const GlobalWords col = (GlobalWords)columns[packed & 0xFF];
             return col[(u64)((packed >> 8) & 0xFF) * a.limb_stride + i];
         };
         // pass 1: length of the tuple pickle = constant bytes + the integer opcodes of this row
         u32 int_bytes = 0;
-#ifdef BFS_ROWS_ABL_NO_PASS1
-        int_bytes = 11 * nints;
-#else
         {
             u32 j = 0;
             for (; j + 8 <= nints; j += 8) {         // eight loads in flight
@@ -170,7 +164,6 @@ __global__ void __launch_bounds__(LEAF_THREADS, BFS_ROW_WAVES) row_leaves_kernel
             }
             for (; j < nints; ++j) int_bytes += pickle_int_len(row_int(ints[j]));
         }
-#endif
         const u32 tuple_len = tuple_const_bytes + int_bytes;
         // pass 2: expand the template into the lane's buffer, compressing block-synchronously.  ROW_UNROLL steps per turn of the loop
         // (the template is padded with empty steps): their descriptors are one scalar load.

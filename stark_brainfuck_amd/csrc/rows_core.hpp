@@ -96,12 +96,7 @@ BFS_HD void row_lane_compress(RowLane& s, unsigned char* buf, bool at_end) {
     u64 m[16];
     BFS_UNROLL
     for (int j = 0; j < 16; ++j) m[j] = (u32)(8 * j) < valid ? w[j] : 0;
-#ifdef BFS_ROWS_ABL_NO_HASH                // timing experiments only (tools/ab_rows.sh): wrong digests
-    BFS_UNROLL
-    for (int j = 0; j < 8; ++j) s.h[j] ^= m[j] + m[j + 8];
-#else
     blake2b_compress(s.h, m, last ? (u64)s.total : (u64)s.consumed + 128, last);
-#endif
     s.consumed += 128;
     s.hashed_any = 1;
     u64* ww = (u64*)buf;

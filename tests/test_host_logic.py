@@ -473,3 +473,24 @@ def test_row_window_entry_points_reject_windows_outside_the_domain():
     # an empty window inside the domain: nothing to do, no device needed
     assert lib.bfs_zerofier_inverses_rows(4, 7, 1, 1, one, val, None, 16, 0, None) == 0
     assert lib.bfs_difference_combine_rows(None, None, 4, 7, 1, ctypes.byref(w), None, None, 5, 0, None) == 0
+
+
+def test_shipped_library_has_no_experiment_switches_and_no_carry_hazards():
+    """round-3 verdict #6 / advice: (1) no timing-only (wrong-result) or A/B branch is left in the product sources and the build
+    defines none; (2) the library in the tree was built from exactly these sources with exactly the default flags; (3) the gfx950
+    listings of that build hold no VALU carry read closer than two wait states to the VALU write of its SGPR pair
+    (tools/isa_hazards.py: the padding inside inline asm is ours to get right)."""
+    import subprocess
+    import sys
+    from stark_brainfuck_amd import build as b
+    hits = []
+    for f in sorted(os.listdir(b.CSRC)):
+        text = open(os.path.join(b.CSRC, f), errors="replace").read()
+        hits += ["%s: %s" % (f, m) for m in re.findall(r"BFS_\w*ABL\w*", text)]
+    assert not hits, hits
+    assert not [f for f in b.FLAGS if f.startswith("-DBFS_")]
+    b.build_library()                                   # no-op when current; rebuilds (with the default flags) otherwise
+    assert b.up_to_date(), "libbfstark_hip.so is not what the default flags build from the sources in the tree"
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "isa_hazards.py")], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-1000:]
+    assert " 0 site(s)" in res.stdout

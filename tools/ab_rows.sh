@@ -1,6 +1,6 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): the zipped-row leaf kernel inside three 2^22-domain proofs, product build against timing-only
-# variants (tools/build_variant.py rows_<X> rows.hip -DBFS_ROWS_ABL_<X>; wrong digests) -> gpurun_out/ab_rows.txt
+# variants (tools/build_variant.py <tag> rows.hip -D...) -> gpurun_out/ab_rows.txt
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/ab_rows.txt
 : > "$OUT"
