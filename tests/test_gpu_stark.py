@@ -133,6 +133,36 @@ def test_combination_by_row_windows_writes_the_reference_proof(name, monkeypatch
 
 
 @pytest.mark.gpu
+def test_combination_kernel_without_the_grouped_shift_pattern(monkeypatch):
+    """air_combine_kernel<TABLE, GROUPED = false>: the launcher takes it when the degree shifts of a run of terms are NOT all equal,
+    which sampled challenges practically never produce (round-3 advice).  Here the shifts are perturbed term by term through the
+    prover's test hook, and the fused kernel's combination must equal what bfs_air_quotients + bfs_combination (one generic
+    weighted sum over the written-out codewords, the keep_intermediates path) compute from the same shifts: same proof bytes."""
+    import numpy as np
+    from stark_brainfuck_amd import brainfuck_stark, salted_merkle, table
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    g = json.load(open(os.path.join(GOLDEN, "stark_two_io.json")))
+    program = VirtualMachine.compile(g["program"])
+    running_time, input_symbols, output_symbols = VirtualMachine.run(program, input_data=list(g["input"]))
+    matrices = VirtualMachine.simulate(program, input_data=list(input_symbols))
+
+    def tweak(shifts):
+        return shifts + (np.arange(len(shifts), dtype=np.uint64) * np.uint64(7)) % np.uint64(5)      # neighbours differ: no run is uniform
+    proofs = {}
+    for keep in (True, False):
+        stark = BrainfuckStark(running_time, len(matrices[1]), program, input_symbols, output_symbols)
+        stark.keep_intermediates = keep
+        stark._shift_tweak = tweak
+        stream = Stream(b"two_io")
+        for mod in (brainfuck_stark, salted_merkle, table):
+            monkeypatch.setattr(mod, "urandom", stream)
+        proofs[keep] = stark.prove(program, *matrices)
+    assert proofs[True] == proofs[False]
+    assert hashlib.sha256(proofs[False]).hexdigest() != g["proof_sha256"]          # (the tweak did change the combination)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", NAMES)
 def test_verify_accepts_reference_proofs_and_rejects_tampering(name):
     """the verifier mirror (brainfuck_stark.py:343-579) on proofs written by the reference itself"""

@@ -484,3 +484,44 @@ def test_vm_pad_extend_against_the_reference_on_many_programs():
         assert [list(t) for t in stark.get_terminals()] == g["terminals"], code
         checked += 1
     assert checked >= 75 and errors >= 5
+
+
+def test_table_caches_follow_the_matrix_object_not_its_id():
+    """Table caches the column-major copy of its matrix and the scan masks derived from it.  The same table objects are given one
+    trace after another of the SAME height (prove() called again, tools, tests); the caches must follow the matrix object -- the old key,
+    (id(matrix), rows), comes back when CPython reuses a freed matrix' address (round-3 advice)"""
+    import gc
+    import numpy as np
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    programs = [VirtualMachine.compile(c) for c in ("++>+++.<-.", "+>++<+.>-.")]         # equal lengths and running times, different traces
+    runs = [VirtualMachine.run(p) for p in programs]
+    assert runs[0][0] == runs[1][0]
+
+    def masks_of(stark, matrices):
+        order = (matrices[0], matrices[2], matrices[1], matrices[3], matrices[4])
+        for table, matrix in zip(stark.tables, order):
+            table.matrix = matrix
+        for table in stark.tables:
+            table.pad()
+        return [[None if m is None else np.array(m, copy=True) for m in t._scan_masks()] for t in stark.tables], [t.base_array().copy() for t in stark.tables]
+
+    def same(a, b):
+        return all((x is None and y is None) or (x is not None and y is not None and np.array_equal(x, y)) for ta, tb in zip(a, b) for x, y in zip(ta, tb))
+    fresh = []
+    for program, (rt, inputs, outputs) in zip(programs, runs):
+        stark = BrainfuckStark(rt, 0, program, inputs, outputs)
+        fresh.append(masks_of(stark, VirtualMachine.simulate(program, input_data=inputs)))
+    assert not same(fresh[0][0], fresh[1][0]) or not all(np.array_equal(a, b) for a, b in zip(fresh[0][1], fresh[1][1]))
+    rt, inputs, outputs = runs[0]
+    reused = BrainfuckStark(rt, 0, programs[0], inputs, outputs)
+    for rep in range(6):
+        k = rep % 2
+        matrices = VirtualMachine.simulate(programs[k], input_data=runs[k][1])
+        masks, arrays = masks_of(reused, matrices)
+        assert same(masks, fresh[k][0]), rep
+        assert all(np.array_equal(a, b) for a, b in zip(arrays, fresh[k][1])), rep
+        del matrices, masks, arrays
+        for t in reused.tables:
+            t.matrix = []                      # drop the padded matrices so that their addresses are free for the next round
+        gc.collect()
