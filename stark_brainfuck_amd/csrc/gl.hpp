@@ -98,7 +98,10 @@ BFS_HD u64 gl_sub(u64 a, u64 b) { return gl_sub5(a, b); }
 #endif
 // the reductions' scalar-carry forms (gl_sub_word4 for lo - hi_hi, gl_fold_word<true> for the tail): everywhere unless a unit opts out
 constexpr bool GL_REDUCE4 = true;
-// a + b: s = a + b and u = s + EPS (= s - p mod 2^64) with both carries; a + b >= p  <=>  either addition carried
+// a + b: s = a + b and u = s + EPS (= s - p mod 2^64) with both carries; a + b >= p  <=>  either addition carried.  Six instructions
+// as the compiler has them.  Five-instruction forms with scalar carries were measured twice (profiles/r03/ab_add5.txt; profiles/r04/
+// ab_add5_power.txt: 4 % fewer VALU instructions per NTT step, the step 0.2-1.3 % SLOWER: each trades two selects for a 64-bit
+// multiply-add, and the step runs at the package power limit) -- not kept.
 BFS_HD u64 gl_add(u64 a, u64 b) {
     u32 c1, c2, c3, c4;
     u32 slo = __builtin_addc((u32)a, (u32)b, 0u, &c1);

@@ -18,7 +18,7 @@ obj = os.path.join(out_dir, "%s_%s.o" % (unit, tag))
 hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 compile_flags = [f for f in b.FLAGS if f != "-shared"]
 subprocess.check_call([hipcc] + compile_flags + flags + ["-c", "-o", obj, os.path.join(b.CSRC, unit)], cwd=b.CSRC)
-others = [os.path.join(b.OBJ, f) for f in sorted(os.listdir(b.OBJ)) if f.endswith(".o") and f != unit + ".o"]
+others = [os.path.join(b.OBJ, f) for f in sorted(os.listdir(b.OBJ)) if f.endswith((".hip.o", ".cpp.o")) and f != unit + ".o"]     # (not the -save-temps device objects)
 lib = os.path.join(out_dir, "lib_%s.so" % tag)
 subprocess.check_call([hipcc, "-shared", "-fPIC", "--offload-arch=" + b.ARCH, "-o", lib, obj] + others, cwd=b.CSRC)
 print(lib)
