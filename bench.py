@@ -81,9 +81,12 @@ def main():
                     help="N > 1: do not time the cooperative proof at all (by default rank 0 runs it as a SEPARATE, time-limited job after "
                          "the main measurement -- see guarded_cooperative -- unless --cooperative already ran it in-job)")
     ap.add_argument("--coop-leg", action="store_true", help=argparse.SUPPRESS)     # internal: the separate job of guarded_cooperative
+    ap.add_argument("--stark-worker", type=float, default=0.0, help=argparse.SUPPRESS)   # internal: one prover PROCESS of bench_stark_concurrent
     ap.add_argument("--no-check", action="store_true", help="skip the post-run round-trip check and root gather (PMC collection runs)")
     args = ap.parse_args()
 
+    if args.stark_worker > 0:
+        raise SystemExit(stark_worker(args.stark_worker))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start the N ranks ourselves -- the same one-process-per-GPU launch the driver uses
         # (torch.distributed.run over 127.0.0.1); rank 0 of that job prints the JSON line on the stdout we share with it
@@ -635,6 +638,76 @@ def bench_fri_concurrent(lib, _lib, log_d, ks=(1, 2, 4), seconds=0.6):
             "note": "K threads x (own stream, own codeword), bfs_fri_prove back to back for %.1f s per K" % seconds}
 
 
+def stark_worker(seconds):
+    """one prover process of bench_stark_concurrent's process mode: proves Hello World once, reports `ready`, waits for `go` on stdin,
+    then proves back to back for `seconds` and prints how many proofs it wrote and the SHA-256 of the first"""
+    import hashlib
+    from stark_brainfuck_amd import randomness
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    program = VirtualMachine.compile(HELLO_WORLD)
+    running_time, inputs, outputs = VirtualMachine.run(program)
+    mats = VirtualMachine.simulate(program, input_data=inputs)
+
+    def one():
+        with randomness.override(FixedRandomness()):
+            return BrainfuckStark(running_time, len(mats[1]), program, inputs, outputs).prove(program, *mats)
+    first = hashlib.sha256(one()).hexdigest()
+    one()
+    print("ready", flush=True)
+    if sys.stdin.readline().strip() != "go":
+        return 1
+    count, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        one()
+        count += 1
+    print(json.dumps({"proofs": count, "seconds": time.perf_counter() - t0, "sha256": first}), flush=True)
+    return 0
+
+
+def stark_process_throughput(K, seconds):
+    """K prover PROCESSES on this GPU (no shared interpreter lock): started, warmed up, released together; proofs per second over
+    the slowest process' window"""
+    import subprocess
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--stark-worker", str(seconds)], stdin=subprocess.PIPE,
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(K)]
+    try:
+        for p in procs:
+            line = p.stdout.readline()
+            if line.strip() != "ready":
+                return {"error": "a prover process did not come up"}
+        for p in procs:
+            p.stdin.write("go\n"); p.stdin.flush()
+        outs = [json.loads(p.stdout.readline()) for p in procs]
+    except Exception as e:                # noqa: BLE001
+        return {"error": repr(e)[:200]}
+    finally:
+        for p in procs:
+            try:
+                p.wait(timeout=30)
+            except Exception:             # noqa: BLE001
+                p.kill()
+    return {"proofs_per_s": sum(o["proofs"] for o in outs) / max(o["seconds"] for o in outs), "sha256": sorted({o["sha256"] for o in outs})}
+
+
+HELLO_WORLD = "++++++++[>++++[>++>+++>+++>+<<<<-]>+>+>->>+[<]<-]>>.>---.+++++++..+++.>>.<-.<.+++.------.--------.>>+.>++."
+
+
+class FixedRandomness:
+    """count -> bytes, the same sequence for every prover and every proof (a stand-in for os.urandom that makes proofs comparable)"""
+    expand_on_device = True
+
+    def __init__(self):
+        import hashlib
+        self.pos, self.buf = 0, hashlib.shake_256(b"bench-concurrent").digest(1 << 16)
+
+    def __call__(self, count):
+        out = self.buf[self.pos:self.pos + count]
+        self.pos += count
+        return out
+
+
 def bench_stark_concurrent(ks=(1, 2, 4), seconds=0.8):
     """the same for the Hello-World proof: K threads, each with its own torch stream (the package enqueues on the thread's current stream)
     and its own BrainfuckStark instance, prove() back to back.  The prover's host side is Python, so the threads share the interpreter
@@ -645,20 +718,9 @@ def bench_stark_concurrent(ks=(1, 2, 4), seconds=0.8):
     from stark_brainfuck_amd import randomness
     from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
     from stark_brainfuck_amd.vm import VirtualMachine
-    code = "++++++++[>++++[>++>+++>+++>+<<<<-]>+>+>->>+[<]<-]>>.>---.+++++++..+++.>>.<-.<.+++.------.--------.>>+.>++."
-    program = VirtualMachine.compile(code)
+    program = VirtualMachine.compile(HELLO_WORLD)
     running_time, inputs, outputs = VirtualMachine.run(program)
-
-    class Fixed:                     # count -> bytes, the same sequence for every prover and every proof
-        expand_on_device = True
-
-        def __init__(self):
-            self.pos, self.buf = 0, hashlib.shake_256(b"bench-concurrent").digest(1 << 16)
-
-        def __call__(self, count):
-            out = self.buf[self.pos:self.pos + count]
-            self.pos += count
-            return out
+    Fixed = FixedRandomness
     out, digests = {}, set()
     for K in ks:
         streams = [torch.cuda.Stream() for _ in range(K)]
@@ -677,9 +739,18 @@ def bench_stark_concurrent(ks=(1, 2, 4), seconds=0.8):
         digests.update(first)
         out[str(K)] = round(r["proofs_per_s"], 1) if "proofs_per_s" in r else r
     base = out.get("1")
-    return {"proofs_per_s_by_provers": out, "best_over_single": (max(v for v in out.values() if isinstance(v, float)) / base) if isinstance(base, float) else None,
+    # the same with K PROCESSES (one interpreter each): what the GPU can take when the host side is not serialised
+    by_process = {}
+    for K in (2, 4):
+        r = stark_process_throughput(K, seconds)
+        by_process[str(K)] = round(r["proofs_per_s"], 1) if "proofs_per_s" in r else r
+        if "sha256" in r:
+            digests.update(r["sha256"])
+    best = max([v for v in list(out.values()) + list(by_process.values()) if isinstance(v, float)] or [0.0])
+    return {"proofs_per_s_by_provers": out, "proofs_per_s_by_prover_processes": by_process,
+            "best_over_single": (best / base) if isinstance(base, float) and base else None,
             "proofs_identical_across_provers": len(digests) == 1,
-            "note": "K threads x (own torch stream, own BrainfuckStark), Hello World, prove() back to back for %.1f s per K; the host side is Python (one interpreter lock)" % seconds}
+            "note": "K threads x (own torch stream, own BrainfuckStark) share one interpreter lock; K processes do not; Hello World, prove() back to back for %.1f s per K" % seconds}
 
 
 VALU_PER_COMPRESSION = 1983     # BLAKE2b-512 compression in VGPRs on gfx950: 801 xor + 576 funnel shifts + 575 64-bit adds + 31

@@ -1,5 +1,5 @@
 """profiles/prover_valu.json from what tools/prof_prover.sh wrote (development tool):
-    python tools/make_prover_valu.py gpurun_out/<tag> [round directory, default profiles/r03]
+    python tools/make_prover_valu.py gpurun_out/<tag> [round directory, default profiles/r04]
 Per kernel of Fri.prove (N = 2^24) and of BrainfuckStark.prove (FRI domain 2^22): launches, average duration (rocprofv3 --stats), VALU
 wave instructions and HBM bytes per launch (PMC; gfx950: reads = 2 * FETCH_SIZE KB, MI355X_MICROARCH.md), and the two fractions a
 reader can recompute from them:  valu_issue_frac = SQ_INSTS_VALU * 4 cycles / (1024 SIMDs * clock) / duration  (clock = the GPU's
@@ -14,7 +14,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = sys.argv[1]
-rdir = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r03")
+rdir = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r04")
 SHORT = re.compile(r"(?:void )?(?:bfs::)?([A-Za-z_0-9]+(?:<[^>]*>)?)")
 
 
