@@ -47,7 +47,12 @@ for w, label in (("fri24", "Fri.prove, N = 2^24 (codeword of 2^24 extension elem
             e["valu_wave_instructions_per_launch"] = p["SQ_INSTS_VALU"]
             e["waves_per_launch"] = p.get("SQ_WAVES")
             e["clock_hz_used"] = clock
-            e["valu_issue_frac"] = p["SQ_INSTS_VALU"] * 4.0 / (1024 * clock) / (s["avg_us"] * 1e-6)
+            f = p["SQ_INSTS_VALU"] * 4.0 / (1024 * clock) / (s["avg_us"] * 1e-6)
+            # the instruction count, the cycle count and the duration come from three separate profiler passes (gpurun refuses combined
+            # ones); for a kernel that sits on the roof their run-to-run spread can put the quotient a per cent above 1
+            e["valu_issue_frac"] = min(f, 1.0)
+            if f > 1.0:
+                e["valu_issue_frac_uncapped"] = f
         if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
             e["hbm_bytes_per_launch"] = 2 * p["FETCH_SIZE"] * 1024 + p["WRITE_SIZE"] * 1024
             e["hbm_frac"] = e["hbm_bytes_per_launch"] / (s["avg_us"] * 1e-6) / 8e12
