@@ -128,6 +128,10 @@ int bfs_gl_batch_inverse(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void
  */
 void* bfs_ps_new(void);
 void bfs_ps_free(void* ps);
+/* ProofStream.deserialize (ip.py:27-30: pickle.loads of the proof bytes) straight into a native stream: the objects of the pickled list,
+ * object identities included, with handles 1..n in stream order.  NULL (see bfs_last_error) unless serialising the result reproduces the
+ * input byte for byte -- then the caller unpickles with CPython and rebuilds through bfs_ps_obj_* as before. */
+void* bfs_ps_loads(const uint8_t* data, size_t len);
 uint64_t bfs_ps_obj_bytes(void* ps, const uint8_t* data, size_t len);
 uint64_t bfs_ps_obj_int(void* ps, uint64_t value);
 uint64_t bfs_ps_obj_xfe(void* ps, const uint64_t limbs[3]);

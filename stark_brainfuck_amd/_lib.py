@@ -52,6 +52,7 @@ _SIGNATURES = {
     "bfs_gl_mul_pointwise": (ci, [vp, vp, vp, u64, vp]),
     "bfs_gl_batch_inverse": (ci, [vp, vp, u64, vp]),
     "bfs_ps_new": (vp, []),
+    "bfs_ps_loads": (vp, [ctypes.c_char_p, sz]),
     "bfs_ps_free": (None, [vp]),
     "bfs_ps_obj_bytes": (u64, [vp, ctypes.c_char_p, sz]),
     "bfs_ps_obj_int": (u64, [vp, u64]),

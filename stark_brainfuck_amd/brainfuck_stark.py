@@ -537,6 +537,19 @@ class BrainfuckStark:
         if proof_stream is None:
             proof_stream = ProofStream()
         proof_stream = proof_stream.deserialize(proof)
+        if hasattr(proof_stream, "pickle_of"):
+            # leaf preimages (pickle.dumps of an opened row / element) come from the native copy of the stream while this call runs
+            from .merkle import leaf_pickle_source
+            token = leaf_pickle_source.set(proof_stream.pickle_of)
+            try:
+                return self._verify_stream(proof_stream)
+            finally:
+                leaf_pickle_source.reset(token)
+        return self._verify_stream(proof_stream)
+
+    def _verify_stream(self, proof_stream):
+        from .air import X0, xadd, xmul, xscale
+        P = air.P
         n = self.fri.domain.length
         offset, omega = self.fri.domain.offset.value, self.fri.domain.omega.value
 

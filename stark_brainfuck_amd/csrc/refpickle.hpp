@@ -12,6 +12,7 @@
 // Pinned by tests against pickle byte strings captured from the reference (tests/golden/pickle.json, fri_*_stream.bin).
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
 #include <string.h>
 
 #include <memory>
@@ -505,6 +506,201 @@ class Pickler {
             }
             default: break;
         }
+    }
+};
+
+// The other direction: a protocol-4 pickle of the kinds above -> the node graph (ProofStream.deserialize, ip.py:27-30 on the
+// verifier's side).  One node per unpickled object, memo references (BINGET / LONG_BINGET) become shared nodes, so the graph has the
+// identities the writer's objects had and the Pickler above writes the same bytes back -- which is how bfs_ps_loads checks the result
+// before anybody uses it.  Opcodes outside this set (None, booleans, negative integers, floats, reducers other than
+// copyreg.__newobj__ with no arguments) make load() fail, and the caller takes the Python route.
+class Unpickler {
+   public:
+    Unpickler(const unsigned char* data, size_t len) : p_(data), n_(len) {}
+    // the unpickled object, or an empty Ref (`why` says what was not understood)
+    Ref load(std::string* why = nullptr) {
+        Ref r = run();
+        if (!r && why) *why = why_;
+        return r;
+    }
+
+   private:
+    const unsigned char* p_;
+    size_t n_, pos_ = 0;
+    std::vector<Ref> stack_, memo_;
+    std::vector<size_t> marks_;
+    std::string why_;
+
+    bool need(size_t k) {
+        if (n_ - pos_ < k) { why_ = "truncated pickle"; return false; }
+        return true;
+    }
+    u64 le(size_t k) {
+        u64 v = 0;
+        for (size_t i = 0; i < k; ++i) v |= (u64)p_[pos_ + i] << (8 * i);
+        pos_ += k;
+        return v;
+    }
+    bool pop(Ref& r) {
+        if (stack_.empty() || (!marks_.empty() && stack_.size() <= marks_.back())) { why_ = "stack underflow"; return false; }
+        r = stack_.back();
+        stack_.pop_back();
+        return true;
+    }
+    bool pop_mark(std::vector<Ref>& items) {
+        if (marks_.empty()) { why_ = "no MARK"; return false; }
+        const size_t m = marks_.back();
+        marks_.pop_back();
+        items.assign(stack_.begin() + m, stack_.end());
+        stack_.resize(m);
+        return true;
+    }
+    bool blob(size_t len_bytes, Kind kind) {
+        if (!need(len_bytes)) return false;
+        const u64 len = le(len_bytes);
+        if (!need(len)) return false;
+        Ref n;
+        if (kind == K_BYTES) n = mk_bytes(p_ + pos_, len);
+        else { n = mk(K_STR); n->data.assign((const char*)p_ + pos_, len); }
+        pos_ += len;
+        stack_.push_back(n);
+        return true;
+    }
+    static bool is_class(const Ref& c, const char* module, const char* name) {
+        return c && c->kind == K_CLASS && c->items.size() == 2 && c->items[0]->data == module && c->items[1]->data == name;
+    }
+    static Ref dict_get(const Ref& d, const char* key) {
+        if (!d || d->kind != K_DICT) return Ref();
+        for (size_t i = 0; i + 1 < d->items.size(); i += 2)
+            if (d->items[i]->kind == K_STR && d->items[i]->data == key) return d->items[i + 1];
+        return Ref();
+    }
+    // what an instance stands for, for bfs_ps_obj_kind / bfs_ps_obj_get_limbs (the pickler does not look at these)
+    static void tag(const Ref& inst) {
+        if (is_class(inst->cls, "algebra", "BaseFieldElement")) {
+            Ref v = dict_get(inst->state, "value");
+            if (v && v->kind == K_INT) { inst->role = R_BFE; inst->limbs[0] = v->ival; }
+        } else if (is_class(inst->cls, "extension_field", "ExtensionFieldElement")) {
+            Ref poly = dict_get(inst->state, "polynomial");
+            Ref coeffs = poly && poly->kind == K_INSTANCE ? dict_get(poly->state, "coefficients") : Ref();
+            if (coeffs && coeffs->kind == K_LIST && coeffs->items.size() <= 3) {
+                inst->role = R_XFE;
+                for (size_t i = 0; i < coeffs->items.size(); ++i) inst->limbs[i] = coeffs->items[i]->limbs[0];
+            }
+        }
+    }
+
+    Ref run() {
+        while (pos_ < n_) {
+            const unsigned char opc = p_[pos_++];
+            Ref a, b;
+            std::vector<Ref> items;
+            switch (opc) {
+                case 0x80: if (!need(1)) return Ref(); if (p_[pos_++] > 5) { why_ = "pickle protocol"; return Ref(); } break;   // PROTO
+                case 0x95: if (!need(8)) return Ref(); pos_ += 8; break;                                  // FRAME (the length is not needed)
+                case 0x5d: stack_.push_back(mk(K_LIST)); break;                                           // EMPTY_LIST
+                case 0x7d: stack_.push_back(mk(K_DICT)); break;                                           // EMPTY_DICT
+                case 0x29: stack_.push_back(mk(K_TUPLE)); break;                                          // EMPTY_TUPLE
+                case 0x94: if (stack_.empty()) { why_ = "MEMOIZE on an empty stack"; return Ref(); } memo_.push_back(stack_.back()); break;
+                case 0x28: marks_.push_back(stack_.size()); break;                                        // MARK
+                case 0x65:                                                                                // APPENDS
+                    if (!pop_mark(items) || stack_.empty() || stack_.back()->kind != K_LIST) { why_ = "APPENDS"; return Ref(); }
+                    stack_.back()->items.insert(stack_.back()->items.end(), items.begin(), items.end());
+                    break;
+                case 0x61:                                                                                // APPEND
+                    if (!pop(a) || stack_.empty() || stack_.back()->kind != K_LIST) { why_ = "APPEND"; return Ref(); }
+                    stack_.back()->items.push_back(a);
+                    break;
+                case 0x75:                                                                                // SETITEMS
+                    if (!pop_mark(items) || (items.size() & 1) || stack_.empty() || stack_.back()->kind != K_DICT) { why_ = "SETITEMS"; return Ref(); }
+                    stack_.back()->items.insert(stack_.back()->items.end(), items.begin(), items.end());
+                    break;
+                case 0x73:                                                                                // SETITEM
+                    if (!pop(b) || !pop(a) || stack_.empty() || stack_.back()->kind != K_DICT) { why_ = "SETITEM"; return Ref(); }
+                    stack_.back()->items.push_back(a);
+                    stack_.back()->items.push_back(b);
+                    break;
+                case 0x43: if (!blob(1, K_BYTES)) return Ref(); break;                                    // SHORT_BINBYTES
+                case 0x42: if (!blob(4, K_BYTES)) return Ref(); break;                                    // BINBYTES
+                case 0x8e: if (!blob(8, K_BYTES)) return Ref(); break;                                    // BINBYTES8
+                case 0x8c: if (!blob(1, K_STR)) return Ref(); break;                                      // SHORT_BINUNICODE
+                case 0x58: if (!blob(4, K_STR)) return Ref(); break;                                      // BINUNICODE
+                case 0x4b: if (!need(1)) return Ref(); stack_.push_back(mk_int(le(1))); break;            // BININT1
+                case 0x4d: if (!need(2)) return Ref(); stack_.push_back(mk_int(le(2))); break;            // BININT2
+                case 0x4a: {                                                                              // BININT (signed)
+                    if (!need(4)) return Ref();
+                    const u64 v = le(4);
+                    if (v >> 31) { why_ = "negative integer"; return Ref(); }
+                    stack_.push_back(mk_int(v));
+                    break;
+                }
+                case 0x8a: {                                                                              // LONG1
+                    if (!need(1)) return Ref();
+                    const size_t len = p_[pos_++];
+                    if (!need(len)) return Ref();
+                    if (len > 9 || (len == 9 && p_[pos_ + 8] != 0) || (len > 0 && len < 9 && (p_[pos_ + len - 1] & 0x80))) {
+                        why_ = "integer outside [0, 2^64)";
+                        return Ref();
+                    }
+                    stack_.push_back(mk_int(le(len > 8 ? 8 : len)));
+                    if (len == 9) ++pos_;
+                    break;
+                }
+                case 0x93:                                                                                // STACK_GLOBAL
+                    if (!pop(b) || !pop(a) || a->kind != K_STR || b->kind != K_STR) { why_ = "STACK_GLOBAL"; return Ref(); }
+                    stack_.push_back(mk_class(a, b));
+                    break;
+                case 0x81: {                                                                              // NEWOBJ: cls.__new__(cls, *args)
+                    if (!pop(b) || !pop(a) || a->kind != K_CLASS || b->kind != K_TUPLE || !b->items.empty()) { why_ = "NEWOBJ"; return Ref(); }
+                    Ref inst = mk(K_INSTANCE);
+                    inst->cls = a;
+                    stack_.push_back(inst);
+                    break;
+                }
+                case 0x62:                                                                                // BUILD: instance.__dict__ = state
+                    if (!pop(a) || a->kind != K_DICT || stack_.empty() || stack_.back()->kind != K_INSTANCE || stack_.back()->state) { why_ = "BUILD"; return Ref(); }
+                    stack_.back()->state = a;
+                    tag(stack_.back());
+                    break;
+                case 0x85: case 0x86: case 0x87: {                                                        // TUPLE1 / 2 / 3
+                    const size_t k = opc - 0x84;
+                    if (stack_.size() < k || (!marks_.empty() && stack_.size() - k < marks_.back())) { why_ = "TUPLEn"; return Ref(); }
+                    Ref t = mk(K_TUPLE);
+                    t->items.assign(stack_.end() - k, stack_.end());
+                    stack_.resize(stack_.size() - k);
+                    stack_.push_back(t);
+                    break;
+                }
+                case 0x74: {                                                                              // TUPLE
+                    if (!pop_mark(items)) return Ref();
+                    Ref t = mk(K_TUPLE);
+                    t->items = items;
+                    stack_.push_back(t);
+                    break;
+                }
+                case 0x68: case 0x6a: {                                                                   // BINGET / LONG_BINGET
+                    const size_t k = opc == 0x68 ? 1 : 4;
+                    if (!need(k)) return Ref();
+                    const u64 idx = le(k);
+                    if (idx >= memo_.size()) { why_ = "memo index"; return Ref(); }
+                    stack_.push_back(memo_[idx]);
+                    break;
+                }
+                case 0x2e:                                                                                // STOP
+                    if (stack_.size() != 1 || !marks_.empty()) { why_ = "STOP with a stack of the wrong depth"; return Ref(); }
+                    for (const Ref& m : memo_)
+                        if (m->kind == K_INSTANCE && !m->state) { why_ = "an instance without state"; return Ref(); }
+                    return stack_.back();
+                default: {
+                    char buf[48];
+                    snprintf(buf, sizeof buf, "opcode 0x%02x is not supported", opc);
+                    why_ = buf;
+                    return Ref();
+                }
+            }
+        }
+        why_ = "no STOP";
+        return Ref();
     }
 };
 

@@ -23,6 +23,31 @@ extern "C" {
 void* bfs_ps_new(void) { return new Transcript(); }
 void bfs_ps_free(void* ps) { delete T(ps); }
 
+// ProofStream.deserialize (ip.py:27-30) without Python objects in between: the pickle of a LIST is read into a new stream whose objects
+// are the list's items, with the identities (shared coefficient objects, BaseField instances, repeated nodes) the writer's objects had.
+// The result is only handed out if serialising it gives the input back byte for byte; otherwise (an opcode or an object kind outside
+// what the reference's proofs contain, or a pickle some other writer laid out differently) NULL with bfs_last_error() saying why --
+// the caller falls back to CPython's unpickler + bfs_ps_obj_*.
+void* bfs_ps_loads(const uint8_t* data, size_t len) {
+    std::string why;
+    rp::Unpickler u(data, len);
+    Ref root = u.load(&why);
+    if (!root) { set_error("bfs_ps_loads: %s", why.c_str()); return nullptr; }
+    if (root->kind != rp::K_LIST) { set_error("bfs_ps_loads: the pickle is not a list"); return nullptr; }
+    Transcript* t = new Transcript();
+    for (const Ref& item : root->items) {
+        t->add(item);                      // handle = index + 1, as bfs_ps_object_at reports it
+        t->objects.push_back(item);
+    }
+    const std::string again = t->serialize(t->objects.size());
+    if (again.size() != len || memcmp(again.data(), data, len) != 0) {
+        delete t;
+        set_error("bfs_ps_loads: the stream does not serialise back to the same %zu bytes", len);
+        return nullptr;
+    }
+    return t;
+}
+
 uint64_t bfs_ps_obj_bytes(void* ps, const uint8_t* data, size_t len) { return T(ps)->add(rp::mk_bytes(data, len)); }
 uint64_t bfs_ps_obj_int(void* ps, uint64_t value) { return T(ps)->add(rp::mk_int(value)); }
 uint64_t bfs_ps_obj_xfe(void* ps, const uint64_t limbs[3]) {

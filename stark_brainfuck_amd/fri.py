@@ -236,6 +236,13 @@ class Fri:
         (an inverse transform's non-zero pattern, two cross products) instead of through Polynomial objects over element objects:
         the reference's interpolations were 2/3 of this package's 15 ms verifier."""
         from .air import P
+        from .merkle import leaf_pickle_source
+        if leaf_pickle_source.get() is None and hasattr(proof_stream, "pickle_of"):
+            token = leaf_pickle_source.set(proof_stream.pickle_of)      # (a bare Fri.verify on a deserialised stream; see BrainfuckStark.verify)
+            try:
+                return self.verify(proof_stream, root)
+            finally:
+                leaf_pickle_source.reset(token)
         omega_v, offset_v = _base_value(self.domain.omega), _base_value(self.domain.offset)
         rounds, t, N = self.num_rounds(), self.num_colinearity_tests, self.domain.length
         roots, alphas = [root], []

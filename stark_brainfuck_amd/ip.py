@@ -21,9 +21,11 @@ _u64 = ctypes.c_uint64
 class NativeTranscript:
     """owns a bfs_ps_* handle and the two-way mapping between Python objects and native object handles."""
 
-    def __init__(self):
+    loaded = False        # True: made by from_bytes -- the native side was read from the pickle, no Python object maps to a handle
+
+    def __init__(self, _handle=None):
         self.lib = _lib.load()
-        self.handle = self.lib.bfs_ps_new()
+        self.handle = self.lib.bfs_ps_new() if _handle is None else _handle
         self._by_id = {}     # id(python object) -> native handle
         self._keep = []      # keeps those python objects alive so ids stay unique
         self._by_handle = {}  # native handle -> python object (identity of objects created natively)
@@ -37,6 +39,27 @@ class NativeTranscript:
             self.lib.bfs_ps_free(self.handle)
         except Exception:
             pass
+
+    @classmethod
+    def from_bytes(cls, data):
+        """the native stream of a serialised proof (bfs_ps_loads: read natively, accepted only if it serialises back to `data`), or
+        None when the bytes hold something the native reader does not take -- the caller then builds the stream from Python objects"""
+        data = bytes(data)
+        handle = _lib.load().bfs_ps_loads(data, len(data))
+        if not handle:
+            return None
+        t = cls(_handle=handle)
+        t.loaded = True
+        return t
+
+    def dumps_handle(self, h):
+        """pickle.dumps of the object behind native handle h, on its own"""
+        lib = self.lib
+        n = ctypes.c_size_t()
+        _lib.check(lib.bfs_ps_obj_dumps(self.handle, h, None, 0, ctypes.byref(n)))
+        buf = ctypes.create_string_buffer(max(n.value, 1))
+        _lib.check(lib.bfs_ps_obj_dumps(self.handle, h, buf, n.value, ctypes.byref(n)))
+        return buf.raw[:n.value]
 
     def scan(self, objs):
         """note which BaseFieldElement objects are coefficients of more than one extension element: those elements must be
@@ -234,7 +257,9 @@ class ProofStream:
         objs = self.objects
         if t is not None:
             k = len(self._cached_ids)
-            stale = k > len(objs) or any(id(o) != i for o, i in zip(objs, self._cached_ids))
+            stale = k > len(objs) or list(map(id, objs[:k])) != self._cached_ids      # (one C-level pass: the verifier asks ~20 times per proof)
+            if not stale and k < len(objs) and t.loaded:
+                stale = True          # read natively from bytes: it has no map from Python objects to handles, so it cannot take more
             if not stale and k < len(objs):
                 new = objs[k:]
                 if t.xfield is None and _find_xfield(new) is not None:
@@ -291,9 +316,37 @@ class ProofStream:
         return self._native().fiat_shamir(self.read_index, num_bytes)
 
     def deserialize(self, bb):
+        """ip.py:27-30.  The Python objects come from CPython's unpickler (into this package's classes); the verifier's Fiat-Shamir
+        calls and leaf pickles need the BYTES of prefixes and of single objects, and those come from a native stream read from the
+        same bytes (bfs_ps_loads) instead of from walking the Python objects again -- that walk was half of verify()'s time."""
         ps = ProofStream()
         ps.objects = _ReferenceUnpickler(io.BytesIO(bb)).load()
+        t = NativeTranscript.from_bytes(bb) if isinstance(ps._objects, list) else None
+        if t is not None and t.num_objects() == len(ps._objects):
+            t.xfield = _find_xfield(ps._objects)
+            ps._cached, ps._cached_ids = t, [id(o) for o in ps._objects]
+            # where a pulled object (or an item of a pulled tuple: FRI's (a, b, c) leaves) sits in the native stream
+            handles = {}
+            for k, o in enumerate(ps._objects):
+                handles[id(o)] = (k + 1, None, o)
+                if isinstance(o, tuple):
+                    for i, c in enumerate(o):
+                        handles.setdefault(id(c), (k + 1, i, c))
+            ps._handles = handles
         return ps
+
+    def pickle_of(self, obj):
+        """pickle.dumps(obj) for an object of a deserialised stream (by identity), from the native stream; None when it is not one"""
+        entry = getattr(self, "_handles", {}).get(id(obj))
+        t = getattr(self, "_cached", None)
+        if entry is None or t is None or not t.loaded or entry[2] is not obj:
+            return None
+        h, item, _ = entry
+        if item is not None:
+            h = t.lib.bfs_ps_obj_item(t.handle, h, item)
+            if not h:
+                return None
+        return t.dumps_handle(h)
 
 
 class _ReferenceUnpickler(pickle.Unpickler):

@@ -19,9 +19,20 @@ from .extension_field import ExtensionFieldElement
 from .ip import NativeTranscript
 
 
+import contextvars
+
+# verify(): the proof stream being verified can hand out the pickle of an object it holds without walking it (ip.ProofStream.pickle_of)
+leaf_pickle_source = contextvars.ContextVar("bfs_leaf_pickle_source", default=None)
+
+
 def leaf_bytes(element, transcript=None):
     """the reference's pickle.dumps(element): native emitter for this package's element classes (and containers
     of them), CPython's pickle for everything else."""
+    source = leaf_pickle_source.get()
+    if source is not None and transcript is None:
+        b = source(element)
+        if b is not None:
+            return b
     try:
         return (transcript or NativeTranscript()).dumps(element)
     except TypeError:
