@@ -672,6 +672,10 @@ def stark_process_throughput(K, seconds):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--stark-worker", str(seconds)], stdin=subprocess.PIPE,
                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(K)]
+    import threading
+    watchdog = threading.Timer(90.0, lambda: [p.kill() for p in procs])      # a stuck prover process must cost this entry, not the line
+    watchdog.daemon = True
+    watchdog.start()
     try:
         for p in procs:
             line = p.stdout.readline()
@@ -683,6 +687,7 @@ def stark_process_throughput(K, seconds):
     except Exception as e:                # noqa: BLE001
         return {"error": repr(e)[:200]}
     finally:
+        watchdog.cancel()
         for p in procs:
             try:
                 p.wait(timeout=30)
