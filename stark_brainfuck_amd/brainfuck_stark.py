@@ -500,6 +500,7 @@ class BrainfuckStark:
         # commitment to the combination codeword, openings (:300-333)
         combination_tree = Merkle(combination)
         proof_stream.push(combination_tree.root())
+        lap("combination_tree")          # (GPU work: 2^22 extension leaves are 1.1 ms; the round-3 breakdown counted it under "openings")
         indices = BrainfuckStark.sample_indices(self.security_level, proof_stream.prover_fiat_shamir(), n)
         unit_distances = list(set(table.unit_distance(n) for table in self.tables))
         known = self._openings_native(proof_stream, base_tree, extension_tree, combination, combination_tree, base_requests(0),

@@ -2,8 +2,7 @@
 answers (tests/golden/ntt24_oracle.json) and timed with HIP events.  Used under rocprofv3 so that the kernel statistics and PMC
 counters under profiles/ are NTT-only (tools/prof_ntt.sh).
 
-    python tools/ntt_only.py [--cols 8] [--logn 24] [--steps 20] [--warmup 3] [--no-check]
-    BFS_NTT_TILE_LOG=12|13 selects the tile size of the multi-pass plans."""
+    python tools/ntt_only.py [--cols 8] [--logn 24] [--steps 20] [--warmup 3] [--no-check]"""
 import argparse
 import ctypes
 import hashlib
