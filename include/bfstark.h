@@ -91,8 +91,13 @@ uint64_t bfs_gl_pow(uint64_t a, uint64_t e);
  *     intt(root, values)                                  ntt.py:26-42    (root := root^-1, post_scale := n^-1)
  *     fast_coset_evaluate(poly, offset, generator, order) ntt.py:164-168  (n_in = len(coefficients), coset_shift = offset)
  *     Fri.Domain.evaluate / xevaluate                     fri.py:26-37    (extension field: batch = 3 limbs)
- * d_in and d_out may alias when n_in == 2^log_n and the strides agree.  Transforms b reads d_in + b*in_stride
- * (n_in elements) and writes d_out + b*out_stride (2^log_n elements).
+ * Transform b reads d_in + b*in_stride (n_in elements) and writes d_out + b*out_stride (2^log_n elements).  The input is left
+ * untouched when input and output do not overlap, and then the transform needs no intermediate memory (its first pass writes the
+ * output, later passes run in place there); the two ranges may also overlap in any way -- d_in == d_out, an output that starts inside
+ * the input -- in which case the first two passes go through a library buffer of the output's size.  Stream-ordered, except that the
+ * first call for a new (d_in, d_out) pair of a transform of >= 256 MiB that reads all n inputs synchronises `stream` once (~14 ms at
+ * 8 x 2^24): it times its first pass directly and through three library buffers and remembers the fastest route for the pair
+ * (BFS_NTT_WS_PROBE=0 turns that off).
  * Errors: BFS_ERR_NOT_ROOT / BFS_ERR_NOT_PRIMITIVE as the reference's asserts; BFS_ERR_TOO_MANY_COEFFS.
  */
 int bfs_gl_ntt(const uint64_t* d_in, uint64_t n_in, uint64_t in_stride, uint64_t* d_out, uint64_t out_stride,
