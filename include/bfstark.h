@@ -392,6 +392,12 @@ typedef struct bfs_comb_source {
 int bfs_poly_support(const uint64_t* d_coeffs, uint64_t stride, uint64_t len, uint32_t batch, uint64_t* h_masks, void* stream);
 int bfs_poly_randomize(uint64_t* d_coeffs, uint64_t stride, uint64_t h, uint32_t batch, uint64_t point, const uint64_t* h_values, void* stream);
 int bfs_air_num_quotients(int table);
+/* The same constraints at ONE point on the host, for the verifier (brainfuck_stark.py:470-560; table.py:283-311 evaluate_*_constraints):
+ * base_row / base_next: the table's base columns at the point and at the next row (next may be NULL: only the transition constraints
+ * read it), ext_row / ext_next: its extension columns, 3 limbs each; out: bfs_air_num_quotients(table) x 3 limbs, boundary, transition,
+ * terminal order (NOT divided by the zerofiers).  Challenges / terminals / params as for bfs_air_quotients. */
+int bfs_air_evaluate(int table, const uint64_t* base_row, const uint64_t* base_next, const uint64_t* ext_row, const uint64_t* ext_next,
+                     const uint64_t* h_challenges, const uint64_t* h_terminals, const uint64_t* h_params, uint64_t* out);
 int bfs_air_quotients(int table, const uint64_t* d_base, const uint64_t* d_ext, uint64_t* d_out, uint32_t log_n, uint64_t unit_distance,
                       uint64_t height, uint64_t omicron_inv, uint64_t offset, uint64_t omega, const uint64_t* h_challenges,
                       const uint64_t* h_terminals, const uint64_t* h_params, void* stream);

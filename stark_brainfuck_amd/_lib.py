@@ -111,6 +111,8 @@ _SIGNATURES = {
     "bfs_poly_support": (ci, [vp, u64, u64, u32, ctypes.POINTER(u64), vp]),
     "bfs_poly_randomize": (ci, [vp, u64, u64, u32, u64, ctypes.POINTER(u64), vp]),
     "bfs_air_num_quotients": (ci, [ci]),
+    "bfs_air_evaluate": (ci, [ci, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64),
+                              ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64)]),
     "bfs_air_quotients": (ci, [ci, vp, vp, vp, u32, u64, u64, u64, u64, u64, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64), vp]),
     "bfs_difference_quotient": (ci, [vp, vp, vp, u32, u64, u64, vp]),
     "bfs_combination": (ci, [vp, u32, vp, ctypes.POINTER(u64), vp, u32, u64, u64, vp]),

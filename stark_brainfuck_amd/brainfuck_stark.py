@@ -616,18 +616,19 @@ class BrainfuckStark:
             for table, point, next_point in zip(self.tables, points, next_points):
                 bb, tb, zb = quotient_bounds[table]
                 omicron_inverse = pow(table.omicron.value, P - 2, P)
-                for value, bound in zip(table.evaluate_constraints("boundary", point, None, challenges, terminals), bb):
+                boundary_values, transition_values, terminal_values = table.evaluate_all_constraints(point, next_point, challenges, terminals)
+                for value, bound in zip(boundary_values, bb):
                     q = xscale(value, boundary_inverse)
                     terms += [q, shifted(q, bound)]
                 if table.height == 0:
                     transition_factor = 0
                 else:
                     transition_factor = (x - omicron_inverse) * pow((pow(x, table.height, P) - 1) % P, P - 2, P) % P
-                for value, bound in zip(table.evaluate_constraints("transition", point, next_point, challenges, terminals), tb):
+                for value, bound in zip(transition_values, tb):
                     q = xscale(value, transition_factor)
                     terms += [q, shifted(q, bound)]
                 terminal_inverse = pow((x - omicron_inverse) % P, P - 2, P)
-                for value, bound in zip(table.evaluate_constraints("terminal", point, None, challenges, terminals), zb):
+                for value, bound in zip(terminal_values, zb):
                     q = xscale(value, terminal_inverse)
                     terms += [q, shifted(q, bound)]
             for arg in self.permutation_arguments:

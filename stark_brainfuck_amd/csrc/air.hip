@@ -746,6 +746,35 @@ int bfs_difference_combine_rows(const uint64_t* d_lhs, const uint64_t* d_rhs, ui
     return BFS_OK;
 }
 
+// the constraints of one table at ONE point, on the host (the verifier: brainfuck_stark.py:470-560 evaluates every constraint
+// polynomial at the opened rows; table.py:283-311).  The same generated straight-line code the kernels run, compiled for the host.
+int bfs_air_evaluate(int table, const uint64_t* base_row, const uint64_t* base_next, const uint64_t* ext_row, const uint64_t* ext_next,
+                     const uint64_t* h_challenges, const uint64_t* h_terminals, const uint64_t* h_params, uint64_t* out) {
+    if (table < 0 || table > 4) { set_error("bfs_air_evaluate: table index %d", table); return BFS_ERR_BAD_ARG; }
+    Xfe ch[11], tm[5], pr[1], xc[4], xn[4], res[32];
+    u64 bc[8], bn[8];
+    for (int i = 0; i < 11; ++i) ch[i] = xfe_from(h_challenges + 3 * i);
+    for (int i = 0; i < 5; ++i) tm[i] = xfe_from(h_terminals + 3 * i);
+    pr[0] = h_params ? xfe_from(h_params) : Xfe{{1, 0, 0}};
+    auto run = [&](auto shape, auto fn) {
+        typedef decltype(shape) S;
+        static_assert(S::BW <= 8 && S::XW <= 4 && S::NB + S::NT + S::NZ <= 32, "row buffers");
+        for (int c = 0; c < S::BW; ++c) { bc[c] = base_row[c] % GL_P; bn[c] = base_next ? base_next[c] % GL_P : 0; }
+        for (int c = 0; c < S::XW; ++c) { xc[c] = xfe_from(ext_row + 3 * c); xn[c] = ext_next ? xfe_from(ext_next + 3 * c) : Xfe{{0, 0, 0}}; }
+        fn(bc, bn, xc, xn, ch, tm, pr, res);
+        for (int q = 0; q < S::NB + S::NT + S::NZ; ++q)
+            for (int l = 0; l < 3; ++l) out[3 * q + l] = res[q].c[l];
+    };
+    switch (table) {
+        case 0: run(AirShape<0>(), airgen::air_processor_values); break;
+        case 1: run(AirShape<1>(), airgen::air_instruction_values); break;
+        case 2: run(AirShape<2>(), airgen::air_memory_values); break;
+        case 3: run(AirShape<3>(), airgen::air_input_values); break;
+        default: run(AirShape<4>(), airgen::air_output_values); break;
+    }
+    return BFS_OK;
+}
+
 int bfs_air_num_quotients(int table) {
     switch (table) {
         case 0: return AirShape<0>::NB + AirShape<0>::NT + AirShape<0>::NZ;

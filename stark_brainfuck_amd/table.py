@@ -780,6 +780,24 @@ class Table:
         return self._constraints_ext("terminal", challenges, terminals)
 
     # ---- host-side evaluation at one point (the verifier's use, table.py:283-311)
+    def evaluate_all_constraints(self, point, next_point, challenges, terminals):
+        """(boundary values, transition values, terminal values) at one point through the generated constraint code compiled for
+        the host (bfs_air_evaluate) -- the same straight-line code the kernels run; evaluate_constraints below walks the expression
+        graphs in Python and is what the tests compare this with.  point / next_point: base columns then extension columns, as
+        limb triples."""
+        lib = _lib.load()
+        bw, xw = self.base_width, self.full_width - self.base_width
+        nb, nt, nz = (len(c) for _, c in self.air.all())
+        params = self.air_params(challenges)
+        out = (_u64 * (3 * (nb + nt + nz)))()
+        _lib.check(lib.bfs_air_evaluate(
+            self.table_index, (_u64 * bw)(*[p[0] for p in point[:bw]]), (_u64 * bw)(*[p[0] for p in next_point[:bw]]),
+            (_u64 * (3 * xw))(*[v for p in point[bw:] for v in p]), (_u64 * (3 * xw))(*[v for p in next_point[bw:] for v in p]),
+            (_u64 * 33)(*[v for c in challenges for v in c]), (_u64 * 15)(*[v for t in terminals for v in t]),
+            (_u64 * 3)(*params[0]) if params else None, out))
+        vals = [tuple(out[3 * q:3 * q + 3]) for q in range(nb + nt + nz)]
+        return vals[:nb], vals[nb:nb + nt], vals[nb + nt:]
+
     def evaluate_constraints(self, kind, point, next_point, challenges, terminals):
         cons = dict(self.air.all())[kind]
         params = self.air_params(challenges)

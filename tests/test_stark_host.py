@@ -570,3 +570,35 @@ def test_native_reader_of_proof_streams_matches_the_python_route():
     assert NativeTranscript.from_bytes(data[:-7]) is None and NativeTranscript.from_bytes(b"") is None
     # a pickle that CPython would lay out differently (protocol 2 of the same list) is refused by the round-trip check, not misread
     assert NativeTranscript.from_bytes(pickle.dumps([b"ab", 7], protocol=2)) is None
+
+
+def test_native_constraint_evaluation_matches_the_expression_graphs():
+    """bfs_air_evaluate (the generated constraint code compiled for the host; what verify() calls since round 4) against air.evaluate
+    walking the expression graphs in Python, for every table, on random rows, challenges, terminals and parameters -- including base
+    values at the edges of the field and all-zero extension elements"""
+    import random
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    P = (1 << 64) - (1 << 32) + 1
+    program = VirtualMachine.compile("++>,<[>+.<-]")
+    running_time, inputs, outputs = VirtualMachine.run(program, input_data=["a"])
+    stark = BrainfuckStark(running_time, 8, program, inputs, outputs)
+    rnd = random.Random(20260930)
+    edge = [0, 1, P - 1, P - 2, (1 << 32) - 1, 1 << 32, (1 << 63) + 5]
+
+    def felt():
+        return rnd.choice(edge) if rnd.random() < 0.3 else rnd.randrange(P)
+
+    def xfelt():
+        return (0, 0, 0) if rnd.random() < 0.1 else (felt(), felt(), felt())
+    for trial in range(40):
+        challenges = tuple(xfelt() for _ in range(11))
+        terminals = [xfelt() for _ in range(5)]
+        for table in stark.tables:
+            bw, xw = table.base_width, table.full_width - table.base_width
+            point = [(felt(), 0, 0) for _ in range(bw)] + [xfelt() for _ in range(xw)]
+            nxt = [(felt(), 0, 0) for _ in range(bw)] + [xfelt() for _ in range(xw)]
+            got = table.evaluate_all_constraints(point, nxt, challenges, terminals)
+            for kind, values in zip(("boundary", "transition", "terminal"), got):
+                want = table.evaluate_constraints(kind, point, nxt, challenges, terminals)
+                assert [tuple(v) for v in want] == [tuple(v) for v in values], (trial, type(table).__name__, kind)
