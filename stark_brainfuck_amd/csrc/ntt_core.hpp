@@ -22,8 +22,8 @@
 // of two (any primitive 16th root of unity in this field is 2^(12u), u odd), multiplies by the inner twiddle
 // and exchanges through LDS once per stage.
 //
-// A wave64 integer instruction costs 4 cycles and the tile kernels issue ~2000 of them per 16 elements, which is about what one
-// pass' HBM time is worth: the first two passes of a 2^24 transform are memory-bound, the last one VALU-bound.
+// A wave64 integer instruction costs 4 cycles and the tile kernels issue ~1600 of them per 16 elements and pass, which is within 5 % of
+// what one pass' HBM time is worth at the clock the package power limit allows: the 8 x 2^24 step sits on both roofs.
 // So the code spends instructions on arithmetic only: tile shape (LOGC) and pass kind (MODE) are template parameters, every
 // global / LDS access is "per-thread base + wave-uniform or immediate offset", digit permutations are wave-uniform scalars,
 // strides are powers of two applied as shifts, power-of-two twiddles are shifts and folds.
@@ -171,7 +171,7 @@ struct PassArgs {
     u32 uinv;            // u^-1 mod 16 where w^(n/16) = 2^(12u)
     u32 has_coset;       // pass 0: multiply input j by s^j
     u64 coset_delta;     // s^(stride of the stage-1 register index)
-    u64 post_scale;      // last pass: n^-1 of intt (folded into tw_last below, or multiplied in at the store of a single-stage pass); else 1
+    u64 post_scale;      // last pass: n^-1 of intt (folded into tw1 / tw2 below, or multiplied in at the store of a single-stage pass); else 1
     u32 streaming;       // data loads / stores are non-temporal (the launcher picks the NT instantiation; kept here for the record)
     // Balanced twiddle schedule of a three-pass plan (ntt_plan.hpp).  The factor in front of pass 2 splits,
     // w_N^(j2 (k0 + n0 k1)) = w_N^(j2 k0) * w_{n1 n2}^(j2 k1), and each piece goes where one of its indices is tile-uniform AND where
