@@ -251,7 +251,7 @@ class Fri:
                 roots.append(proof_stream.pull())
             alphas.append(self.field.sample(proof_stream.verifier_fiat_shamir()))
         last_codeword = proof_stream.pull()
-        if roots[-1] != Merkle(last_codeword).root():
+        if roots[-1] != _host_merkle_root(last_codeword):
             print("last codeword is not well formed")
             return False
         n_last = len(last_codeword)
@@ -299,6 +299,21 @@ class Fri:
                         return False
             omega_v, offset_v = omega_v * omega_v % P, offset_v * offset_v % P
         return True
+
+
+def _host_merkle_root(leaves):
+    """Merkle(leaves).root() (merkle.py:8-44) with hashlib, for the verifier's check of the last codeword -- a few dozen elements.  The
+    verifier runs on the host throughout, like the reference's (fri.py:201-319), so verify() needs no GPU; the prover's trees are
+    built by the kernels of csrc/merkle.hip and compared with this construction by the tests."""
+    from hashlib import blake2b
+    from .merkle import leaf_bytes
+    n = len(leaves)
+    if n == 0 or n & (n - 1):
+        return Merkle(leaves).root()            # (never the case for a FRI codeword; the reference's padding rules live in Merkle)
+    level = [blake2b(leaf_bytes(e)).digest() for e in leaves]
+    while len(level) > 1:
+        level = [blake2b(level[2 * i] + level[2 * i + 1]).digest() for i in range(len(level) // 2)]
+    return level[0]
 
 
 def _interpolant_degree(omega, values):

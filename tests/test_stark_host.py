@@ -602,3 +602,57 @@ def test_native_constraint_evaluation_matches_the_expression_graphs():
             for kind, values in zip(("boundary", "transition", "terminal"), got):
                 want = table.evaluate_constraints(kind, point, nxt, challenges, terminals)
                 assert [tuple(v) for v in want] == [tuple(v) for v in values], (trial, type(table).__name__, kind)
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_verify_on_the_host_accepts_reference_proofs_and_rejects_tampering(name):
+    """the verifier mirror (brainfuck_stark.py:343-579) on proofs written by the reference itself, WITHOUT a GPU: since round 4 the
+    verifier's one tree (the last FRI codeword) is hashed with hashlib like every path check, so verify() is host code throughout, as in
+    the reference"""
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    g = json.load(open(os.path.join(GOLDEN, "stark_%s.json" % name)))
+    path = os.path.join(GOLDEN, "stark_%s_proof.bin" % name)
+    if not os.path.exists(path):
+        pytest.skip("no proof bytes committed for this fixture")
+    program = VirtualMachine.compile(g["program"])
+    running_time, input_symbols, output_symbols = VirtualMachine.run(program, input_data=list(g["input"]))
+    _, mm, _, _, _ = VirtualMachine.simulate(program, input_data=list(input_symbols))
+    proof = open(path, "rb").read()
+    stark = BrainfuckStark(running_time, len(mm), program, input_symbols, output_symbols)
+    assert stark.verify(proof) is True
+    other = BrainfuckStark(running_time, len(mm), program, input_symbols, list(output_symbols) + ["!"])
+    try:
+        assert other.verify(proof) is False          # a claim about a different output
+    except AssertionError:
+        pass
+    pos = proof.index(bytes.fromhex(g["combination_tree"]["root"])) + 200
+    bad = bytearray(proof)
+    bad[pos] ^= 1                                     # one bit inside an opened digest
+    try:
+        assert stark.verify(bytes(bad)) is False
+    except (AssertionError, Exception):
+        pass
+
+
+@pytest.mark.parametrize("tag", ["d16_t2", "d64_t8", "d1024_t4", "test_fri_valid", "test_fri_disturbed", "d16_t2_prepushed"])
+def test_fri_verify_on_the_host_golden_transcripts(tag):
+    """Fri.verify (fri.py:201-319) on the transcripts the reference's Fri.prove wrote, read from their bytes, without a GPU: the verdict
+    is the reference's (the disturbed codeword is rejected), and a stream with a wrong first root is rejected"""
+    import stark_brainfuck_amd as sb
+    from conftest import golden_bytes, load_golden
+    rec = load_golden("fri.json")[tag]
+    XF = sb.ExtensionField.main()
+    BF = XF.modulus.coefficients[0].field
+    fri = sb.Fri(BF.generator(), BF.primitive_nth_root(rec["N"]), rec["N"], rec["expansion"], rec["num_colinearity_tests"], XF)
+    data = golden_bytes("fri_%s_stream.bin" % tag)
+    vs = sb.ProofStream().deserialize(data)
+    vs.read_index = rec["num_prepushed"]
+    root0 = bytes.fromhex(rec["roots"][0])
+    assert fri.verify(vs, root0) == rec["verify"]
+    if rec["rounds"] > 1:
+        bad = sb.ProofStream()
+        bad.objects = list(vs.objects)
+        bad.read_index = rec["num_prepushed"]
+        bad.objects[rec["num_prepushed"]] = bytes(64)
+        assert not fri.verify(bad, root0)
