@@ -149,6 +149,10 @@ size_t bfs_ps_num_objects(void* ps);
 uint64_t bfs_ps_object_at(void* ps, size_t index);
 int bfs_ps_serialize(void* ps, size_t count, uint8_t* out, size_t capacity, size_t* length);
 int bfs_ps_fiat_shamir(void* ps, size_t count, uint8_t* out, size_t num_bytes);
+/* ProofStream.verifier_fiat_shamir (ip.py:27-30) ahead of time: the hashes over objects[:counts[i]] of a stream made by bfs_ps_loads
+ * are offered to the library's helper threads; a later bfs_ps_fiat_shamir(ps, counts[i], ..., num_bytes) picks the result up (or
+ * computes it itself when no helper has got to it).  Returns how many were offered (0 without helper threads: not an error). */
+size_t bfs_ps_prefetch_fiat_shamir(void* ps, const size_t* counts, size_t n, size_t num_bytes);
 /* push(bytes(digest)) followed by fiat_shamir over everything, computed the way bfs_fri_commit overlaps it with a tree kernel: the
  * SHAKE256 blocks in front of the digest's payload are absorbed before the digest is known (same result as the two calls). */
 int bfs_ps_push_digest_fiat_shamir(void* ps, const uint8_t digest[64], uint8_t* out, size_t num_bytes);

@@ -65,6 +65,7 @@ _SIGNATURES = {
     "bfs_ps_num_objects": (sz, [vp]),
     "bfs_ps_object_at": (u64, [vp, sz]),
     "bfs_ps_serialize": (ci, [vp, sz, vp, sz, ctypes.POINTER(sz)]),
+    "bfs_ps_prefetch_fiat_shamir": (sz, [vp, ctypes.POINTER(sz), sz, sz]),
     "bfs_ps_fiat_shamir": (ci, [vp, sz, vp, sz]),
     "bfs_sample_weights": (ci, [ctypes.c_char_p, sz, sz, ctypes.POINTER(u64)]),
     "bfs_ps_push_digest_fiat_shamir": (ci, [vp, ctypes.c_char_p, vp, sz]),

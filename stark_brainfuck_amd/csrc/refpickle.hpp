@@ -15,7 +15,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <atomic>
+#include <functional>
 #include <memory>
+#include <thread>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -730,8 +733,62 @@ struct Transcript {
         return p.dumps(lst);
     }
     void fiat_shamir(size_t count, unsigned char* out, size_t num_bytes) const {
+        if (!prefetched.empty()) {
+            auto it = prefetched.find(count < objects.size() ? count : objects.size());
+            if (it != prefetched.end() && it->second->num_bytes == num_bytes) {
+                it->second->run();                                   // does the work here unless a helper has it (then waits for that helper)
+                memcpy(out, it->second->out, num_bytes);
+                return;
+            }
+        }
         std::string s = serialize(count);
         shake256(s.data(), s.size(), out, num_bytes);
+    }
+
+    // The verifier's side of Fiat-Shamir (ip.py:27-30): shake_256(pickle.dumps(objects[:read_index])) at ~20 read positions of a stream
+    // that does not change any more.  The hashes are independent of each other (the pickle's frame header carries the prefix' length, so
+    // no two share a sponge state) and of everything else the verifier does, so a stream read from bytes (bfs_ps_loads) can have them
+    // computed ahead by the helper threads.  Jobs are OFFERS (helper_pool.hpp): whoever needs a result first computes it; a job owns
+    // the objects of its prefix, so it outlives the stream if it has to.
+    struct PrefixHash {
+        std::vector<Ref> prefix;
+        size_t num_bytes = 0;
+        unsigned char out[64];
+        std::atomic<int> state{0};                                   // 0 offered, 1 somebody is computing, 2 done
+        void run() {
+            int expected = 0;
+            if (state.compare_exchange_strong(expected, 1)) {
+                Ref lst = mk(K_LIST);
+                lst->items = prefix;
+                Pickler p(nullptr);                                  // (streams read from bytes hold no compact elements: no World needed)
+                const std::string s = p.dumps(lst);
+                shake256(s.data(), s.size(), out, num_bytes);
+                state.store(2, std::memory_order_release);
+                return;
+            }
+            while (state.load(std::memory_order_acquire) != 2) std::this_thread::yield();
+        }
+    };
+    std::unordered_map<size_t, std::shared_ptr<PrefixHash>> prefetched;
+    bool loaded_from_bytes = false;
+    // offers the hashes over objects[:counts[i]] to the helper pool; returns how many were offered (0: no helpers, or not a loaded stream)
+    size_t prefetch_fiat_shamir(const size_t* counts, size_t n, size_t num_bytes) {
+        if (!loaded_from_bytes || num_bytes == 0 || num_bytes > 64) return 0;
+        HelperPool* pool = HelperPool::get();
+        if (pool == nullptr) return 0;
+        std::vector<std::function<void()>> work;
+        for (size_t i = 0; i < n; ++i) {
+            const size_t k = counts[i] < objects.size() ? counts[i] : objects.size();
+            if (prefetched.count(k)) continue;
+            std::shared_ptr<PrefixHash> job = std::make_shared<PrefixHash>();
+            job->prefix.assign(objects.begin(), objects.begin() + k);
+            job->num_bytes = num_bytes;
+            prefetched[k] = job;
+            work.push_back([job] { int s = job->state.load(); if (s == 0) job->run(); });
+        }
+        const size_t offered = work.size();
+        if (offered) pool->submit(std::move(work));
+        return offered;
     }
 
     // Fiat-Shamir over a stream whose LAST object is a 64-byte digest that is still being computed (a Merkle root on its way from the

@@ -39,6 +39,7 @@ void* bfs_ps_loads(const uint8_t* data, size_t len) {
         t->add(item);                      // handle = index + 1, as bfs_ps_object_at reports it
         t->objects.push_back(item);
     }
+    t->loaded_from_bytes = true;
     const std::string again = t->serialize(t->objects.size());
     if (again.size() != len || memcmp(again.data(), data, len) != 0) {
         delete t;
@@ -118,6 +119,12 @@ int bfs_ps_obj_dumps(void* ps, uint64_t handle, uint8_t* out, size_t capacity, s
     *length = s.size();
     if (out && capacity >= s.size()) memcpy(out, s.data(), s.size());
     return BFS_OK;
+}
+
+// the verifier knows (roughly) at which read positions it will ask: the hashes over those prefixes are offered to the helper threads
+// (only for a stream made by bfs_ps_loads, which no longer changes).  Returns the number of hashes offered; 0 is not an error.
+size_t bfs_ps_prefetch_fiat_shamir(void* ps, const size_t* counts, size_t n, size_t num_bytes) {
+    return T(ps)->prefetch_fiat_shamir(counts, n, num_bytes);
 }
 
 int bfs_ps_fiat_shamir(void* ps, size_t count, uint8_t* out, size_t num_bytes) {

@@ -333,6 +333,18 @@ class ProofStream:
                     for i, c in enumerate(o):
                         handles.setdefault(id(c), (k + 1, i, c))
             ps._handles = handles
+            # Fiat-Shamir ahead of time: the verifiers ask right before / after a top-level digest (a Merkle root) and after a codeword;
+            # those prefixes go to the helper threads now (a position that was not foreseen is simply hashed when it is asked for)
+            at = set()
+            for k, o in enumerate(ps._objects):
+                if isinstance(o, (bytes, bytearray)) and len(o) == 64:
+                    at.update((k, k + 1))
+                elif isinstance(o, list) and o and isinstance(o[0], ExtensionFieldElement):
+                    at.add(k + 1)
+            at.discard(0)
+            if at:
+                counts = (ctypes.c_size_t * len(at))(*sorted(at, reverse=True))          # the long prefixes first
+                t.lib.bfs_ps_prefetch_fiat_shamir(t.handle, counts, len(at), 32)
         return ps
 
     def pickle_of(self, obj):
