@@ -592,8 +592,13 @@ class BrainfuckStark:
         for index in indices:
             x = offset * pow(omega, index, P) % P
 
+            powers = {}                 # x^shift for the few distinct shifts of a proof (151 terms share ~20 degree bounds)
+
             def shifted(value, bound):
-                return xscale(value, pow(x, self.max_degree - bound, P))
+                f = powers.get(bound)
+                if f is None:
+                    f = powers[bound] = pow(x, self.max_degree - bound, P)
+                return xscale(value, f)
             row = rows[index]
             terms = [row[0]]
             for i in range(num_base):

@@ -21,6 +21,7 @@ _u64 = ctypes.c_uint64
 class NativeTranscript:
     """owns a bfs_ps_* handle and the two-way mapping between Python objects and native object handles."""
 
+    _dump_buffer = None   # dumps_handle's scratch, per instance (verifiers may run in several threads)
     loaded = False        # True: made by from_bytes -- the native side was read from the pickle, no Python object maps to a handle
 
     def __init__(self, _handle=None):
@@ -56,10 +57,14 @@ class NativeTranscript:
         """pickle.dumps of the object behind native handle h, on its own"""
         lib = self.lib
         n = ctypes.c_size_t()
-        _lib.check(lib.bfs_ps_obj_dumps(self.handle, h, None, 0, ctypes.byref(n)))
-        buf = ctypes.create_string_buffer(max(n.value, 1))
-        _lib.check(lib.bfs_ps_obj_dumps(self.handle, h, buf, n.value, ctypes.byref(n)))
-        return buf.raw[:n.value]
+        buf = self._dump_buffer                 # one call when the pickle fits (a row of 26 elements is < 4 KiB)
+        if buf is None:
+            buf = self._dump_buffer = ctypes.create_string_buffer(8192)
+        _lib.check(lib.bfs_ps_obj_dumps(self.handle, h, buf, len(buf), ctypes.byref(n)))
+        if n.value > len(buf):
+            buf = self._dump_buffer = ctypes.create_string_buffer(2 * n.value)
+            _lib.check(lib.bfs_ps_obj_dumps(self.handle, h, buf, len(buf), ctypes.byref(n)))
+        return buf.raw[:n.value] if n.value * 4 > len(buf) else ctypes.string_at(buf, n.value)
 
     def scan(self, objs):
         """note which BaseFieldElement objects are coefficients of more than one extension element: those elements must be
