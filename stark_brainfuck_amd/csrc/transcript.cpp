@@ -21,21 +21,7 @@ static int bad_handle(uint64_t h) {
 extern "C" {
 
 void* bfs_ps_new(void) { return new Transcript(); }
-void bfs_ps_free(void* ps) {
-    Transcript* t = T(ps);
-    if (t == nullptr) return;
-    // a stream read from bytes is ~10^4 nodes; tearing it down is 0.4 ms that the verifier's thread need not spend (nothing else can
-    // hold its handle: the caller has just given it up)
-    if (t->loaded_from_bytes) {
-        if (HelperPool* pool = HelperPool::get()) {
-            std::vector<std::function<void()>> job;
-            job.push_back([t] { delete t; });
-            pool->submit(std::move(job));
-            return;
-        }
-    }
-    delete t;
-}
+void bfs_ps_free(void* ps) { delete T(ps); }
 
 // ProofStream.deserialize (ip.py:27-30) without Python objects in between: the pickle of a LIST is read into a new stream whose objects
 // are the list's items, with the identities (shared coefficient objects, BaseField instances, repeated nodes) the writer's objects had.
