@@ -523,8 +523,29 @@ class Unpickler {
     // the unpickled object, or an empty Ref (`why` says what was not understood)
     Ref load(std::string* why = nullptr) {
         Ref r = run();
+        if (r && !shallow(r)) { r.reset(); why_ = "objects nested deeper than 200 levels"; }
         if (!r && why) *why = why_;
         return r;
+    }
+
+    // The Pickler walks the graph recursively, and the bytes come from whoever wrote the proof: a stream nested a million lists deep
+    // must be refused here, not overflow the stack there.  Depth along the pickler's own traversal (children in order, a node that was
+    // seen before is a memo reference and is not entered again).
+    static bool shallow(const Ref& root, size_t limit = 200) {
+        std::vector<std::pair<const Node*, size_t>> todo;
+        std::unordered_map<const Node*, char> seen;
+        todo.emplace_back(root.get(), 1);
+        while (!todo.empty()) {
+            const Node* n = todo.back().first;
+            const size_t depth = todo.back().second;
+            todo.pop_back();
+            if (n == nullptr || n->kind == K_INT || !seen.emplace(n, 1).second) continue;
+            if (depth > limit) return false;
+            for (size_t i = n->items.size(); i-- > 0;) todo.emplace_back(n->items[i].get(), depth + 1);
+            if (n->state) todo.emplace_back(n->state.get(), depth + 1);
+            if (n->cls) todo.emplace_back(n->cls.get(), depth + 1);
+        }
+        return true;
     }
 
    private:
@@ -595,6 +616,9 @@ class Unpickler {
 
     Ref run() {
         while (pos_ < n_) {
+            // (nesting is built from stack depth, and nodes are freed recursively: a reference proof never has more than ~1100 objects
+            //  on the stack -- one batch of 1000 list items plus a few levels)
+            if (stack_.size() > 20000) { why_ = "unpickling stack deeper than 20000"; return Ref(); }
             const unsigned char opc = p_[pos_++];
             Ref a, b;
             std::vector<Ref> items;

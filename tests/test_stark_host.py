@@ -568,6 +568,10 @@ def test_native_reader_of_proof_streams_matches_the_python_route():
     ps = ProofStream().deserialize(odd)
     assert ps.objects == [b"\x01" * 64, None, True, -5] and getattr(ps, "_cached", None) is None
     assert NativeTranscript.from_bytes(data[:-7]) is None and NativeTranscript.from_bytes(b"") is None
+    # bytes from a hostile prover: a list nested 100 000 deep must be refused by the native reader (its pickler is recursive), not crash it
+    for depth in (1000, 100000, 3000000):
+        deep = b"\x80\x04" + b"]" * depth + b"a" * (depth - 1) + b"."
+        assert NativeTranscript.from_bytes(deep) is None
     # a pickle that CPython would lay out differently (protocol 2 of the same list) is refused by the round-trip check, not misread
     assert NativeTranscript.from_bytes(pickle.dumps([b"ab", 7], protocol=2)) is None
 
