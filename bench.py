@@ -746,7 +746,7 @@ def bench_stark_concurrent(ks=(1, 2, 4), seconds=0.8):
     base = out.get("1")
     # the same with K PROCESSES (one interpreter each): what the GPU can take when the host side is not serialised
     by_process = {}
-    for K in (2, 4):
+    for K in (2, 4, 8):
         r = stark_process_throughput(K, seconds)
         by_process[str(K)] = round(r["proofs_per_s"], 1) if "proofs_per_s" in r else r
         if "sha256" in r:
