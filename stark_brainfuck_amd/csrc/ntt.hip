@@ -1,6 +1,7 @@
 // ntt.hip -- gfx950 kernels and launcher for bfs_gl_ntt() (algorithm and reference citations: ntt_core.hpp)
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
@@ -290,9 +291,18 @@ static int ntt_route(const NttPlan& p, const NttTables& tb, const u64* d_in, u64
                      u64 root, u64 shift, u64 post_scale, u32 streaming, hipStream_t stream, int* route) {
     *route = -1;
     const u64 n = 1ull << p.log_n;
-    static const bool enabled = [] { const char* e = getenv("BFS_NTT_WS_PROBE"); return !(e && e[0] == '0'); }();
+    // BFS_NTT_WS_PROBE: "0" always direct, "direct" / "buffer0" / "buffer1" / "buffer2" that route without measuring (the GPU tests run a
+    // large transform over every route), anything else or unset: measure
+    static const int mode = [] {
+        const char* e = getenv("BFS_NTT_WS_PROBE");
+        if (!e) return -2;
+        if (e[0] == '0' || !strcmp(e, "direct")) return -1;
+        if (!strncmp(e, "buffer", 6) && e[6] >= '0' && e[6] < '0' + NTT_ROUTE_CANDIDATES && !e[7]) return e[6] - '0';
+        return -2;
+    }();
     static const bool log = [] { const char* e = getenv("BFS_NTT_WS_PROBE_LOG"); return e && e[0] == '1'; }();
-    if (!enabled || n_in != n || (u64)n * batch * sizeof(u64) < NTT_ROUTE_MIN_BYTES) return BFS_OK;
+    if (mode == -1 || n_in != n || (u64)n * batch * sizeof(u64) < NTT_ROUTE_MIN_BYTES) return BFS_OK;
+    if (mode >= 0) { *route = mode; return BFS_OK; }
     int dev = 0;
     BFS_HIP(hipGetDevice(&dev));
     const auto key = std::make_tuple(dev, stream, (const void*)d_in, (const void*)d_out, in_stride, out_stride, ((u64)p.log_n << 32) | batch);

@@ -116,6 +116,46 @@ def test_config5_2p24_columns(sb, oracle):
         assert sha_u64(raw_ntt(sb, v[c * n:(c + 1) * n], logn, w)) == g["columns"][c]["output_sha256"]
 
 
+@pytest.mark.parametrize("route", ["direct", "buffer0", "buffer2", "measure"])
+def test_large_transform_over_every_route(route):
+    """bfs_gl_ntt of >= 256 MiB picks where its first pass writes by measurement (ntt.hip: ntt_route): straight into the output or through
+    one of three library buffers.  Each route forced in a process of its own (the choice is read once), and the measuring default, on
+    three 2^24 columns of the bench workload: the oracle's known answers (tests/golden/ntt24_oracle.json) on every route, twice (the
+    second call takes the remembered route), and the input untouched."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, json, hashlib
+sys.path.insert(0, %r)
+import numpy as np
+from oracle import ref_oracle as o
+from stark_brainfuck_amd import _lib
+from stark_brainfuck_amd.device import DeviceBuffer, synchronize
+lib = _lib.load()
+g = json.load(open(%r))
+logn, n, cols = 24, 1 << 24, 3
+v = np.concatenate([o.felt_array(0x5EED + (c << 32), 0, n) for c in range(cols)])
+din, dout = DeviceBuffer.from_numpy(v), DeviceBuffer(n * cols)
+for rep in range(2):
+    _lib.check(lib.bfs_gl_ntt(din.ptr, n, n, dout.ptr, n, logn, cols, g["root"], 1, 1, 0)); synchronize(0)
+    out = dout.to_numpy()
+    for c in range(cols):
+        assert hashlib.sha256(np.ascontiguousarray(out[c * n:(c + 1) * n], dtype="<u8").tobytes()).hexdigest() == g["columns"][c]["output_sha256"], (rep, c)
+assert (din.to_numpy() == v).all()
+print("ok")
+''' % (ROOT, os.path.join(GOLDEN, "ntt24_oracle.json"))
+    env = dict(os.environ, BFS_NTT_WS_PROBE_LOG="1")
+    if route != "measure":
+        env["BFS_NTT_WS_PROBE"] = route
+    else:
+        env.pop("BFS_NTT_WS_PROBE", None)
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
+    if route == "measure":
+        assert "bfs ntt route" in res.stderr          # the probe ran (once: the second call found the pair remembered)
+        assert res.stderr.count("bfs ntt route") == 1
+
+
 def test_ntt_other_roots_and_batches(sb, oracle):
     for logn in (6, 11, 13, 17):
         n = 1 << logn
