@@ -15,7 +15,7 @@
 namespace bfs {
 
 // One workgroup per tile: T/16 threads hold 16 elements each.  LDS = tile (padded) + the stage-1 -> stage-2 twiddles.
-// Used by single-pass plans (n <= 4096: up to three register stages) and by the single-stage (4-bit) digits of multi-pass plans.
+// Used by single-pass plans (n <= 4096: up to three register stages).
 // (A persistent variant with next-tile prefetch and 16-byte paired-lane accesses was measured slower: hardware workgroup turnover
 //  already overlaps HBM latency)
 template <int B1, int B2, int B3, int LOGC, int MODE, bool NT>
@@ -153,11 +153,10 @@ static int launch_tile(const PassArgs& a, u32 grid_x, u32 batch, hipStream_t str
     return BFS_OK;
 }
 
-// multi-pass plans use 4096-element tiles (logC = 12 - S, S = 4..8); single-pass plans one column of 2^S rows (S = 4..12)
+// multi-pass plans use 4096-element tiles (logC = 12 - S, S = 5..8: two register stages, split exchange); single-pass plans one column of 2^S rows (S = 4..12)
 template <int MODE>
 static int dispatch_multi(const PassArgs& a, u32 S, u32 grid_x, u32 batch, hipStream_t stream) {
     switch (S) {
-        case 4: return launch_tile<4, 0, 0, 8, MODE>(a, grid_x, batch, stream);
         case 5: return launch_tile_split<4, 1, 0, 7, MODE>(a, grid_x, batch, stream);
         case 6: return launch_tile_split<4, 2, 0, 6, MODE>(a, grid_x, batch, stream);
         case 7: return launch_tile_split<4, 3, 0, 5, MODE>(a, grid_x, batch, stream);

@@ -69,15 +69,16 @@ inline bool ntt_make_plan(u32 log_n, u64 root, NttPlan& p) {
     }
     u32 m = (log_n + NTT_MAX_PASS_BITS - 1) / NTT_MAX_PASS_BITS;
     if (m > 4) return false;
-    // enumerate splits S_0..S_{m-1} in [4,8]; tiles are 4096 elements (C_t = 2^(12 - S_t) columns); pick the most balanced feasible one
+    // enumerate splits S_0..S_{m-1} in [5,8] (two register stages per tile; every log n in 13..32 has such a split); tiles are 4096
+    // elements (C_t = 2^(12 - S_t) columns); pick the most balanced feasible one
     u32 best[4] = {0, 0, 0, 0};
     u32 best_score = ~0u;
     u32 s[4];
     u32 total = 1;
-    for (u32 i = 0; i < m; ++i) total *= 5;
+    for (u32 i = 0; i < m; ++i) total *= 4;
     for (u32 code = 0; code < total; ++code) {
         u32 c = code, sum = 0, mx = 0, mn = 99;
-        for (u32 i = 0; i < m; ++i) { s[i] = 4 + c % 5; c /= 5; sum += s[i]; mx = s[i] > mx ? s[i] : mx; mn = s[i] < mn ? s[i] : mn; }
+        for (u32 i = 0; i < m; ++i) { s[i] = 5 + c % 4; c /= 4; sum += s[i]; mx = s[i] > mx ? s[i] : mx; mn = s[i] < mn ? s[i] : mn; }
         if (sum != log_n) continue;
         // pass 0: its C_0 columns are values of l = (j_1|..|j_{m-1}) < n / n_0 -- always enough for log n > 12.
         // pass t >= 1: its C_t columns are values of K < n_0 .. n_{t-1}

@@ -37,7 +37,6 @@ static void run_pass(const PassArgs& a, u32 grid_x, u32 batch) {
 template <int MODE>
 static void dispatch_multi(const PassArgs& a, u32 S, u32 grid_x, u32 batch) {
     switch (S) {
-        case 4: run_pass<4, 0, 0, 8, MODE>(a, grid_x, batch); break;
         case 5: run_pass<4, 1, 0, 7, MODE>(a, grid_x, batch); break;
         case 6: run_pass<4, 2, 0, 6, MODE>(a, grid_x, batch); break;
         case 7: run_pass<4, 3, 0, 5, MODE>(a, grid_x, batch); break;

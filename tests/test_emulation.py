@@ -154,7 +154,7 @@ def test_planner(emu, oracle):
         assert emu.emu_plan(logn, root, ctypes.byref(npass), bits, logc, ctypes.byref(uinv)) == 0
         assert sum(bits[:npass.value]) == logn
         if npass.value > 1:
-            assert all(4 <= b <= 8 for b in bits[:npass.value])
+            assert all(5 <= b <= 8 for b in bits[:npass.value])
             assert all(bits[i] + logc[i] == 12 for i in range(npass.value))
         # the radix-16 root of the reference is 2^(12u): u * uinv == 1 (mod 16)
         w16 = oracle.power(root, (1 << logn) // 16)
