@@ -423,18 +423,23 @@ def test_collectives_and_cooperative_proof_over_rccl_one_rank_per_gpu():
     for p in procs:
         p.start()
     got = []
-    for _ in procs:
-        for attempt in range(300):
-            try:
-                got.append(q.get(timeout=2))
-                break
-            except Exception:
-                assert all(p.is_alive() or p.exitcode == 0 for p in procs), "a worker failed: %r" % [p.exitcode for p in procs]
-        else:
-            raise AssertionError("timed out")
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    try:
+        for _ in procs:
+            for attempt in range(300):
+                try:
+                    got.append(q.get(timeout=2))
+                    break
+                except Exception:
+                    assert all(p.is_alive() or p.exitcode == 0 for p in procs), "a worker failed: %r" % [p.exitcode for p in procs]
+            else:
+                raise AssertionError("timed out")
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:                 # a rank stuck in a collective must not outlive the test
+            if p.is_alive():
+                p.kill()
     for o in got:
         assert o["roots_ok"] and o["zipped_ok"] and o["rows_ok"] and o["proof_ok"] and o["fresh_verified"], o
     assert len({o["fresh_sha"] for o in got}) == 1
