@@ -7,6 +7,9 @@
 // so results are bit-identical to the reference's Python ints.
 #pragma once
 #include <stdint.h>
+#ifdef BFS_CHECK_CANONICAL
+#include <cassert>
+#endif
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -110,6 +113,29 @@ BFS_HD u64 gl_add(u64 a, u64 b) {
     u32 uhi = __builtin_addc(shi, 0u, c3, &c4);
     const bool over = (c2 | c4) != 0;
     return over ? (((u64)uhi << 32) | ulo) : (((u64)shi << 32) | slo);
+}
+
+// a + b for ANY 64-bit a and canonical b: congruent to a + b, in [0, 2^64), not necessarily canonical -- FOUR instructions with scalar
+// carries (gl_add: six).  s = a + b with carry K; a wrap means + 2^64 = + EPS, which cannot wrap again because b < p: low word s_lo - K
+// (borrow B: s_lo was 0), high word s_hi + (K and not B).  Such a value may be a minuend (gl_sub4), the first operand of another lazy
+// sum, an operand of mul_pow2 or of a product, and may be stored for a later pass that multiplies what it loads; it must never be a
+// subtrahend, the second operand of a sum, or an operand of gl_add (ntt_core.hpp: dif_level says which sums qualify; the host
+// emulation asserts the rule on every operand, tests/emu/build_emu.py -DBFS_CHECK_CANONICAL).
+BFS_HD u64 gl_add_lazy(u64 a, u64 b) {
+    u32 rlo, rhi;
+    u64 sk, sb;
+    asm("v_add_co_u32 %0, vcc, %4, %6\n\t"
+        "s_nop 1\n\t"
+        "v_addc_co_u32 %1, %2, %5, %7, vcc\n\t"
+        "s_nop 1\n\t"
+        "v_subb_co_u32 %0, %3, %0, 0, %2\n\t"
+        "s_nop 1\n\t"
+        "s_andn2_b64 %2, %2, %3\n\t"
+        "v_addc_co_u32 %1, vcc, %1, 0, %2"
+        : "=&v"(rlo), "=&v"(rhi), "=&s"(sk), "=&s"(sb)
+        : "v"((u32)a), "v"((u32)(a >> 32)), "v"((u32)b), "v"((u32)(b >> 32))
+        : "vcc", "scc");
+    return ((u64)rhi << 32) | rlo;
 }
 
 // a VGPR holding 0 that the optimiser cannot see through: `x - 0 - borrow` written with it compiles to one v_subb_co_u32,
@@ -254,16 +280,33 @@ BFS_HD u64 gl_mul_other_form(u64 a, u64 b) {
     return gl_reduce128_t<true, !GL_REDUCE4>(hi, lo);
 }
 #else
+// -DBFS_CHECK_CANONICAL (the host emulation of the kernels, tests/emu): every operand that has to be canonical is checked -- the NTT
+// keeps some sums unreduced (gl_add_lazy) and the rule which operands may be such values is enforced here on every emulated transform
+#ifdef BFS_CHECK_CANONICAL
+#define BFS_CANONICAL(x) assert((x) < GL_P)
+#else
+#define BFS_CANONICAL(x) ((void)0)
+#endif
 BFS_HD u64 gl_add(u64 a, u64 b) {
+    BFS_CANONICAL(a); BFS_CANONICAL(b);
     u64 s = a + b;
     // a, b < p: either the 64-bit add wrapped (then s + EPS is the canonical value) or s may be >= p
     if (s < a) return s + GL_EPS;
     return s >= GL_P ? s - GL_P : s;
 }
 
+// any 64-bit a, canonical b
 BFS_HD u64 gl_sub(u64 a, u64 b) {
+    BFS_CANONICAL(b);
     u64 d = a - b;
     return a < b ? d - GL_EPS : d;  // borrow: add p (== subtract EPS in wrapped arithmetic)
+}
+
+// the device's lazy sum (any 64-bit a, canonical b; result in [0, 2^64), not necessarily canonical)
+BFS_HD u64 gl_add_lazy(u64 a, u64 b) {
+    BFS_CANONICAL(b);
+    u64 s = a + b;
+    return s < a ? s + GL_EPS : s;
 }
 BFS_HD u64 gl_sub4(u64 a, u64 b) { return gl_sub(a, b); }      // the device's two instruction sequences (selftest.hip compares both with this)
 BFS_HD u64 gl_sub5(u64 a, u64 b) { return gl_sub(a, b); }

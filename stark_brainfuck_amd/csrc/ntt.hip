@@ -3,6 +3,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <tuple>
@@ -276,12 +277,23 @@ static int ntt_run_pass(const NttPlan& p, u32 t, NttTables tb, const u64* d_in, 
 // not move (profiles/r03/buffer_placement.txt, profiles/r04/ab_ws_probe.txt; address-translation counters are flat, so it is not the
 // TLB).  The library cannot move the caller's buffers, but it can put one of its own in between at no cost in traffic: pass 0 ->
 // intermediate, pass 1 intermediate -> output (pass 1 is indifferent to being out of place).  So the first time a (input, output)
-// pair is seen, passes 0 and 1 are timed on the direct route and through each of NTT_ROUTE_CANDIDATES library buffers (one
-// stream synchronisation, 32 launches = ~14 ms at 8 x 2^24, only for transforms of >= NTT_ROUTE_MIN_BYTES that read all n inputs) and the fastest is
-// remembered for the pair.  BFS_NTT_WS_PROBE=0: always direct.  BFS_NTT_WS_PROBE_LOG=1: the measurements go to stderr.
+// pair has been seen NTT_ROUTE_SIGHTINGS times (a pair that keeps coming back: the bench step, a prover's pooled buffers -- a one-off
+// transform never pays), passes 0 and 1 are timed on the direct route and through each of NTT_ROUTE_CANDIDATES library buffers and the
+// fastest is remembered for the pair.  The measurement has to be taken in the state the transform will run in, the power-limited
+// clock: NTT_ROUTE_WARM untimed rounds over all routes first, then NTT_ROUTE_REPS timed ones, every other one backwards, median per
+// route (18 rounds x 8 launches = ~63 ms at 8 x 2^24, one stream synchronisation).  A short probe straight after idle (one warm-up
+// round, minimum of four) read 0.89-0.94 ms for routes that run at 0.85 and did not tell fast from slow: 5 of 12 processes
+// ended on a slow pair against 0 of 12 with the long one (profiles/r04/ab_ws_probe.txt).  Only transforms of >= NTT_ROUTE_MIN_BYTES
+// that read all n inputs.  BFS_NTT_WS_PROBE=0: always direct.  BFS_NTT_WS_PROBE_LOG=1: the measurements go to stderr.
 constexpr int NTT_ROUTE_CANDIDATES = 3;
+constexpr int NTT_ROUTE_SIGHTINGS = 3;
+#ifndef NTT_ROUTE_WARM
+#define NTT_ROUTE_WARM 10
+#define NTT_ROUTE_REPS 8
+#endif
 constexpr int NTT_ROUTE_SLOT0 = 16;                      // workspace slots 16.. hold the candidates
 constexpr u64 NTT_ROUTE_MIN_BYTES = 256ull << 20;
+constexpr int ROUTE_UNSEEN = -100;
 namespace {
 std::mutex g_route_mu;
 std::map<std::tuple<int, hipStream_t, const void*, const void*, u64, u64, u64>, int> g_routes;
@@ -307,10 +319,12 @@ static int ntt_route(const NttPlan& p, const NttTables& tb, const u64* d_in, u64
     const auto key = std::make_tuple(dev, stream, (const void*)d_in, (const void*)d_out, in_stride, out_stride, ((u64)p.log_n << 32) | batch);
     {
         std::lock_guard<std::mutex> lock(g_route_mu);
-        auto it = g_routes.find(key);
-        if (it != g_routes.end()) { *route = it->second; return BFS_OK; }
+        if (g_routes.size() >= 256 && !g_routes.count(key)) g_routes.clear();
+        int& state = g_routes.emplace(key, ROUTE_UNSEEN).first->second;          // a route (>= -1), or ROUTE_UNSEEN - sightings so far
+        if (state >= -1) { *route = state; return BFS_OK; }
+        if (ROUTE_UNSEEN - --state < NTT_ROUTE_SIGHTINGS) return BFS_OK;         // direct until the pair has come back often enough
     }
-    constexpr int R = NTT_ROUTE_CANDIDATES + 1, REPS = 3;
+    constexpr int R = NTT_ROUTE_CANDIDATES + 1, REPS = NTT_ROUTE_REPS, WARM = NTT_ROUTE_WARM;
     u64* cand[R] = {nullptr};                            // [0]: direct
     for (int k = 0; k < NTT_ROUTE_CANDIDATES; ++k) {
         void* w = nullptr;
@@ -319,10 +333,13 @@ static int ntt_route(const NttPlan& p, const NttTables& tb, const u64* d_in, u64
     }
     hipEvent_t ev[REPS][R][2];
     for (auto& rep : ev) for (auto& r : rep) for (auto& e : r) BFS_HIP(hipEventCreate(&e));
-    // one untimed round first (a freshly allocated buffer is slow the first time it is written: 1.2 ms against 0.85), then REPS timed
-    // rounds over all routes, round-robin so that a drifting clock touches every route alike; the minimum per route counts
-    for (int rep = -1; rep < REPS; ++rep)
-        for (int r = 0; r < R; ++r) {
+    // untimed rounds first (a freshly allocated buffer is slow the first time it is written, 1.2 ms against 0.85, and the clock takes
+    // tens of ms of load to settle at the power limit), then REPS timed rounds over all routes; the median per route counts
+    for (int rep = -WARM; rep < REPS; ++rep)
+        for (int k = 0; k < R; ++k) {
+            // (every other round backwards: while the clock is still ramping after idle, whatever is measured later in a round looks
+            //  faster -- the first version always found direct > buffer 0 > buffer 1 > buffer 2, the order it measured them in)
+            const int r = (rep & 1) ? R - 1 - k : k;
             if (rep >= 0) BFS_HIP(hipEventRecord(ev[rep][r][0], stream));
             for (u32 t = 0; t < 2; ++t)
                 BFS_TRY(ntt_run_pass(p, t, tb, d_in, n_in, in_stride, d_out, out_stride, cand[r], batch, root, shift, post_scale, streaming, stream));
@@ -332,12 +349,10 @@ static int ntt_route(const NttPlan& p, const NttTables& tb, const u64* d_in, u64
     float ms[R];
     int best = 0;
     for (int r = 0; r < R; ++r) {
-        ms[r] = 1e30f;
-        for (int rep = 0; rep < REPS; ++rep) {
-            float t = 0;
-            BFS_HIP(hipEventElapsedTime(&t, ev[rep][r][0], ev[rep][r][1]));
-            ms[r] = t < ms[r] ? t : ms[r];
-        }
+        float t[REPS];
+        for (int rep = 0; rep < REPS; ++rep) BFS_HIP(hipEventElapsedTime(&t[rep], ev[rep][r][0], ev[rep][r][1]));
+        std::sort(t, t + REPS);
+        ms[r] = 0.5f * (t[(REPS - 1) / 2] + t[REPS / 2]);
         if (ms[r] < ms[best]) best = r;
     }
     for (auto& rep : ev) for (auto& r : rep) for (auto& e : r) (void)hipEventDestroy(e);
@@ -349,7 +364,6 @@ static int ntt_route(const NttPlan& p, const NttTables& tb, const u64* d_in, u64
     }
     *route = best - 1;
     std::lock_guard<std::mutex> lock(g_route_mu);
-    if (g_routes.size() >= 256) g_routes.clear();
     g_routes[key] = *route;
     return BFS_OK;
 }

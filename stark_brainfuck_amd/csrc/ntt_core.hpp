@@ -80,25 +80,32 @@ BFS_HD u64 mul_pow2(u64 x) {
 }
 
 // one level of the radix-Q decimation-in-frequency network, twiddle w_Q = 2^(192/Q).
-// (Sums left unreduced where only the minuend role follows -- "lazy sums" -- were built and measured in round 3: more instructions,
-//  not fewer, once every non-canonical descendant is accounted for; profiles/r03/ab_ntt_three_experiments.txt.)
-template <int Q, int I>
+// OUT_LAZY: the block's outputs may be unreduced 64-bit values (every one of them is multiplied next, or stored for a pass that
+// multiplies what it loads).  Then a sum that is only ever a FIRST operand below -- index I < Q/4 of its block: the minuend / first
+// summand of the next level -- and every sum of the last level stays unreduced (gl_add_lazy: four instructions instead of six; 20 of
+// the 32 sums of a radix-16 block); the second operands (the upper half of every block: sums with I >= Q/4, twiddled differences) are
+// canonical by construction, and an untwiddled difference of a lazy minuend lands on index 0 of its sub-block, a first operand again.
+// (Round 3 tried this with the compiler's six-instruction lazy sum and lost; the scalar-carry form is what makes it pay:
+// profiles/r04/ab_lazy_sums.txt.)
+template <int Q, int I, bool OUT_LAZY>
 BFS_HD void dif_level(u64* x) {
     if constexpr (I < Q / 2) {
         u64 a = x[I], b = x[I + Q / 2];
-        x[I] = gl_add(a, b);
+        constexpr bool lazy_sum = OUT_LAZY && (Q == 2 || I < Q / 4);
+        if constexpr (lazy_sum) x[I] = gl_add_lazy(a, b);
+        else x[I] = gl_add(a, b);
         x[I + Q / 2] = mul_pow2<(192 / Q) * I>(gl_sub(a, b));
-        dif_level<Q, I + 1>(x);
+        dif_level<Q, I + 1, OUT_LAZY>(x);
     }
 }
 
-// Q-point NTT with root 2^(192/Q); result for output index k is left in x[bitrev(k)]
-template <int Q>
+// Q-point NTT with root 2^(192/Q); result for output index k is left in x[bitrev(k)].  Inputs canonical; outputs canonical unless OUT_LAZY
+template <int Q, bool OUT_LAZY = false>
 BFS_HD void dif(u64* x) {
     if constexpr (Q >= 2) {
-        dif_level<Q, 0>(x);
-        dif<Q / 2>(x);
-        dif<Q / 2>(x + Q / 2);
+        dif_level<Q, 0, OUT_LAZY>(x);
+        dif<Q / 2, OUT_LAZY>(x);
+        dif<Q / 2, OUT_LAZY>(x + Q / 2);
     }
 }
 
@@ -452,7 +459,7 @@ BFS_HD void ntt_stage1_values(const PassArgs& a, const u64* tw, const u64* rowtw
             if (d + 1 < Q) f = gl_mul_lazy(f, del);   // only ever multiplied again: no canonical form needed
         }
     }
-    dif<Q>(x);
+    dif<Q, (Cfg::U >= 2)>(x);          // U >= 2: every output meets an inner twiddle below (the one with a unit twiddle is reduced there)
     if constexpr (Cfg::U == 1) {
         final_store<Cfg, LOGC, MODE, B1, NT>(a, g, x, 0, 0, c, srow);
     } else {
@@ -465,6 +472,7 @@ BFS_HD void ntt_stage1_values(const PassArgs& a, const u64* tw, const u64* rowtw
             // table -- a wave-uniform question, so a forward transform skips that product
             const bool unit = (m == 0) && a.unit0;
             if (!unit) x[m] = gl_mul(x[m], tw[e]);
+            else x[m] = gl_canon(x[m]);
         }
     }
 }
@@ -501,7 +509,9 @@ BFS_HD void ntt_stage2_from(const PassArgs& a, u64* smem, u32 tid, u32 bid_x, u3
         const TileGeom g = tile_geom<Cfg, LOGC, MODE>(a, bid_x, bid_y);
         u32 c, f1, f3;
         stage2_pos<B1, B2, B3, LOGC, MODE>((u32)s * Cfg::W + tid, c, f1, f3);
-        dif<Q>(x);
+        // unreduced outputs where all of them are multiplied next: by the inner twiddles of a third stage, or -- first pass of a multi-pass
+        // plan -- by the store-time row here or by the next pass, which multiplies everything it loads
+        dif<Q, (Cfg::U == 3 || MODE == PASS_FIRST)>(x);
         if constexpr (Cfg::U == 2) {
             final_store<Cfg, LOGC, MODE, B2, NT>(a, g, x, f1, B1, c, srow);
         } else {

@@ -7,7 +7,7 @@
 
 namespace bfs {
 
-constexpr int ST_OPS = 42;
+constexpr int ST_OPS = 50;
 
 BFS_HD void selftest_ops(u64 a, u64 b, u64* o) {
     const u64 d = gl_sub(a, b), s = gl_add(a, b), m = gl_mul(a, b);
@@ -27,6 +27,10 @@ BFS_HD void selftest_ops(u64 a, u64 b, u64* o) {
     // both instruction sequences of the subtraction and of the reduction's first step (gl_sub4 / gl_sub5, gl_reduce128_t<.., SUB4>)
     o[34] = gl_sub5(a, b); o[35] = gl_sub5(gl_sub5(b, a), 2ULL); o[36] = gl_add(gl_sub5(a, b), 1ULL); o[37] = gl_sub4(gl_sub5(m, s), d);
     o[38] = gl_sub4(b, a); o[39] = gl_add(gl_sub4(gl_sub4(a, b), b), 1ULL); o[40] = gl_mul_other_form(a, b); o[41] = gl_mul_other_form(gl_mul_other_form(d, s), m);
+    // the unreduced sum (gl_add_lazy: any 64-bit first operand, canonical second) and everything that may consume it
+    const u64 l = gl_add_lazy(a, b), any = ~a;
+    o[42] = l; o[43] = gl_add_lazy(l, d); o[44] = gl_sub(l, d); o[45] = mul_pow2<48>(l); o[46] = gl_mul(l, m);
+    o[47] = gl_add_lazy(any, b); o[48] = gl_canon(gl_sub(any, b)); o[49] = mul_pow2<12>(gl_add_lazy(gl_add_lazy(any, b), s));
 }
 
 __global__ void selftest_kernel(const u64* in, u64* out, u64 n) {

@@ -15,7 +15,7 @@ def build_emulation(force=False):
     srcs = sorted(os.path.join(EMU, f) for f in os.listdir(EMU) if f.endswith(".cpp"))
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".h"))]
     out = os.path.join(EMU, "libbfs_emu.so")
-    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-shared", "-fPIC", "-o", out + ".tmp"] + srcs
+    cmd = [os.environ.get("CXX", "g++"), "-O2", "-std=c++17", "-DBFS_CHECK_CANONICAL", "-shared", "-fPIC", "-o", out + ".tmp"] + srcs
     return hashed_build(out, srcs + headers, cmd, force=force, what="libbfs_emu.so")
 
 

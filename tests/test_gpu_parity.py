@@ -120,8 +120,8 @@ def test_config5_2p24_columns(sb, oracle):
 def test_large_transform_over_every_route(route):
     """bfs_gl_ntt of >= 256 MiB picks where its first pass writes by measurement (ntt.hip: ntt_route): straight into the output or through
     one of three library buffers.  Each route forced in a process of its own (the choice is read once), and the measuring default, on
-    three 2^24 columns of the bench workload: the oracle's known answers (tests/golden/ntt24_oracle.json) on every route, twice (the
-    second call takes the remembered route), and the input untouched."""
+    three 2^24 columns of the bench workload: the oracle's known answers (tests/golden/ntt24_oracle.json) on every route, four times (the
+    measurement is taken the third time a pair of buffers is seen, the fourth call takes the remembered route), and the input untouched."""
     import subprocess
     import sys
     code = r'''
@@ -136,7 +136,8 @@ g = json.load(open(%r))
 logn, n, cols = 24, 1 << 24, 3
 v = np.concatenate([o.felt_array(0x5EED + (c << 32), 0, n) for c in range(cols)])
 din, dout = DeviceBuffer.from_numpy(v), DeviceBuffer(n * cols)
-for rep in range(2):
+for rep in range(4):
+    _lib.check(lib.bfs_memset(dout.ptr, 0, 8 * n * cols, 0))
     _lib.check(lib.bfs_gl_ntt(din.ptr, n, n, dout.ptr, n, logn, cols, g["root"], 1, 1, 0)); synchronize(0)
     out = dout.to_numpy()
     for c in range(cols):
@@ -152,7 +153,7 @@ print("ok")
     res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0 and "ok" in res.stdout, res.stdout[-2000:] + res.stderr[-3000:]
     if route == "measure":
-        assert "bfs ntt route" in res.stderr          # the probe ran (once: the second call found the pair remembered)
+        assert "bfs ntt route" in res.stderr          # the probe ran (once, at the third call: the fourth found the pair remembered)
         assert res.stderr.count("bfs ntt route") == 1
 
 
