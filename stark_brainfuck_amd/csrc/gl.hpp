@@ -7,9 +7,6 @@
 // so results are bit-identical to the reference's Python ints.
 #pragma once
 #include <stdint.h>
-#ifdef BFS_CHECK_CANONICAL
-#include <cassert>
-#endif
 
 #if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
@@ -281,9 +278,12 @@ BFS_HD u64 gl_mul_other_form(u64 a, u64 b) {
 }
 #else
 // -DBFS_CHECK_CANONICAL (the host emulation of the kernels, tests/emu): every operand that has to be canonical is checked -- the NTT
-// keeps some sums unreduced (gl_add_lazy) and the rule which operands may be such values is enforced here on every emulated transform
+// keeps some sums unreduced (gl_add_lazy) and the rule which operands may be such values is enforced here on every emulated transform:
+// violations are counted (tests/emu: emu_canonical_violations) and the tests want zero.  An unreduced sum is only actually >= p
+// when it lands within 2^32 of p -- once in 2^32 for random operands -- so the tests that mean it feed values next to 0 and p.
 #ifdef BFS_CHECK_CANONICAL
-#define BFS_CANONICAL(x) assert((x) < GL_P)
+inline unsigned long long& gl_canonical_violations() { static unsigned long long count = 0; return count; }      // (the emulation is single-threaded)
+#define BFS_CANONICAL(x) do { if (!((x) < GL_P)) ++gl_canonical_violations(); } while (0)
 #else
 #define BFS_CANONICAL(x) ((void)0)
 #endif

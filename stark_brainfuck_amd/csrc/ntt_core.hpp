@@ -81,17 +81,22 @@ BFS_HD u64 mul_pow2(u64 x) {
 
 // one level of the radix-Q decimation-in-frequency network, twiddle w_Q = 2^(192/Q).
 // OUT_LAZY: the block's outputs may be unreduced 64-bit values (every one of them is multiplied next, or stored for a pass that
-// multiplies what it loads).  Then a sum that is only ever a FIRST operand below -- index I < Q/4 of its block: the minuend / first
-// summand of the next level -- and every sum of the last level stays unreduced (gl_add_lazy: four instructions instead of six; 20 of
-// the 32 sums of a radix-16 block); the second operands (the upper half of every block: sums with I >= Q/4, twiddled differences) are
-// canonical by construction, and an untwiddled difference of a lazy minuend lands on index 0 of its sub-block, a first operand again.
-// (Round 3 tried this with the compiler's six-instruction lazy sum and lost; the scalar-carry form is what makes it pay:
+// multiplies what it loads).  Then the sums that may stay unreduced (gl_add_lazy: four instructions instead of six) are those whose
+// every later use accepts one: index 0 of each block at every level -- below, it is the first operand of the next lazy sum and the
+// minuend of a difference, never a second operand -- and all sums of the last level: 15 of the 32 sums of a radix-16 block.  Every
+// other operand is canonical by construction: sums with I >= 1 (gl_add), twiddled differences (mul_pow2<K>, K > 0); the untwiddled
+// difference of a lazy minuend lands on index 0 of its sub-block, where an unreduced value is allowed again.
+// (A first version also kept the sums with 1 <= I < Q/4 unreduced, which then met gl_add as first operands one level down; gl_add adds
+// EPS once for "wrapped or >= p" and such an operand can need both.  Random data never shows that -- an unreduced sum is >= p once in
+// 2^32 -- but trace columns (0, small counters, p - 1) do: tools/soak_stark.py found a proof with a codeword value >= p.  The emulation
+// now counts non-canonical operands on inputs next to 0 and p, tests/test_emulation.py, and the GPU tests transform such inputs too.)
+// (Round 3 tried lazy sums with the compiler's six-instruction form and lost; the scalar-carry form is what makes it pay:
 // profiles/r04/ab_lazy_sums.txt.)
 template <int Q, int I, bool OUT_LAZY>
 BFS_HD void dif_level(u64* x) {
     if constexpr (I < Q / 2) {
         u64 a = x[I], b = x[I + Q / 2];
-        constexpr bool lazy_sum = OUT_LAZY && (Q == 2 || I < Q / 4);
+        constexpr bool lazy_sum = OUT_LAZY && (Q == 2 || I == 0);
         if constexpr (lazy_sum) x[I] = gl_add_lazy(a, b);
         else x[I] = gl_add(a, b);
         x[I + Q / 2] = mul_pow2<(192 / Q) * I>(gl_sub(a, b));

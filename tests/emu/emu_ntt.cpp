@@ -62,6 +62,12 @@ static void dispatch_single(const PassArgs& a, u32 S, u32 batch) {
 
 static int emu_force_ws = 0;
 extern "C" void emu_set_force_ws(int v) { emu_force_ws = v; }
+// operands that had to be canonical and were not, since the last reset (gl.hpp, BFS_CHECK_CANONICAL)
+extern "C" unsigned long long emu_canonical_violations(int reset) {
+    const unsigned long long c = gl_canonical_violations();
+    if (reset) gl_canonical_violations() = 0;
+    return c;
+}
 
 extern "C" int emu_gl_ntt(const u64* in, u64 n_in, u64 in_stride, u64* out, u64 out_stride, u32 log_n, u32 batch,
                           u64 root, u64 shift, u64 post_scale) {

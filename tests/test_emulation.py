@@ -12,6 +12,7 @@ import pytest
 from conftest import ROOT, load_golden
 
 SEED = 0x5EED
+P = (1 << 64) - (1 << 32) + 1
 EMU_DIR = os.path.join(ROOT, "tests", "emu")
 u64, vp = ctypes.c_uint64, ctypes.c_void_p
 
@@ -26,6 +27,8 @@ def emu():
     lib.emu_gl_ntt.argtypes = [vp, u64, u64, vp, u64, ctypes.c_uint32, ctypes.c_uint32, u64, u64, u64]
     lib.emu_set_schedule.argtypes = [ctypes.c_int, ctypes.c_uint32, u64]
     lib.emu_set_force_ws.argtypes = [ctypes.c_int]
+    lib.emu_canonical_violations.argtypes = [ctypes.c_int]
+    lib.emu_canonical_violations.restype = ctypes.c_ulonglong
     lib.emu_plan.argtypes = [ctypes.c_uint32, u64, vp, vp, vp, vp]
     lib.emu_merkle_xfe.argtypes = [vp, u64, u64, vp]
     lib.emu_xfe_leaf_stream.argtypes = [vp, u64, u64, ctypes.c_int, vp]
@@ -39,9 +42,25 @@ def emu_ntt(lib, v, logn, root, shift=1, scale=1, n_in=None, batch=1):
     v = np.ascontiguousarray(v, dtype=np.uint64)
     n_in = n if n_in is None else n_in
     out = np.zeros(n * batch, dtype=np.uint64)
+    lib.emu_canonical_violations(1)
     rc = lib.emu_gl_ntt(v.ctypes.data, n_in, n_in, out.ctypes.data, n, logn, batch, root, shift, scale)
     assert rc == 0, rc
+    # the emulation is built with -DBFS_CHECK_CANONICAL: every operand that must be a canonical residue was one (gl.hpp)
+    assert lib.emu_canonical_violations(1) == 0
     return out
+
+
+def edge_values(n, seed):
+    """values next to 0 and next to p, a few random ones in between: an unreduced sum (gl_add_lazy) is only really >= p when it
+    lands within 2^32 of p, which random operands do once in 2^32 and these do all the time -- the trace columns of a proof look like
+    this (small counters, 0, p - 1), and a proof is where a non-canonical value slipped through in round 4 (tools/soak_stark.py)"""
+    rng = np.random.default_rng(seed)
+    small = rng.integers(0, 6, n, dtype=np.uint64)
+    kind = rng.integers(0, 8, n)
+    v = np.where(kind < 3, small, np.uint64(P) - np.uint64(1) - small)
+    v = np.where(kind == 6, rng.integers(0, P, n, dtype=np.uint64), v)
+    v = np.where(kind == 7, (np.uint64(1) << np.uint64(32)) - small, v)            # around EPS
+    return np.ascontiguousarray(v, dtype=np.uint64)
 
 
 @pytest.mark.parametrize("logn", list(range(0, 15)) + [16, 17, 18, 20])
@@ -53,6 +72,21 @@ def test_tile_kernels_match_oracle(emu, oracle, logn):
     assert (emu_ntt(emu, v, logn, oracle.inv(w), 1, oracle.inv(n)) == oracle.intt(w, v)).all()
     d = max(1, n // 4)
     assert (emu_ntt(emu, v[:d], logn, w, 7, 1, n_in=d) == oracle.fast_coset_evaluate(v[:d], 7, w, n)).all()
+
+
+@pytest.mark.parametrize("logn", list(range(1, 15)) + [16, 17, 18])
+def test_values_next_to_zero_and_p_stay_canonical(emu, oracle, logn):
+    """every plan shape on operands that make unreduced sums actually exceed p: the oracle's transform, bit for bit, and no
+    non-canonical operand anywhere a canonical one is required (emu_ntt asserts the emulation's violation count)"""
+    n = 1 << logn
+    w = oracle.primitive_nth_root(n)
+    for seed in range(3 if logn <= 14 else 1):
+        v = edge_values(n, 1000 * logn + seed)
+        assert (emu_ntt(emu, v, logn, w) == oracle.ntt(w, v)).all(), seed
+        assert (emu_ntt(emu, v, logn, oracle.inv(w), 1, oracle.inv(n)) == oracle.intt(w, v)).all(), seed
+        d = max(1, n // 4)
+        assert (emu_ntt(emu, v[:d], logn, w, 7, 1, n_in=d) == oracle.fast_coset_evaluate(v[:d], 7, w, n)).all(), seed
+        assert (emu_ntt(emu, v[:d], logn, w, 1, 1, n_in=d) == oracle.fast_coset_evaluate(v[:d], 1, w, n)).all(), seed
 
 
 @pytest.mark.parametrize("logn", [17, 18, 19, 20])

@@ -13,6 +13,7 @@ from conftest import GOLDEN, ROOT, golden_bytes, load_golden
 
 pytestmark = pytest.mark.gpu
 SEED = 0x5EED
+P = (1 << 64) - (1 << 32) + 1
 
 
 @pytest.fixture(scope="module")
@@ -59,6 +60,38 @@ def test_ntt_intt_coset_vs_oracle(sb, oracle, logn):
     assert (raw_ntt(sb, v, logn, oracle.inv(w), 1, oracle.inv(n)) == oracle.intt(w, v)).all()
     d = max(1, n // 4)
     assert (raw_ntt(sb, v[:d], logn, w, 7, 1, n_in=d) == oracle.fast_coset_evaluate(v[:d], 7, w, n)).all()
+
+
+def edge_values(n, seed):
+    """values next to 0, next to p and around 2^32, a few random ones: what trace columns look like, and what makes an unreduced
+    butterfly sum (gl.hpp: gl_add_lazy) actually exceed p -- random operands do that once in 2^32 (tests/test_emulation.py has the
+    same generator and also counts non-canonical operands inside the emulated kernels)"""
+    rng = np.random.default_rng(seed)
+    small = rng.integers(0, 6, n, dtype=np.uint64)
+    kind = rng.integers(0, 8, n)
+    v = np.where(kind < 3, small, np.uint64(P) - np.uint64(1) - small)
+    v = np.where(kind == 6, rng.integers(0, P, n, dtype=np.uint64), v)
+    v = np.where(kind == 7, (np.uint64(1) << np.uint64(32)) - small, v)
+    return np.ascontiguousarray(v, dtype=np.uint64)
+
+
+@pytest.mark.parametrize("logn", list(range(1, 23)))
+def test_ntt_on_values_next_to_zero_and_p(sb, oracle, logn):
+    """every plan shape on operands that drive the unreduced sums of the butterfly blocks over p: forward, inverse, coset and plain
+    zero-padded transforms equal the oracle's bit for bit -- in particular every output is a canonical residue.  (Round 4: a first
+    version of the lazy sums passed every random-data test and put a value >= p into a proof's codeword.)"""
+    n = 1 << logn
+    w = oracle.primitive_nth_root(n)
+    for seed in range(3 if logn <= 16 else 1):
+        v = edge_values(n, 1000 * logn + seed)
+        assert (raw_ntt(sb, v, logn, w) == oracle.ntt(w, v)).all(), seed
+        assert (raw_ntt(sb, v, logn, oracle.inv(w), 1, oracle.inv(n)) == oracle.intt(w, v)).all(), seed
+        d = max(1, n // 4)
+        assert (raw_ntt(sb, v[:d], logn, w, 7, 1, n_in=d) == oracle.fast_coset_evaluate(v[:d], 7, w, n)).all(), seed
+        assert (raw_ntt(sb, v[:d], logn, w, 1, 1, n_in=d) == oracle.fast_coset_evaluate(v[:d], 1, w, n)).all(), seed
+    # all-(p - 1) and alternating 1 / p - 1 columns: sums of exactly p and 2p - 2 at the first level
+    for v in (np.full(n, P - 1, dtype=np.uint64), np.where(np.arange(n) % 2 == 0, np.uint64(1), np.uint64(P - 1)).astype(np.uint64)):
+        assert (raw_ntt(sb, v, logn, w) == oracle.ntt(w, v)).all()
 
 
 def test_ntt_golden_vectors(sb):

@@ -208,6 +208,62 @@ def test_prove_then_verify_fresh_randomness():
     assert BrainfuckStark(running_time, len(mm), program, input_symbols, output_symbols).verify(proof_b) is True
 
 
+WRAPPING_PROGRAMS = [
+    "[->+<][>]+>[-]+++++[>+[>+<-]<-]-++++.----",      # the one tools/soak_stark.py found in round 4 (cells pass through p - 1)
+    "-+.", "--++.", "->-<+.>++.", "+[-]-[+]+.", "-[>-<+]>+.", "++[>--<-]>++++.", "-->-<[>+<+]>+++.", "->->-<<+[>+>+<<-]>>+.",
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("code", WRAPPING_PROGRAMS)
+def test_traces_full_of_values_next_to_zero_and_p_prove_and_verify(code, monkeypatch):
+    """trace columns are counters, zeros and p - 1: the values for which an unreduced butterfly sum really exceeds p.  Round 4: a
+    first version of the NTT's lazy sums passed every random-data comparison and all ten reference proofs, and wrote a codeword
+    value >= p into the proof of the first program here (found by tools/soak_stark.py; verify() rejected it).  Both prover paths
+    must write the same bytes, verify() -- host code that shares no kernel with the prover -- must accept them, and every integer
+    in the proof must be a canonical residue.  (In that proof the value >= p sat at an unopened position; what broke was downstream
+    arithmetic that relies on canonical operands.  The NTT's own outputs on such inputs are compared with the oracle bit for bit in
+    tests/test_gpu_parity.py::test_ntt_on_values_next_to_zero_and_p.)"""
+    from stark_brainfuck_amd import brainfuck_stark, salted_merkle, table
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    import pickle
+    program = VirtualMachine.compile(code)
+    matrices = VirtualMachine.simulate(program, input_data=[], max_cycles=5000)
+    rt = len(matrices[0])
+    outputs = [chr(int(v) % 256) for v in matrices[4].values.reshape(-1)]
+    proofs = []
+    for keep in (False, True):
+        stream = Stream(code.encode())
+        for mod in (brainfuck_stark, salted_merkle, table):
+            monkeypatch.setattr(mod, "urandom", stream)
+        stark = BrainfuckStark(rt, len(matrices[1]), program, [], outputs)
+        stark.keep_intermediates = keep
+        proofs.append(stark.prove(program, *matrices))
+    assert proofs[0] == proofs[1]
+    assert BrainfuckStark(rt, len(matrices[1]), program, [], outputs).verify(proofs[0]) is True
+    P = (1 << 64) - (1 << 32) + 1
+
+    def integers(o):
+        if isinstance(o, bool) or type(o).__name__ in ("BaseField", "ExtensionField"):          # (a field object holds p itself)
+            return
+        if isinstance(o, int):
+            yield o
+        elif isinstance(o, (list, tuple)):
+            for c in o:
+                yield from integers(c)
+        elif hasattr(o, "__dict__"):
+            for c in vars(o).values():
+                yield from integers(c)
+        elif hasattr(o, "__slots__"):
+            for name in o.__slots__:
+                yield from integers(getattr(o, name, None))
+    from stark_brainfuck_amd.ip import ProofStream
+    objects = ProofStream().deserialize(proofs[0]).objects
+    values = [v for v in integers(objects)]
+    assert len(values) > 100 and all(0 <= v < P for v in values)
+
+
 @pytest.mark.gpu
 def test_prove_and_verify_with_other_protocol_parameters():
     """expansion factor 16 with 32 colinearity checks and 128 opened indices (the reference hard-codes 4 / 1 / 2 "for speed",
