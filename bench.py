@@ -367,7 +367,8 @@ def main():
                             "traffic": traffic, "wasted_traffic_ratio": (traffic / bytes_per_launch) if traffic else None,
                             "kernel": "ntt_tile_kernel_split<4,4,0,4,MODE,NT> (pass 0: MODE 2 = transposing first pass; passes 1-2: MODE 0 = in place)",
                             "launches_per_step": npass, "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
-                            "valu": valu, "hbm_physical": hbm_phys, "bound_actual": bound_actual, "static": static}
+                            "valu": valu, "hbm_physical": hbm_phys, "bound_actual": bound_actual, "static": static,
+                            "route_probe": route_probe_info(lib)}
         if log_n == 24 and not args.no_single:
             line["single_column_2p24"] = bench_single_column(lib, _lib, d_in, d_out, n, log_n, root, stream)
             line["single_column_2p24_ms"] = line["single_column_2p24"]["ms"]
@@ -408,6 +409,18 @@ def main():
             del d_in, d_out
             line["stark_prove_cooperative"] = guarded_cooperative(world)
         print(json.dumps(slim(line, world), separators=(",", ":")), flush=True)
+
+
+def route_probe_info(lib):
+    """what bfs_gl_ntt's route measurement read in this process (ntt.hip: ntt_route; taken inside the untimed spin-up, the third time the
+    step's buffer pair was seen): passes 0 + 1 straight into the output and through each of three library buffers, and which it kept --
+    when all four read alike the box has no fast pair to offer and the step is what it is (profiles/r04/ab_ws_probe.txt)"""
+    import ctypes
+    us, route, probes = (ctypes.c_float * 4)(), ctypes.c_int(-1), ctypes.c_ulonglong(0)
+    if lib.bfs_ntt_route_probe_info(us, ctypes.byref(route), ctypes.byref(probes)) != 0 or probes.value == 0:
+        return {"probes": 0}
+    return {"probes": int(probes.value), "passes_0_1_us": {"direct": us[0], "buffer0": us[1], "buffer1": us[2], "buffer2": us[3]},
+            "chosen": "direct" if route.value < 0 else "buffer%d" % route.value}
 
 
 def slim(line, world):

@@ -104,6 +104,11 @@ int bfs_gl_ntt(const uint64_t* d_in, uint64_t n_in, uint64_t in_stride, uint64_t
                uint32_t log_n, uint32_t batch, uint64_t root, uint64_t coset_shift, uint64_t post_scale,
                void* stream);
 
+/* Diagnostics of bfs_gl_ntt's route measurement (no reference counterpart): what the LAST measurement of this process read.
+ * us[0] = passes 0 + 1 straight into the output, us[1..3] = through library buffer 0..2 (microseconds); *route = -1 direct or the
+ * buffer chosen; *probes = measurements taken so far (0: none yet, us / route are then 0 / -1).  Any pointer may be NULL. */
+int bfs_ntt_route_probe_info(float* us, int* route, unsigned long long* probes);
+
 /* Polynomial.scale(factor): out[b][i] = in[b][i] * factor^i                         univariate.py:168-169 */
 int bfs_gl_scale(const uint64_t* d_in, uint64_t* d_out, uint64_t n, uint64_t stride, uint32_t batch, uint64_t factor,
                  void* stream);

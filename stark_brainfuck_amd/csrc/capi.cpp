@@ -72,6 +72,8 @@ int bfs_gl_ntt(const uint64_t* d_in, uint64_t n_in, uint64_t in_stride, uint64_t
     return ntt_launch(d_in, n_in, in_stride, d_out, out_stride, log_n, batch, root, coset_shift, post_scale, (hipStream_t)stream);
 }
 
+int bfs_ntt_route_probe_info(float* us, int* route, unsigned long long* probes) { return ntt_route_probe_info(us, route, probes); }
+
 int bfs_gl_scale(const uint64_t* d_in, uint64_t* d_out, uint64_t n, uint64_t stride, uint32_t batch, uint64_t factor, void* stream) {
     return scale_launch(d_in, d_out, n, stride, batch, factor, (hipStream_t)stream);
 }

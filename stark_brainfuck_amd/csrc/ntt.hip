@@ -297,6 +297,15 @@ constexpr int ROUTE_UNSEEN = -100;
 namespace {
 std::mutex g_route_mu;
 std::map<std::tuple<int, hipStream_t, const void*, const void*, u64, u64, u64>, int> g_routes;
+struct { float us[NTT_ROUTE_CANDIDATES + 1] = {0}; int route = -1; unsigned long long probes = 0; } g_last_probe;      // (under g_route_mu)
+}
+// what the last route measurement of this process read (bfs_ntt_route_probe_info; bench.py prints it next to the step it explains)
+int ntt_route_probe_info(float* us, int* route, unsigned long long* probes) {
+    std::lock_guard<std::mutex> lock(g_route_mu);
+    if (us) for (int k = 0; k <= NTT_ROUTE_CANDIDATES; ++k) us[k] = g_last_probe.us[k];
+    if (route) *route = g_last_probe.route;
+    if (probes) *probes = g_last_probe.probes;
+    return BFS_OK;
 }
 static int ntt_route(const NttPlan& p, const NttTables& tb, const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_stride, u32 batch,
                      u64 root, u64 shift, u64 post_scale, u32 streaming, hipStream_t stream, int* route) {
@@ -365,6 +374,9 @@ static int ntt_route(const NttPlan& p, const NttTables& tb, const u64* d_in, u64
     *route = best - 1;
     std::lock_guard<std::mutex> lock(g_route_mu);
     g_routes[key] = *route;
+    for (int r = 0; r < R; ++r) g_last_probe.us[r] = ms[r] * 1e3f;
+    g_last_probe.route = *route;
+    ++g_last_probe.probes;
     return BFS_OK;
 }
 

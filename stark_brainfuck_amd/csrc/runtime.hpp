@@ -72,6 +72,7 @@ int merkle_build_xfe_fold_launch(const FriFoldArgs& fold, u64* d_cw, u64 cw_stri
 int fri_round_fused_launch(const FriFoldArgs& fold, u64* d_cw, u64 cw_stride, u64 n, u64* d_nodes, hipStream_t stream, u64* root_out, u64 seq);
 
 // ---- internal entry points (device pointers, current device) ----
+int ntt_route_probe_info(float* us, int* route, unsigned long long* probes);
 int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_stride, u32 log_n, u32 batch, u64 root,
                u64 shift, u64 post_scale, hipStream_t stream);
 

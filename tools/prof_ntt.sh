@@ -11,7 +11,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 for TL in $TILES; do
   : # (one tile size since round 2; the loop variable only names the output files)
-  python "$ROOT/tools/ntt_only.py" --steps 30 > "$OUT/plain_tile$TL.json" 2>&1
+  BFS_NTT_WS_PROBE_LOG=1 python "$ROOT/tools/ntt_only.py" --steps 30 > "$OUT/plain_tile$TL.json" 2> "$OUT/route_probe_tile$TL.log"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/raw$TL" -o ntt -- python "$ROOT/tools/ntt_only.py" --steps 30 > "$OUT/rocprof_stdout_tile$TL.log" 2>&1
   find "$OUT/raw$TL" -name "*kernel_stats.csv" -exec cp {} "$OUT/ntt_only_kernel_stats_tile$TL.csv" \;
   find "$OUT/raw$TL" -name "*kernel_trace.csv" -exec sh -c 'head -1 "$1" > "$2"; tail -90 "$1" >> "$2"' _ {} "$OUT/ntt_only_kernel_trace_tail_tile$TL.csv" \;
@@ -23,6 +23,6 @@ for TL in $TILES; do
       rm -rf "$OUT/pmc$TL$C"
     done
   fi
-  cat "$OUT/plain_tile$TL.json"
+  cat "$OUT/plain_tile$TL.json"; grep "ntt route" "$OUT/route_probe_tile$TL.log"
   head -8 "$OUT/ntt_only_kernel_stats_tile$TL.csv"
 done
