@@ -138,6 +138,8 @@ class BrainfuckStark:
 
     # ------------------------------------------------------------------------------------------------------------
     keep_intermediates = False      # True: prove() leaves trees, quotient codewords and the combination codeword in `_last` (tests)
+    stage_timing = False            # True: prove() synchronises its stream after every stage so that `timing` splits the GPU time by stage
+                                    # (bench.py's breakdown, tools/); False: `timing` holds host time per stage and the stages overlap freely
 
     # ---- several GPUs on one proof (shard.RowShardedSaltedMerkle): every rank runs the polynomial stages on all columns and hashes
     # only its range of the zipped rows; set by cooperate() and used inside shard.shared_randomness()
@@ -266,8 +268,10 @@ class BrainfuckStark:
         import time
         self.timing = {}
         mark = [time.perf_counter()]
+        sync_stages = self.stage_timing
         def lap(name):
-            synchronize(stream)
+            if sync_stages:
+                synchronize(stream)
             now = time.perf_counter()
             self.timing[name] = self.timing.get(name, 0.0) + now - mark[0]
             mark[0] = now

@@ -29,6 +29,15 @@ while time.time() < t_end:
     v = rng.integers(0, P, in_stride * batch, dtype=np.uint64)
     if rng.integers(0, 4) == 0:
         v[rng.integers(0, 2, v.size) == 0] = 0
+    if rng.integers(0, 2) == 0:
+        # values next to 0, p and 2^32: what trace columns look like, and the only operands for which an unreduced sum of the butterfly
+        # blocks really exceeds p (random ones do once in 2^32: round 4's first lazy-sum rule passed 5 922 random configurations here)
+        small = rng.integers(0, 6, v.size, dtype=np.uint64)
+        kind = rng.integers(0, 8, v.size)
+        edge = np.where(kind < 3, small, np.uint64(P - 1) - small)
+        edge = np.where(kind == 7, (np.uint64(1) << np.uint64(32)) - small, edge)
+        v = np.where(kind == 6, v, edge).astype(np.uint64)
+        stats["edge"] = stats.get("edge", 0) + 1
     din, dout = DeviceBuffer.from_numpy(v), DeviceBuffer(out_stride * batch)
     _lib.check(lib.bfs_gl_ntt(din.ptr, n_in, in_stride, dout.ptr, out_stride, logn, batch, root, shift, scale, 0))
     synchronize(0)

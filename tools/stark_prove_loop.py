@@ -13,5 +13,6 @@ rt, inp, out = VirtualMachine.run(program)
 m = VirtualMachine.simulate(program, input_data=inp)
 for rep in range(reps):
     stark = BrainfuckStark(rt, len(m[1]), program, inp, out)
+    stark.stage_timing = True
     t = time.perf_counter(); proof = stark.prove(program, *m); dt = time.perf_counter() - t
     print("prove %.1f ms" % (dt * 1e3), {k: round(v * 1e3, 2) for k, v in stark.timing.items()}, flush=True)

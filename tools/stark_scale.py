@@ -15,6 +15,7 @@ for outer in (8, 16, 32, 64, 128):
     best, proof = None, None
     for rep in range(2):
         stark = BrainfuckStark(rt, len(m[1]), program, inp, out)
+        stark.stage_timing = True
         t = time.perf_counter()
         proof = stark.prove(program, *m)
         dt = time.perf_counter() - t
