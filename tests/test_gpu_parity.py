@@ -94,6 +94,35 @@ def test_ntt_on_values_next_to_zero_and_p(sb, oracle, logn):
         assert (raw_ntt(sb, v, logn, w) == oracle.ntt(w, v)).all()
 
 
+@pytest.mark.parametrize("logn", [1, 4, 7, 10, 13, 16])
+def test_elementwise_primitives_on_values_next_to_zero_and_p(sb, oracle, logn):
+    """the same edge operands through the other arithmetic entry points: Polynomial.scale, the pointwise product, the batch inverse and
+    one split-and-fold round (unreduced dot products, lazy.hpp) -- against the oracle, bit for bit"""
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.device import DeviceBuffer, synchronize
+    lib = _lib.load()
+    n = 1 << logn
+    a, b = edge_values(n, 7 * logn + 1), edge_values(n, 7 * logn + 2)
+    da, db, dout = DeviceBuffer.from_numpy(a), DeviceBuffer.from_numpy(b), DeviceBuffer(n)
+    for factor in (1, 2, P - 1, P - 2, (1 << 32) - 1, 1 << 32, oracle.felt(SEED, logn)):
+        _lib.check(lib.bfs_gl_scale(da.ptr, dout.ptr, n, n, 1, factor, 0)); synchronize(0)
+        assert (dout.to_numpy() == oracle.scale(factor, a)).all(), factor
+    _lib.check(lib.bfs_gl_mul_pointwise(da.ptr, db.ptr, dout.ptr, n, 0)); synchronize(0)
+    assert (dout.to_numpy() == oracle.hadamard(a, b)).all()
+    nz = np.where(a == 0, np.uint64(P - 1), a)
+    dnz = DeviceBuffer.from_numpy(nz)
+    _lib.check(lib.bfs_gl_batch_inverse(dnz.ptr, dout.ptr, n, 0)); synchronize(0)
+    assert (dout.to_numpy() == oracle.batch_inverse(nz)).all()
+    if logn >= 1:
+        soa = np.stack([edge_values(n, 7 * logn + 3 + k) for k in range(3)])
+        dcw, dfold = DeviceBuffer.from_numpy(np.ascontiguousarray(soa.reshape(-1))), DeviceBuffer(3 * (n // 2))
+        omega = oracle.primitive_nth_root(n)
+        for alpha in ((P - 1, P - 1, P - 1), (1, 0, 0), (0, P - 1, 1), tuple(oracle.felt(SEED + 5, 3 * logn + k) for k in range(3))):
+            for offset in (1, 7, P - 1):
+                _lib.check(lib.bfs_xfe_fold(dcw.ptr, n, dfold.ptr, n // 2, logn, (ctypes.c_uint64 * 3)(*alpha), offset, omega, 0)); synchronize(0)
+                assert (dfold.to_numpy().reshape(3, -1) == oracle.fri_fold(soa, alpha, offset, omega)).all(), (alpha, offset)
+
+
 def test_ntt_golden_vectors(sb):
     g = load_golden("ntt.json")
     import oracle.ref_oracle as o
