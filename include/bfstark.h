@@ -97,7 +97,8 @@ uint64_t bfs_gl_pow(uint64_t a, uint64_t e);
  * the input -- in which case the first two passes go through a library buffer of the output's size.  Stream-ordered, except that the
  * THIRD call with the same (d_in, d_out) pair for a transform of >= 256 MiB that reads all n inputs synchronises `stream` once (~63 ms
  * at 8 x 2^24, output written as usual): it times its first pass directly and through three library buffers of the output's size, at
- * the settled clock, and remembers the fastest route for the pair (BFS_NTT_WS_PROBE=0 turns that off; a pair seen once or twice never pays).
+ * the settled clock, and remembers the fastest route for the pair; afterwards at most one of the three buffers stays allocated
+ * (BFS_NTT_WS_PROBE=0 turns all of that off; a pair seen once or twice never pays).
  * Errors: BFS_ERR_NOT_ROOT / BFS_ERR_NOT_PRIMITIVE as the reference's asserts; BFS_ERR_TOO_MANY_COEFFS.
  */
 int bfs_gl_ntt(const uint64_t* d_in, uint64_t n_in, uint64_t in_stride, uint64_t* d_out, uint64_t out_stride,

@@ -337,7 +337,14 @@ static int ntt_route(const NttPlan& p, const NttTables& tb, const u64* d_in, u64
     u64* cand[R] = {nullptr};                            // [0]: direct
     for (int k = 0; k < NTT_ROUTE_CANDIDATES; ++k) {
         void* w = nullptr;
-        BFS_TRY(workspace(NTT_ROUTE_SLOT0 + k, (size_t)n * batch * sizeof(u64), stream, &w));
+        if (workspace(NTT_ROUTE_SLOT0 + k, (size_t)n * batch * sizeof(u64), stream, &w) != BFS_OK) {
+            // no room for the candidates: this is an optimisation, not a requirement -- the pair stays on the direct route
+            (void)hipGetLastError();
+            for (int j = 0; j < k; ++j) (void)workspace_release(NTT_ROUTE_SLOT0 + j, stream);
+            std::lock_guard<std::mutex> lock(g_route_mu);
+            g_routes[key] = -1;
+            return BFS_OK;
+        }
         cand[k + 1] = (u64*)w;
     }
     hipEvent_t ev[REPS][R][2];
@@ -372,11 +379,20 @@ static int ntt_route(const NttPlan& p, const NttTables& tb, const u64* d_in, u64
         fprintf(stderr, " -> %s\n", best == 0 ? "direct" : (std::string("buffer ") + std::to_string(best - 1)).c_str());
     }
     *route = best - 1;
-    std::lock_guard<std::mutex> lock(g_route_mu);
-    g_routes[key] = *route;
-    for (int r = 0; r < R; ++r) g_last_probe.us[r] = ms[r] * 1e3f;
-    g_last_probe.route = *route;
-    ++g_last_probe.probes;
+    // the candidates that lost go back to the driver (the stream is idle: synchronised above).  Slot NTT_ROUTE_SLOT0 + k is buffer k for
+    // every pair of this stream, so a buffer another pair was routed through must stay
+    {
+        std::lock_guard<std::mutex> lock(g_route_mu);
+        g_routes[key] = *route;
+        for (int r = 0; r < R; ++r) g_last_probe.us[r] = ms[r] * 1e3f;
+        g_last_probe.route = *route;
+        ++g_last_probe.probes;
+        bool used[NTT_ROUTE_CANDIDATES] = {false};
+        for (const auto& kv : g_routes)
+            if (std::get<0>(kv.first) == dev && std::get<1>(kv.first) == stream && kv.second >= 0) used[kv.second] = true;
+        for (int k = 0; k < NTT_ROUTE_CANDIDATES; ++k)
+            if (!used[k]) (void)workspace_release(NTT_ROUTE_SLOT0 + k, stream);
+    }
     return BFS_OK;
 }
 

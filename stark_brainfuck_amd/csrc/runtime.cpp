@@ -270,6 +270,19 @@ int workspace(int slot, size_t bytes, hipStream_t stream, void** out) {
     return BFS_OK;
 }
 
+// give one scratch buffer back to the driver (the NTT's route measurement keeps only the candidate it chose); the stream must be idle
+int workspace_release(int slot, hipStream_t stream) {
+    int dev = 0;
+    BFS_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_scratch.find(std::make_tuple(dev, stream, slot));
+    if (it != g_scratch.end()) {
+        if (it->second.ptr) (void)hipFree(it->second.ptr);
+        g_scratch.erase(it);
+    }
+    return BFS_OK;
+}
+
 // bfs_stream_destroy: the stream's scratch buffers go back to the driver and pooled blocks that were released on it no longer
 // name it (a later stream may get the same handle value)
 int stream_retire(hipStream_t stream) {

@@ -29,6 +29,7 @@ const char* last_error();
 
 // grow-only scratch buffer keyed by (device, stream, slot); contents are only valid within one API call
 int workspace(int slot, size_t bytes, hipStream_t stream, void** out);
+int workspace_release(int slot, hipStream_t stream);
 
 // Pooled HBM and pinned-host memory.  hipMalloc / hipFree cost 50-500 us and hipFree synchronises the device, which at
 // 288 GB of HBM is the wrong trade: freed blocks go back to a size-class free list (8 classes per octave above 1 MiB,

@@ -198,6 +198,13 @@ g = json.load(open(%r))
 logn, n, cols = 24, 1 << 24, 3
 v = np.concatenate([o.felt_array(0x5EED + (c << 32), 0, n) for c in range(cols)])
 din, dout = DeviceBuffer.from_numpy(v), DeviceBuffer(n * cols)
+import ctypes
+hip = ctypes.CDLL("libamdhip64.so")
+def free_bytes():
+    f, t = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+    return f.value
+before = free_bytes()
 for rep in range(4):
     _lib.check(lib.bfs_memset(dout.ptr, 0, 8 * n * cols, 0))
     _lib.check(lib.bfs_gl_ntt(din.ptr, n, n, dout.ptr, n, logn, cols, g["root"], 1, 1, 0)); synchronize(0)
@@ -205,6 +212,9 @@ for rep in range(4):
     for c in range(cols):
         assert hashlib.sha256(np.ascontiguousarray(out[c * n:(c + 1) * n], dtype="<u8").tobytes()).hexdigest() == g["columns"][c]["output_sha256"], (rep, c)
 assert (din.to_numpy() == v).all()
+# the measurement keeps at most the one candidate buffer it chose (the others went back to the driver): <= one transform's size + tables
+held = before - free_bytes()
+assert held <= 8 * n * cols + (64 << 20), held
 print("ok")
 ''' % (ROOT, os.path.join(GOLDEN, "ntt24_oracle.json"))
     env = dict(os.environ, BFS_NTT_WS_PROBE_LOG="1")
