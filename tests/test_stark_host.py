@@ -408,13 +408,13 @@ def test_runaway_programs_stop_at_the_cycle_limit():
         VirtualMachine.run(program, max_cycles=100000)
     with pytest.raises(AssertionError, match="more than 5000 cycles"):
         VirtualMachine.simulate_objects(program, max_cycles=5000)
-    assert time.perf_counter() - t0 < 20.0         # ~0.1 s here; the bound only has to tell "stops" from "runs away" on a busy machine
+    assert time.perf_counter() - t0 < 120.0        # ~1.4 s here (18 s seen once on a cold page cache); the bound only has to tell "stops" from "runs away"
     # the default limit (no argument) is finite as well: 2^24 cycles of the native machine
     assert VirtualMachine.DEFAULT_MAX_CYCLES == 1 << 24
     t0 = time.perf_counter()
     with pytest.raises(AssertionError, match=f"more than {1 << 24} cycles"):
         VirtualMachine.simulate(program)
-    assert time.perf_counter() - t0 < 60.0
+    assert time.perf_counter() - t0 < 300.0        # ~2 s here
     # a program that stays under the limit is not affected by it
     assert len(VirtualMachine.simulate(VirtualMachine.compile("+++[-]"), max_cycles=100)[0]) == 11
     # 0 and None mean the default (as in bfs_vm_trace_new), UNLIMITED means the reference's behaviour (no cap)
