@@ -265,6 +265,31 @@ def test_traces_full_of_values_next_to_zero_and_p_prove_and_verify(code, monkeyp
 
 
 @pytest.mark.gpu
+def test_stage_timing_changes_the_timing_not_the_proof(monkeypatch):
+    """BrainfuckStark.stage_timing = True synchronises the stream after every stage (bench.py's breakdown_ms); the default lets the
+    stages overlap.  Same proof bytes either way, and `timing` names the same stages"""
+    from stark_brainfuck_amd import brainfuck_stark, salted_merkle, table
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    program = VirtualMachine.compile("++>+++[<+>-]<.")
+    rt, inputs, outputs = VirtualMachine.run(program)
+    matrices = VirtualMachine.simulate(program, input_data=inputs)
+    proofs, stages = [], []
+    for staged in (False, True):
+        stream = Stream(b"stage-timing")
+        for mod in (brainfuck_stark, salted_merkle, table):
+            monkeypatch.setattr(mod, "urandom", stream)
+        stark = BrainfuckStark(rt, len(matrices[1]), program, inputs, outputs)
+        stark.stage_timing = staged
+        proofs.append(stark.prove(program, *matrices))
+        stages.append(list(stark.timing))
+        assert all(v >= 0 for v in stark.timing.values())
+    assert proofs[0] == proofs[1] and stages[0] == stages[1]
+    assert {"base_lde", "base_tree", "ext_tree", "combination", "fri"} <= set(stages[0])
+    assert BrainfuckStark.stage_timing is False
+
+
+@pytest.mark.gpu
 def test_prove_and_verify_with_other_protocol_parameters():
     """expansion factor 16 with 32 colinearity checks and 128 opened indices (the reference hard-codes 4 / 1 / 2 "for speed",
     brainfuck_stark.py:31-36; FRI caps the number of checks at the length of the last codeword, fri.py:69-70)"""

@@ -31,6 +31,19 @@ def test_library_exports_every_declared_symbol(sb):
     assert _lib.load().bfs_version() >= 1
 
 
+def test_route_measurement_report_before_any_measurement(sb):
+    """bfs_ntt_route_probe_info (diagnostics of bfs_gl_ntt's route measurement; bench.py prints it): no measurement yet -> zeros, route -1,
+    count 0; every pointer may be NULL"""
+    from stark_brainfuck_amd import _lib
+    lib = _lib.load()
+    us, route, probes = (ctypes.c_float * 4)(1, 2, 3, 4), ctypes.c_int(7), ctypes.c_ulonglong(9)
+    assert lib.bfs_ntt_route_probe_info(us, ctypes.byref(route), ctypes.byref(probes)) == 0
+    import torch
+    if not torch.cuda.is_available():
+        assert list(us) == [0.0] * 4 and route.value == -1 and probes.value == 0
+    assert lib.bfs_ntt_route_probe_info(None, None, None) == 0
+
+
 def test_no_gpu_means_loud_failure(sb):
     import torch
     if torch.cuda.is_available():
