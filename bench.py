@@ -343,6 +343,8 @@ def main():
                 static = {"file": "profiles/ntt_traffic.json", "taken_at": t.get("source_commit"), "kernel_sources_sha16": t.get("kernel_sources_sha16"),
                           "current_sources_sha16": kernel_sources_sha16(), "fields": ["traffic", "valu.wave_instructions_per_step"]}
                 static["stale"] = bool(static["kernel_sources_sha16"]) and static["kernel_sources_sha16"] != static["current_sources_sha16"]
+                if not static["stale"]:
+                    del static["current_sources_sha16"]          # (equal: said once)
                 instr = t["valu_wave_instructions_per_step"]
                 sclk = (sustained or {}).get("sclk_mhz_under_load")
                 valu = {"wave_instructions_per_step": instr, "instructions_per_element": instr * 64.0 / (n * cols),
@@ -365,7 +367,7 @@ def main():
                 vf, "sampled" if "issue_frac_at_sampled_sclk" in valu else "nominal", hbm_phys["frac_of_tile_copy_roof_5200"])
         line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                             "traffic": traffic, "wasted_traffic_ratio": (traffic / bytes_per_launch) if traffic else None,
-                            "kernel": "ntt_tile_kernel_split<4,4,0,4,MODE,NT> (pass 0: MODE 2 = transposing first pass; passes 1-2: MODE 0 = in place)",
+                            "kernel": "ntt_tile_kernel_split<4,4,0,4,MODE,NT> (MODE 2: transposing pass 0; MODE 0: in-place passes 1-2)",
                             "launches_per_step": npass, "avg_launch_ms": avg_launch_s * 1e3, "algorithmic_bytes_per_launch": bytes_per_launch,
                             "valu": valu, "hbm_physical": hbm_phys, "bound_actual": bound_actual, "static": static,
                             "route_probe": route_probe_info(lib)}
@@ -394,7 +396,7 @@ def main():
             line["stark_prove_2p22"]["roofline"] = stark_roofline(line["stark_prove_2p22"])
             if world == 1 and not args.no_concurrent:
                 line["stark_prove"]["concurrent"] = bench_stark_concurrent()
-            line["per_kernel_tables"] = "profiles/prover_valu.json (static: rocprofv3 --stats + --pmc of tools/prof_prover.sh; not part of this line)"
+            line["per_kernel_tables"] = "profiles/prover_valu.json (static; tools/prof_prover.sh)"
         if coop is not None:
             line["stark_prove_cooperative"] = coop
         if sustained is not None:
