@@ -118,6 +118,14 @@ int bfs_gl_scale(const uint64_t* d_in, uint64_t* d_out, uint64_t n, uint64_t str
  * bfs_gl_batch_inverse synchronises the stream and returns BFS_ERR_ZERO_IN_BATCH_INVERSE if any input is 0. */
 int bfs_gl_mul_pointwise(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_out, uint64_t n, void* stream);
 int bfs_gl_batch_inverse(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void* stream);
+/* The same two over the cubic extension F_p[X]/(X^3 - X + 1) (limb planes `*_stride` words apart): what fast_multiply's
+ * hadamard_product (ntt.py:74-76) and fast_coset_divide's batch_inverse (ntt.py:226-229) compute when their operands are
+ * ExtensionFieldElements -- the way Table.ldex reaches them (table.py:133-134 -> ntt.py:126-161 -> 82-98 -> 45-79), with
+ * ExtensionField.multiply / inverse (extension_field.py:71-83) per point.  In place (d_out == an input) is allowed.
+ * bfs_xfe_batch_inverse synchronises the stream; a zero element gives BFS_ERR_ZERO_IN_BATCH_INVERSE (its output is zero). */
+int bfs_xfe_mul_pointwise(const uint64_t* d_a, uint64_t a_stride, const uint64_t* d_b, uint64_t b_stride, uint64_t* d_out, uint64_t out_stride,
+                          uint64_t n, void* stream);
+int bfs_xfe_batch_inverse(const uint64_t* d_in, uint64_t in_stride, uint64_t* d_out, uint64_t out_stride, uint64_t n, void* stream);
 
 /* ---- proof stream / Fiat-Shamir (host) -------------------------------------------------------------------- */
 /*

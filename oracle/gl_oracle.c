@@ -206,6 +206,34 @@ void xo_pow(const uint64_t a[3], uint64_t e, uint64_t r[3]) {
     memcpy(r, acc, sizeof acc);
 }
 
+/* ntt.py:76 and ntt.py:177-188 on ExtensionFieldElement operands (the way table.py:133-134 reaches them through fast_interpolate):
+ * limb-major arrays c0[n] c1[n] c2[n].  xo_batch_inverse returns 5 if any element is zero (assert at ntt.py:178). */
+void xo_hadamard(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t x[3] = {a[i], a[n + i], a[2 * n + i]}, y[3] = {b[i], b[n + i], b[2 * n + i]}, r[3];
+        xo_mul(x, y, r);
+        out[i] = r[0]; out[n + i] = r[1]; out[2 * n + i] = r[2];
+    }
+}
+
+static void xo_get(const uint64_t* a, size_t n, size_t i, uint64_t r[3]) { r[0] = a[i]; r[1] = a[n + i]; r[2] = a[2 * n + i]; }
+static void xo_put(uint64_t* a, size_t n, size_t i, const uint64_t r[3]) { a[i] = r[0]; a[n + i] = r[1]; a[2 * n + i] = r[2]; }
+
+int xo_batch_inverse(const uint64_t* in, uint64_t* out, size_t n) {
+    if (n == 0) return 0;
+    uint64_t x[3], y[3], acc[3], t[3];
+    for (size_t i = 0; i < n; ++i) { xo_get(in, n, i, x); if (!(x[0] | x[1] | x[2])) return 5; }
+    xo_get(in, n, 0, x); xo_put(out, n, 0, x);
+    for (size_t i = 1; i < n; ++i) { xo_get(out, n, i - 1, x); xo_get(in, n, i, y); xo_mul(x, y, t); xo_put(out, n, i, t); }
+    xo_get(out, n, n - 1, x); xo_inv(x, acc);
+    for (size_t i = n - 1; i >= 1; --i) {
+        xo_get(out, n, i - 1, x); xo_mul(acc, x, t); xo_put(out, n, i, t);
+        xo_get(in, n, i, y); xo_mul(acc, y, t); memcpy(acc, t, sizeof t);
+    }
+    xo_put(out, n, 0, acc);
+    return 0;
+}
+
 /* ---- fri.py:127-128  one split-and-fold round over an SoA codeword (limb-major: c0[n], c1[n], c2[n]) ----
  * out[i] = 2^-1 * ((1 + alpha/(offset*omega^i)) * cw[i] + (1 - alpha/(offset*omega^i)) * cw[n/2+i]),  i < n/2.
  * offset and omega are base-field elements lifted into the extension (fri.py:94-95). */

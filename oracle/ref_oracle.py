@@ -74,6 +74,7 @@ def _load():
         ("xo_add", None, [vp, vp, vp]), ("xo_sub", None, [vp, vp, vp]), ("xo_mul", None, [vp, vp, vp]),
         ("xo_inv", None, [vp, vp]), ("xo_pow", None, [vp, u64, vp]),
         ("xo_fri_fold", None, [vp, sz, vp, u64, u64, vp]),
+        ("xo_hadamard", None, [vp, vp, vp, sz]), ("xo_batch_inverse", ctypes.c_int, [vp, vp, sz]),
         ("glo_felt", u64, [u64, u64]), ("glo_felt_fill", None, [u64, u64, vp, sz]),
     ]:
         fn = getattr(lib, name)
@@ -304,6 +305,90 @@ def xntt_soa(root, limbs_soa):
 
 def xintt_soa(root, limbs_soa):
     return np.stack([intt(root, limbs_soa[k]) for k in range(3)])
+
+
+def _xsoa(elems, n=None):
+    """list of 3-limb elements -> (3, n) limb-major array, zero padded to n"""
+    n = len(elems) if n is None else n
+    soa = np.zeros((3, n), dtype=np.uint64)
+    for i, e in enumerate(elems):
+        for k, v in enumerate(e):
+            soa[k, i] = int(v)
+    return soa
+
+
+def _xlist(soa, count=None):
+    count = soa.shape[1] if count is None else count
+    return [[int(soa[0, i]), int(soa[1, i]), int(soa[2, i])] for i in range(count)]
+
+
+def xhadamard(a_soa, b_soa):
+    a, b = np.ascontiguousarray(a_soa, dtype=np.uint64), np.ascontiguousarray(b_soa, dtype=np.uint64)
+    out = np.empty_like(a)
+    _lib.xo_hadamard(_ptr(a), _ptr(b), _ptr(out), a.shape[1]); return out
+
+
+def xbatch_inverse(soa):
+    """ntt.py:177-188 on extension elements, (3, n) in / out"""
+    a = np.ascontiguousarray(soa, dtype=np.uint64); out = np.empty_like(a)
+    _check(_lib.xo_batch_inverse(_ptr(a), _ptr(out), a.shape[1])); return out
+
+
+def _xdegree(c):
+    d = len(c) - 1
+    while d >= 0 and not any(int(v) for v in c[d]):
+        d -= 1
+    return d
+
+
+def _xschoolbook(l, r):
+    """univariate.py:40-51 over the extension field"""
+    if len(l) == 0 or len(r) == 0:
+        return []
+    out = [[0, 0, 0] for _ in range(len(l) + len(r) - 1)]
+    for i, a in enumerate(l):
+        for j, b in enumerate(r):
+            out[i + j] = xadd(out[i + j], xmul(a, b))
+    return out
+
+
+def xfast_multiply(lhs, rhs, root, order):
+    """ntt.py:45-79 on polynomials with ExtensionFieldElement coefficients (lists of 3 limbs) and a lifted root of unity
+    (table.py:133-134): three limb transforms per operand, the Hadamard product in the extension field, three inverse ones."""
+    assert power(root, order) == 1, "supplied root does not have supplied order"
+    assert power(root, order // 2) != 1, "supplied root is not primitive root of supplied order"
+    dl, dr = _xdegree(lhs), _xdegree(rhs)
+    if dl < 0 or dr < 0:
+        return []
+    degree = dl + dr
+    if degree < 8:
+        return _xschoolbook(list(lhs), list(rhs))          # ntt.py:59-60: lhs * rhs with the operands as given
+    while degree < order // 2:
+        root, order = mul(root, root), order // 2
+    a, b = _xsoa(lhs[:dl + 1], order), _xsoa(rhs[:dr + 1], order)
+    prod = xintt_soa(root, xhadamard(xntt_soa(root, a), xntt_soa(root, b)))
+    return _xlist(prod, degree + 1)
+
+
+def xfast_coset_divide(lhs, rhs, offset, root, order):
+    """ntt.py:191-235 on extension polynomials whose division is exact, degree >= 8 (below that the reference does a long division);
+    offset and root are base-field values (lifted in the reference)."""
+    assert power(root, order) == 1, "supplied root does not have supplied order"
+    assert power(root, order // 2) != 1, "supplied root is not primitive root of supplied order"
+    dl, dr = _xdegree(lhs), _xdegree(rhs)
+    assert dr >= 0, "cannot divide by zero polynomial"
+    if dl < 0:
+        return []
+    assert dr <= dl, "cannot divide by polynomial of larger degree"
+    degree = max(dl, dr)
+    assert degree >= 8, "oracle restates the transform branch only"
+    while degree < order // 2:
+        root, order = mul(root, root), order // 2
+    a = np.stack([fast_coset_evaluate(_xsoa(lhs[:dl + 1])[k], offset, root, order) for k in range(3)])
+    b = np.stack([fast_coset_evaluate(_xsoa(rhs[:dr + 1])[k], offset, root, order) for k in range(3)])
+    quo = xintt_soa(root, xhadamard(a, xbatch_inverse(b)))
+    quo = np.stack([scale(inv(offset), quo[k]) for k in range(3)])
+    return _xlist(quo, dl - dr + 1)
 
 
 def xevaluate_soa(coeff_soa, offset, omega, length):

@@ -52,6 +52,8 @@ _SIGNATURES = {
     "bfs_gl_scale": (ci, [vp, vp, u64, u64, u32, u64, vp]),
     "bfs_gl_mul_pointwise": (ci, [vp, vp, vp, u64, vp]),
     "bfs_gl_batch_inverse": (ci, [vp, vp, u64, vp]),
+    "bfs_xfe_mul_pointwise": (ci, [vp, u64, vp, u64, vp, u64, u64, vp]),
+    "bfs_xfe_batch_inverse": (ci, [vp, u64, vp, u64, u64, vp]),
     "bfs_ps_new": (vp, []),
     "bfs_ps_loads": (vp, [ctypes.c_char_p, sz]),
     "bfs_ps_free": (None, [vp]),

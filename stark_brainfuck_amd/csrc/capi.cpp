@@ -9,6 +9,8 @@ namespace bfs {
 int mul_pointwise_launch(const u64* a, const u64* b, u64* out, u64 n, hipStream_t stream);
 int batch_inverse_launch(const u64* in, u64* out, u64 n, hipStream_t stream);
 int scale_launch(const u64* in, u64* out, u64 n, u64 stride, u32 batch, u64 factor, hipStream_t stream);
+int xfe_mul_pointwise_launch(const u64* a, u64 a_stride, const u64* b, u64 b_stride, u64* out, u64 out_stride, u64 n, hipStream_t stream);
+int xfe_batch_inverse_launch(const u64* in, u64 in_stride, u64* out, u64 out_stride, u64 n, hipStream_t stream);
 int merkle_build_xfe_launch(const u64* d_limbs, u64 limb_stride, u64 n, u64* d_nodes, hipStream_t stream, u64* root_out = nullptr, u64 seq = 0);
 int merkle_build_bfe_launch(const u64* d_values, u64 n, u64* d_nodes, hipStream_t stream);
 int merkle_build_bytes_launch(const u64* d_data, const u64* d_offsets, const u32* d_lengths, u64 n, u64* d_nodes, hipStream_t stream);
@@ -84,6 +86,15 @@ int bfs_gl_mul_pointwise(const uint64_t* d_a, const uint64_t* d_b, uint64_t* d_o
 
 int bfs_gl_batch_inverse(const uint64_t* d_in, uint64_t* d_out, uint64_t n, void* stream) {
     return batch_inverse_launch(d_in, d_out, n, (hipStream_t)stream);
+}
+
+int bfs_xfe_mul_pointwise(const uint64_t* d_a, uint64_t a_stride, const uint64_t* d_b, uint64_t b_stride, uint64_t* d_out, uint64_t out_stride,
+                          uint64_t n, void* stream) {
+    return xfe_mul_pointwise_launch(d_a, a_stride, d_b, b_stride, d_out, out_stride, n, (hipStream_t)stream);
+}
+
+int bfs_xfe_batch_inverse(const uint64_t* d_in, uint64_t in_stride, uint64_t* d_out, uint64_t out_stride, uint64_t n, void* stream) {
+    return xfe_batch_inverse_launch(d_in, in_stride, d_out, out_stride, n, (hipStream_t)stream);
 }
 
 static int check_nodes(const void* d_nodes) {

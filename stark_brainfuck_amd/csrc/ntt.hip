@@ -515,6 +515,41 @@ __global__ void __launch_bounds__(BINV_T) gl_batch_inverse_kernel(const u64* in,
     }
 }
 
+// ---- the same two over the cubic extension (limb planes): the Hadamard product of fast_multiply (ntt.py:76) and the batch_inverse of
+// fast_coset_divide (ntt.py:226) when Table.ldex interpolates extension columns (table.py:133-134 -> ntt.py:126-161 -> 82-98 -> 45-79)
+__global__ void xfe_mul_pointwise_kernel(const u64* a, u64 a_stride, const u64* b, u64 b_stride, u64* out, u64 out_stride, u64 n) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const Xfe x{{a[i], a[a_stride + i], a[2 * a_stride + i]}}, y{{b[i], b[b_stride + i], b[2 * b_stride + i]}};
+        const Xfe r = xfe_mul(x, y);
+        out[i] = r.c[0]; out[out_stride + i] = r.c[1]; out[2 * out_stride + i] = r.c[2];
+    }
+}
+
+// 1 / a = adj(M_a) e_0 / det(M_a), M_a the matrix of multiplication by a = a0 + a1 X + a2 X^2 modulo X^3 - X + 1:
+//     M_a = [ a0  -a2      -a1     ]
+//           [ a1   a0+a2    a1-a2  ]
+//           [ a2   a1       a0+a2  ]
+// det(M_a) is the norm of a, an element of F_p that is zero only for a = 0: the norms go through the base field's batch inversion
+// (one field inversion per 2048 elements) and the cofactors are scaled by the result.
+__global__ void xfe_cofactors_kernel(const u64* in, u64 in_stride, u64* out, u64 out_stride, u64* norm, u64 n) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 a0 = in[i], a1 = in[in_stride + i], a2 = in[2 * in_stride + i];
+        const u64 s = gl_add(a0, a2), d = gl_sub(a1, a2);
+        const u64 c0 = gl_sub(gl_mul(s, s), gl_mul(d, a1));                      // (a0+a2)^2 - (a1-a2) a1
+        const u64 c1 = gl_sub(gl_mul(d, a2), gl_mul(a1, s));                      // (a1-a2) a2 - a1 (a0+a2)
+        const u64 c2 = gl_sub(gl_mul(a1, a1), gl_mul(s, a2));                     // a1^2 - (a0+a2) a2
+        norm[i] = gl_sub(gl_mul(a0, c0), gl_add(gl_mul(a2, c1), gl_mul(a1, c2))); // first row of M_a times the cofactors
+        out[i] = c0; out[out_stride + i] = c1; out[2 * out_stride + i] = c2;
+    }
+}
+
+__global__ void xfe_scale_by_kernel(u64* x, u64 stride, const u64* f, u64 n) {
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u64 s = f[i];
+        x[i] = gl_mul(x[i], s); x[stride + i] = gl_mul(x[stride + i], s); x[2 * stride + i] = gl_mul(x[2 * stride + i], s);
+    }
+}
+
 // power tables of an arbitrary factor, built on the device (bfs_gl_scale: no host tables, no copies, no synchronisation)
 __global__ void gl_power_tables_kernel(u64* lo, u64* hi, u32 lo_bits, u32 hi_bits, u64 factor) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -558,6 +593,29 @@ int batch_inverse_launch(const u64* in, u64* out, u64 n, hipStream_t stream) {
     if (e != hipSuccess) { set_error("batch inverse: %s", hipGetErrorString(e)); return BFS_ERR_HIP; }
     if (flag) { set_error("batch inverse does not work when input contains a zero"); return BFS_ERR_ZERO_IN_BATCH_INVERSE; }
     return BFS_OK;
+}
+
+int xfe_mul_pointwise_launch(const u64* a, u64 a_stride, const u64* b, u64 b_stride, u64* out, u64 out_stride, u64 n, hipStream_t stream) {
+    if (!n) return BFS_OK;
+    hipLaunchKernelGGL(xfe_mul_pointwise_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, a, a_stride, b, b_stride, out, out_stride, n);
+    BFS_HIP(hipGetLastError());
+    return BFS_OK;
+}
+
+int xfe_batch_inverse_launch(const u64* in, u64 in_stride, u64* out, u64 out_stride, u64 n, hipStream_t stream) {
+    if (!n) return BFS_OK;
+    void* w = nullptr;
+    BFS_TRY(workspace(8, n * sizeof(u64), stream, &w));
+    u64* norm = (u64*)w;
+    hipLaunchKernelGGL(xfe_cofactors_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, in, in_stride, out, out_stride, norm, n);
+    BFS_HIP(hipGetLastError());
+    // a zero element has norm zero: the base field's launch reports it (BFS_ERR_ZERO_IN_BATCH_INVERSE, ntt.py:178-179) and leaves
+    // inverse(0) = 0 in its place, so the output of a zero is zero as in extension_field.py:80-83 (xgcd of the zero polynomial)
+    const int rc = batch_inverse_launch(norm, norm, n, stream);
+    if (rc != BFS_OK && rc != BFS_ERR_ZERO_IN_BATCH_INVERSE) return rc;
+    hipLaunchKernelGGL(xfe_scale_by_kernel, dim3(grid_for(n, 256)), dim3(256), 0, stream, out, out_stride, norm, n);
+    BFS_HIP(hipGetLastError());
+    return rc;
 }
 
 int scale_launch(const u64* in, u64* out, u64 n, u64 stride, u32 batch, u64 factor, hipStream_t stream) {

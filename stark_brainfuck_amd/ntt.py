@@ -97,11 +97,39 @@ def _check_root(primitive_root, root_order):
     return w
 
 
-def _coeff_array(coeffs, order, field):
-    """zero-padded device array of the first len(coeffs) coefficients (list of elements)."""
-    if coeffs and isinstance(coeffs[0], ExtensionFieldElement):
+def _is_xlist(coeffs):
+    return bool(coeffs) and isinstance(coeffs[0], ExtensionFieldElement)
+
+
+def _coeff_array(coeffs, as_x=None):
+    """device array of a coefficient list: an XArray when the coefficients are ExtensionFieldElements or `as_x` asks for the
+    lifted form (a base polynomial next to an extension one: extension_field.py:113-116), else a BaseArray."""
+    if as_x is None:
+        as_x = _is_xlist(coeffs)
+    if not as_x:
+        return BaseArray.from_elements(coeffs)
+    if _is_xlist(coeffs):
         return XArray.from_elements(coeffs)
-    return BaseArray.from_elements(coeffs)
+    soa = np.zeros((3, len(coeffs)), dtype=np.uint64)
+    soa[0] = np.fromiter((e.value for e in coeffs), dtype=np.uint64, count=len(coeffs))
+    return XArray.from_numpy(soa)
+
+
+def _hadamard(lc, rc, order):
+    """lc <- lc * rc point by point (ntt.py:76), base field or cubic extension."""
+    lib = _lib.load()
+    if isinstance(lc, XArray):
+        _lib.check(lib.bfs_xfe_mul_pointwise(lc.ptr, lc.stride, rc.ptr, rc.stride, lc.ptr, lc.stride, order, current_stream()))
+    else:
+        _lib.check(lib.bfs_gl_mul_pointwise(lc.ptr, rc.ptr, lc.ptr, order, current_stream()))
+
+
+def _inverse_in_place(arr, count):
+    lib = _lib.load()
+    if isinstance(arr, XArray):
+        _lib.check(lib.bfs_xfe_batch_inverse(arr.ptr, arr.stride, arr.ptr, arr.stride, count, current_stream()))
+    else:
+        _lib.check(lib.bfs_gl_batch_inverse(arr.ptr, arr.ptr, count, current_stream()))
 
 
 def fast_multiply(lhs, rhs, primitive_root, root_order):
@@ -111,17 +139,16 @@ def fast_multiply(lhs, rhs, primitive_root, root_order):
     degree = lhs.degree() + rhs.degree()
     if degree < 8:
         return lhs * rhs                                    # ntt.py:59-60
+    lib = _lib.load()
     order = root_order
     while degree < order // 2:
-        w, order = _lib.load().bfs_gl_mul(w, w), order // 2
-    lib = _lib.load()
-    la = _coeff_array(lhs.coefficients[:lhs.degree() + 1], order, None)
-    ra = _coeff_array(rhs.coefficients[:rhs.degree() + 1], order, None)
-    if isinstance(la, XArray) or isinstance(ra, XArray):
-        raise NotImplementedError("fast_multiply over the extension field is not on the hot path")
+        w, order = lib.bfs_gl_mul(w, w), order // 2
+    lco, rco = lhs.coefficients[:lhs.degree() + 1], rhs.coefficients[:rhs.degree() + 1]
+    as_x = _is_xlist(lco) or _is_xlist(rco)                 # extension operands: three limb planes per transform (table.py:133-134)
+    la, ra = _coeff_array(lco, as_x), _coeff_array(rco, as_x)
     lc = _transform(la, la.n, order, w, 1, 1)
     rc = _transform(ra, ra.n, order, w, 1, 1)
-    _lib.check(lib.bfs_gl_mul_pointwise(lc.ptr, rc.ptr, lc.ptr, order, current_stream()))
+    _hadamard(lc, rc, order)
     prod = _transform(lc, order, order, lib.bfs_gl_inv(w), 1, lib.bfs_gl_inv(order))
     return Polynomial(prod.to_elements()[:degree + 1])
 
@@ -131,7 +158,7 @@ def fast_coset_evaluate(polynomial, offset, generator, order):
     assert len(coeffs) <= order, "polynomial has more coefficients than the evaluation domain has points"
     if not coeffs:
         return [offset.field.zero() for _ in range(order)]  # ntt of `order` zeros (ntt.py:166-167)
-    src = _coeff_array(coeffs, order, None)
+    src = _coeff_array(coeffs)
     out = _transform(src, len(coeffs), order, _base_value(generator), _base_value(offset), 1)
     return out.to_elements()
 
@@ -162,15 +189,16 @@ def batch_inverse(array):
         out = BaseArray.empty(array.n, array.field, array.batch)
         _lib.check(_lib.load().bfs_gl_batch_inverse(array.ptr, out.ptr, array.n * array.batch, current_stream()))
         return out
+    if isinstance(array, XArray):
+        out = XArray.empty(array.n, array.field)
+        _lib.check(_lib.load().bfs_xfe_batch_inverse(array.ptr, array.stride, out.ptr, out.stride, array.n, current_stream()))
+        return out
     assert all(not a.is_zero() for a in array), "batch inverse does not work when input contains a zero"
     if not array:
         return []
-    if isinstance(array[0], ExtensionFieldElement):
-        return [a.inverse() for a in array]                 # not on the hot path
-    src = BaseArray.from_elements(array)
-    out = BaseArray.empty(src.n, src.field)
-    _lib.check(_lib.load().bfs_gl_batch_inverse(src.ptr, out.ptr, src.n, current_stream()))
-    return out.to_elements()
+    src = _coeff_array(array)
+    _inverse_in_place(src, src.n)
+    return src.to_elements()
 
 
 def fast_coset_divide(lhs, rhs, offset, primitive_root, root_order):
@@ -188,14 +216,18 @@ def fast_coset_divide(lhs, rhs, offset, primitive_root, root_order):
     while degree < order // 2:
         w, order = lib.bfs_gl_mul(w, w), order // 2
     off = _base_value(offset)
-    la = BaseArray.from_elements(lhs.coefficients[:lhs.degree() + 1])
-    ra = BaseArray.from_elements(rhs.coefficients[:rhs.degree() + 1])
+    lco, rco = lhs.coefficients[:lhs.degree() + 1], rhs.coefficients[:rhs.degree() + 1]
+    as_x = _is_xlist(lco) or _is_xlist(rco)
+    la, ra = _coeff_array(lco, as_x), _coeff_array(rco, as_x)
     lc = _transform(la, la.n, order, w, off, 1)
     rc = _transform(ra, ra.n, order, w, off, 1)
-    _lib.check(lib.bfs_gl_batch_inverse(rc.ptr, rc.ptr, order, current_stream()))
-    _lib.check(lib.bfs_gl_mul_pointwise(lc.ptr, rc.ptr, lc.ptr, order, current_stream()))
+    _inverse_in_place(rc, order)
+    _hadamard(lc, rc, order)
     quo = _transform(lc, order, order, lib.bfs_gl_inv(w), 1, lib.bfs_gl_inv(order))
-    _lib.check(lib.bfs_gl_scale(quo.ptr, quo.ptr, order, order, 1, lib.bfs_gl_inv(off), current_stream()))
+    if as_x:
+        _lib.check(lib.bfs_gl_scale(quo.ptr, quo.ptr, order, quo.stride, 3, lib.bfs_gl_inv(off), current_stream()))
+    else:
+        _lib.check(lib.bfs_gl_scale(quo.ptr, quo.ptr, order, order, 1, lib.bfs_gl_inv(off), current_stream()))
     return Polynomial(quo.to_elements()[:lhs.degree() - rhs.degree() + 1])
 
 

@@ -273,6 +273,61 @@ def gen_poly2():
     dump("poly2.json", out)
 
 
+def gen_polyx():
+    """The fast_* family over the cubic extension (ntt.py:45-79, 82-161, 177-235 on ExtensionFieldElement operands with a lifted
+    root), the way Table.ldex reaches it (table.py:112-149: interpolate_columns lifts omicron powers, one odd power of omega and omega
+    itself into the extension field and calls fast_interpolate on extension values)."""
+    out = {}
+    def XP(seed, n, limbs=3):
+        return [[felt(seed, 3 * i + k) if k < limbs else 0 for k in range(3)] for i in range(n)]
+    cases = []
+    # (root order, deg lhs, deg rhs, limbs lhs, limbs rhs): degree sums 7 (schoolbook, ntt.py:59-60), 8, 63 (no halving at order 64),
+    # 64..126 at order 128, halving of a larger order down to the product's size, operands that are lifted base polynomials, zero
+    for (n, dl, dr, ll, lr) in [(64, -1, 5, 3, 3), (64, 3, 4, 3, 3), (64, 4, 4, 3, 3), (64, 0, 8, 3, 3), (64, 31, 32, 3, 3), (64, 40, 23, 3, 1),
+                                (128, 31, 32, 3, 3), (128, 63, 63, 3, 3), (128, 64, 1, 2, 3), (128, 9, 7, 1, 1), (1024, 20, 13, 3, 3)]:
+        w = XF.lift(BF.primitive_nth_root(n))
+        lc, rc = XP(SEED + 1100 + dl, dl + 1, ll), XP(SEED + 1200 + dr, dr + 1, lr)
+        if (dl, dr) == (40, 23):
+            lc = lc + [[0, 0, 0], [0, 0, 0]]          # trailing zero coefficients must not change the product
+        lhs, rhs = Polynomial([X(v) for v in lc]), Polynomial([X(v) for v in rc])
+        prod = refntt.fast_multiply(lhs, rhs, w, n)
+        rec = {"order": n, "lhs": lc, "rhs": rc, "product": [xl3(c) for c in prod.coefficients]}
+        if dl >= 0 and dr >= 0:
+            q = refntt.fast_coset_divide(prod, lhs, XF.lift(BF.generator()), w, n)
+            rec["quotient_by_lhs"] = [xl3(c) for c in q.coefficients]
+        cases.append(rec)
+    out["fast_multiply"] = cases
+    arr = XP(SEED + 1300, 37) + [[5, 0, 0], [0, 9, 0], [0, 0, P - 1], [P - 1, P - 1, P - 1], [1, 0, 0]]
+    out["batch_inverse"] = {"in": arr, "out": [xl3(e) for e in refntt.batch_inverse([X(v) for v in arr])],
+                            "zero_message": assertion_message(lambda: refntt.batch_inverse([X([1, 2, 3]), X([])]))}
+    # the domain shape of table.py:120-124: omicron^i for i < height, then omega^(2 i + 1) for the randomizers
+    interp = []
+    for (N, height, nrand) in [(64, 8, 1), (128, 16, 1), (256, 32, 1), (64, 4, 2), (128, 1, 1)]:
+        omega = BF.primitive_nth_root(N)
+        omicron = BF.primitive_nth_root(height) if height > 1 else BF.one()
+        dom = [XF.lift(omicron ^ i) for i in range(height)] + [XF.lift(omega ^ (2 * i + 1)) for i in range(nrand)]
+        vals = XP(SEED + 1400 + N + height, height + nrand)
+        w = XF.lift(omega)
+        z = refntt.fast_zerofier(dom, w, N)
+        poly = refntt.fast_interpolate(dom, [X(v) for v in vals], w, N)
+        back = refntt.fast_evaluate(poly, dom, w, N)
+        interp.append({"N": N, "height": height, "num_randomizers": nrand, "domain": [xl3(d) for d in dom], "values": vals,
+                       "zerofier": [xl3(c) for c in z.coefficients], "interpolant": [xl3(c) for c in poly.coefficients],
+                       "interpolant_degree": poly.degree(), "evaluated_back": [xl3(e) for e in back]})
+    out["interpolate_columns"] = interp
+    # generic extension-field points (not lifted): the subproduct tree over a domain with all three limbs in use
+    N = 64
+    w = XF.lift(BF.primitive_nth_root(N))
+    dom, vals = XP(SEED + 1500, 19), XP(SEED + 1600, 19)
+    poly = refntt.fast_interpolate([X(v) for v in dom], [X(v) for v in vals], w, N)
+    pc = XP(SEED + 1700, 25)
+    ev = refntt.fast_evaluate(Polynomial([X(v) for v in pc]), [X(v) for v in dom], w, N)
+    out["generic_points"] = {"N": N, "domain": dom, "values": vals, "interpolant": [xl3(c) for c in poly.coefficients],
+                             "zerofier": [xl3(c) for c in refntt.fast_zerofier([X(v) for v in dom], w, N).coefficients],
+                             "poly": pc, "poly_evaluated": [xl3(e) for e in ev]}
+    dump("polyx.json", out)
+
+
 def leaf_record(obj, limbs):
     bs = pickle.dumps(obj)
     return {"limbs": limbs, "pickle": bs.hex(), "blake2b": hashlib.blake2b(bs).hexdigest()}
@@ -497,7 +552,7 @@ def gen_fri20():
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "small"
     if what == "small":
-        gen_field(); gen_ntt(); gen_poly(); gen_poly2(); gen_pickle(); gen_merkle(); gen_fri()
+        gen_field(); gen_ntt(); gen_poly(); gen_poly2(); gen_polyx(); gen_pickle(); gen_merkle(); gen_fri()
     else:
         {"field": gen_field, "ntt": gen_ntt, "poly": gen_poly, "pickle": gen_pickle, "merkle": gen_merkle,
-         "fri": gen_fri, "ntt20": gen_ntt20, "fri20": gen_fri20, "poly2": gen_poly2}[what]()
+         "fri": gen_fri, "ntt20": gen_ntt20, "fri20": gen_fri20, "poly2": gen_poly2, "polyx": gen_polyx}[what]()

@@ -343,6 +343,140 @@ def test_subproduct_tree_goldens_and_reference_test_interpolate(sb):
         assert sb.fast_evaluate(poly, domain, w, n)[:N] == values
 
 
+def _xpoly(sb, XF, limbs_list):
+    return sb.Polynomial([XF.from_limbs(list(l)) for l in limbs_list])
+
+
+def _xl3(e):
+    c = [x.value for x in e.polynomial.coefficients]
+    return c + [0] * (3 - len(c))
+
+
+def test_fast_family_over_the_extension_field_goldens(sb):
+    """fast_multiply / fast_coset_divide / batch_inverse / fast_zerofier / fast_evaluate / fast_interpolate on ExtensionFieldElement
+    operands with a lifted root (ntt.py:45-79, 82-161, 177-235 as Table.ldex calls them, table.py:112-149) against the reference's
+    own outputs (tests/golden/polyx.json)."""
+    g = load_golden("polyx.json")
+    XF = sb.ExtensionField.main()
+    BF = XF._base()
+    for c in g["fast_multiply"]:
+        w = XF.lift(BF.primitive_nth_root(c["order"]))
+        lhs, rhs = _xpoly(sb, XF, c["lhs"]), _xpoly(sb, XF, c["rhs"])
+        prod = sb.fast_multiply(lhs, rhs, w, c["order"])
+        assert [_xl3(x) for x in prod.coefficients] == c["product"]
+        if "quotient_by_lhs" in c:
+            q = sb.fast_coset_divide(prod, lhs, XF.lift(BF.generator()), w, c["order"])
+            assert [_xl3(x) for x in q.coefficients] == c["quotient_by_lhs"]
+    b = g["batch_inverse"]
+    assert [_xl3(x) for x in sb.batch_inverse([XF.from_limbs(l) for l in b["in"]])] == b["out"]
+    with pytest.raises(AssertionError) as e:
+        sb.batch_inverse([XF.from_limbs([1, 2, 3]), XF.zero()])
+    assert str(e.value) == b["zero_message"]
+    for c in g["interpolate_columns"] + [dict(g["generic_points"], height=None)]:
+        N = c["N"]
+        w = XF.lift(BF.primitive_nth_root(N))
+        D = [XF.from_limbs(l) for l in c["domain"]]
+        assert [_xl3(x) for x in sb.fast_zerofier(D, w, N).coefficients] == c["zerofier"]
+        poly = sb.fast_interpolate(D, [XF.from_limbs(l) for l in c["values"]], w, N)
+        assert [_xl3(x) for x in poly.coefficients][:len(c["interpolant"])] == c["interpolant"]
+        assert all(x.is_zero() for x in poly.coefficients[len(c["interpolant"]):])
+        if c["height"] is not None:
+            assert poly.degree() == c["interpolant_degree"]
+            assert [_xl3(x) for x in sb.fast_evaluate(poly, D, w, N)] == c["evaluated_back"] == c["values"]
+        else:
+            assert [_xl3(x) for x in sb.fast_evaluate(_xpoly(sb, XF, c["poly"]), D, w, N)] == c["poly_evaluated"]
+
+
+def test_interpolate_columns_shape_through_the_reference_call(sb):
+    """Table.interpolate_columns of the reference (table.py:112-136) written out against this package: omicron powers plus one odd
+    power of omega, lifted; the interpolant must agree with the rank-one form the prover uses (bfs_poly_randomize)."""
+    XF = sb.ExtensionField.main()
+    BF = XF._base()
+    rng = np.random.default_rng(7)
+    for (N, height) in [(256, 32), (1024, 64), (4096, 256)]:
+        omega, omicron = BF.primitive_nth_root(N), BF.primitive_nth_root(height)
+        domain = [XF.lift(omicron ^ i) for i in range(height)] + [XF.lift(omega)]
+        values = [XF.from_limbs([int(v) for v in rng.integers(0, P, 3, dtype=np.uint64)]) for _ in range(height + 1)]
+        poly = sb.fast_interpolate(domain, values, XF.lift(omega), N)
+        assert poly.degree() <= height
+        assert all(poly.evaluate(d) == v for d, v in zip(domain, values))
+        # f = f0 + c (X^h - 1) with f0 = intt of the trace values over <omicron>
+        f0 = sb.intt(XF.lift(omicron), values[:height])
+        x = XF.lift(omega)
+        c = (values[height] - sb.Polynomial(f0).evaluate(x)) / ((x ^ height) - XF.one())
+        expect = list(f0) + [XF.zero()]
+        expect[0] = expect[0] - c
+        expect[height] = expect[height] + c
+        assert sb.Polynomial(expect) == poly
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 255, 256, 2047, 2048, 2049, 100003, (1 << 20) + 5])
+def test_extension_field_pointwise_through_the_c_abi(sb, oracle, n):
+    """bfs_xfe_mul_pointwise / bfs_xfe_batch_inverse against the oracle: ragged sizes, strided planes, in place, operands next to 0 and p"""
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.device import DeviceBuffer, synchronize
+    lib = _lib.load()
+    stride = n + 5
+    rng = np.random.default_rng(n)
+    a = np.zeros((3, stride), dtype=np.uint64)
+    b = np.zeros((3, stride), dtype=np.uint64)
+    for k in range(3):
+        a[k, :n] = edge_values(n, 3 * n + k) if n % 2 else oracle.felt_array(SEED + k, n, n)
+        b[k, :n] = edge_values(n, 5 * n + k)
+    b[0, :n] = np.where((b[0, :n] | b[1, :n] | b[2, :n]) == 0, np.uint64(1), b[0, :n])      # no zero elements
+    da, db, dout = DeviceBuffer.from_numpy(a.reshape(-1)), DeviceBuffer.from_numpy(b.reshape(-1)), DeviceBuffer(3 * n)
+    _lib.check(lib.bfs_xfe_mul_pointwise(da.ptr, stride, db.ptr, stride, dout.ptr, n, n, 0))
+    synchronize(0)
+    want = oracle.xhadamard(a[:, :n], b[:, :n])
+    assert (dout.to_numpy(3 * n).reshape(3, n) == want).all()
+    _lib.check(lib.bfs_xfe_batch_inverse(db.ptr, stride, dout.ptr, n, n, 0))
+    inv = dout.to_numpy(3 * n).reshape(3, n)
+    if n <= 3000:
+        assert (inv == oracle.xbatch_inverse(b[:, :n])).all()
+    one = oracle.xhadamard(inv, b[:, :n])
+    assert (one[0] == 1).all() and not one[1:].any()
+    # in place, strided on both sides
+    _lib.check(lib.bfs_xfe_batch_inverse(db.ptr, stride, db.ptr, stride, n, 0))
+    _lib.check(lib.bfs_xfe_mul_pointwise(da.ptr, stride, db.ptr, stride, da.ptr, stride, n, 0))
+    synchronize(0)
+    got = da.to_numpy(3 * stride).reshape(3, stride)
+    assert (got[:, :n] == oracle.xhadamard(a[:, :n], inv)).all() and not got[:, n:].any()
+    # a zero element: the reference's assert (ntt.py:178-179), and inverse(0) = 0 in its place
+    z = b[:, :n].copy()
+    z[:, n // 2] = 0
+    dz = DeviceBuffer.from_numpy(z.reshape(-1))
+    assert lib.bfs_xfe_batch_inverse(dz.ptr, n, dz.ptr, n, n, 0) == 5
+    assert "zero" in lib.bfs_last_error().decode()
+    back = dz.to_numpy(3 * n).reshape(3, n)
+    assert not back[:, n // 2].any()
+    keep = np.arange(n) != n // 2
+    assert (back[:, keep] == inv[:, keep]).all()
+
+
+def test_fast_multiply_over_the_extension_field_vs_oracle(sb, oracle):
+    """sizes the goldens do not reach: every halving of the root order, products up to degree 2^13"""
+    XF = sb.ExtensionField.main()
+    BF = XF._base()
+    rng = np.random.default_rng(11)
+    for (order, dl, dr) in [(1 << 14, 4000, 4100), (1 << 14, 100, 28), (1 << 10, 511, 512), (1 << 12, 3000, 9)]:
+        lc = [[int(v) for v in rng.integers(0, P, 3, dtype=np.uint64)] for _ in range(dl + 1)]
+        rc = [[int(v) for v in rng.integers(0, P, 3, dtype=np.uint64)] for _ in range(dr + 1)]
+        w = oracle.primitive_nth_root(order)
+        prod = sb.fast_multiply(_xpoly(sb, XF, lc), _xpoly(sb, XF, rc), XF.lift(BF(w)), order)
+        want = oracle.xfast_multiply(lc, rc, w, order)
+        assert [_xl3(x) for x in prod.coefficients] == want
+        q = sb.fast_coset_divide(prod, _xpoly(sb, XF, rc), XF.lift(BF.generator()), XF.lift(BF(w)), order)
+        assert [_xl3(x) for x in q.coefficients] == lc == oracle.xfast_coset_divide(want, rc, 7, w, order)
+    # a base-field polynomial next to an extension one (lifted on the way in)
+    F = sb.BaseField.main()
+    lhs = sb.Polynomial([F(int(v)) for v in rng.integers(0, P, 20, dtype=np.uint64)])
+    rhs = _xpoly(sb, XF, [[int(v) for v in rng.integers(0, P, 3, dtype=np.uint64)] for _ in range(30)])
+    w = oracle.primitive_nth_root(64)
+    prod = sb.fast_multiply(rhs, lhs, XF.lift(BF(w)), 64)
+    want = oracle.xfast_multiply([_xl3(x) for x in rhs.coefficients], [[x.value, 0, 0] for x in lhs.coefficients], w, 64)
+    assert [_xl3(x) for x in prod.coefficients] == want
+
+
 def test_reference_test_coset_evaluate_and_batch_inverse(sb):
     F = sb.BaseField.main()
     n = 512

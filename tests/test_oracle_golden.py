@@ -130,6 +130,28 @@ def test_fast_multiply_and_coset(oracle):
     assert oracle.xevaluate_soa(xs, d["offset"], d["omega"], 64).T.tolist() == d["xevaluate"]
 
 
+def test_fast_family_over_the_extension_field(oracle):
+    """ntt.py:45-79, 177-235 on ExtensionFieldElement operands with a lifted root -- the call Table.ldex makes (table.py:133-134)"""
+    g = load_golden("polyx.json")
+    for c in g["fast_multiply"]:
+        w = oracle.primitive_nth_root(c["order"])
+        assert oracle.xfast_multiply(c["lhs"], c["rhs"], w, c["order"]) == c["product"]
+        if "quotient_by_lhs" in c and oracle._xdegree(c["product"]) >= 8:
+            assert oracle.xfast_coset_divide(c["product"], c["lhs"], 7, w, c["order"]) == c["quotient_by_lhs"]
+    b = g["batch_inverse"]
+    assert oracle._xlist(oracle.xbatch_inverse(oracle._xsoa(b["in"]))) == b["out"]
+    assert all(oracle.xmul(x, y) == [1, 0, 0] for x, y in zip(b["in"], b["out"]))
+    with pytest.raises(AssertionError, match="zero"):
+        oracle.xbatch_inverse(oracle._xsoa([[1, 2, 3], [0, 0, 0]]))
+    # the interpolants the reference's subproduct tree returns take the given values on the domain of table.py:120-124
+    for c in g["interpolate_columns"]:
+        for x, v in zip(c["domain"], c["values"]):
+            acc = [0, 0, 0]
+            for coeff in reversed(c["interpolant"]):
+                acc = oracle.xadd(oracle.xmul(acc, x), coeff)
+            assert acc == v
+
+
 def test_leaf_pickles(oracle):
     g = load_golden("pickle.json")
     for r in g["bfe_leaves"]:
