@@ -56,6 +56,38 @@ def felt_array(seed, start, n):
     return z % np.uint64(P)
 
 
+def edge_array(seed, n):
+    """values next to 0, next to p and around 2^32, one in eight uniform: what trace columns look like and what drives the unreduced
+    butterfly sums of the kernels over p (random operands do that once in 2^32: round 4's first lazy-sum rule passed every
+    random-data test).  h = splitmix64(seed + i): kind = h & 7, small = (h >> 3) mod 6; kind 0-2: small, 3-5: p - 1 - small,
+    6: h mod p, 7: 2^32 - small.  The post-run guard and tests/golden/gen_ntt24_oracle.py share this recipe."""
+    with np.errstate(over="ignore"):
+        x = (np.arange(0, n, dtype=np.uint64) + np.uint64(seed & 0xFFFFFFFFFFFFFFFF)) + np.uint64(0x9E3779B97F4A7C15)
+        z = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        h = z ^ (z >> np.uint64(31))
+    kind = h & np.uint64(7)
+    small = (h >> np.uint64(3)) % np.uint64(6)
+    v = np.where(kind < 3, small, np.uint64(P - 1) - small)
+    v = np.where(kind == 6, h % np.uint64(P), v)
+    v = np.where(kind == 7, np.uint64(1 << 32) - small, v)
+    return np.ascontiguousarray(v, dtype=np.uint64)
+
+
+def edge_columns(n, count=8):
+    """the `count` columns of the guard's edge-value transform: edge_array with seeds 0xED6E + c, except column 1 = all p - 1 and
+    column 2 = 1, p - 1, 1, p - 1, ... (sums of exactly p and 2p - 2 at the first butterfly level)"""
+    cols = []
+    for c in range(count):
+        if c == 1:
+            cols.append(np.full(n, P - 1, dtype=np.uint64))
+        elif c == 2:
+            cols.append(np.where(np.arange(n) % 2 == 0, np.uint64(1), np.uint64(P - 1)).astype(np.uint64))
+        else:
+            cols.append(edge_array(0xED6E + c, n))
+    return cols
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +114,7 @@ def main():
                          "the main measurement -- see guarded_cooperative -- unless --cooperative already ran it in-job)")
     ap.add_argument("--coop-leg", action="store_true", help=argparse.SUPPRESS)     # internal: the separate job of guarded_cooperative
     ap.add_argument("--stark-worker", type=float, default=0.0, help=argparse.SUPPRESS)   # internal: one prover PROCESS of bench_stark_concurrent
+    ap.add_argument("--no-tune", action="store_true", help="do not call bfs_ntt_tune on the step's buffer pair (every step takes the direct route)")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run round-trip check and root gather (PMC collection runs)")
     args = ap.parse_args()
 
@@ -166,6 +199,15 @@ def main():
     def step():
         _lib.check(lib.bfs_gl_ntt(d_in.ptr, n, n, d_out.ptr, n, log_n, cols, root, 1, 1, stream))
 
+    # The step repeats one (input, output) pair of buffers: the explicit, documented tuning call of the library (bfs_ntt_tune: ~63 ms,
+    # untimed, before everything) chooses where the first pass writes.  bfs_gl_ntt itself never measures anything (round 5); the same
+    # K steps on the DIRECT route are timed after the headline region and printed beside it (ms_per_step_direct_route).
+    tuned_route = None
+    if not args.no_tune:
+        r = ctypes.c_int(-1)
+        _lib.check(lib.bfs_ntt_tune(d_in.ptr, n, d_out.ptr, n, log_n, cols, root, stream, ctypes.byref(r)))
+        tuned_route = r.value
+
     def sync_all():
         _lib.check(lib.bfs_stream_synchronize(stream))
         torch.cuda.synchronize()
@@ -235,6 +277,26 @@ def main():
     else:
         kern = kern_ms.value
 
+    # ---- the same K steps on the direct route (what a caller who never calls bfs_ntt_tune gets): remembered pairs forgotten, W warm-up
+    # steps, K timed ones between HIP events
+    direct_ms = None
+    if tuned_route is not None:
+        _lib.check(lib.bfs_ntt_route_forget(None, None))
+        for _ in range(max(args.warmup, 1)):
+            step()
+        lib.bfs_event_record(ev0, stream)
+        for _ in range(args.steps):
+            step()
+        lib.bfs_event_record(ev1, stream)
+        _lib.check(lib.bfs_stream_synchronize(stream))
+        dm = ctypes.c_float()
+        _lib.check(lib.bfs_event_elapsed_ms(ev0, ev1, ctypes.byref(dm)))
+        direct_ms = dm.value / args.steps
+        if dist is not None:
+            t = torch.tensor([direct_ms], dtype=torch.float64, device=coll_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            direct_ms = float(t[0])
+
     # ---- after the timed region: correctness guard + the one collective of the design (roots of all columns)
     from stark_brainfuck_amd.arrays import BaseArray
     from stark_brainfuck_amd.merkle import Merkle
@@ -265,8 +327,22 @@ def main():
             tree = Merkle(BaseArray(DeviceView(d_out, j * n, n), n))       # leaves hashed where the transform left them
             local_roots[c] = tree.root()
             del tree, col
+        # (4) rank 0: the same call shape (8 columns of 2^24, same buffers, same route) on EDGE values -- operands next to 0, p and 2^32,
+        # which random columns never contain and which the kernels' unreduced butterfly sums must survive -- against the oracle's known
+        # answers for them (tests/golden/ntt24_oracle.json: edge_columns, made by gen_ntt24_oracle.py with edge_columns() above)
+        edge_checked = 0
+        if rank == 0 and known is not None and g.get("edge_columns") and cols == len(g["edge_columns"]):
+            _lib.check(lib.bfs_memcpy_h2d(d_in.ptr, np.concatenate(edge_columns(n, cols)).ctypes.data, 8 * n * cols, stream))
+            step()
+            for j in range(cols):
+                col = d_out.to_numpy(n, offset=j * n)
+                sha = hashlib.sha256(np.ascontiguousarray(col, dtype="<u8").tobytes()).hexdigest()
+                assert sha == g["edge_columns"][j]["output_sha256"], "edge-value column %d differs from the oracle's known answer" % j
+                edge_checked += 1
+                del col
+            _lib.check(lib.bfs_memcpy_h2d(d_in.ptr, host_in.ctypes.data, 8 * n * cols, stream))
         guard = {"columns_round_tripped": cols, "columns_sha256_vs_oracle_known_answers": checked,
-                 "merkle_leaves_per_column": n}
+                 "edge_value_columns_vs_oracle_known_answers": edge_checked, "merkle_leaves_per_column": n}
     world_roots = None
     if not args.no_check:
         # the one collective of the design: all-gather of the per-column roots (RCCL over xGMI when world > 1)
@@ -297,6 +373,8 @@ def main():
         "rccl_ranks_seen": ranks_seen, "collective_backend": (backend if dist is not None else None), "rank_devices": rank_devices,
         "algorithmic_GBps": 16.0 * elems / elapsed / 1e9,
         "clock_spinup": {"ms": args.spinup_ms, "untimed_steps": spin_steps},
+        "ms_per_step_direct_route": direct_ms,
+        "ntt_tune": None if tuned_route is None else ("direct" if tuned_route < 0 else "buffer%d" % tuned_route),
     }
     # FRI replicas: one independent Fri.prove per GPU at the same time (a single FRI instance is sequential in its rounds
     # and is not sharded); every rank reports, rank 0 prints the slowest and the aggregate rate
@@ -414,8 +492,8 @@ def main():
 
 
 def route_probe_info(lib):
-    """what bfs_gl_ntt's route measurement read in this process (ntt.hip: ntt_route; taken inside the untimed spin-up, the third time the
-    step's buffer pair was seen): passes 0 + 1 straight into the output and through each of three library buffers, and which it kept --
+    """what bfs_ntt_tune read in this process (ntt.hip: ntt_measure_route; called once on the step's buffer pair before anything is
+    timed): passes 0 + 1 straight into the output and through each of three library buffers, and which it kept --
     when all four read alike the box has no fast pair to offer and the step is what it is (profiles/r04/ab_ws_probe.txt)"""
     import ctypes
     us, route, probes = (ctypes.c_float * 4)(), ctypes.c_int(-1), ctypes.c_ulonglong(0)

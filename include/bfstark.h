@@ -94,18 +94,36 @@ uint64_t bfs_gl_pow(uint64_t a, uint64_t e);
  * Transform b reads d_in + b*in_stride (n_in elements) and writes d_out + b*out_stride (2^log_n elements).  The input is left
  * untouched when input and output do not overlap, and then the transform needs no intermediate memory (its first pass writes the
  * output, later passes run in place there); the two ranges may also overlap in any way -- d_in == d_out, an output that starts inside
- * the input -- in which case the first two passes go through a library buffer of the output's size.  Stream-ordered, except that the
- * THIRD call with the same (d_in, d_out) pair for a transform of >= 256 MiB that reads all n inputs synchronises `stream` once (~63 ms
- * at 8 x 2^24, output written as usual): it times its first pass directly and through three library buffers of the output's size, at
- * the settled clock, and remembers the fastest route for the pair; afterwards at most one of the three buffers stays allocated
- * (BFS_NTT_WS_PROBE=0 turns all of that off; a pair seen once or twice never pays).
+ * the input -- in which case the first two passes go through a library buffer of the output's size.  Stream-ordered: the call only
+ * enqueues kernels (it never measures, synchronises or allocates candidate buffers by itself; it may be captured into a hipGraph once
+ * its tables exist, i.e. after one plain call of the same shape).  A pair of buffers that bfs_ntt_tune() found a faster route for is
+ * served through the library buffer that call kept.
  * Errors: BFS_ERR_NOT_ROOT / BFS_ERR_NOT_PRIMITIVE as the reference's asserts; BFS_ERR_TOO_MANY_COEFFS.
  */
 int bfs_gl_ntt(const uint64_t* d_in, uint64_t n_in, uint64_t in_stride, uint64_t* d_out, uint64_t out_stride,
                uint32_t log_n, uint32_t batch, uint64_t root, uint64_t coset_shift, uint64_t post_scale,
                void* stream);
 
-/* Diagnostics of bfs_gl_ntt's route measurement (no reference counterpart): what the LAST measurement of this process read.
+/*
+ * bfs_ntt_tune (no reference counterpart; optional): for a LARGE out-of-place transform (>= 256 MiB, all n inputs read, several
+ * passes) that the caller is going to repeat on the same (d_in, d_out) pair -- a benchmark step, a prover's pooled buffers --, choose by
+ * measurement where the first pass writes: straight into the output or through one of three library buffers of the output's size
+ * (how fast the first, transposing pass streams depends on the physical placement of the PAIR of buffers: 405-510 us for the same
+ * launch between different pairs).  What the call does, so that nobody is surprised by it: it allocates three buffers of
+ * the output's size (only if four such sizes are free, otherwise the pair stays direct), runs passes 0 + 1 of the transform 18 x 4
+ * times (~63 ms at 8 x 2^24; d_out ends up holding an unfinished transform), synchronises `stream` once, frees the buffers that lost and
+ * KEEPS the winner, if any, for as long as the pair is remembered (*route: -1 direct -- nothing kept --, 0..2 that buffer).  Not to be
+ * called on a stream that is being captured (BFS_ERR_BAD_ARG).  Transforms too small to matter, overlapping buffers and
+ * BFS_NTT_WS_PROBE=0 make it a no-op.  The pair is forgotten -- and its buffer released at the next bfs_pool_trim() / bfs_ntt_tune() --
+ * when either buffer goes back to the library's pool (bfs_free, bfs_free_async); for memory the library does not own, call
+ * bfs_ntt_route_forget(ptr) before freeing it (NULL: forget every pair), which synchronises the device and frees what is no longer
+ * needed at once.  *forgotten (optional): how many pairs went.
+ */
+int bfs_ntt_tune(const uint64_t* d_in, uint64_t in_stride, uint64_t* d_out, uint64_t out_stride, uint32_t log_n, uint32_t batch, uint64_t root,
+                 void* stream, int* route);
+int bfs_ntt_route_forget(const void* d_ptr, size_t* forgotten);
+
+/* Diagnostics of the route measurement (no reference counterpart): what the LAST measurement of this process read.
  * us[0] = passes 0 + 1 straight into the output, us[1..3] = through library buffer 0..2 (microseconds); *route = -1 direct or the
  * buffer chosen; *probes = measurements taken so far (0: none yet, us / route are then 0 / -1).  Any pointer may be NULL. */
 int bfs_ntt_route_probe_info(float* us, int* route, unsigned long long* probes);

@@ -49,6 +49,8 @@ _SIGNATURES = {
     "bfs_gl_pow": (u64, [u64, u64]),
     "bfs_gl_ntt": (ci, [vp, u64, u64, vp, u64, u32, u32, u64, u64, u64, vp]),
     "bfs_ntt_route_probe_info": (ci, [vp, vp, vp]),
+    "bfs_ntt_tune": (ci, [vp, u64, vp, u64, u32, u32, u64, vp, ctypes.POINTER(ci)]),
+    "bfs_ntt_route_forget": (ci, [vp, ctypes.POINTER(sz)]),
     "bfs_gl_scale": (ci, [vp, vp, u64, u64, u32, u64, vp]),
     "bfs_gl_mul_pointwise": (ci, [vp, vp, vp, u64, vp]),
     "bfs_gl_batch_inverse": (ci, [vp, vp, u64, vp]),

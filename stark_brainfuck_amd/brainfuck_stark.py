@@ -44,6 +44,10 @@ from .vm import VirtualMachine
 _u64 = ctypes.c_uint64
 
 
+class _MalformedProof(Exception):
+    """an object in the proof is not what its position requires (verify() answers False)"""
+
+
 class BrainfuckStark:
     field = BaseField.main()
     xfield = ExtensionField.main()
@@ -547,10 +551,16 @@ class BrainfuckStark:
             from .merkle import leaf_pickle_source
             token = leaf_pickle_source.set(proof_stream.pickle_of)
             try:
-                return self._verify_stream(proof_stream)
+                return self._verify_checked(proof_stream)
             finally:
                 leaf_pickle_source.reset(token)
-        return self._verify_stream(proof_stream)
+        return self._verify_checked(proof_stream)
+
+    def _verify_checked(self, proof_stream):
+        try:
+            return self._verify_stream(proof_stream)
+        except _MalformedProof:
+            return False
 
     def _verify_stream(self, proof_stream):
         from .air import X0, xadd, xmul, xscale
@@ -559,7 +569,16 @@ class BrainfuckStark:
         offset, omega = self.fri.domain.offset.value, self.fri.domain.omega.value
 
         def limbs(e):
-            return tuple(e.limbs()) if hasattr(e, "limbs") else (e.value % P, 0, 0)
+            """value of an element read from the proof, as canonical residues: the prover chooses the representation (any Python int
+            unpickles), the reference reduces in every operation (algebra.py:89-99) and so sees v mod p -- and so must every
+            consumer here: bfs_air_evaluate's host arithmetic assumes canonical operands and ctypes truncates above 2^64
+            (round-4 advice).  An extension element with more than three coefficients is not an element: the proof is refused."""
+            if hasattr(e, "limbs"):
+                c = e.limbs()
+                if len(c) != 3:
+                    raise _MalformedProof("extension element with %d coefficients" % len(c))
+                return (c[0] % P, c[1] % P, c[2] % P)
+            return (e.value % P, 0, 0)
 
         base_root = proof_stream.pull()
         challenges = tuple(BrainfuckStark._sample_weights(11, proof_stream.verifier_fiat_shamir()))
@@ -652,7 +671,9 @@ class BrainfuckStark:
             combination_path = proof_stream.pull()
             if not Merkle.verify(combination_root, index, combination_path, combination_leaf):
                 return False
-            if limbs(combination_leaf) != inner_product:
+            # brainfuck_stark.py:567 compares the leaf OBJECT with the inner product (coefficient values as stored, algebra.py:36):
+            # a leaf whose coefficients are not canonical residues is unequal there, and here
+            if not hasattr(combination_leaf, "limbs") or tuple(combination_leaf.limbs()) != inner_product:
                 return False
 
         verdict = self.fri.verify(proof_stream, combination_root)

@@ -103,8 +103,7 @@ def build_library(force=False, verbose=False, extra_flags=()):
     from concurrent.futures import ThreadPoolExecutor
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
-    # -save-temps=obj leaves each unit's gfx950 listing next to its object (_build/*-gfx950.s): tools/isa_hazards.py scans what ships
-    compile_flags = [f for f in FLAGS if f != "-shared"] + ["-save-temps=obj"] + list(extra_flags)
+    compile_flags = [f for f in FLAGS if f != "-shared"] + list(extra_flags)
     key = " ".join([hipcc] + compile_flags)
     jobs, objects = [], []
     for src in sources():
@@ -142,6 +141,42 @@ def build_library(force=False, verbose=False, extra_flags=()):
     os.replace(LIB + ".tmp", LIB)
     record(LIB, _library_key(extra_flags))
     return LIB
+
+
+def build_listings(force=False, extra_flags=()):
+    """gfx950 assembly listings of the device code, one per .hip unit, in _build/listings/<unit>-gfx950.s: a separate device-only -S
+    pass with the library's flags (the product build keeps no temporaries).  tools/isa_hazards.py and tools/isa_mix.py read them;
+    listings are remade when any source, header or the command changed."""
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    out_dir = os.path.join(OBJ, "listings")
+    os.makedirs(out_dir, exist_ok=True)
+    flags = [f for f in FLAGS if f not in ("-shared", "-fPIC")] + list(extra_flags) + ["--cuda-device-only", "-S"]
+    key = content_key(_deps(), [hipcc] + flags)          # any source or header change remakes the listings (no per-unit dependency files here)
+    jobs, listings = [], []
+    for src in sources():
+        if not src.endswith(".hip"):
+            continue
+        lst = os.path.join(out_dir, os.path.basename(src)[:-4] + "-gfx950.s")
+        listings.append(lst)
+        if force or not is_current(lst, key):
+            jobs.append((src, lst))
+
+    def one(job):
+        src, lst = job
+        res = subprocess.run([hipcc] + flags + ["-o", lst, src], cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if res.returncode == 0:
+            record(lst, key)
+        return src, res
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:
+        results = list(pool.map(one, jobs))
+    failed = [src for src, res in results if res.returncode != 0]
+    if failed:
+        for src, res in results:
+            if res.returncode != 0:
+                sys.stderr.write(res.stdout)
+        raise RuntimeError("hipcc -S failed for " + ", ".join(os.path.basename(f) for f in failed))
+    return listings
 
 
 def build_fastlist(force=False):

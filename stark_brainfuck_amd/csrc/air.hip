@@ -753,14 +753,17 @@ int bfs_air_evaluate(int table, const uint64_t* base_row, const uint64_t* base_n
     if (table < 0 || table > 4) { set_error("bfs_air_evaluate: table index %d", table); return BFS_ERR_BAD_ARG; }
     Xfe ch[11], tm[5], pr[1], xc[4], xn[4], res[32];
     u64 bc[8], bn[8];
-    for (int i = 0; i < 11; ++i) ch[i] = xfe_from(h_challenges + 3 * i);
-    for (int i = 0; i < 5; ++i) tm[i] = xfe_from(h_terminals + 3 * i);
-    pr[0] = h_params ? xfe_from(h_params) : Xfe{{1, 0, 0}};
+    // every operand is reduced on the way in: opened rows and terminals come out of a proof somebody else wrote, and the field
+    // primitives below assume canonical residues (the reference reduces in every operation, algebra.py:89-99) -- round-4 advice
+    auto canon = [](const uint64_t* l) { return Xfe{{l[0] % GL_P, l[1] % GL_P, l[2] % GL_P}}; };
+    for (int i = 0; i < 11; ++i) ch[i] = canon(h_challenges + 3 * i);
+    for (int i = 0; i < 5; ++i) tm[i] = canon(h_terminals + 3 * i);
+    pr[0] = h_params ? canon(h_params) : Xfe{{1, 0, 0}};
     auto run = [&](auto shape, auto fn) {
         typedef decltype(shape) S;
         static_assert(S::BW <= 8 && S::XW <= 4 && S::NB + S::NT + S::NZ <= 32, "row buffers");
         for (int c = 0; c < S::BW; ++c) { bc[c] = base_row[c] % GL_P; bn[c] = base_next ? base_next[c] % GL_P : 0; }
-        for (int c = 0; c < S::XW; ++c) { xc[c] = xfe_from(ext_row + 3 * c); xn[c] = ext_next ? xfe_from(ext_next + 3 * c) : Xfe{{0, 0, 0}}; }
+        for (int c = 0; c < S::XW; ++c) { xc[c] = canon(ext_row + 3 * c); xn[c] = ext_next ? canon(ext_next + 3 * c) : Xfe{{0, 0, 0}}; }
         fn(bc, bn, xc, xn, ch, tm, pr, res);
         for (int q = 0; q < S::NB + S::NT + S::NZ; ++q)
             for (int l = 0; l < 3; ++l) out[3 * q + l] = res[q].c[l];

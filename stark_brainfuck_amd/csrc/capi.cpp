@@ -76,6 +76,18 @@ int bfs_gl_ntt(const uint64_t* d_in, uint64_t n_in, uint64_t in_stride, uint64_t
 
 int bfs_ntt_route_probe_info(float* us, int* route, unsigned long long* probes) { return ntt_route_probe_info(us, route, probes); }
 
+int bfs_ntt_tune(const uint64_t* d_in, uint64_t in_stride, uint64_t* d_out, uint64_t out_stride, uint32_t log_n, uint32_t batch, uint64_t root,
+                 void* stream, int* route) {
+    return ntt_tune(d_in, in_stride, d_out, out_stride, log_n, batch, root, (hipStream_t)stream, route);
+}
+
+int bfs_ntt_route_forget(const void* d_ptr, size_t* forgotten) {
+    BFS_HIP(hipDeviceSynchronize());             // candidate buffers nobody is routed through any more are freed: nothing may be in flight
+    const size_t gone = ntt_route_forget_range(d_ptr, 0, true);
+    if (forgotten) *forgotten = gone;
+    return BFS_OK;
+}
+
 int bfs_gl_scale(const uint64_t* d_in, uint64_t* d_out, uint64_t n, uint64_t stride, uint32_t batch, uint64_t factor, void* stream) {
     return scale_launch(d_in, d_out, n, stride, batch, factor, (hipStream_t)stream);
 }

@@ -4,7 +4,10 @@
 #include <cstring>
 #include <map>
 #include <algorithm>
+#include <atomic>
+#include <vector>
 #include <mutex>
+#include <set>
 #include <string>
 #include <tuple>
 
@@ -276,15 +279,22 @@ static int ntt_run_pass(const NttPlan& p, u32 t, NttTables tb, const u64* d_in, 
 // cannot see: 405-510 us for the same launch between different pairs of 1 GiB buffers of one process, while the in-place passes do
 // not move (profiles/r03/buffer_placement.txt, profiles/r04/ab_ws_probe.txt; address-translation counters are flat, so it is not the
 // TLB).  The library cannot move the caller's buffers, but it can put one of its own in between at no cost in traffic: pass 0 ->
-// intermediate, pass 1 intermediate -> output (pass 1 is indifferent to being out of place).  So the first time a (input, output)
-// pair has been seen NTT_ROUTE_SIGHTINGS times (a pair that keeps coming back: the bench step, a prover's pooled buffers -- a one-off
-// transform never pays), passes 0 and 1 are timed on the direct route and through each of NTT_ROUTE_CANDIDATES library buffers and the
-// fastest is remembered for the pair.  The measurement has to be taken in the state the transform will run in, the power-limited
-// clock: NTT_ROUTE_WARM untimed rounds over all routes first, then NTT_ROUTE_REPS timed ones, every other one backwards, median per
-// route (18 rounds x 8 launches = ~63 ms at 8 x 2^24, one stream synchronisation).  A short probe straight after idle (one warm-up
-// round, minimum of four) read 0.89-0.94 ms for routes that run at 0.85 and did not tell fast from slow: 5 of 12 processes
-// ended on a slow pair against 0 of 12 with the long one (profiles/r04/ab_ws_probe.txt).  Only transforms of >= NTT_ROUTE_MIN_BYTES
-// that read all n inputs.  BFS_NTT_WS_PROBE=0: always direct.  BFS_NTT_WS_PROBE_LOG=1: the measurements go to stderr.
+// intermediate, pass 1 intermediate -> output (pass 1 is indifferent to being out of place).
+//
+// Since round 5 this is OPT-IN (round-4 advice: a measurement hidden inside the third call of a stream-ordered entry point allocated
+// three buffers of the transform's size, synchronised the stream and broke under stream capture): a caller that keeps coming back with
+// the same (input, output) pair -- the bench step, a prover's pooled buffers -- calls bfs_ntt_tune() ONCE, outside anything it times or
+// captures; bfs_gl_ntt itself only looks the pair up and never measures, allocates candidates or synchronises.  ntt_tune times passes
+// 0 + 1 on the direct route and through each of NTT_ROUTE_CANDIDATES library buffers in the state the transform will run in, the
+// power-limited clock: NTT_ROUTE_WARM untimed rounds over all routes first, then NTT_ROUTE_REPS timed ones, every other one
+// backwards, median per route (18 rounds x 8 launches = ~63 ms at 8 x 2^24, one stream synchronisation).  A short probe straight after
+// idle (one warm-up round, minimum of four) read 0.89-0.94 ms for routes that run at 0.85 and did not tell fast from slow: 5 of 12
+// processes ended on a slow pair against 0 of 12 with the long one (profiles/r04/ab_ws_probe.txt).  Only transforms of >=
+// NTT_ROUTE_MIN_BYTES.  A remembered route dies with either buffer: bfs_free / bfs_free_async of a block drops every pair that
+// touches it (ntt_route_forget_range, called by the pool), and bfs_ntt_route_forget() is there for memory the library does not own.
+// BFS_NTT_WS_PROBE: "0" never route (tune becomes a no-op), "direct" / "buffer0..2" that route for every large transform without
+// measuring (the GPU tests run a large transform over every route), "auto" the round-4 behaviour (bfs_gl_ntt tunes a pair by itself
+// the third time it sees it).  BFS_NTT_WS_PROBE_LOG=1: the measurements go to stderr.
 constexpr int NTT_ROUTE_CANDIDATES = 3;
 constexpr int NTT_ROUTE_SIGHTINGS = 3;
 #ifndef NTT_ROUTE_WARM
@@ -296,8 +306,48 @@ constexpr u64 NTT_ROUTE_MIN_BYTES = 256ull << 20;
 constexpr int ROUTE_UNSEEN = -100;
 namespace {
 std::mutex g_route_mu;
-std::map<std::tuple<int, hipStream_t, const void*, const void*, u64, u64, u64>, int> g_routes;
+struct RouteKey {
+    int dev; hipStream_t stream; const void* in; const void* out; u64 in_stride, out_stride, shape; u64 in_bytes, out_bytes;
+    bool operator<(const RouteKey& o) const {
+        return std::tie(dev, stream, in, out, in_stride, out_stride, shape) < std::tie(o.dev, o.stream, o.in, o.out, o.in_stride, o.out_stride, o.shape);
+    }
+};
+std::map<RouteKey, int> g_routes;                       // a route (>= -1), or ROUTE_UNSEEN - sightings so far ("auto" mode)
+std::set<std::pair<int, hipStream_t>> g_candidate_owners;   // (device, stream) pairs that may hold candidate buffers
 struct { float us[NTT_ROUTE_CANDIDATES + 1] = {0}; int route = -1; unsigned long long probes = 0; } g_last_probe;      // (under g_route_mu)
+int route_mode() {
+    static const int mode = [] {
+        const char* e = getenv("BFS_NTT_WS_PROBE");
+        if (!e) return -2;                                                   // default: remembered routes only (bfs_ntt_tune)
+        if (e[0] == '0' || !strcmp(e, "direct")) return -1;
+        if (!strncmp(e, "buffer", 6) && e[6] >= '0' && e[6] < '0' + NTT_ROUTE_CANDIDATES && !e[7]) return e[6] - '0';
+        if (!strcmp(e, "auto") || !strcmp(e, "1")) return -3;
+        return -2;
+    }();
+    return mode;
+}
+// the candidate buffers no remembered pair of (dev, stream) is routed through go back to the driver; the stream must be idle
+void release_unused_candidates_locked(int dev, hipStream_t stream) {
+    bool used[NTT_ROUTE_CANDIDATES] = {false};
+    for (const auto& kv : g_routes)
+        if (kv.first.dev == dev && kv.first.stream == stream && kv.second >= 0) used[kv.second] = true;
+    for (int k = 0; k < NTT_ROUTE_CANDIDATES; ++k)
+        if (!used[k]) (void)workspace_release(NTT_ROUTE_SLOT0 + k, stream);
+}
+// hipEvents of one measurement: destroyed on every way out of ntt_tune (the round-4 version leaked all of them when a launch failed)
+struct EventGrid {
+    std::vector<hipEvent_t> ev;
+    int make(size_t count) {
+        ev.reserve(count);
+        for (size_t i = 0; i < count; ++i) {
+            hipEvent_t e = nullptr;
+            BFS_HIP(hipEventCreate(&e));
+            ev.push_back(e);
+        }
+        return BFS_OK;
+    }
+    ~EventGrid() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); }
+};
 }
 // what the last route measurement of this process read (bfs_ntt_route_probe_info; bench.py prints it next to the step it explains)
 int ntt_route_probe_info(float* us, int* route, unsigned long long* probes) {
@@ -307,71 +357,133 @@ int ntt_route_probe_info(float* us, int* route, unsigned long long* probes) {
     if (probes) *probes = g_last_probe.probes;
     return BFS_OK;
 }
-static int ntt_route(const NttPlan& p, const NttTables& tb, const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_stride, u32 batch,
-                     u64 root, u64 shift, u64 post_scale, u32 streaming, hipStream_t stream, int* route) {
-    *route = -1;
-    const u64 n = 1ull << p.log_n;
-    // BFS_NTT_WS_PROBE: "0" always direct, "direct" / "buffer0" / "buffer1" / "buffer2" that route without measuring (the GPU tests run a
-    // large transform over every route), anything else or unset: measure
-    static const int mode = [] {
-        const char* e = getenv("BFS_NTT_WS_PROBE");
-        if (!e) return -2;
-        if (e[0] == '0' || !strcmp(e, "direct")) return -1;
-        if (!strncmp(e, "buffer", 6) && e[6] >= '0' && e[6] < '0' + NTT_ROUTE_CANDIDATES && !e[7]) return e[6] - '0';
-        return -2;
-    }();
-    static const bool log = [] { const char* e = getenv("BFS_NTT_WS_PROBE_LOG"); return e && e[0] == '1'; }();
-    if (mode == -1 || n_in != n || (u64)n * batch * sizeof(u64) < NTT_ROUTE_MIN_BYTES) return BFS_OK;
-    if (mode >= 0) { *route = mode; return BFS_OK; }
-    int dev = 0;
-    BFS_HIP(hipGetDevice(&dev));
-    const auto key = std::make_tuple(dev, stream, (const void*)d_in, (const void*)d_out, in_stride, out_stride, ((u64)p.log_n << 32) | batch);
-    {
-        std::lock_guard<std::mutex> lock(g_route_mu);
-        if (g_routes.size() >= 256 && !g_routes.count(key)) g_routes.clear();
-        int& state = g_routes.emplace(key, ROUTE_UNSEEN).first->second;          // a route (>= -1), or ROUTE_UNSEEN - sightings so far
-        if (state >= -1) { *route = state; return BFS_OK; }
-        if (ROUTE_UNSEEN - --state < NTT_ROUTE_SIGHTINGS) return BFS_OK;         // direct until the pair has come back often enough
+
+// forget every remembered pair with a buffer inside [lo, lo + bytes) (bytes == 0: the pair whose buffer STARTS at lo; lo == nullptr:
+// everything); candidate buffers that no pair needs any more are freed when `may_free` (the device must then be idle on those streams:
+// the callers below synchronise first).  Returns the number of pairs forgotten.
+size_t ntt_route_forget_range(const void* lo, size_t bytes, bool may_free) {
+    std::lock_guard<std::mutex> lock(g_route_mu);
+    size_t gone = 0;
+    std::vector<std::pair<int, hipStream_t>> touched;
+    for (auto it = g_routes.begin(); it != g_routes.end();) {
+        const RouteKey& k = it->first;
+        auto hits = [&](const void* p, u64 span) {
+            if (lo == nullptr) return true;
+            const char *a = (const char*)p, *b = (const char*)lo;
+            if (bytes == 0) return a == b;
+            return a < b + bytes && b < a + span;
+        };
+        if (hits(k.in, k.in_bytes) || hits(k.out, k.out_bytes)) {
+            touched.emplace_back(k.dev, k.stream);
+            it = g_routes.erase(it);
+            ++gone;
+        } else {
+            ++it;
+        }
     }
+    if (may_free) {
+        int cur = 0;
+        (void)hipGetDevice(&cur);
+        for (const auto& ds : touched) {
+            if (ds.first != cur && hipSetDevice(ds.first) != hipSuccess) continue;
+            if (hipStreamSynchronize(ds.second) == hipSuccess) release_unused_candidates_locked(ds.first, ds.second);
+            else (void)hipGetLastError();
+        }
+        (void)hipSetDevice(cur);
+    }
+    return gone;
+}
+
+// bfs_pool_trim (the device is idle): candidate buffers that no remembered pair is routed through any more go back to the driver
+void ntt_route_trim() {
+    std::lock_guard<std::mutex> lock(g_route_mu);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    for (const auto& ds : g_candidate_owners)
+        if (ds.first == cur) release_unused_candidates_locked(ds.first, ds.second);
+}
+
+static RouteKey route_key(int dev, hipStream_t stream, const NttPlan& p, const u64* d_in, u64 n_in, u64 in_stride, const u64* d_out, u64 out_stride, u32 batch) {
+    const u64 n = 1ull << p.log_n;
+    return RouteKey{dev, stream, d_in, d_out, in_stride, out_stride, ((u64)p.log_n << 32) | batch,
+                    ((u64)(batch - 1) * in_stride + n_in) * sizeof(u64), ((u64)(batch - 1) * out_stride + n) * sizeof(u64)};
+}
+
+// the measurement itself (bfs_ntt_tune, or bfs_gl_ntt in "auto" mode).  Overwrites the output with passes 0 + 1 of the transform,
+// synchronises the stream.  *route: -1 direct, k >= 0 through candidate buffer k.  Not being able to measure (no memory for the
+// candidates) is not an error: the pair stays direct.
+static int ntt_measure_route(const NttPlan& p, const NttTables& tb, const RouteKey& key, const u64* d_in, u64 n_in, u64 in_stride, u64* d_out,
+                             u64 out_stride, u32 batch, u64 root, u64 shift, u64 post_scale, u32 streaming, hipStream_t stream, int* route) {
+    *route = -1;
+    static const bool log = [] { const char* e = getenv("BFS_NTT_WS_PROBE_LOG"); return e && e[0] == '1'; }();
+    const u64 n = 1ull << p.log_n;
+    const size_t bytes = (size_t)n * batch * sizeof(u64);
     constexpr int R = NTT_ROUTE_CANDIDATES + 1, REPS = NTT_ROUTE_REPS, WARM = NTT_ROUTE_WARM;
+    auto stay_direct = [&](const char* why) {
+        if (log) fprintf(stderr, "bfs ntt route: in %p out %p 2^%u x %u: not measured (%s) -> direct\n", (const void*)d_in, (void*)d_out, p.log_n, batch, why);
+        std::lock_guard<std::mutex> lock(g_route_mu);
+        g_routes[key] = -1;
+        return BFS_OK;
+    };
+    // room for the candidates AND for whatever the caller allocates next: four transform sizes free, or the pair stays direct
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return stay_direct("hipMemGetInfo failed"); }
+    size_t held = 0;                                     // candidates of this stream that are already allocated count as free
+    {
+        void* w = nullptr;
+        for (int k = 0; k < NTT_ROUTE_CANDIDATES; ++k)
+            if (workspace_peek(NTT_ROUTE_SLOT0 + k, stream, &w, nullptr) && w) held += bytes;
+    }
+    if (free_b + held < 4 * bytes) return stay_direct("less than four transform sizes of free memory");
     u64* cand[R] = {nullptr};                            // [0]: direct
+    { std::lock_guard<std::mutex> lock(g_route_mu); g_candidate_owners.emplace(key.dev, stream); }
     for (int k = 0; k < NTT_ROUTE_CANDIDATES; ++k) {
         void* w = nullptr;
-        if (workspace(NTT_ROUTE_SLOT0 + k, (size_t)n * batch * sizeof(u64), stream, &w) != BFS_OK) {
-            // no room for the candidates: this is an optimisation, not a requirement -- the pair stays on the direct route
+        if (workspace(NTT_ROUTE_SLOT0 + k, bytes, stream, &w) != BFS_OK) {
             (void)hipGetLastError();
-            for (int j = 0; j < k; ++j) (void)workspace_release(NTT_ROUTE_SLOT0 + j, stream);
-            std::lock_guard<std::mutex> lock(g_route_mu);
-            g_routes[key] = -1;
-            return BFS_OK;
+            (void)hipStreamSynchronize(stream);
+            { std::lock_guard<std::mutex> lock(g_route_mu); g_routes[key] = -1; release_unused_candidates_locked(key.dev, stream); }
+            return stay_direct("no memory for the candidate buffers");
         }
         cand[k + 1] = (u64*)w;
     }
-    hipEvent_t ev[REPS][R][2];
-    for (auto& rep : ev) for (auto& r : rep) for (auto& e : r) BFS_HIP(hipEventCreate(&e));
-    // untimed rounds first (a freshly allocated buffer is slow the first time it is written, 1.2 ms against 0.85, and the clock takes
-    // tens of ms of load to settle at the power limit), then REPS timed rounds over all routes; the median per route counts
-    for (int rep = -WARM; rep < REPS; ++rep)
-        for (int k = 0; k < R; ++k) {
-            // (every other round backwards: while the clock is still ramping after idle, whatever is measured later in a round looks
-            //  faster -- the first version always found direct > buffer 0 > buffer 1 > buffer 2, the order it measured them in)
-            const int r = (rep & 1) ? R - 1 - k : k;
-            if (rep >= 0) BFS_HIP(hipEventRecord(ev[rep][r][0], stream));
-            for (u32 t = 0; t < 2; ++t)
-                BFS_TRY(ntt_run_pass(p, t, tb, d_in, n_in, in_stride, d_out, out_stride, cand[r], batch, root, shift, post_scale, streaming, stream));
-            if (rep >= 0) BFS_HIP(hipEventRecord(ev[rep][r][1], stream));
+    int rc = BFS_OK;
+    float ms[R] = {0};
+    {
+        EventGrid grid;                                  // REPS x R x {start, stop}; gone when this block ends, however it ends
+        rc = grid.make((size_t)REPS * R * 2);
+        auto ev = [&](int rep, int r, int which) { return grid.ev[((size_t)rep * R + r) * 2 + which]; };
+        // untimed rounds first (a freshly allocated buffer is slow the first time it is written, 1.2 ms against 0.85, and the clock takes
+        // tens of ms of load to settle at the power limit), then REPS timed rounds over all routes; the median per route counts
+        for (int rep = -WARM; rc == BFS_OK && rep < REPS; ++rep)
+            for (int k = 0; rc == BFS_OK && k < R; ++k) {
+                // (every other round backwards: while the clock is still ramping after idle, whatever is measured later in a round looks
+                //  faster -- the first version always found direct > buffer 0 > buffer 1 > buffer 2, the order it measured them in)
+                const int r = (rep & 1) ? R - 1 - k : k;
+                if (rep >= 0 && hipEventRecord(ev(rep, r, 0), stream) != hipSuccess) { set_error("hipEventRecord failed in the route measurement"); rc = BFS_ERR_HIP; break; }
+                for (u32 t = 0; rc == BFS_OK && t < 2; ++t)
+                    rc = ntt_run_pass(p, t, tb, d_in, n_in, in_stride, d_out, out_stride, cand[r], batch, root, shift, post_scale, streaming, stream);
+                if (rc == BFS_OK && rep >= 0 && hipEventRecord(ev(rep, r, 1), stream) != hipSuccess) { set_error("hipEventRecord failed in the route measurement"); rc = BFS_ERR_HIP; }
+            }
+        if (hipStreamSynchronize(stream) != hipSuccess && rc == BFS_OK) { set_error("hipStreamSynchronize failed in the route measurement"); rc = BFS_ERR_HIP; }
+        for (int r = 0; rc == BFS_OK && r < R; ++r) {
+            float t[REPS];
+            for (int rep = 0; rep < REPS; ++rep)
+                if (hipEventElapsedTime(&t[rep], ev(rep, r, 0), ev(rep, r, 1)) != hipSuccess) { set_error("hipEventElapsedTime failed in the route measurement"); rc = BFS_ERR_HIP; break; }
+            std::sort(t, t + REPS);
+            ms[r] = 0.5f * (t[(REPS - 1) / 2] + t[REPS / 2]);
         }
-    BFS_HIP(hipStreamSynchronize(stream));
-    float ms[R];
-    int best = 0;
-    for (int r = 0; r < R; ++r) {
-        float t[REPS];
-        for (int rep = 0; rep < REPS; ++rep) BFS_HIP(hipEventElapsedTime(&t[rep], ev[rep][r][0], ev[rep][r][1]));
-        std::sort(t, t + REPS);
-        ms[r] = 0.5f * (t[(REPS - 1) / 2] + t[REPS / 2]);
-        if (ms[r] < ms[best]) best = r;
     }
-    for (auto& rep : ev) for (auto& r : rep) for (auto& e : r) (void)hipEventDestroy(e);
+    if (rc != BFS_OK) {                                   // a failed measurement leaves nothing behind: no events (above), no candidates, no route
+        (void)hipGetLastError();
+        (void)hipStreamSynchronize(stream);
+        std::lock_guard<std::mutex> lock(g_route_mu);
+        g_routes.erase(key);
+        release_unused_candidates_locked(key.dev, stream);
+        return rc;
+    }
+    int best = 0;
+    for (int r = 1; r < R; ++r) if (ms[r] < ms[best]) best = r;
     if (ms[0] <= ms[best] * 1.01f) best = 0;             // the direct route unless an intermediate buffer is clearly faster
     if (log) {
         fprintf(stderr, "bfs ntt route: in %p out %p 2^%u x %u: passes 0+1 direct %.1f us", (const void*)d_in, (void*)d_out, p.log_n, batch, ms[0] * 1e3);
@@ -383,16 +495,69 @@ static int ntt_route(const NttPlan& p, const NttTables& tb, const u64* d_in, u64
     // every pair of this stream, so a buffer another pair was routed through must stay
     {
         std::lock_guard<std::mutex> lock(g_route_mu);
+        if (g_routes.size() >= 256 && !g_routes.count(key)) g_routes.clear();
         g_routes[key] = *route;
         for (int r = 0; r < R; ++r) g_last_probe.us[r] = ms[r] * 1e3f;
         g_last_probe.route = *route;
         ++g_last_probe.probes;
-        bool used[NTT_ROUTE_CANDIDATES] = {false};
-        for (const auto& kv : g_routes)
-            if (std::get<0>(kv.first) == dev && std::get<1>(kv.first) == stream && kv.second >= 0) used[kv.second] = true;
-        for (int k = 0; k < NTT_ROUTE_CANDIDATES; ++k)
-            if (!used[k]) (void)workspace_release(NTT_ROUTE_SLOT0 + k, stream);
+        release_unused_candidates_locked(key.dev, stream);
     }
+    return BFS_OK;
+}
+
+// bfs_gl_ntt's side: the remembered route of the pair, nothing else (unless BFS_NTT_WS_PROBE forces a route or asks for "auto")
+static int ntt_route(const NttPlan& p, const NttTables& tb, const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_stride, u32 batch,
+                     u64 root, u64 shift, u64 post_scale, u32 streaming, hipStream_t stream, int* route) {
+    *route = -1;
+    const u64 n = 1ull << p.log_n;
+    const int mode = route_mode();
+    if (mode == -1 || n_in != n || (u64)n * batch * sizeof(u64) < NTT_ROUTE_MIN_BYTES) return BFS_OK;
+    if (mode >= 0) { *route = mode; return BFS_OK; }
+    int dev = 0;
+    BFS_HIP(hipGetDevice(&dev));
+    const RouteKey key = route_key(dev, stream, p, d_in, n_in, in_stride, d_out, out_stride, batch);
+    {
+        std::lock_guard<std::mutex> lock(g_route_mu);
+        auto it = g_routes.find(key);
+        if (it != g_routes.end() && it->second >= -1) { *route = it->second; return BFS_OK; }
+        if (mode != -3) return BFS_OK;                                           // default: pairs nobody tuned run direct
+        if (g_routes.size() >= 256 && it == g_routes.end()) { g_routes.clear(); it = g_routes.end(); }
+        int& state = it != g_routes.end() ? it->second : g_routes.emplace(key, ROUTE_UNSEEN).first->second;
+        if (ROUTE_UNSEEN - --state < NTT_ROUTE_SIGHTINGS) return BFS_OK;         // "auto": direct until the pair has come back often enough
+    }
+    return ntt_measure_route(p, tb, key, d_in, n_in, in_stride, d_out, out_stride, batch, root, shift, post_scale, streaming, stream, route);
+}
+
+// bfs_ntt_tune (include/bfstark.h)
+int ntt_tune(const u64* d_in, u64 in_stride, u64* d_out, u64 out_stride, u32 log_n, u32 batch, u64 root, hipStream_t stream, int* route_out) {
+    if (route_out) *route_out = -1;
+    if (log_n > 32 || batch == 0 || batch > 65535 || d_in == nullptr || d_out == nullptr) { set_error("bfs_ntt_tune: bad argument"); return BFS_ERR_BAD_ARG; }
+    const u64 n = 1ull << log_n;
+    if (batch > 1 && (out_stride < n || in_stride < n)) { set_error("bfs_ntt_tune: transforms of a batch overlap"); return BFS_ERR_BAD_ARG; }
+    int rc = ntt_check_root(root, log_n);
+    if (rc != BFS_OK) { set_error("bfs_ntt_tune: the root is not a primitive 2^%u-th root of unity", log_n); return rc; }
+    NttPlan p;
+    if (!ntt_make_plan(log_n, root, p)) { set_error("no NTT plan for log_n = %u", log_n); return BFS_ERR_BAD_ARG; }
+    const u64* in_end = d_in + (u64)(batch - 1) * in_stride + n;
+    const u64* out_end = d_out + (u64)(batch - 1) * out_stride + n;
+    const bool overlap = d_in < out_end && d_out < in_end;
+    const int mode = route_mode();
+    if (p.npass < 2 || overlap || (mode != -2 && mode != -3) || (u64)n * batch * sizeof(u64) < NTT_ROUTE_MIN_BYTES) return BFS_OK;   // nothing to choose
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+        set_error("bfs_ntt_tune: the stream is being captured (the measurement synchronises it)");
+        return BFS_ERR_BAD_ARG;
+    }
+    (void)hipGetLastError();
+    NttTables tb;
+    BFS_TRY(get_tables(p, root, 1, 1, tb));
+    const u32 streaming = (u32)((u64)n * batch * sizeof(u64) > NTT_STREAMING_BYTES);
+    int dev = 0;
+    BFS_HIP(hipGetDevice(&dev));
+    const RouteKey key = route_key(dev, stream, p, d_in, n, in_stride, d_out, out_stride, batch);
+    int route = -1;
+    BFS_TRY(ntt_measure_route(p, tb, key, d_in, n, in_stride, d_out, out_stride, batch, root, 1, 1, streaming, stream, &route));
+    if (route_out) *route_out = route;
     return BFS_OK;
 }
 

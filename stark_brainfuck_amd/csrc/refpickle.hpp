@@ -53,6 +53,35 @@ struct Node {
         inl = nullptr;
         data.assign((const char*)p, len);
     }
+    unsigned depth = 1;      // Unpickler only: 1 + the deepest child at the time the children were attached (early refusal of deep nesting)
+    // Teardown without recursion: a node that dies hands its children to a worklist owned by the outermost destructor on this thread,
+    // so a chain of a million nested tuples (which the Unpickler can be made to build from two bytes per level) is freed in a loop
+    // instead of a million nested ~Node calls (round-4 advice: a 2 MB proof killed the verifier's process with a stack overflow).
+    ~Node() {
+        if (items.empty() && !cls && !state) return;
+        static thread_local std::vector<Ref>* pending = nullptr;
+        if (pending) { release_children(*pending); return; }
+        std::vector<Ref> work;
+        pending = &work;
+        release_children(work);
+        while (!work.empty()) {
+            Ref r = std::move(work.back());
+            work.pop_back();
+            r.reset();               // a last reference: ~Node of that child runs with `pending` set and only appends to `work`
+        }
+        pending = nullptr;
+    }
+    Node() = default;
+    Node(const Node&) = delete;
+    Node& operator=(const Node&) = delete;
+
+   private:
+    void release_children(std::vector<Ref>& out) {
+        for (Ref& r : items) if (r) out.push_back(std::move(r));
+        items.clear();
+        if (cls) out.push_back(std::move(cls));
+        if (state) out.push_back(std::move(state));
+    }
 };
 // a 64-byte BYTES node in ONE allocation (node + payload) instead of two (node, std::string buffer): a FRI proof makes ~2 500 of them
 struct DigestNode : Node {
@@ -523,29 +552,53 @@ class Unpickler {
     // the unpickled object, or an empty Ref (`why` says what was not understood)
     Ref load(std::string* why = nullptr) {
         Ref r = run();
-        if (r && !shallow(r)) { r.reset(); why_ = "objects nested deeper than 200 levels"; }
-        if (!r && why) *why = why_;
+        if (r) {
+            const char* bad = check_shape(r);
+            if (bad) { r.reset(); why_ = bad; }
+        }
+        if (!r) {
+            // a refused graph may hold reference cycles (a list appended to itself through the memo): every cycle passes through a
+            // memoised node, so emptying those lets the shared pointers free the rest (iteratively, ~Node)
+            for (Ref& m : memo_) { m->items.clear(); m->cls.reset(); m->state.reset(); }
+            stack_.clear();
+            memo_.clear();
+            if (why) *why = why_;
+        }
         return r;
     }
 
     // The Pickler walks the graph recursively, and the bytes come from whoever wrote the proof: a stream nested a million lists deep
-    // must be refused here, not overflow the stack there.  Depth along the pickler's own traversal (children in order, a node that was
-    // seen before is a memo reference and is not entered again).
-    static bool shallow(const Ref& root, size_t limit = 200) {
-        std::vector<std::pair<const Node*, size_t>> todo;
-        std::unordered_map<const Node*, char> seen;
-        todo.emplace_back(root.get(), 1);
-        while (!todo.empty()) {
-            const Node* n = todo.back().first;
-            const size_t depth = todo.back().second;
-            todo.pop_back();
-            if (n == nullptr || n->kind == K_INT || !seen.emplace(n, 1).second) continue;
-            if (depth > limit) return false;
-            for (size_t i = n->items.size(); i-- > 0;) todo.emplace_back(n->items[i].get(), depth + 1);
-            if (n->state) todo.emplace_back(n->state.get(), depth + 1);
-            if (n->cls) todo.emplace_back(n->cls.get(), depth + 1);
+    // must be refused here, not overflow the stack there; and a graph with a cycle (which pickle can express and the reference's
+    // proofs never contain) would never be freed by reference counting.  Iterative depth-first walk along the pickler's own traversal
+    // (children in order; a finished node is a memo reference and is not entered again).  nullptr when the graph is fine.
+    static const char* check_shape(const Ref& root, size_t limit = 200) {
+        struct Frame { const Node* n; size_t next; };
+        std::vector<Frame> path;
+        std::unordered_map<const Node*, char> state;                 // 1: on the current path, 2: finished
+        auto child = [](const Node* n, size_t i) -> const Node* {
+            if (i < n->items.size()) return n->items[i].get();
+            i -= n->items.size();
+            if (i == 0) return n->state.get();
+            return n->cls.get();
+        };
+        if (!root) return nullptr;
+        path.push_back({root.get(), 0});
+        state[root.get()] = 1;
+        while (!path.empty()) {
+            Frame& f = path.back();
+            if (f.next >= f.n->items.size() + 2) { state[f.n] = 2; path.pop_back(); continue; }
+            const Node* c = child(f.n, f.next++);
+            if (c == nullptr || c->kind == K_INT) continue;
+            auto it = state.find(c);
+            if (it != state.end()) {
+                if (it->second == 1) return "the object graph has a cycle";
+                continue;
+            }
+            if (path.size() + 1 > limit) return "objects nested deeper than 200 levels";
+            state[c] = 1;
+            path.push_back({c, 0});
         }
-        return true;
+        return nullptr;
     }
 
    private:
@@ -614,10 +667,22 @@ class Unpickler {
         }
     }
 
+    // parent now holds `child`: depth bookkeeping for the early refusal (exact check: check_shape)
+    bool deepen(const Ref& parent, const Ref& child) {
+        if (child && child->depth + 1 > parent->depth) parent->depth = child->depth + 1;
+        if (parent->depth > 200) { why_ = "objects nested deeper than 200 levels"; return false; }
+        return true;
+    }
+    bool deepen(const Ref& parent, const std::vector<Ref>& children) {
+        for (const Ref& c : children) if (!deepen(parent, c)) return false;
+        return true;
+    }
+
     Ref run() {
         while (pos_ < n_) {
-            // (nesting is built from stack depth, and nodes are freed recursively: a reference proof never has more than ~1100 objects
-            //  on the stack -- one batch of 1000 list items plus a few levels)
+            // (a reference proof never has more than ~1100 objects on the stack -- one batch of 1000 list items plus a few levels.
+            //  Nesting does NOT need stack depth: TUPLE1 pops one object and pushes one, so every container operation below also
+            //  carries the depth of what it builds and refuses early; load() checks the finished graph exactly.)
             if (stack_.size() > 20000) { why_ = "unpickling stack deeper than 20000"; return Ref(); }
             const unsigned char opc = p_[pos_++];
             Ref a, b;
@@ -633,19 +698,23 @@ class Unpickler {
                 case 0x65:                                                                                // APPENDS
                     if (!pop_mark(items) || stack_.empty() || stack_.back()->kind != K_LIST) { why_ = "APPENDS"; return Ref(); }
                     stack_.back()->items.insert(stack_.back()->items.end(), items.begin(), items.end());
+                    if (!deepen(stack_.back(), items)) return Ref();
                     break;
                 case 0x61:                                                                                // APPEND
                     if (!pop(a) || stack_.empty() || stack_.back()->kind != K_LIST) { why_ = "APPEND"; return Ref(); }
                     stack_.back()->items.push_back(a);
+                    if (!deepen(stack_.back(), a)) return Ref();
                     break;
                 case 0x75:                                                                                // SETITEMS
                     if (!pop_mark(items) || (items.size() & 1) || stack_.empty() || stack_.back()->kind != K_DICT) { why_ = "SETITEMS"; return Ref(); }
                     stack_.back()->items.insert(stack_.back()->items.end(), items.begin(), items.end());
+                    if (!deepen(stack_.back(), items)) return Ref();
                     break;
                 case 0x73:                                                                                // SETITEM
                     if (!pop(b) || !pop(a) || stack_.empty() || stack_.back()->kind != K_DICT) { why_ = "SETITEM"; return Ref(); }
                     stack_.back()->items.push_back(a);
                     stack_.back()->items.push_back(b);
+                    if (!deepen(stack_.back(), a) || !deepen(stack_.back(), b)) return Ref();
                     break;
                 case 0x43: if (!blob(1, K_BYTES)) return Ref(); break;                                    // SHORT_BINBYTES
                 case 0x42: if (!blob(4, K_BYTES)) return Ref(); break;                                    // BINBYTES
@@ -687,6 +756,7 @@ class Unpickler {
                 case 0x62:                                                                                // BUILD: instance.__dict__ = state
                     if (!pop(a) || a->kind != K_DICT || stack_.empty() || stack_.back()->kind != K_INSTANCE || stack_.back()->state) { why_ = "BUILD"; return Ref(); }
                     stack_.back()->state = a;
+                    if (!deepen(stack_.back(), a)) return Ref();
                     tag(stack_.back());
                     break;
                 case 0x85: case 0x86: case 0x87: {                                                        // TUPLE1 / 2 / 3
@@ -695,6 +765,7 @@ class Unpickler {
                     Ref t = mk(K_TUPLE);
                     t->items.assign(stack_.end() - k, stack_.end());
                     stack_.resize(stack_.size() - k);
+                    if (!deepen(t, t->items)) return Ref();
                     stack_.push_back(t);
                     break;
                 }
@@ -702,6 +773,7 @@ class Unpickler {
                     if (!pop_mark(items)) return Ref();
                     Ref t = mk(K_TUPLE);
                     t->items = items;
+                    if (!deepen(t, t->items)) return Ref();
                     stack_.push_back(t);
                     break;
                 }

@@ -156,9 +156,21 @@ struct PoolInit { PoolInit() { g_host_pool.pinned = true; } } g_pool_init;
 }  // namespace
 
 int device_alloc(size_t bytes, hipStream_t stream, void** out) { return g_device_pool.alloc(bytes, stream, out); }
-int device_release(void* ptr, hipStream_t stream) { return g_device_pool.release(ptr, stream); }
+int device_release(void* ptr, hipStream_t stream) {
+    // a transform route remembered for a pair of buffers (bfs_ntt_tune) dies with either of them: the next owner of this block is
+    // another buffer at the same address
+    size_t cls = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_device_pool.mu);
+        auto it = g_device_pool.live.find(ptr);
+        if (it != g_device_pool.live.end()) cls = it->second.second;
+    }
+    if (cls) (void)ntt_route_forget_range(ptr, cls, false);
+    return g_device_pool.release(ptr, stream);
+}
 int device_pool_trim() {
     BFS_HIP(hipDeviceSynchronize());
+    ntt_route_trim();
     std::lock_guard<std::mutex> lock(g_device_pool.mu);
     g_device_pool.trim_locked();
     return BFS_OK;
@@ -268,6 +280,17 @@ int workspace(int slot, size_t bytes, hipStream_t stream, void** out) {
     }
     *out = s.ptr;
     return BFS_OK;
+}
+
+bool workspace_peek(int slot, hipStream_t stream, void** ptr, size_t* bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(g_mu);
+    auto it = g_scratch.find(std::make_tuple(dev, stream, slot));
+    if (it == g_scratch.end() || !it->second.ptr) return false;
+    if (ptr) *ptr = it->second.ptr;
+    if (bytes) *bytes = it->second.bytes;
+    return true;
 }
 
 // give one scratch buffer back to the driver (the NTT's route measurement keeps only the candidate it chose); the stream must be idle

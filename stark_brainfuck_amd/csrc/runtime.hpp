@@ -30,6 +30,7 @@ const char* last_error();
 // grow-only scratch buffer keyed by (device, stream, slot); contents are only valid within one API call
 int workspace(int slot, size_t bytes, hipStream_t stream, void** out);
 int workspace_release(int slot, hipStream_t stream);
+bool workspace_peek(int slot, hipStream_t stream, void** ptr, size_t* bytes);   // the slot's buffer if it exists (no allocation)
 
 // Pooled HBM and pinned-host memory.  hipMalloc / hipFree cost 50-500 us and hipFree synchronises the device, which at
 // 288 GB of HBM is the wrong trade: freed blocks go back to a size-class free list (8 classes per octave above 1 MiB,
@@ -74,6 +75,9 @@ int fri_round_fused_launch(const FriFoldArgs& fold, u64* d_cw, u64 cw_stride, u6
 
 // ---- internal entry points (device pointers, current device) ----
 int ntt_route_probe_info(float* us, int* route, unsigned long long* probes);
+int ntt_tune(const u64* d_in, u64 in_stride, u64* d_out, u64 out_stride, u32 log_n, u32 batch, u64 root, hipStream_t stream, int* route_out);
+size_t ntt_route_forget_range(const void* lo, size_t bytes, bool may_free);
+void ntt_route_trim();
 int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_stride, u32 log_n, u32 batch, u64 root,
                u64 shift, u64 post_scale, hipStream_t stream);
 

@@ -1,7 +1,7 @@
 """Known answers for BASELINE config 5 (8 columns x 2^24-point forward NTT, SURVEY.md 8d: column c = felt(seed + c * 2^32, i)).
 The reference would need ~1.8 h per column, so these digests come from the CPU oracle (oracle/gl_oracle.c, the
 restatement of ntt.py:4-23 that tests/test_oracle_golden.py pins against the reference's own outputs up to 2^20), not from the
-reference itself: the fixture says so.  ~40 s on one core.
+reference itself: the fixture says so.  ~80 s on one core.
 
     python tests/golden/gen_ntt24_oracle.py
 """
@@ -27,4 +27,14 @@ for c in range(COLS):
                            "output_sha256": hashlib.sha256(np.ascontiguousarray(f, dtype="<u8").tobytes()).hexdigest(),
                            "output_head": [int(x) for x in f[:3]]})
     print(c, out["columns"][-1]["output_sha256"], flush=True)
+# the guard's edge-value columns (bench.py: edge_columns): operands next to 0, p and 2^32, all-(p - 1), alternating 1 / p - 1
+from bench import edge_columns  # noqa: E402
+out["edge_recipe"] = "bench.py: edge_columns(n, 8) -- edge_array(0xED6E + c, n), column 1 all p - 1, column 2 alternating 1 / p - 1"
+out["edge_columns"] = []
+for c, v in enumerate(edge_columns(n, COLS)):
+    f = o.ntt(w, v)
+    out["edge_columns"].append({"input_sha256": hashlib.sha256(np.ascontiguousarray(v, dtype="<u8").tobytes()).hexdigest(),
+                                "output_sha256": hashlib.sha256(np.ascontiguousarray(f, dtype="<u8").tobytes()).hexdigest(),
+                                "output_head": [int(x) for x in f[:3]]})
+    print("edge", c, out["edge_columns"][-1]["output_sha256"], flush=True)
 json.dump(out, open(os.path.join(HERE, "ntt24_oracle.json"), "w"), indent=1)

@@ -572,6 +572,48 @@ def test_native_reader_of_proof_streams_matches_the_python_route():
     for depth in (1000, 100000, 3000000):
         deep = b"\x80\x04" + b"]" * depth + b"a" * (depth - 1) + b"."
         assert NativeTranscript.from_bytes(deep) is None
+    # round-4 advice: nesting does not need stack depth -- TUPLE1 (0x85) pops one object and pushes one, so two million of them build a
+    # chain two million deep with one object on the stack; freeing such a graph recursively overflowed the C stack (rc 139).  Run in a
+    # child process so that a crash fails this test instead of ending the suite.
+    import subprocess
+    import sys
+    hostile = r"""
+import sys
+sys.path.insert(0, %r)
+from stark_brainfuck_amd.ip import NativeTranscript, ProofStream
+chain = b'\x80\x04])' + b'\x85' * 2000000 + b'a.'
+assert NativeTranscript.from_bytes(chain) is None
+from stark_brainfuck_amd import _lib
+assert b'deeper than 200' in _lib.load().bfs_last_error()
+ps = ProofStream().deserialize(chain)                       # CPython reads it: the Python route ends in an ordinary object
+assert isinstance(ps.objects, list) and len(ps.objects) == 1
+# depth hidden from bookkeeping done at attach time: A_k+1 = [B_k+1] is two levels deep when it goes into B_k, and B_k already
+# sits inside A_k, so no node is ever seen deeper than 3 while it is attached; the finished graph is 800 levels deep from A_0 on
+def get(i):
+    return b'j' + i.to_bytes(4, 'little')
+parts = [b'\x80\x04]\x94(']                                # the outer list (memo 0), MARK
+memo, prev_b = 1, None
+for k in range(400):
+    parts.append(b']\x94]\x94a')                            # A_k = [B_k]; memo: A_k, B_k
+    a, b = memo, memo + 1
+    memo += 2
+    if prev_b is not None:
+        parts.append(get(prev_b) + get(a) + b'a')             # B_k-1.append(A_k)
+    prev_b = b
+parts.append(b'e.')                                           # outer.extend(everything on the stack)
+hidden = b''.join(parts)
+import pickle
+assert len(pickle.loads(hidden)) == 799                       # a pickle CPython reads
+assert NativeTranscript.from_bytes(hidden) is None
+from stark_brainfuck_amd import _lib
+assert b'deeper than 200' in _lib.load().bfs_last_error()
+# a list that contains itself, and a two-node cycle through a tuple
+assert NativeTranscript.from_bytes(b'\x80\x04]\x94h\x00a.') is None
+assert NativeTranscript.from_bytes(b'\x80\x04]\x94]\x94h\x00\x85ah\x01a.') is None
+print('survived')
+""" % ROOT
+    res = subprocess.run([sys.executable, "-c", hostile], capture_output=True, text=True)
+    assert res.returncode == 0 and "survived" in res.stdout, (res.returncode, res.stderr[-2000:])
     # a pickle that CPython would lay out differently (protocol 2 of the same list) is refused by the round-trip check, not misread
     assert NativeTranscript.from_bytes(pickle.dumps([b"ab", 7], protocol=2)) is None
 
@@ -606,6 +648,15 @@ def test_native_constraint_evaluation_matches_the_expression_graphs():
             for kind, values in zip(("boundary", "transition", "terminal"), got):
                 want = table.evaluate_constraints(kind, point, nxt, challenges, terminals)
                 assert [tuple(v) for v in want] == [tuple(v) for v in values], (trial, type(table).__name__, kind)
+            # round-4 advice: the same elements in another representation (v + p where that fits 64 bits -- what a prover may pickle
+            # into a proof) must evaluate to the same values: bfs_air_evaluate reduces every operand on the way in
+            def other(v):
+                return v + P if v + P < (1 << 64) and rnd.random() < 0.7 else v
+
+            def recode(row):
+                return [tuple(other(v) for v in e) for e in row]
+            again = table.evaluate_all_constraints(recode(point), recode(nxt), tuple(recode(challenges)), recode(terminals))
+            assert [[tuple(v) for v in part] for part in again] == [[tuple(v) for v in part] for part in got], (trial, type(table).__name__)
 
 
 @pytest.mark.parametrize("name", NAMES)

@@ -7,8 +7,8 @@ v_subbrev_co, v_cndmask, v_div_fmas).  hipcc pads its own sequences (`s_nop 1`),
 csrc/gl.hpp and csrc/lazy.hpp keep carries in explicit SGPR pairs across asm statements -- so the padding there is ours to get
 right (round-3 advice: gl_mul_fused once had a single `s_nop 0` between the two for a constant operand).
 
-    python tools/isa_hazards.py [listing.s ...]      default: every *-gfx950.s the build left in stark_brainfuck_amd/_build/
-                                                      (build.py compiles with -save-temps=obj)
+    python tools/isa_hazards.py [listing.s ...]      default: the listings of every .hip unit, made by stark_brainfuck_amd.build.build_listings()
+                                                      (a device-only -S pass with the library's flags, cached in _build/listings/)
 
 Prints one line per site and exits 1 when there is any.  tests/test_host_logic.py runs it over the shipped build."""
 import glob
@@ -109,9 +109,13 @@ def scan(path):
 
 
 def main(argv):
-    paths = argv or sorted(glob.glob(os.path.join(ROOT, "stark_brainfuck_amd", "_build", "*-gfx950.s")))
+    paths = argv
     if not paths:
-        print("no listings: build the library first (python -m stark_brainfuck_amd.build)", file=sys.stderr)
+        sys.path.insert(0, ROOT)
+        from stark_brainfuck_amd import build
+        paths = build.build_listings()                 # device-only -S pass with the library's flags (cached by content)
+    if not paths:
+        print("no listings", file=sys.stderr)
         return 2
     total = 0
     for p in paths:
