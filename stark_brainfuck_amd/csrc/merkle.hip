@@ -13,38 +13,19 @@ namespace bfs {
 constexpr int LEAF_THREADS = 64;  // one wavefront per workgroup
 
 // One wave hashes 64 leaves whose limbs it already holds (c0, c1, c2; `active` = the lane has a leaf) in the streaming form of
-// merkle_core.hpp: 20 words of LDS per lane = 10 KiB per wave instead of 18.  BFS_LEAF_STAGED (A/B, profiles/r03/ab_leaf_streaming.txt):
-// the staged form of rounds 1-2 (whole tail in LDS, then hashed).
-#ifdef BFS_LEAF_STAGED
-constexpr int LEAF_STAGE_WORDS = XFE_TAIL_MAX_WORDS * LEAF_THREADS;
-#else
+// merkle_core.hpp: 20 words of LDS per lane = 10 KiB per wave instead of 18 (the staged form of rounds 1-2 -- whole tail in LDS, then
+// hashed -- was the slower side of profiles/r03/ab_leaf_streaming.txt and is gone).
 constexpr int LEAF_STAGE_WORDS = XFE_STREAM_WORDS * LEAF_THREADS;
-#endif
-
-__device__ __forceinline__ void xfe_leaf_staged_lane(u64 c0, u64 c1, u64 c2, u32 k, u64* stage, u32 stride, u64 h[8], const u64* midstates) {
-    const u32 body = xfe_leaf_body_len(k, c0, c1, c2);
-    const u64* ms = midstates + ((size_t)(k == 1 ? 0 : 1) * LEAF_MS_LEN + body) * 8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) h[j] = ms[j];
-    LeafWriter w;
-    w.init(stage, stride);
-    encode_xfe_leaf_tail(w, k, c0, c1, c2);
-    blake2b_staged_tail(stage, stride, body + 11, h);
-}
 
 __device__ __forceinline__ void xfe_leaves_wave(u64 c0, u64 c1, u64 c2, bool active, u64* stage /* LEAF_STAGE_WORDS */, u64 h[8], const u64* midstates) {
     const u32 lane = threadIdx.x;
     const u32 k = active ? xfe_leaf_k(c0, c1, c2) : 0u;
     if (active && k == 0) merkle_leaf_xfe_zero(h, midstates);
-#ifdef BFS_LEAF_STAGED
-    if (k != 0) xfe_leaf_staged_lane(c0, c1, c2, k, stage + lane, LEAF_THREADS, h, midstates);
-#else
     // class by class (wave-uniform branches): a wave of random extension elements, or of lifted base-field elements, takes exactly one
     // of the three; a mixed wave takes its classes in turn with the other lanes idle
     if (__ballot(k == 3) != 0) { if (k == 3) merkle_leaf_xfe_stream<3>(c0, c1, c2, stage + lane, LEAF_THREADS, h, midstates); }
     if (__ballot(k == 2) != 0) { if (k == 2) merkle_leaf_xfe_stream<2>(c0, c1, c2, stage + lane, LEAF_THREADS, h, midstates); }
     if (__ballot(k == 1) != 0) { if (k == 1) merkle_leaf_xfe_stream<1>(c0, c1, c2, stage + lane, LEAF_THREADS, h, midstates); }
-#endif
 }
 
 __global__ void __launch_bounds__(LEAF_THREADS) merkle_leaves_xfe_kernel(const u64* limbs, u64 limb_stride, u64 n, u64* leaf_digests, const u64* midstates) {

@@ -96,15 +96,11 @@ BFS_HD void merkle_leaf_xfe_body(const u64* limbs, u64 limb_stride, u64 i, u64* 
 // point depends on the class K (how many coefficients the element stores), so the wave-level caller (merkle.hip: xfe_leaves_wave)
 // runs the classes present in a wave one after the other -- exactly one for every codeword of random extension elements and for every
 // lifted base-field codeword.
-#ifdef BFS_LEAF_STREAM_21                     // A/B only: the first form (split 16 bytes into the last segment: up to 165 bytes before the first compression)
-constexpr int XFE_STREAM_WORDS = 21;
-#else
 constexpr int XFE_STREAM_WORDS = 20;         // 10 KiB per wave: sixteen waves per CU
-#endif
 template <int K> struct XfeStreamSplit;      // bytes of the class' last constant segment written BEFORE the first compression
 template <> struct XfeStreamSplit<1> { static constexpr int BYTES = 96; };   // 41 + int + 96 = 139..148 >= 128
 template <> struct XfeStreamSplit<2> { static constexpr int BYTES = 24; };   // 42 + int + 58 + int + 24 = 128..146
-template <> struct XfeStreamSplit<3> { static constexpr int BYTES = XFE_STREAM_WORDS == 21 ? 16 : 8; };    // 42 + int + 58 + int + 16 + int + 8 = 130..157 (20 words); the rest of the tail is <= 20 words as well
+template <> struct XfeStreamSplit<3> { static constexpr int BYTES = 8; };    // 42 + int + 58 + int + 16 + int + 8 = 130..157 (20 words); the rest of the tail is <= 20 words as well
 
 template <int K>
 BFS_HD void merkle_leaf_xfe_stream(u64 c0, u64 c1, u64 c2, u64* stage, u32 stride, u64 h[8], const u64* midstates) {
