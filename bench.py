@@ -332,7 +332,9 @@ def main():
         # answers for them (tests/golden/ntt24_oracle.json: edge_columns, made by gen_ntt24_oracle.py with edge_columns() above)
         edge_checked = 0
         if rank == 0 and known is not None and g.get("edge_columns") and cols == len(g["edge_columns"]):
-            _lib.check(lib.bfs_memcpy_h2d(d_in.ptr, np.concatenate(edge_columns(n, cols)).ctypes.data, 8 * n * cols, stream))
+            edge_in = np.concatenate(edge_columns(n, cols))
+            _lib.check(lib.bfs_memcpy_h2d(d_in.ptr, edge_in.ctypes.data, 8 * n * cols, stream))
+            del edge_in
             step()
             for j in range(cols):
                 col = d_out.to_numpy(n, offset=j * n)
