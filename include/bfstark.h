@@ -485,6 +485,63 @@ int bfs_difference_combine_rows(const uint64_t* d_lhs, const uint64_t* d_rhs, ui
 int bfs_zerofier_inverses_rows(uint32_t log_n, uint64_t offset, uint64_t omega, uint32_t count, const uint32_t* h_is_power, const uint64_t* h_values,
                                uint64_t* d_out, uint64_t first_row, uint64_t num_rows, void* stream);
 
+/* ---- BrainfuckStark.prove between its Fiat-Shamir points, as two calls (csrc/prover.cpp) ------------------------------------------
+ *
+ * The stages of the reference's prove() (brainfuck_stark.py:134-341) driven natively instead of call by call from the host language:
+ * for a small proof the host's glue between ~110 kernel launches was two thirds of the time.
+ *
+ *   bfs_stark_commit   (:143-195) pads the five trace matrices (processor_table.py:24-35, instruction_table.py:19-25, memory_table.py:
+ *       40-44, io_table.py:17-21), interpolates and low-degree-extends the base columns (table.py:112-148), commits to the zipped rows
+ *       (:178-179), pushes the root, draws the eleven challenges (:181-183), extends the tables (the `extend` methods as prefix scans)
+ *       and QUEUES the extension columns' low-degree extension; it returns while the GPU runs that.
+ *       tables[5]: processor, instruction, memory, input, output matrices as VirtualMachine.simulate returns them (vm.py:172-306),
+ *       row-major.  out_challenges: 11 x 3 limbs.  out_scan_terminals: 9 x 3 limbs, the final value of every extension column in the
+ *       order processor (instruction permutation, memory permutation, input evaluation, output evaluation), instruction (permutation,
+ *       evaluation), memory (permutation), input, output.  out_io_terminals: 2 x 3 limbs, the input / output evaluation after the last
+ *       REAL row (io_table.py:106-110).  out_ms (optional, 5 doubles): host wall-clock of pad, base LDE, base tree, extension, queueing.
+ *   [caller]  what hangs on object identity and symbolic degrees in the reference stays with the caller: the five terminal OBJECTS
+ *       (processor_table.py:390-404; made through bfs_ps_obj_*, not pushed) and the degree bounds of all terms (:203-221, 245-293).
+ *   bfs_stark_finish   (:197-336) commits to the zipped extension rows, pushes that root and the five terminal objects, draws the
+ *       weights, accumulates the non-linear combination with the quotients folded in, commits to it, samples the indices, pushes the
+ *       openings and runs FRI on the combination codeword.
+ *       degree_bounds: one per term in the reference's order (base columns, extension columns, quotients table by table, the two
+ *       permutation arguments); base_field_id: the BaseField instance the base codewords' elements point at (as bfs_ps_obj_bfe);
+ *       distances: the tables' distinct unit distances in the order the caller's `set` iterates them (:312); out_indices:
+ *       security_level indices; out_weights_seed: 32 bytes; out_fri_indices: num_colinearity_checks; out_ms (optional, 5 doubles):
+ *       extension tree, combination, its tree + indices, openings, FRI.
+ * Both synchronise `stream` several times (every commitment's root goes to the host).  A session serves one proof at a time; its
+ * device memory comes from the library's pool and goes back when bfs_stark_finish returns (or the session is freed).
+ */
+typedef struct bfs_stark_params {
+    uint32_t log_n;                    /* FRI domain length 2^log_n */
+    uint32_t expansion_factor, num_colinearity_checks, security_level;
+    uint64_t offset, omega;            /* the FRI domain's coset offset and generator */
+    uint64_t max_degree;
+    uint64_t heights[3];               /* padded heights of the processor, instruction and memory tables (their constructors') */
+} bfs_stark_params;
+typedef struct bfs_stark_table_in {
+    const uint64_t* values;            /* rows x row_stride words, row-major; the first base_width words of a row are used */
+    uint64_t rows, row_stride;
+} bfs_stark_table_in;
+typedef struct bfs_stark_randomness {  /* every random draw of prove(), in the order it makes them (exactly one of each seed / data pair) */
+    const uint8_t* randomizer_seed;    /* 32 bytes expanded on the GPU into the randomizer polynomial (bfs_xfe_sample_fill) ... */
+    const uint64_t* randomizer_limbs;  /* ... or its max_degree + 1 coefficients as three limb planes (brainfuck_stark.py:162-165) */
+    const uint64_t* base_randomizers;  /* one value per base column of the processor, instruction and memory tables (table.py:125-127) */
+    const uint8_t* base_salt_seed;     /* 32 bytes expanded on the GPU into the salts of the base commitment (bfs_random_fill) ... */
+    const uint8_t* base_salts;         /* ... or 24 bytes per leaf (salted_merkle.py:25) */
+    uint64_t initials[6];              /* the two permutation arguments' initial values, 3 limbs each (brainfuck_stark.py:184-185) */
+    const uint64_t* ext_randomizers;   /* three limbs per extension column of the same three tables */
+    const uint8_t* ext_salt_seed;
+    const uint8_t* ext_salts;
+} bfs_stark_randomness;
+void* bfs_stark_session_new(void);
+void bfs_stark_session_free(void* session);
+int bfs_stark_commit(void* session, void* ps, const bfs_stark_params* params, const bfs_stark_table_in* tables, const bfs_stark_randomness* randomness,
+                     uint64_t* out_challenges, uint64_t* out_scan_terminals, uint64_t* out_io_terminals, double* out_ms, void* stream);
+int bfs_stark_finish(void* session, void* ps, const uint64_t* terminal_handles, const uint64_t* terminals, const uint64_t* degree_bounds,
+                     uint32_t num_terms, int32_t base_field_id, const uint64_t* distances, uint32_t n_distances, uint64_t* out_indices,
+                     uint8_t* out_weights_seed, uint64_t* out_fri_indices, double* out_ms, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

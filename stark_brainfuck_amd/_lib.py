@@ -131,6 +131,11 @@ _SIGNATURES = {
                                   ctypes.POINTER(u64), vp, ctypes.POINTER(vp), u64, u64, vp]),
     "bfs_difference_combine_rows": (ci, [vp, vp, u32, u64, u64, vp, vp, vp, u64, u64, vp]),
     "bfs_zerofier_inverses_rows": (ci, [u32, u64, u64, u32, ctypes.POINTER(u32), ctypes.POINTER(u64), vp, u64, u64, vp]),
+    "bfs_stark_session_new": (vp, []),
+    "bfs_stark_session_free": (None, [vp]),
+    "bfs_stark_commit": (ci, [vp, vp, vp, vp, vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_double), vp]),
+    "bfs_stark_finish": (ci, [vp, vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64), u32, ctypes.c_int32, ctypes.POINTER(u64), u32,
+                              ctypes.POINTER(u64), vp, ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_double), vp]),
 }
 
 
@@ -153,6 +158,23 @@ class ScanSpec(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("record_before", ctypes.c_int32), ("d_x1", vp), ("d_x2", vp), ("d_x3", vp), ("shift1", u64),
                 ("d_mask", vp), ("n", u64), ("constants", u64 * 12), ("initial", u64 * 3), ("d_out", vp), ("out_stride", u64),
                 ("d_terminal", vp)]
+
+
+class StarkParams(ctypes.Structure):
+    """bfs_stark_params (include/bfstark.h)"""
+    _fields_ = [("log_n", u32), ("expansion_factor", u32), ("num_colinearity_checks", u32), ("security_level", u32), ("offset", u64),
+                ("omega", u64), ("max_degree", u64), ("heights", u64 * 3)]
+
+
+class StarkTableIn(ctypes.Structure):
+    """bfs_stark_table_in (include/bfstark.h)"""
+    _fields_ = [("values", vp), ("rows", u64), ("row_stride", u64)]
+
+
+class StarkRandomness(ctypes.Structure):
+    """bfs_stark_randomness (include/bfstark.h)"""
+    _fields_ = [("randomizer_seed", vp), ("randomizer_limbs", vp), ("base_randomizers", vp), ("base_salt_seed", vp), ("base_salts", vp),
+                ("initials", u64 * 6), ("ext_randomizers", vp), ("ext_salt_seed", vp), ("ext_salts", vp)]
 
 
 class CombWeight(ctypes.Structure):

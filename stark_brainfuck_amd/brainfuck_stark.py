@@ -263,8 +263,185 @@ class BrainfuckStark:
         finally:
             gc.unfreeze()
 
+    # ---- the production path: the stages between the Fiat-Shamir points run natively (csrc/prover.cpp), two calls per proof
+    native_stages = True            # False: every stage is driven from Python (the path below; what the tests compare the native one with)
+
+    def _native_session(self):
+        lib = _lib.load()
+        s = getattr(self, "_stark_session", None)
+        if s is None:
+            import weakref
+            s = self._stark_session = lib.bfs_stark_session_new()
+            weakref.finalize(self, lib.bfs_stark_session_free, s)
+        return s
+
+    @staticmethod
+    def _matrix_values(matrix, width):
+        """the uint64 array behind a trace matrix of this package's VM (rows x >= width, C order), or None for plain lists of rows"""
+        values = getattr(matrix, "values", None)
+        if values is None or not isinstance(values, np.ndarray) or values.dtype != np.uint64 or values.ndim != 2:
+            return None
+        if values.shape[0] != len(matrix) or (values.shape[0] and (values.shape[1] < width or not values.flags.c_contiguous)):
+            return None
+        return values
+
+    def _prove_native(self, program, matrices, proof_stream):
+        """prove() through bfs_stark_commit / bfs_stark_finish.  Returns the proof bytes, or None when this route does not apply (the
+        caller then takes the Python path): plain-list matrices, a foreign proof stream, a cooperative proof, test hooks."""
+        import os
+        from . import salted_merkle as salted_mod, table as table_mod
+        from .table import sample_base
+        if os.environ.get("BFS_NATIVE_PROVE", "1") == "0" or not self.native_stages:
+            return None
+        if (self._cooperation is not None or self.keep_intermediates or self.stage_timing or self._row_windows is not None
+                or self._shift_tweak is not None):
+            return None
+        # tables in the order of self.tables: processor, instruction, memory, input, output
+        pm, mm, im, inm, om = matrices
+        ordered = (pm, im, mm, inm, om)
+        values = [BrainfuckStark._matrix_values(m, t.base_width) for m, t in zip(ordered, self.tables)]
+        if any(v is None for v in values):
+            return None
+        if proof_stream is None:
+            proof_stream = ProofStream()
+        if not hasattr(proof_stream, "_adopt_lazy"):
+            return None
+        lib, stream = _lib.load(), current_stream()
+        xf, n = self.xfield, self.fri.domain.length
+        transcript = proof_stream._native()
+        if getattr(proof_stream, "_cached", None) is not transcript or (transcript.xfield is not None and transcript.xfield is not xf) or transcript.loaded:
+            return None
+        if transcript.xfield is None:
+            transcript.xfield = xf
+        import time
+        t_begin = time.perf_counter()
+        for table, matrix in zip(self.tables, ordered):
+            table.matrix = matrix
+        for table, v in zip(self.tables[3:], values[3:]):                       # io_table.py:17-21: length and height follow the symbols
+            table.length = v.shape[0]
+            table.height = v.shape[0] + table._padding_length(v.shape[0])
+        for table, v in zip(self.tables[:3], values[:3]):
+            if v.shape[0] + table._padding_length(v.shape[0]) != table.height:
+                return None                                                     # (the Python path raises where the reference would)
+        # ---- every random draw of prove(), in its order, from the sources the Python path reads (tests replace them module by module)
+        rnd = _lib.StarkRandomness()
+        keep = []                                                               # buffers the structure points at
+        draw = random_source(urandom)
+        count = self.max_degree + 1
+        if draw is os.urandom or getattr(draw, "expand_on_device", False):
+            keep.append(ctypes.create_string_buffer(draw(32), 32))
+            rnd.randomizer_seed = ctypes.cast(keep[-1], ctypes.c_void_p)
+        else:
+            keep.append(np.ascontiguousarray(sample_ext_many(draw(3 * 9 * count), count, 9), dtype=np.uint64))
+            rnd.randomizer_limbs = keep[-1].ctypes.data
+        tdraw = random_source(table_mod.urandom)
+        base_rand = [sample_base(tdraw(3 * 8)) for t in self.tables[:3] if t.height for _ in range(t.base_width)]
+        keep.append((_u64 * max(len(base_rand), 1))(*base_rand))
+        rnd.base_randomizers = ctypes.cast(keep[-1], ctypes.c_void_p)
+
+        def salts(field_seed, field_data):
+            sdraw = random_source(salted_mod.urandom)
+            if sdraw is os.urandom or getattr(sdraw, "expand_on_device", False):
+                keep.append(ctypes.create_string_buffer(sdraw(32), 32))
+                setattr(rnd, field_seed, ctypes.cast(keep[-1], ctypes.c_void_p))
+            else:
+                data = sdraw(24 * n)
+                keep.append(ctypes.create_string_buffer(data, len(data)))
+                setattr(rnd, field_data, ctypes.cast(keep[-1], ctypes.c_void_p))
+        salts("base_salt_seed", "base_salts")
+        initials = [sample_ext(draw(3 * 8)) for _ in self.permutation_arguments]
+        rnd.initials = (_u64 * 6)(*[v for i in initials for v in i])
+        ext_rand = [v for t in self.tables[:3] if t.height for _ in range(t.full_width - t.base_width) for v in sample_ext(tdraw(3 * 8))]
+        keep.append((_u64 * max(len(ext_rand), 1))(*ext_rand))
+        rnd.ext_randomizers = ctypes.cast(keep[-1], ctypes.c_void_p)
+        salts("ext_salt_seed", "ext_salts")
+
+        params = _lib.StarkParams(n.bit_length() - 1, self.expansion_factor, self.num_colinearity_checks, self.security_level,
+                                  self.fri.domain.offset.value, self.fri.domain.omega.value, self.max_degree,
+                                  (_u64 * 3)(*[t.height for t in self.tables[:3]]))
+        tabs = (_lib.StarkTableIn * 5)()
+        for slot, v in zip(tabs, values):
+            slot.values, slot.rows, slot.row_stride = (v.ctypes.data if v.shape[0] else None), v.shape[0], (v.shape[1] if v.shape[0] else 0)
+        session = self._native_session()
+        before = transcript.num_objects()
+        out_ch, out_scan, out_io = (_u64 * 33)(), (_u64 * 27)(), (_u64 * 6)()
+        ms_a, ms_b = (ctypes.c_double * 5)(), (ctypes.c_double * 5)()
+        try:
+            _lib.check(lib.bfs_stark_commit(session, transcript.handle, ctypes.byref(params), tabs, ctypes.byref(rnd), out_ch, out_scan, out_io,
+                                            ms_a, stream))
+            t_commit = time.perf_counter()
+            # ---- while the GPU extends the extension columns: terminals, their objects, degree bounds
+            challenges = tuple((out_ch[3 * i], out_ch[3 * i + 1], out_ch[3 * i + 2]) for i in range(11))
+            scan = [(out_scan[3 * i], out_scan[3 * i + 1], out_scan[3 * i + 2]) for i in range(9)]
+            pt, it, mt = self.processor_table, self.instruction_table, self.memory_table
+            (pt.instruction_permutation_terminal, pt.memory_permutation_terminal, pt.input_evaluation_terminal,
+             pt.output_evaluation_terminal) = scan[0:4]
+            it.permutation_terminal, it.evaluation_terminal = scan[4], scan[5]
+            mt.permutation_terminal = scan[6]
+            self.input_table.evaluation_terminal = (out_io[0], out_io[1], out_io[2])
+            self.output_table.evaluation_terminal = (out_io[3], out_io[4], out_io[5])
+            ci = values[0][:, 2]
+            pt.evaluation_terminal_identities = (pt._identity(None, scan[2], challenges[8], np.nonzero(ci == ord(","))[0] + 1),
+                                                 pt._identity(None, scan[3], challenges[9], np.nonzero(ci == ord("."))[0]))
+            terminals = self.get_terminals()
+            terminal_objects = self._terminal_objects(terminals)
+            transcript.scan(terminal_objects)
+            handles = (_u64 * 5)(*[transcript.to_native(t) for t in terminal_objects])
+            bounds = [t.interpolant_degree() for t in self.tables for _ in range(t.base_width)]
+            bounds += [t.interpolant_degree() for t in self.tables for _ in range(t.full_width - t.base_width)]
+            quotient_degree_bounds = [b for table in self.tables for b in table.all_quotient_degree_bounds(challenges, terminals)]
+            quotient_degree_bounds += [pa.quotient_degree_bound() for pa in self.permutation_arguments]
+            bounds += quotient_degree_bounds
+            unit_distances = list(set(table.unit_distance(n) for table in self.tables))
+            dist = (_u64 * (1 + len(unit_distances)))(0, *unit_distances)
+            out_idx, out_top = (_u64 * max(self.security_level, 1))(), (_u64 * max(self.num_colinearity_checks, 1))()
+            wseed = ctypes.create_string_buffer(32)
+            t_host = time.perf_counter()
+            _lib.check(lib.bfs_stark_finish(session, transcript.handle, handles, (_u64 * 15)(*[v for t in terminals for v in t]),
+                                            (_u64 * len(bounds))(*bounds), len(bounds), transcript._field_id(BrainfuckStark.field), dist, len(dist),
+                                            out_idx, wseed, out_top, ms_b, stream))
+        except Exception:
+            proof_stream._cached = None          # native code may have appended objects the Python list does not have
+            raise
+        proof_stream._adopt_lazy(transcript, before, transcript.num_objects(), xf)
+        t_finish = time.perf_counter()
+        proof = proof_stream.serialize()
+        self._last = {"challenges": challenges, "terminals": terminals, "indices": [int(v) for v in out_idx[:self.security_level]],
+                      "weights_seed": wseed.raw, "quotient_degree_bounds": quotient_degree_bounds}
+        self.timing = {"pad": ms_a[0] * 1e-3 + (t_commit - t_begin - sum(ms_a) * 1e-3), "randomizer": 0.0, "base_lde": ms_a[1] * 1e-3,
+                       "base_tree": ms_a[2] * 1e-3, "extend": ms_a[3] * 1e-3, "ext_lde": ms_a[4] * 1e-3 + (t_host - t_commit),
+                       "ext_tree": ms_b[0] * 1e-3, "quotients": 0.0, "combination": ms_b[1] * 1e-3, "combination_tree": ms_b[2] * 1e-3,
+                       "openings": ms_b[3] * 1e-3, "fri": ms_b[4] * 1e-3 + (t_finish - t_host - sum(ms_b) * 1e-3),
+                       "serialize": time.perf_counter() - t_finish}
+        return proof
+
+    def _terminal_objects(self, terminals):
+        """the five terminals as the OBJECTS the reference pushes (:223-224).  The input and output evaluations both start from ONE zero
+        object (processor_table.py:340-347) and stay that object when the program never reads / writes; pickle then writes the second
+        one as a back-reference.  The running evaluations are sums `evaluation * challenge + lift(symbol)`; the first one is `zero +
+        lift(symbol)`, which returns the lifted symbol's polynomial, and from then on the left operand's coefficients --
+        BaseFieldElements of the VM's BaseField instance (vm.py:70), not of the extension field's own -- decide the field of every
+        result (processor_table.py:390-404, univariate.py:23-35): pickle writes that third BaseField instance out."""
+        xf = self.xfield
+        terminal_objects = [xf.from_limbs(t) for t in terminals]
+        for k, identity in zip((2, 3), self.processor_table.evaluation_terminal_identities):
+            limbs = list(terminals[k])
+            while limbs and limbs[-1] == 0:
+                limbs.pop()
+            if limbs and identity is not None and identity[0] == "object":
+                terminal_objects[k] = ExtensionFieldElement(Polynomial([identity[1]]), xf)
+            elif limbs:
+                base = identity[1] if identity is not None else VirtualMachine.field
+                terminal_objects[k] = ExtensionFieldElement(Polynomial([BaseFieldElement(v, base) for v in limbs]), xf)
+        if not any(terminals[2]) and not any(terminals[3]):
+            terminal_objects[3] = terminal_objects[2]
+        return terminal_objects
+
     def _prove(self, program, processor_matrix, memory_matrix, instruction_matrix, input_matrix, output_matrix, proof_stream=None):
         assert len(processor_matrix) + len(program) == len(instruction_matrix)
+        proof = self._prove_native(program, (processor_matrix, memory_matrix, instruction_matrix, input_matrix, output_matrix), proof_stream)
+        if proof is not None:
+            return proof
         lib, stream = _lib.load(), current_stream()
         xf, n = self.xfield, self.fri.domain.length
         log_n = n.bit_length() - 1
@@ -405,24 +582,7 @@ class BrainfuckStark:
                 quotient_degree_bounds.append(pa.quotient_degree_bound())
 
         lap("quotients")
-        # :223-224.  The input and output evaluations both start from ONE zero object (processor_table.py:340-347) and
-        # stay that object when the program never reads / writes; pickle then writes the second one as a back-reference.
-        # The running evaluations are sums `evaluation * challenge + lift(symbol)`; the first one is `zero + lift(symbol)`,
-        # which returns the lifted symbol's polynomial, and from then on the left operand's coefficients -- BaseFieldElements
-        # of the VM's BaseField instance (vm.py:70), not of the extension field's own -- decide the field of every result
-        # (processor_table.py:390-404, univariate.py:23-35): pickle writes that third BaseField instance out.
-        terminal_objects = [xf.from_limbs(t) for t in terminals]
-        for k, identity in zip((2, 3), self.processor_table.evaluation_terminal_identities):
-            limbs = list(terminals[k])
-            while limbs and limbs[-1] == 0:
-                limbs.pop()
-            if limbs and identity is not None and identity[0] == "object":
-                terminal_objects[k] = ExtensionFieldElement(Polynomial([identity[1]]), xf)
-            elif limbs:
-                base = identity[1] if identity is not None else VirtualMachine.field
-                terminal_objects[k] = ExtensionFieldElement(Polynomial([BaseFieldElement(v, base) for v in limbs]), xf)
-        if not any(terminals[2]) and not any(terminals[3]):
-            terminal_objects[3] = terminal_objects[2]
+        terminal_objects = self._terminal_objects(terminals)          # :223-224
         for t in terminal_objects:
             proof_stream.push(t)
 
