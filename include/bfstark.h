@@ -504,8 +504,8 @@ int bfs_zerofier_inverses_rows(uint32_t log_n, uint64_t offset, uint64_t omega, 
  *   bfs_stark_finish   (:197-336) commits to the zipped extension rows, pushes that root and the five terminal objects, draws the
  *       weights, accumulates the non-linear combination with the quotients folded in, commits to it, samples the indices, pushes the
  *       openings and runs FRI on the combination codeword.
- *       degree_bounds: one per term in the reference's order (base columns, extension columns, quotients table by table, the two
- *       permutation arguments); base_field_id: the BaseField instance the base codewords' elements point at (as bfs_ps_obj_bfe);
+ *       shifts: max_degree - degree bound of every term (:245-293; a quotient that vanishes has bound -1), in the reference's order
+ *       (base columns, extension columns, quotients table by table, the two permutation arguments); base_field_id: the BaseField instance the base codewords' elements point at (as bfs_ps_obj_bfe);
  *       distances: the tables' distinct unit distances in the order the caller's `set` iterates them (:312); out_indices:
  *       security_level indices; out_weights_seed: 32 bytes; out_fri_indices: num_colinearity_checks; out_ms (optional, 5 doubles):
  *       extension tree, combination, its tree + indices, openings, FRI.
@@ -538,7 +538,7 @@ void* bfs_stark_session_new(void);
 void bfs_stark_session_free(void* session);
 int bfs_stark_commit(void* session, void* ps, const bfs_stark_params* params, const bfs_stark_table_in* tables, const bfs_stark_randomness* randomness,
                      uint64_t* out_challenges, uint64_t* out_scan_terminals, uint64_t* out_io_terminals, double* out_ms, void* stream);
-int bfs_stark_finish(void* session, void* ps, const uint64_t* terminal_handles, const uint64_t* terminals, const uint64_t* degree_bounds,
+int bfs_stark_finish(void* session, void* ps, const uint64_t* terminal_handles, const uint64_t* terminals, const uint64_t* shifts,
                      uint32_t num_terms, int32_t base_field_id, const uint64_t* distances, uint32_t n_distances, uint64_t* out_indices,
                      uint8_t* out_weights_seed, uint64_t* out_fri_indices, double* out_ms, void* stream);
 

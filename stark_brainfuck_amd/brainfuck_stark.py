@@ -389,8 +389,7 @@ class BrainfuckStark:
             handles = (_u64 * 5)(*[transcript.to_native(t) for t in terminal_objects])
             bounds = [t.interpolant_degree() for t in self.tables for _ in range(t.base_width)]
             bounds += [t.interpolant_degree() for t in self.tables for _ in range(t.full_width - t.base_width)]
-            quotient_degree_bounds = [b for table in self.tables for b in table.all_quotient_degree_bounds(challenges, terminals)]
-            quotient_degree_bounds += [pa.quotient_degree_bound() for pa in self.permutation_arguments]
+            quotient_degree_bounds = self._quotient_degree_bounds_cached(challenges, terminals)
             bounds += quotient_degree_bounds
             unit_distances = list(set(table.unit_distance(n) for table in self.tables))
             dist = (_u64 * (1 + len(unit_distances)))(0, *unit_distances)
@@ -398,7 +397,7 @@ class BrainfuckStark:
             wseed = ctypes.create_string_buffer(32)
             t_host = time.perf_counter()
             _lib.check(lib.bfs_stark_finish(session, transcript.handle, handles, (_u64 * 15)(*[v for t in terminals for v in t]),
-                                            (_u64 * len(bounds))(*bounds), len(bounds), transcript._field_id(BrainfuckStark.field), dist, len(dist),
+                                            (_u64 * len(bounds))(*[self.max_degree - b for b in bounds]), len(bounds), transcript._field_id(BrainfuckStark.field), dist, len(dist),
                                             out_idx, wseed, out_top, ms_b, stream))
         except Exception:
             proof_stream._cached = None          # native code may have appended objects the Python list does not have
@@ -414,6 +413,34 @@ class BrainfuckStark:
                        "openings": ms_b[3] * 1e-3, "fri": ms_b[4] * 1e-3 + (t_finish - t_host - sum(ms_b) * 1e-3),
                        "serialize": time.perf_counter() - t_finish}
         return proof
+
+    _bounds_cache = {}
+
+    def _quotient_degree_bounds_cached(self, challenges, terminals):
+        """all quotient degree bounds of a proof (:203-221) -- Table.all_quotient_degree_bounds of every table, then the permutation
+        arguments -- remembered per SHAPE of the inputs.  Which monomials of the composed constraints survive depends on the numeric
+        challenges, terminals and parameters only through cancellations (stark_brainfuck_amd/table.py: _degree_bounds); values that
+        look sampled (more than 32 significant bits) behave generically except with negligible probability, small ones (zero, the
+        `iota^0 = 1` of an IO table without padding, a crafted test value) are part of the key as they are.  The per-table code draws the
+        same line but falls back to the exact symbolic expansion whenever ANY value is small -- every proof of a program without input
+        does, 160 us of host time between the two native calls."""
+        values = list(challenges) + list(terminals) + [p for t in self.tables for p in t.air_params(challenges)]
+        sampled = [v for v in values if v[0] >> 32 or v[1] or v[2]]
+        if len(set(sampled)) == len(sampled):
+            key = (tuple(t.height for t in self.tables), tuple(t.length for t in self.tables[3:]),
+                   tuple("s" if (v[0] >> 32 or v[1] or v[2]) else tuple(v) for v in values))
+            hit = BrainfuckStark._bounds_cache.get(key)
+            if hit is not None:
+                return list(hit)
+        else:
+            key = None
+        out = [b for table in self.tables for b in table.all_quotient_degree_bounds(challenges, terminals)]
+        out += [pa.quotient_degree_bound() for pa in self.permutation_arguments]
+        if key is not None:
+            if len(BrainfuckStark._bounds_cache) > 1024:
+                BrainfuckStark._bounds_cache.clear()
+            BrainfuckStark._bounds_cache[key] = tuple(out)
+        return out
 
     def _terminal_objects(self, terminals):
         """the five terminals as the OBJECTS the reference pushes (:223-224).  The input and output evaluations both start from ONE zero

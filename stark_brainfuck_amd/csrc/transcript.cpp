@@ -192,12 +192,30 @@ int bfs_ps_obj_get_limbs(void* ps, uint64_t handle, uint64_t limbs[3]) {
 /* BrainfuckStark.sample_weights (brainfuck_stark.py:104-112): weight i = ExtensionField.sample(blake2b(randomness + bytes(i)).digest()),
  * bytes(i) being i zero bytes; out: 3 * count limbs */
 int bfs_sample_weights(const uint8_t* randomness, size_t len, size_t count, uint64_t* out) {
-    std::vector<unsigned char> msg(len + count, 0);
+    // message i = randomness followed by i zero bytes: all messages share their full 128-byte blocks with the longer ones, so the
+    // chaining value after k full blocks is computed once (a proof draws ~300 weights from messages of up to three blocks: one
+    // compression per weight instead of up to three)
+    std::vector<unsigned char> msg(len + count + 128, 0);
     if (len) memcpy(msg.data(), randomness, len);
+    u64 chain[8];                                           // state after `full` blocks of the common prefix
+    blake2b_init(chain);
+    size_t full = 0;
     for (size_t i = 0; i < count; ++i) {
-        unsigned char digest[64];
-        blake2b_host(msg.data(), len + i, digest);
-        const Xfe x = rp::sample_xfe(digest, 64);          // three chunks of 64 // 3 = 21 bytes; the 64th byte is not used
+        const size_t L = len + i;
+        // blocks before the last one: a message of L bytes has ceil(L / 128) blocks (one, empty, for L = 0); the last is final
+        const size_t before = L ? (L - 1) / 128 : 0;
+        while (full < before) {
+            u64 m[16];
+            memcpy(m, msg.data() + 128 * full, 128);
+            ++full;
+            blake2b_compress(chain, m, 128 * full, false);
+        }
+        u64 h[8], m[16];
+        memcpy(h, chain, sizeof h);
+        memset(m, 0, sizeof m);
+        if (L - 128 * before) memcpy(m, msg.data() + 128 * before, L - 128 * before);
+        blake2b_compress(h, m, L, true);
+        const Xfe x = rp::sample_xfe((const unsigned char*)h, 64);          // three chunks of 64 // 3 = 21 bytes; the 64th byte is not used
         for (int k = 0; k < 3; ++k) out[3 * i + k] = x.c[k];
     }
     return BFS_OK;

@@ -11,7 +11,7 @@ running_time, inp, out = VirtualMachine.run(program)
 pm, mm, im, inm, om = VirtualMachine.simulate(program, input_data=inp)
 t1 = time.perf_counter()
 stark = BrainfuckStark(running_time, len(mm), program, inp, out)
-stark.stage_timing = True
+stark.stage_timing = os.environ.get("STAGE_TIMING", "0") == "1"      # 1: synchronise after every stage (Python path); 0: the production path
 t2 = time.perf_counter()
 print("running time %d, memory rows %d, FRI domain 2^%d, setup %.3f s (vm %.3f s)" % (running_time, len(mm), stark.fri.domain.length.bit_length() - 1, t2 - t1, t1 - t0), flush=True)
 reps = int(os.environ.get("REPS", "3"))
