@@ -25,6 +25,8 @@
 
 #include <chrono>
 #include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 using namespace bfs;
@@ -84,6 +86,14 @@ struct StarkSession {
     bool have_ext_salt_seed = false;
     bool committed = false;
     hipStream_t stream = nullptr;
+    // The commitment to the zipped extension rows is the first thing bfs_stark_finish needs and depends on nothing the caller does
+    // between the two calls, so bfs_stark_commit hands it to a thread of its own: the GPU hashes rows while the caller's interpreter
+    // makes terminal objects and degree bounds.  Joined by bfs_stark_finish (or by whatever ends the session first).
+    std::thread ext_tree_thread;
+    int ext_tree_rc = BFS_OK;
+    std::string ext_tree_error;
+    uint8_t ext_root[64];
+    void join_ext_tree() { if (ext_tree_thread.joinable()) ext_tree_thread.join(); }
     // Side streams.  At the sizes where this driver matters the kernels of a proof are small (10-20 us, a handful of workgroups) and
     // queue faster than they run, so independent chains -- the randomizer's sampling + transform, each table's interpolation +
     // randomizer correction -- run side by side instead of one after the other: fork / join with events around them.
@@ -113,7 +123,7 @@ struct StarkSession {
         if (fork_ev) { (void)hipEventDestroy(fork_ev); fork_ev = nullptr; }
         if (rand_ev) { (void)hipEventDestroy(rand_ev); rand_ev = nullptr; }
     }
-    ~StarkSession() { drop_streams(); }
+    ~StarkSession() { join_ext_tree(); drop_streams(); }
 };
 
 u64 padding_length(u64 rows) {                              // table.py: rows to add so that the count becomes a power of two (0 and 2^k stay)
@@ -179,6 +189,7 @@ int bfs_stark_commit(void* session, void* ps, const bfs_stark_params* params, co
     StarkSession& S = *(StarkSession*)session;
     hipStream_t stream = (hipStream_t)stream_;
     const double t0 = now_ms();
+    S.join_ext_tree();                                     // (a commit that was never finished)
     S.P = *params;
     S.stream = stream;
     S.committed = false;
@@ -449,6 +460,32 @@ int bfs_stark_commit(void* session, void* ps, const bfs_stark_params* params, co
     if (rnd->ext_salt_seed) memcpy(S.ext_salt_seed, rnd->ext_salt_seed, 32);
     else if (rnd->ext_salts) S.ext_salts_host.assign(rnd->ext_salts, rnd->ext_salts + 24 * n);
     else { set_error("bfs_stark_commit: no salts for the extension commitment"); return BFS_ERR_BAD_ARG; }
+    // ---- commitment to the zipped extension rows (brainfuck_stark.py:197-198), on a thread of its own (see StarkSession)
+    BFS_TRY(S.ext_nodes.get(2 * n * 64, stream));
+    if (S.have_ext_salt_seed) {
+        const u64 words = (3 * n + 7) / 8 * 8;
+        BFS_TRY(S.ext_salts_dev.get(words * 8, stream));
+        BFS_TRY(bfs_random_fill(S.ext_salt_seed, S.ext_salts_dev.words(), words, stream));
+        S.ext_salts_on_device = true;
+    } else {
+        S.ext_salts_on_device = false;
+    }
+    {
+        int dev = 0;
+        BFS_HIP(hipGetDevice(&dev));
+        StarkSession* sp = &S;
+        S.ext_tree_rc = BFS_OK;
+        S.ext_tree_thread = std::thread([sp, dev, n, stream] {
+            StarkSession& T = *sp;
+            if (hipSetDevice(dev) != hipSuccess) { T.ext_tree_rc = BFS_ERR_HIP; T.ext_tree_error = "hipSetDevice failed on the commitment thread"; return; }
+            bfs_row_column cols[32];
+            u32 nc = 0;
+            for (u32 c = 0; c < T.total_ext; ++c) cols[nc++] = bfs_row_column{T.ext_cw.words() + 3ull * c * n, 1, 0};
+            const uint8_t* salts = T.ext_salts_on_device ? (const uint8_t*)T.ext_salts_dev.ptr : T.ext_salts_host.data();
+            T.ext_tree_rc = bfs_merkle_build_rows_root(cols, nc, n, n, salts, T.ext_salts_on_device ? 1 : 0, (uint8_t*)T.ext_nodes.ptr, T.ext_root, stream);
+            if (T.ext_tree_rc != BFS_OK) T.ext_tree_error = bfs_last_error();
+        });
+    }
     S.committed = true;
     guard.ok = true;
     if (out_ms) {
@@ -469,22 +506,10 @@ int bfs_stark_finish(void* session, void* ps, const uint64_t* terminal_handles, 
     const double t0 = now_ms();
     const bfs_stark_params& P = S.P;
     const u64 n = S.n, offset = P.offset, omega = P.omega;
-    // ---- commitment to the zipped extension rows (brainfuck_stark.py:197-198), terminals (:223-224)
-    bfs_row_column cols[32];
-    u32 nc = 0;
-    for (u32 c = 0; c < S.total_ext; ++c) cols[nc++] = bfs_row_column{S.ext_cw.words() + 3ull * c * n, 1, 0};
-    BFS_TRY(S.ext_nodes.get(2 * n * 64, stream));
-    uint8_t root[64];
-    if (S.have_ext_salt_seed) {
-        const u64 words = (3 * n + 7) / 8 * 8;
-        BFS_TRY(S.ext_salts_dev.get(words * 8, stream));
-        BFS_TRY(bfs_random_fill(S.ext_salt_seed, S.ext_salts_dev.words(), words, stream));
-        S.ext_salts_on_device = true;
-        BFS_TRY(bfs_merkle_build_rows_root(cols, nc, n, n, (const uint8_t*)S.ext_salts_dev.ptr, 1, (uint8_t*)S.ext_nodes.ptr, root, stream));
-    } else {
-        S.ext_salts_on_device = false;
-        BFS_TRY(bfs_merkle_build_rows_root(cols, nc, n, n, S.ext_salts_host.data(), 0, (uint8_t*)S.ext_nodes.ptr, root, stream));
-    }
+    // ---- the commitment to the zipped extension rows was started by bfs_stark_commit; its root, then the terminals (:197-224)
+    S.join_ext_tree();
+    if (S.ext_tree_rc != BFS_OK) { set_error("%s", S.ext_tree_error.c_str()); return S.ext_tree_rc; }
+    const uint8_t* root = S.ext_root;
     {
         const uint64_t h = bfs_ps_obj_bytes(ps, root, 64);
         BFS_TRY(bfs_ps_push(ps, h));
