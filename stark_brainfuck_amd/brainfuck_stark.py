@@ -266,14 +266,28 @@ class BrainfuckStark:
     # ---- the production path: the stages between the Fiat-Shamir points run natively (csrc/prover.cpp), two calls per proof
     native_stages = True            # False: every stage is driven from Python (the path below; what the tests compare the native one with)
 
-    def _native_session(self):
-        lib = _lib.load()
-        s = getattr(self, "_stark_session", None)
-        if s is None:
-            import weakref
-            s = self._stark_session = lib.bfs_stark_session_new()
-            weakref.finalize(self, lib.bfs_stark_session_free, s)
-        return s
+    _thread_sessions = None         # threading.local: one native session per proving THREAD (created on first use, freed with the thread)
+
+    @staticmethod
+    def _native_session():
+        """the calling thread's bfs_stark session.  A session owns side streams, events and scratch buffers (csrc/prover.cpp), which
+        cost far more to make than a small proof takes, so it belongs to the thread, not to the BrainfuckStark object: provers are
+        made per claim (running time, program, symbols) and thrown away, threads stay."""
+        import threading
+        import weakref
+        if BrainfuckStark._thread_sessions is None:
+            BrainfuckStark._thread_sessions = threading.local()
+        local = BrainfuckStark._thread_sessions
+        holder = getattr(local, "holder", None)
+        if holder is None:
+            lib = _lib.load()
+
+            class _Holder:
+                pass
+            holder = local.holder = _Holder()
+            holder.session = lib.bfs_stark_session_new()
+            weakref.finalize(holder, lib.bfs_stark_session_free, holder.session)
+        return holder.session
 
     @staticmethod
     def _matrix_values(matrix, width):
@@ -362,7 +376,7 @@ class BrainfuckStark:
         tabs = (_lib.StarkTableIn * 5)()
         for slot, v in zip(tabs, values):
             slot.values, slot.rows, slot.row_stride = (v.ctypes.data if v.shape[0] else None), v.shape[0], (v.shape[1] if v.shape[0] else 0)
-        session = self._native_session()
+        session = BrainfuckStark._native_session()
         before = transcript.num_objects()
         out_ch, out_scan, out_io = (_u64 * 33)(), (_u64 * 27)(), (_u64 * 6)()
         ms_a, ms_b = (ctypes.c_double * 5)(), (ctypes.c_double * 5)()
@@ -407,8 +421,8 @@ class BrainfuckStark:
         proof = proof_stream.serialize()
         self._last = {"challenges": challenges, "terminals": terminals, "indices": [int(v) for v in out_idx[:self.security_level]],
                       "weights_seed": wseed.raw, "quotient_degree_bounds": quotient_degree_bounds}
-        self.timing = {"pad": ms_a[0] * 1e-3 + (t_commit - t_begin - sum(ms_a) * 1e-3), "randomizer": 0.0, "base_lde": ms_a[1] * 1e-3,
-                       "base_tree": ms_a[2] * 1e-3, "extend": ms_a[3] * 1e-3, "ext_lde": ms_a[4] * 1e-3 + (t_host - t_commit),
+        self.timing = {"host_prepare": t_commit - t_begin - sum(ms_a) * 1e-3, "pad": ms_a[0] * 1e-3, "randomizer": 0.0, "base_lde": ms_a[1] * 1e-3,
+                       "base_tree": ms_a[2] * 1e-3, "extend": ms_a[3] * 1e-3, "ext_lde": ms_a[4] * 1e-3, "host_between_calls": t_host - t_commit,
                        "ext_tree": ms_b[0] * 1e-3, "quotients": 0.0, "combination": ms_b[1] * 1e-3, "combination_tree": ms_b[2] * 1e-3,
                        "openings": ms_b[3] * 1e-3, "fri": ms_b[4] * 1e-3 + (t_finish - t_host - sum(ms_b) * 1e-3),
                        "serialize": time.perf_counter() - t_finish}
