@@ -182,9 +182,16 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
     rp::Transcript::Lookahead look;
     static const bool lookahead_on = getenv("BFS_FRI_LOOKAHEAD") == nullptr || atoi(getenv("BFS_FRI_LOOKAHEAD")) != 0;
     static const bool trace = getenv("BFS_FRI_TRACE") != nullptr;      // development aid: host timeline of every round on stderr
-    const double t_look = trace ? now_ms() : 0;
-    const bool looking = lookahead_on && R >= 3 && ps.lookahead_begin(look, R - 2);
-    if (trace) fprintf(stderr, "fri look-ahead %s: %.1f us, %zu objects in front\n", looking ? "on" : "off", 1e3 * (now_ms() - t_look), ps.objects.size());      // development aid: host timeline of every round on stderr
+    // (begun behind round 1's launch, below: laying out the R - 2 pickles takes ~50 us with a STARK proof's openings in front, and
+    //  nothing is pushed before round 1's root -- so the GPU hashes round 1 meanwhile instead of waiting for it)
+    bool looking = false, look_begun = false;
+    auto begin_lookahead = [&]() {
+        if (look_begun) return;
+        look_begun = true;
+        const double t_look = trace ? now_ms() : 0;
+        looking = lookahead_on && R >= 3 && ps.lookahead_begin(look, R - 2);
+        if (trace) fprintf(stderr, "fri look-ahead %s: %.1f us, %zu objects in front\n", looking ? "on" : "off", 1e3 * (now_ms() - t_look), ps.objects.size());
+    };
     for (u32 r = 0; r < R; ++r) {
         FriRound& fr = S.rounds[r];
         unsigned char seed[32];
@@ -199,6 +206,7 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
             BFS_TRY(fri_round_fused_launch(pending, (u64*)fr.cw, fr.stride, fr.length, fr.nodes, stream, S.mailbox.dev, seq));
             pending.in = nullptr;
             if (trace) t_launched = now_ms();
+            if (r >= 1) begin_lookahead();
             if (r + 1 < R) {
                 if (r == 0) { ps.fiat_shamir(ps.objects.size(), seed, 32); have_seed = true; }
                 else if (!looking) { ps.speculate(speculation); speculating = true; }
@@ -231,6 +239,7 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
             // of KB -- as long as the tree kernels of the late rounds.  Everything in front of the root's 64 bytes is known already,
             // so the sponge absorbs it now and only the last block or two wait for the root.
             if (trace) t_launched = now_ms();
+            if (r >= 1) begin_lookahead();
             if (r + 1 < R) {
                 if (r == 0) { ps.fiat_shamir(ps.objects.size(), seed, 32); have_seed = true; }
                 else if (!looking) { ps.speculate(speculation); speculating = true; }
@@ -248,6 +257,7 @@ int fri_commit(FriSession& S, rp::Transcript& ps, const u64* d_cw, u64 stride, u
             memcpy(fr.root, S.mailbox.host, 64);
         } else {
             BFS_TRY(merkle_build_xfe_launch(fr.cw, fr.stride, fr.length, fr.nodes, stream));
+            if (r >= 1) begin_lookahead();
             BFS_HIP(hipMemcpyAsync(fr.root, fr.nodes + 8, 64, hipMemcpyDeviceToHost, stream));
             BFS_HIP(hipStreamSynchronize(stream));
         }
