@@ -289,6 +289,28 @@ def test_bench_with_two_ranks_on_one_gpu():
     assert line["roots_sha256"]
 
 
+def test_bench_with_eight_ranks_on_one_gpu():
+    """the rank count the driver's scaling run uses (`bench.py --gpus 8`): eight ranks share this box's one GPU and exchange over gloo.
+    One column per rank (`columns_per_gpu [1] * 8`, shard.assign_columns), every replica leg all-gathered over eight ranks, the roots
+    of all eight columns gathered, and the cooperative proof of world size 8 (row ranges of 1/8 of the domain, eight subtree roots)
+    equal to what verify() accepts.  No scaling number comes out of this -- it exercises the code path at the driver's world size."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--total-columns", "8", "--log-n", "20", "--no-cpu", "--spinup-ms", "0", "--cooperative", "--no-single", "--no-concurrent"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BFS_BENCH_BACKEND="gloo", BFS_BENCH_DEVICE="0")
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=2400, cwd=ROOT)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["config"]["columns_per_gpu"] == [1] * 8
+    assert line["rccl_ranks_seen"] == 8 and len(line["rank_devices"]) == 8
+    assert len(line["fri_prove"]["replicas"]["per_gpu_ms"]) == 8 and len(line["stark_prove"]["replicas"]["per_gpu_ms"]) == 8
+    assert line["stark_prove"]["verified"] is True
+    assert line["stark_prove_cooperative"]["ranks"] == 8 and line["stark_prove_cooperative"]["verified"] is True
+    assert line["guard"]["columns_round_tripped"] == 1 and line["roots_sha256"]
+
+
 def test_plain_bench_command_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it (what a driver that reuses its N = 1 command line runs): bench.py starts
     the two ranks itself under torch.distributed.run and rank 0's JSON line arrives on the caller's stdout; the cooperative proof runs as

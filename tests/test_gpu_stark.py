@@ -284,7 +284,8 @@ def test_stage_timing_changes_the_timing_not_the_proof(monkeypatch):
         proofs.append(stark.prove(program, *matrices))
         stages.append(list(stark.timing))
         assert all(v >= 0 for v in stark.timing.values())
-    assert proofs[0] == proofs[1] and stages[0] == stages[1]
+    # (the unstaged proof takes the native stage driver, which also reports the host time in front of and between its two calls)
+    assert proofs[0] == proofs[1] and [s for s in stages[0] if not s.startswith("host_")] == stages[1]
     assert {"base_lde", "base_tree", "ext_tree", "combination", "fri"} <= set(stages[0])
     assert BrainfuckStark.stage_timing is False
 

@@ -1,0 +1,140 @@
+// valu_rate.hip -- issue cost of the integer VALU opcode classes the NTT kernels are made of, on gfx950 (development tool; run through
+// gpurun: hipcc --offload-arch=gfx950 -O3 -o valu_rate valu_rate.hip && ./valu_rate).
+//
+// Question (round-4 verdict, next #5b): the roofline accounting prices one wave64 VALU instruction at 4 SIMD cycles (16 lanes per
+// clock), while the micro-architecture guide has a "2 cycles (SIMD-32)" line.  Which is it for the opcodes this code uses, and is
+// v_lshl_add_u64 -- a 64-bit add without a carry-out -- cheaper than the v_add_co / v_addc_co pair?
+//
+// Method: every thread runs N unrolled instructions of ONE class over EIGHT independent dependency chains (so that instruction latency
+// never limits a wave), W waves per SIMD (W = 1, 2, 4, 6, 8) on every SIMD of the chip, and wave 0 of every workgroup reads the shader
+// clock (s_memtime) around the block.  cycles per wave-instruction = (clock after - clock before) * (waves on the SIMD that issue) / N
+// ... reported as the time a SIMD is busy per wave-instruction: with W waves sharing a SIMD, one wave's N instructions take W * c * N
+// cycles when the SIMD is the limit, so c = delta / (W * N).  The clock counter runs at the shader clock, so no rocm-smi sample enters.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+enum Op { ADD_U32, XOR_B32, ADD_CO_PAIR, LSHL_ADD_U64, CNDMASK, MAD_U64_U32, SUBB_SGPR, MUL_LO_U32, ALIGNBIT, ADD_LAZY4, OPS };
+static const char* NAMES[OPS] = {"v_add_u32", "v_xor_b32", "v_add_co_u32 + v_addc_co_u32 (vcc)", "v_lshl_add_u64", "v_cndmask_b32 (vcc)",
+                                 "v_mad_u64_u32", "v_sub_co + s_nop 1 + v_subb_co (SGPR pair)", "v_mul_lo_u32", "v_alignbit_b32",
+                                 "gl_add_lazy shape: add_co, addc_co, cndmask, add_co... (4 instr)"};
+static const int INSTR_PER_STEP[OPS] = {1, 1, 2, 1, 1, 1, 2, 1, 1, 4};
+
+// one step = the class applied to chain k.  Everything is inline asm (volatile) so the compiler neither folds nor reorders the work;
+// the loop is unrolled by hand through the macro below.
+template <int OP>
+__device__ __forceinline__ void step(uint32_t& lo, uint32_t& hi, uint32_t c) {
+    if (OP == ADD_U32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(lo) : "v"(c));
+    else if (OP == XOR_B32) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(lo) : "v"(c));
+    else if (OP == ADD_CO_PAIR) asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %2, vcc" : "+v"(lo), "+v"(hi) : "v"(c) : "vcc");
+    else if (OP == LSHL_ADD_U64) {
+        uint64_t x = ((uint64_t)hi << 32) | lo, y = c;
+        asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(x) : "v"(y));
+        lo = (uint32_t)x; hi = (uint32_t)(x >> 32);
+    } else if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(lo) : "v"(c) : "vcc");
+    else if (OP == MAD_U64_U32) {
+        uint64_t x = ((uint64_t)hi << 32) | lo;
+        asm volatile("v_mad_u64_u32 %0, s[40:41], %1, %2, %0" : "+v"(x) : "v"(lo), "v"(c) : "s40", "s41");
+        lo = (uint32_t)x; hi = (uint32_t)(x >> 32);
+    } else if (OP == SUBB_SGPR) asm volatile("v_sub_co_u32 %0, s[42:43], %0, %2\n\ts_nop 1\n\tv_subb_co_u32 %1, s[42:43], %1, %2, s[42:43]"
+                                             : "+v"(lo), "+v"(hi) : "v"(c) : "s42", "s43");
+    else if (OP == MUL_LO_U32) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(lo) : "v"(c));
+    else if (OP == ALIGNBIT) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(lo) : "v"(hi));
+    else if (OP == ADD_LAZY4) asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %2, vcc\n\tv_cndmask_b32 %0, %0, %2, vcc\n\tv_add_co_u32 %0, vcc, %0, %1"
+                                           : "+v"(lo), "+v"(hi) : "v"(c) : "vcc");
+}
+
+constexpr int CHAINS = 8, ROUNDS = 256;              // ROUNDS * CHAINS steps per thread, fully unrolled (2048 steps)
+
+template <int OP>
+__global__ void __launch_bounds__(64) rate_kernel(uint64_t* cycles, uint32_t* sink, uint32_t seed) {
+    uint32_t lo[CHAINS], hi[CHAINS];
+#pragma unroll
+    for (int k = 0; k < CHAINS; ++k) { lo[k] = seed * (k + 3) + threadIdx.x; hi[k] = seed ^ (k * 2654435761u); }
+    const uint32_t c = seed | 1;
+    __builtin_amdgcn_s_barrier();
+    const uint64_t t0 = __builtin_readcyclecounter();
+#pragma unroll
+    for (int r = 0; r < ROUNDS; ++r) {
+#pragma unroll
+        for (int k = 0; k < CHAINS; ++k) step<OP>(lo[k], hi[k], c);
+    }
+    const uint64_t t1 = __builtin_readcyclecounter();
+    uint32_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < CHAINS; ++k) acc ^= lo[k] ^ hi[k];
+    sink[(size_t)blockIdx.x * 64 + threadIdx.x] = acc;
+    if (threadIdx.x == 0) cycles[blockIdx.x] = t1 - t0;
+}
+
+template <int OP>
+void run(int waves_per_simd, uint64_t* d_cycles, uint32_t* d_sink, int num_cu) {
+    // one-wave workgroups; waves_per_simd * 4 SIMDs * num_cu of them fill every SIMD W deep (the dispatcher spreads workgroups
+    // round-robin over the CUs and their SIMDs)
+    const int blocks = waves_per_simd * 4 * num_cu;
+    hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(64), 0, 0, d_cycles, d_sink, 12345u);     // warm-up (code cache, clocks)
+    hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(64), 0, 0, d_cycles, d_sink, 12345u);
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+    CK(hipEventRecord(a));
+    hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(64), 0, 0, d_cycles, d_sink, 777u);
+    CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    std::vector<uint64_t> h(blocks);
+    CK(hipMemcpy(h.data(), d_cycles, blocks * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    std::sort(h.begin(), h.end());
+    const double med = (double)h[blocks / 2];
+    const double instr = (double)ROUNDS * CHAINS * INSTR_PER_STEP[OP];
+    printf("  W = %d waves/SIMD: median %9.0f clock ticks per wave for %5.0f instructions -> %6.3f ticks per wave-instruction per SIMD slot (%.3f ms)\n",
+           waves_per_simd, med, instr, med / (waves_per_simd * instr), ms);
+    CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
+}
+
+template <int OP>
+void sweep(uint64_t* d_cycles, uint32_t* d_sink, int num_cu) {
+    printf("%s\n", NAMES[OP]);
+    for (int w : {1, 2, 4, 6, 8}) run<OP>(w, d_cycles, d_sink, num_cu);
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    const int num_cu = prop.multiProcessorCount;
+    printf("%s, %d CUs, clockRate %d kHz (the tick counter below is s_memtime: it runs at a constant rate -- see the calibration line)\n", prop.name, num_cu, prop.clockRate);
+    uint64_t* d_cycles; uint32_t* d_sink;
+    CK(hipMalloc(&d_cycles, 8 * 4 * num_cu * sizeof(uint64_t)));
+    CK(hipMalloc(&d_sink, (size_t)8 * 4 * num_cu * 64 * sizeof(uint32_t)));
+    // calibration: ticks of the in-kernel counter per millisecond of a long kernel (so ticks can be turned into time, and with the
+    // sampled shader clock into cycles)
+    {
+        hipEvent_t a, b;
+        CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        hipLaunchKernelGGL(rate_kernel<MAD_U64_U32>, dim3(4 * num_cu * 8), dim3(64), 0, 0, d_cycles, d_sink, 1u);
+        CK(hipEventRecord(a));
+        hipLaunchKernelGGL(rate_kernel<MAD_U64_U32>, dim3(4 * num_cu * 8), dim3(64), 0, 0, d_cycles, d_sink, 1u);
+        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
+        float ms; CK(hipEventElapsedTime(&ms, a, b));
+        std::vector<uint64_t> h(4 * num_cu * 8);
+        CK(hipMemcpy(h.data(), d_cycles, h.size() * 8, hipMemcpyDeviceToHost));
+        std::sort(h.begin(), h.end());
+        printf("calibration: a kernel of %.3f ms (events) shows %llu ticks in its median wave: <= %.1f MHz tick rate if the wave ran the whole time\n", ms,
+               (unsigned long long)h[h.size() / 2], h[h.size() / 2] / (ms * 1e3));
+    }
+    sweep<ADD_U32>(d_cycles, d_sink, num_cu);
+    sweep<XOR_B32>(d_cycles, d_sink, num_cu);
+    sweep<ADD_CO_PAIR>(d_cycles, d_sink, num_cu);
+    sweep<LSHL_ADD_U64>(d_cycles, d_sink, num_cu);
+    sweep<CNDMASK>(d_cycles, d_sink, num_cu);
+    sweep<MAD_U64_U32>(d_cycles, d_sink, num_cu);
+    sweep<SUBB_SGPR>(d_cycles, d_sink, num_cu);
+    sweep<MUL_LO_U32>(d_cycles, d_sink, num_cu);
+    sweep<ALIGNBIT>(d_cycles, d_sink, num_cu);
+    sweep<ADD_LAZY4>(d_cycles, d_sink, num_cu);
+    return 0;
+}

@@ -17,7 +17,7 @@ for TL in $TILES; do
   find "$OUT/raw$TL" -name "*kernel_trace.csv" -exec sh -c 'head -1 "$1" > "$2"; tail -90 "$1" >> "$2"' _ {} "$OUT/ntt_only_kernel_trace_tail_tile$TL.csv" \;
   rm -rf "$OUT/raw$TL"
   if [ "${PMC:-0}" = "1" ]; then
-    for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT; do
+    for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_ACTIVE_INST_ANY; do
       rocprofv3 --pmc $C --output-format csv -d "$OUT/pmc$TL$C" -o ntt -- python "$ROOT/tools/ntt_only.py" --steps 3 --warmup 1 --no-check > /dev/null 2>&1
       find "$OUT/pmc$TL$C" -name "*counter_collection.csv" -exec python "$ROOT/tools/pmc_summary.py" {} $C \; >> "$OUT/ntt_only_pmc_tile$TL.txt"
       rm -rf "$OUT/pmc$TL$C"
