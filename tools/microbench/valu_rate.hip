@@ -5,11 +5,12 @@
 // clock), while the micro-architecture guide has a "2 cycles (SIMD-32)" line.  Which is it for the opcodes this code uses, and is
 // v_lshl_add_u64 -- a 64-bit add without a carry-out -- cheaper than the v_add_co / v_addc_co pair?
 //
-// Method: every thread runs N unrolled instructions of ONE class over EIGHT independent dependency chains (so that instruction latency
-// never limits a wave), W waves per SIMD (W = 1, 2, 4, 6, 8) on every SIMD of the chip, and wave 0 of every workgroup reads the shader
-// clock (s_memtime) around the block.  cycles per wave-instruction = (clock after - clock before) * (waves on the SIMD that issue) / N
-// ... reported as the time a SIMD is busy per wave-instruction: with W waves sharing a SIMD, one wave's N instructions take W * c * N
-// cycles when the SIMD is the limit, so c = delta / (W * N).  The clock counter runs at the shader clock, so no rocm-smi sample enters.
+// Method: every thread runs a long block of ONE instruction class over EIGHT independent dependency chains (so that instruction
+// latency never limits a wave), W one-wave workgroups per SIMD (W = 1, 2, 4, 6, 8) on every SIMD of the chip, kernels of milliseconds
+// (every wave resident for the whole kernel).  Reported: the chip-wide rate in wave-instructions per second (HIP events), the same per
+// SIMD and per cycle of the in-kernel counter (s_memtime; its rate is measured against the events: median wave ticks / kernel time),
+// and the ticks one wave spends per instruction.  If a SIMD retires one wave64 instruction per 4 cycles the per-SIMD figure saturates
+// at 0.25 per cycle; at 2 cycles (32 lanes per clock) at 0.5.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>
@@ -51,18 +52,22 @@ __device__ __forceinline__ void step(uint32_t& lo, uint32_t& hi, uint32_t c) {
 
 constexpr int CHAINS = 8, ROUNDS = 256;              // ROUNDS * CHAINS steps per thread, fully unrolled (2048 steps)
 
+constexpr int OUTER = 200;                          // the unrolled block is repeated: kernels of milliseconds, every wave resident throughout
+
 template <int OP>
-__global__ void __launch_bounds__(64) rate_kernel(uint64_t* cycles, uint32_t* sink, uint32_t seed) {
+__global__ void __launch_bounds__(64) rate_kernel(uint64_t* cycles, uint32_t* sink, uint32_t seed, int outer) {
     uint32_t lo[CHAINS], hi[CHAINS];
 #pragma unroll
     for (int k = 0; k < CHAINS; ++k) { lo[k] = seed * (k + 3) + threadIdx.x; hi[k] = seed ^ (k * 2654435761u); }
     const uint32_t c = seed | 1;
     __builtin_amdgcn_s_barrier();
     const uint64_t t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < outer; ++it) {
 #pragma unroll
-    for (int r = 0; r < ROUNDS; ++r) {
+        for (int r = 0; r < ROUNDS; ++r) {
 #pragma unroll
-        for (int k = 0; k < CHAINS; ++k) step<OP>(lo[k], hi[k], c);
+            for (int k = 0; k < CHAINS; ++k) step<OP>(lo[k], hi[k], c);
+        }
     }
     const uint64_t t1 = __builtin_readcyclecounter();
     uint32_t acc = 0;
@@ -74,15 +79,14 @@ __global__ void __launch_bounds__(64) rate_kernel(uint64_t* cycles, uint32_t* si
 
 template <int OP>
 void run(int waves_per_simd, uint64_t* d_cycles, uint32_t* d_sink, int num_cu) {
-    // one-wave workgroups; waves_per_simd * 4 SIMDs * num_cu of them fill every SIMD W deep (the dispatcher spreads workgroups
-    // round-robin over the CUs and their SIMDs)
+    // one-wave workgroups, waves_per_simd * 4 * num_cu of them: with kernels of milliseconds they are all resident at once, W per
+    // SIMD (a CU takes up to 8 waves per SIMD; the dispatcher fills CUs and SIMDs evenly)
     const int blocks = waves_per_simd * 4 * num_cu;
-    hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(64), 0, 0, d_cycles, d_sink, 12345u);     // warm-up (code cache, clocks)
-    hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(64), 0, 0, d_cycles, d_sink, 12345u);
+    hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(64), 0, 0, d_cycles, d_sink, 12345u, 20);     // warm-up (code cache, clocks)
     hipEvent_t a, b;
     CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
     CK(hipEventRecord(a));
-    hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(64), 0, 0, d_cycles, d_sink, 777u);
+    hipLaunchKernelGGL(rate_kernel<OP>, dim3(blocks), dim3(64), 0, 0, d_cycles, d_sink, 777u, OUTER);
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float ms = 0;
     CK(hipEventElapsedTime(&ms, a, b));
@@ -90,9 +94,12 @@ void run(int waves_per_simd, uint64_t* d_cycles, uint32_t* d_sink, int num_cu) {
     CK(hipMemcpy(h.data(), d_cycles, blocks * sizeof(uint64_t), hipMemcpyDeviceToHost));
     std::sort(h.begin(), h.end());
     const double med = (double)h[blocks / 2];
-    const double instr = (double)ROUNDS * CHAINS * INSTR_PER_STEP[OP];
-    printf("  W = %d waves/SIMD: median %9.0f clock ticks per wave for %5.0f instructions -> %6.3f ticks per wave-instruction per SIMD slot (%.3f ms)\n",
-           waves_per_simd, med, instr, med / (waves_per_simd * instr), ms);
+    const double instr = (double)OUTER * ROUNDS * CHAINS * INSTR_PER_STEP[OP];
+    // chip-wide: wave-instructions per second, and what one SIMD spends per wave-instruction if the clock was `mhz`
+    const double rate = (double)blocks * instr / (ms * 1e-3);
+    const double tick_mhz = med / (ms * 1e3);            // the median wave runs (almost) the whole kernel
+    printf("  W = %d: kernel %7.3f ms, %6.1f G wave-instr/s chip-wide = %5.3f per SIMD per tick-counter cycle (counter %.0f MHz); one wave: %.2f ticks per instruction\n",
+           waves_per_simd, ms, rate / 1e9, rate / (4.0 * num_cu) / (tick_mhz * 1e6), tick_mhz, med / instr);
     CK(hipEventDestroy(a)); CK(hipEventDestroy(b));
 }
 
@@ -110,22 +117,6 @@ int main() {
     uint64_t* d_cycles; uint32_t* d_sink;
     CK(hipMalloc(&d_cycles, 8 * 4 * num_cu * sizeof(uint64_t)));
     CK(hipMalloc(&d_sink, (size_t)8 * 4 * num_cu * 64 * sizeof(uint32_t)));
-    // calibration: ticks of the in-kernel counter per millisecond of a long kernel (so ticks can be turned into time, and with the
-    // sampled shader clock into cycles)
-    {
-        hipEvent_t a, b;
-        CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
-        hipLaunchKernelGGL(rate_kernel<MAD_U64_U32>, dim3(4 * num_cu * 8), dim3(64), 0, 0, d_cycles, d_sink, 1u);
-        CK(hipEventRecord(a));
-        hipLaunchKernelGGL(rate_kernel<MAD_U64_U32>, dim3(4 * num_cu * 8), dim3(64), 0, 0, d_cycles, d_sink, 1u);
-        CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
-        float ms; CK(hipEventElapsedTime(&ms, a, b));
-        std::vector<uint64_t> h(4 * num_cu * 8);
-        CK(hipMemcpy(h.data(), d_cycles, h.size() * 8, hipMemcpyDeviceToHost));
-        std::sort(h.begin(), h.end());
-        printf("calibration: a kernel of %.3f ms (events) shows %llu ticks in its median wave: <= %.1f MHz tick rate if the wave ran the whole time\n", ms,
-               (unsigned long long)h[h.size() / 2], h[h.size() / 2] / (ms * 1e3));
-    }
     sweep<ADD_U32>(d_cycles, d_sink, num_cu);
     sweep<XOR_B32>(d_cycles, d_sink, num_cu);
     sweep<ADD_CO_PAIR>(d_cycles, d_sink, num_cu);
