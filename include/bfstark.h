@@ -185,6 +185,13 @@ int bfs_ps_fiat_shamir(void* ps, size_t count, uint8_t* out, size_t num_bytes);
  * are offered to the library's helper threads; a later bfs_ps_fiat_shamir(ps, counts[i], ..., num_bytes) picks the result up (or
  * computes it itself when no helper has got to it).  Returns how many were offered (0 without helper threads: not an error). */
 size_t bfs_ps_prefetch_fiat_shamir(void* ps, const size_t* counts, size_t n, size_t num_bytes);
+/* Merkle.verify / SaltedMerkle.verify (merkle.py:54-63, salted_merkle.py:55-68) on objects of this stream, natively: leaf =
+ * blake2b(pickle.dumps(element) [+ pickle.dumps(salt)]; salt_handle 0 = unsalted), then the path (a list of byte strings) folded by the
+ * parity of `index`; *ok = 1 when the result equals root.  bfs_xfe_inner_product: sum of weights[i] * terms[i] over the extension field
+ * (3 limbs each), the verifier's inner product (brainfuck_stark.py:553-554). */
+int bfs_ps_merkle_verify(void* ps, uint64_t element_handle, uint64_t salt_handle, uint64_t path_handle, uint64_t index, const uint8_t* root,
+                         size_t root_len, int* ok);
+int bfs_xfe_inner_product(const uint64_t* weights, const uint64_t* terms, size_t count, uint64_t out[3]);
 /* push(bytes(digest)) followed by fiat_shamir over everything, computed the way bfs_fri_commit overlaps it with a tree kernel: the
  * SHAKE256 blocks in front of the digest's payload are absorbed before the digest is known (same result as the two calls). */
 int bfs_ps_push_digest_fiat_shamir(void* ps, const uint8_t digest[64], uint8_t* out, size_t num_bytes);

@@ -76,6 +76,8 @@ _SIGNATURES = {
     "bfs_ps_push_digest_fiat_shamir": (ci, [vp, ctypes.c_char_p, vp, sz]),
     "bfs_ps_push_digests_fiat_shamir": (ci, [vp, ctypes.c_char_p, sz, vp, sz, ctypes.POINTER(ci)]),
     "bfs_ps_obj_dumps": (ci, [vp, u64, vp, sz, ctypes.POINTER(sz)]),
+    "bfs_ps_merkle_verify": (ci, [vp, u64, u64, u64, u64, ctypes.c_char_p, sz, ctypes.POINTER(ci)]),
+    "bfs_xfe_inner_product": (ci, [ctypes.POINTER(u64), ctypes.POINTER(u64), sz, ctypes.POINTER(u64)]),
     "bfs_ps_obj_kind": (ci, [vp, u64]),
     "bfs_ps_obj_len": (sz, [vp, u64]),
     "bfs_ps_obj_item": (u64, [vp, u64, sz]),

