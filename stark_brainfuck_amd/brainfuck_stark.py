@@ -349,7 +349,14 @@ class BrainfuckStark:
             keep.append(np.ascontiguousarray(sample_ext_many(draw(3 * 9 * count), count, 9), dtype=np.uint64))
             rnd.randomizer_limbs = keep[-1].ctypes.data
         tdraw = random_source(table_mod.urandom)
-        base_rand = [sample_base(tdraw(3 * 8)) for t in self.tables[:3] if t.height for _ in range(t.base_width)]
+
+        def draws(source, count):
+            """`count` draws of 24 bytes (table.py:125-127), as integers; the operating system's generator is asked once for all of them"""
+            if source is os.urandom:
+                blob = source(24 * count)
+                return [int.from_bytes(blob[24 * i:24 * i + 24], "big") for i in range(count)]
+            return [int.from_bytes(source(24), "big") for _ in range(count)]
+        base_rand = [v % P_GOLDILOCKS for v in draws(tdraw, sum(t.base_width for t in self.tables[:3] if t.height))]
         keep.append((_u64 * max(len(base_rand), 1))(*base_rand))
         rnd.base_randomizers = ctypes.cast(keep[-1], ctypes.c_void_p)
 
@@ -365,7 +372,9 @@ class BrainfuckStark:
         salts("base_salt_seed", "base_salts")
         initials = [sample_ext(draw(3 * 8)) for _ in self.permutation_arguments]
         rnd.initials = (_u64 * 6)(*[v for i in initials for v in i])
-        ext_rand = [v for t in self.tables[:3] if t.height for _ in range(t.full_width - t.base_width) for v in sample_ext(tdraw(3 * 8))]
+        mask64 = (1 << 64) - 1              # ExtensionField.sample of 24 bytes: three big-endian 8-byte chunks mod p (extension_field.py:100-111)
+        ext_rand = [c % P_GOLDILOCKS for v in draws(tdraw, sum(t.full_width - t.base_width for t in self.tables[:3] if t.height))
+                    for c in (v >> 128, (v >> 64) & mask64, v & mask64)]
         keep.append((_u64 * max(len(ext_rand), 1))(*ext_rand))
         rnd.ext_randomizers = ctypes.cast(keep[-1], ctypes.c_void_p)
         salts("ext_salt_seed", "ext_salts")

@@ -169,14 +169,20 @@ class NativeTranscript:
     def push(self, obj):
         _lib.check(self.lib.bfs_ps_push(self.handle, self.to_native(obj)))
 
+    _serialize_buffer = None      # per instance, grows to the largest stream seen (one native call per serialize() when it fits)
+
     def serialize(self, count=None):
         lib = self.lib
         count = (1 << 62) if count is None else count
         n = ctypes.c_size_t()
-        _lib.check(lib.bfs_ps_serialize(self.handle, count, None, 0, ctypes.byref(n)))
-        buf = ctypes.create_string_buffer(max(n.value, 1))
-        _lib.check(lib.bfs_ps_serialize(self.handle, count, buf, n.value, ctypes.byref(n)))
-        return buf.raw[:n.value]
+        buf = self._serialize_buffer
+        if buf is None:
+            buf = self._serialize_buffer = ctypes.create_string_buffer(1 << 16)
+        _lib.check(lib.bfs_ps_serialize(self.handle, count, buf, len(buf), ctypes.byref(n)))
+        if n.value > len(buf):
+            buf = self._serialize_buffer = ctypes.create_string_buffer(2 * n.value)
+            _lib.check(lib.bfs_ps_serialize(self.handle, count, buf, len(buf), ctypes.byref(n)))
+        return ctypes.string_at(buf, n.value)
 
     def dumps(self, obj):
         """pickle.dumps(obj) for one object on its own (leaf preimages)."""
