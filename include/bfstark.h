@@ -435,6 +435,8 @@ typedef struct bfs_comb_source {
 int bfs_poly_support(const uint64_t* d_coeffs, uint64_t stride, uint64_t len, uint32_t batch, uint64_t* h_masks, void* stream);
 int bfs_poly_randomize(uint64_t* d_coeffs, uint64_t stride, uint64_t h, uint32_t batch, uint64_t point, const uint64_t* h_values, void* stream);
 int bfs_air_num_quotients(int table);
+/* the same split by kind: counts[0..2] = boundary, transition, terminal constraints of `table` (table.py:148-168, 176-236, 249-281) */
+int bfs_air_counts(int table, int counts[3]);
 /* The same constraints at ONE point on the host, for the verifier (brainfuck_stark.py:470-560; table.py:283-311 evaluate_*_constraints):
  * base_row / base_next: the table's base columns at the point and at the next row (next may be NULL: only the transition constraints
  * read it), ext_row / ext_next: its extension columns, 3 limbs each; out: bfs_air_num_quotients(table) x 3 limbs, boundary, transition,
@@ -548,6 +550,32 @@ int bfs_stark_commit(void* session, void* ps, const bfs_stark_params* params, co
 int bfs_stark_finish(void* session, void* ps, const uint64_t* terminal_handles, const uint64_t* terminals, const uint64_t* shifts,
                      uint32_t num_terms, int32_t base_field_id, const uint64_t* distances, uint32_t n_distances, uint64_t* out_indices,
                      uint8_t* out_weights_seed, uint64_t* out_fri_indices, double* out_ms, void* stream);
+
+/* ---- BrainfuckStark.verify on a stream read by bfs_ps_loads (csrc/verifier.cpp; host only) -------------------------------------------
+ * The reference's verifier (brainfuck_stark.py:343-579, fri.py:201-319) as two calls on the native object graph of the proof, so that a proof is
+ * checked without one host-language object per pulled item:
+ *   bfs_stark_verify_begin   reads the two roots and the five terminals, draws the eleven challenges (Fiat-Shamir at the reference's read
+ *                            positions) and offers the later prefix hashes to the helper threads.  out_challenges: 11 x 3 limbs,
+ *                            out_terminals: 5 x 3 limbs (canonical residues).
+ *   [caller]                 the degree bounds of the 151 terms (symbolic; they depend on challenges and terminals)
+ *   bfs_stark_verify_finish  weights, indices, opened rows with their salted paths, the constraints at the opened points, the inner product
+ *                            against the combination leaf, FRI, the evaluation arguments against input / output / program.
+ *                            shifts: max_degree - degree bound per term, in the order of bfs_stark_finish.
+ * *verdict: 1 = True, 0 = False, 2 = the reference raises AssertionError (message: bfs_last_error()), 3 = the stream holds an object of a
+ * kind the native checks do not model at that position: run the host-language verifier instead (it decides as the reference would).
+ */
+typedef struct bfs_stark_verify_params {
+    uint32_t log_n, expansion_factor, num_colinearity_checks, security_level;
+    uint64_t offset, omega;
+    uint64_t heights[5], lengths[5], omicrons[5];      /* tables in the prover's order; lengths: unpadded (the IO tables' matter) */
+    uint32_t num_distances, pad;
+    uint64_t distances[8];                             /* the tables' distinct unit distances, in the caller's iteration order (:396) */
+    const uint64_t* program; size_t program_len;       /* compiled words (vm.py:78-105) */
+    const uint64_t* input; size_t n_input;             /* input / output symbols as code points */
+    const uint64_t* output; size_t n_output;
+} bfs_stark_verify_params;
+int bfs_stark_verify_begin(void* ps, uint64_t* out_challenges, uint64_t* out_terminals, int* verdict);
+int bfs_stark_verify_finish(void* ps, const bfs_stark_verify_params* params, const uint64_t* shifts, uint32_t num_terms, int* verdict);
 
 #ifdef __cplusplus
 }

@@ -133,6 +133,9 @@ _SIGNATURES = {
                                   ctypes.POINTER(u64), vp, ctypes.POINTER(vp), u64, u64, vp]),
     "bfs_difference_combine_rows": (ci, [vp, vp, u32, u64, u64, vp, vp, vp, u64, u64, vp]),
     "bfs_zerofier_inverses_rows": (ci, [u32, u64, u64, u32, ctypes.POINTER(u32), ctypes.POINTER(u64), vp, u64, u64, vp]),
+    "bfs_air_counts": (ci, [ci, ctypes.POINTER(ci)]),
+    "bfs_stark_verify_begin": (ci, [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(ci)]),
+    "bfs_stark_verify_finish": (ci, [vp, vp, ctypes.POINTER(u64), u32, ctypes.POINTER(ci)]),
     "bfs_stark_session_new": (vp, []),
     "bfs_stark_session_free": (None, [vp]),
     "bfs_stark_commit": (ci, [vp, vp, vp, vp, vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_double), vp]),
@@ -166,6 +169,13 @@ class StarkParams(ctypes.Structure):
     """bfs_stark_params (include/bfstark.h)"""
     _fields_ = [("log_n", u32), ("expansion_factor", u32), ("num_colinearity_checks", u32), ("security_level", u32), ("offset", u64),
                 ("omega", u64), ("max_degree", u64), ("heights", u64 * 3)]
+
+
+class StarkVerifyParams(ctypes.Structure):
+    """bfs_stark_verify_params (include/bfstark.h)"""
+    _fields_ = [("log_n", u32), ("expansion_factor", u32), ("num_colinearity_checks", u32), ("security_level", u32), ("offset", u64),
+                ("omega", u64), ("heights", u64 * 5), ("lengths", u64 * 5), ("omicrons", u64 * 5), ("num_distances", u32), ("pad", u32),
+                ("distances", u64 * 8), ("program", vp), ("program_len", sz), ("input", vp), ("n_input", sz), ("output", vp), ("n_output", sz)]
 
 
 class StarkTableIn(ctypes.Structure):

@@ -753,6 +753,10 @@ class BrainfuckStark:
         terminals against the public input, output and program."""
         from .air import X0, xadd, xmul, xscale
         P = air.P
+        if proof_stream is None and self.native_stages:
+            verdict = self._verify_native(proof)
+            if verdict is not None:
+                return verdict
         if proof_stream is None:
             proof_stream = ProofStream()
         proof_stream = proof_stream.deserialize(proof)
@@ -765,6 +769,61 @@ class BrainfuckStark:
             finally:
                 leaf_pickle_source.reset(token)
         return self._verify_checked(proof_stream)
+
+    def _verify_native(self, proof):
+        """verify() on the native object graph of the proof (csrc/verifier.cpp: bfs_stark_verify_begin / _finish): the same checks in the same
+        order as _verify_stream / Fri.verify below, without a Python object per pulled item.  Returns True / False, raises the reference's
+        AssertionError -- or returns None when this route does not apply (the bytes are not something the native reader takes, or the stream
+        holds an object the native checks do not model): the Python verifier below then decides, as the reference would."""
+        import os
+        if os.environ.get("BFS_NATIVE_VERIFY", "1") == "0":
+            return None
+        from .ip import NativeTranscript
+        try:
+            data = bytes(proof)
+        except TypeError:
+            return None
+        t = NativeTranscript.from_bytes(data)
+        if t is None:
+            return None
+        lib = _lib.load()
+        n = self.fri.domain.length
+        out_ch, out_tm, verdict = (_u64 * 33)(), (_u64 * 15)(), ctypes.c_int(3)
+        _lib.check(lib.bfs_stark_verify_begin(t.handle, out_ch, out_tm, ctypes.byref(verdict)))
+        if verdict.value == 2:
+            raise AssertionError(lib.bfs_last_error().decode("utf-8", "replace"))
+        if verdict.value != 1:
+            return None if verdict.value == 3 else False
+        challenges = tuple((out_ch[3 * i], out_ch[3 * i + 1], out_ch[3 * i + 2]) for i in range(11))
+        terminals = [(out_tm[3 * i], out_tm[3 * i + 1], out_tm[3 * i + 2]) for i in range(5)]
+        bounds = [t_.interpolant_degree() for t_ in self.tables for _ in range(t_.base_width)]
+        bounds += [t_.interpolant_degree() for t_ in self.tables for _ in range(t_.full_width - t_.base_width)]
+        bounds += self._quotient_degree_bounds_cached(challenges, terminals)
+        unit_distances = list(set(table.unit_distance(n) for table in self.tables))
+        if len(unit_distances) > 8:
+            return None
+        words = (_u64 * max(len(self.program), 1))(*[w.value if hasattr(w, "value") else int(w) for w in self.program])
+        ins = (_u64 * max(len(self.input_symbols), 1))(*[ord(c) for c in self.input_symbols])
+        outs = (_u64 * max(len(self.output_symbols), 1))(*[ord(c) for c in self.output_symbols])
+        params = _lib.StarkVerifyParams()
+        params.log_n, params.expansion_factor = n.bit_length() - 1, self.expansion_factor
+        params.num_colinearity_checks, params.security_level = self.num_colinearity_checks, self.security_level
+        params.offset, params.omega = self.fri.domain.offset.value, self.fri.domain.omega.value
+        params.heights = (_u64 * 5)(*[t_.height for t_ in self.tables])
+        params.lengths = (_u64 * 5)(*[t_.length for t_ in self.tables])
+        params.omicrons = (_u64 * 5)(*[t_.omicron.value for t_ in self.tables])
+        params.num_distances = len(unit_distances)
+        params.distances = (_u64 * 8)(*(unit_distances + [0] * (8 - len(unit_distances))))
+        params.program, params.program_len = ctypes.cast(words, ctypes.c_void_p), len(self.program)
+        params.input, params.n_input = ctypes.cast(ins, ctypes.c_void_p), len(self.input_symbols)
+        params.output, params.n_output = ctypes.cast(outs, ctypes.c_void_p), len(self.output_symbols)
+        shifts = (_u64 * len(bounds))(*[self.max_degree - b for b in bounds])
+        _lib.check(lib.bfs_stark_verify_finish(t.handle, ctypes.byref(params), shifts, len(bounds), ctypes.byref(verdict)))
+        if verdict.value == 2:
+            raise AssertionError(lib.bfs_last_error().decode("utf-8", "replace"))
+        if verdict.value == 3:
+            return None
+        return verdict.value == 1
 
     def _verify_checked(self, proof_stream):
         try:

@@ -778,6 +778,18 @@ int bfs_air_evaluate(int table, const uint64_t* base_row, const uint64_t* base_n
     return BFS_OK;
 }
 
+int bfs_air_counts(int table, int counts[3]) {
+    switch (table) {
+        case 0: counts[0] = AirShape<0>::NB; counts[1] = AirShape<0>::NT; counts[2] = AirShape<0>::NZ; return BFS_OK;
+        case 1: counts[0] = AirShape<1>::NB; counts[1] = AirShape<1>::NT; counts[2] = AirShape<1>::NZ; return BFS_OK;
+        case 2: counts[0] = AirShape<2>::NB; counts[1] = AirShape<2>::NT; counts[2] = AirShape<2>::NZ; return BFS_OK;
+        case 3: counts[0] = AirShape<3>::NB; counts[1] = AirShape<3>::NT; counts[2] = AirShape<3>::NZ; return BFS_OK;
+        case 4: counts[0] = AirShape<4>::NB; counts[1] = AirShape<4>::NT; counts[2] = AirShape<4>::NZ; return BFS_OK;
+    }
+    set_error("bfs_air_counts: table index %d", table);
+    return BFS_ERR_BAD_ARG;
+}
+
 int bfs_air_num_quotients(int table) {
     switch (table) {
         case 0: return AirShape<0>::NB + AirShape<0>::NT + AirShape<0>::NZ;

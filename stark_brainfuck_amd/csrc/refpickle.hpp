@@ -661,8 +661,13 @@ class Unpickler {
             Ref poly = dict_get(inst->state, "polynomial");
             Ref coeffs = poly && poly->kind == K_INSTANCE ? dict_get(poly->state, "coefficients") : Ref();
             if (coeffs && coeffs->kind == K_LIST && coeffs->items.size() <= 3) {
-                inst->role = R_XFE;
-                for (size_t i = 0; i < coeffs->items.size(); ++i) inst->limbs[i] = coeffs->items[i]->limbs[0];
+                bool all_base = true;                       // every coefficient a BaseFieldElement with an integer value (else: no role --
+                for (const Ref& c : coeffs->items)          // readers of limbs then see "not an element" instead of a silent zero)
+                    all_base = all_base && c && c->kind == K_INSTANCE && c->role == R_BFE;
+                if (all_base) {
+                    inst->role = R_XFE;
+                    for (size_t i = 0; i < coeffs->items.size(); ++i) inst->limbs[i] = coeffs->items[i]->limbs[0];
+                }
             }
         }
     }

@@ -690,6 +690,126 @@ def test_verify_on_the_host_accepts_reference_proofs_and_rejects_tampering(name)
         pass
 
 
+def _verdict(stark_args, proof, native):
+    """('value', bool) / ('assert', message) / ('error', exception type) of BrainfuckStark(*stark_args).verify(proof) on one of the two routes"""
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    old = os.environ.get("BFS_NATIVE_VERIFY")
+    os.environ["BFS_NATIVE_VERIFY"] = "1" if native else "0"
+    try:
+        return ("value", BrainfuckStark(*stark_args).verify(proof))
+    except AssertionError as e:
+        return ("assert", str(e))
+    except Exception as e:          # noqa: BLE001 -- whatever the Python verifier raises, the native route must end in the same
+        return ("error", type(e).__name__)
+    finally:
+        if old is None:
+            os.environ.pop("BFS_NATIVE_VERIFY", None)
+        else:
+            os.environ["BFS_NATIVE_VERIFY"] = old
+
+
+@pytest.mark.parametrize("name", ["plus1", "io", "two_io", "loop", "countdown"])
+def test_native_verifier_agrees_with_the_python_verifier_on_mutated_proofs(name):
+    """csrc/verifier.cpp (bfs_stark_verify_begin / _finish: the verifier on the native object graph of the proof, round 5) against
+    _verify_stream / Fri.verify in Python, which mirror brainfuck_stark.py:343-579 and fri.py:201-319: the reference's proof and ~70 mutations of
+    it at the OBJECT level -- a bit in a root, a limb of an opened element (also as the non-canonical v + p), an element replaced by one of the
+    other kind, a salt, a path node, a path of the wrong length, a leaf of a FRI triple, an element of the last codeword, objects dropped /
+    doubled / swapped, a truncated stream, a different claim -- must end the same way on both routes: the same boolean, the same AssertionError
+    message, or the same exception type (the native route hands anything it does not model to the Python verifier)."""
+    import random
+    from stark_brainfuck_amd import ExtensionFieldElement, BaseFieldElement, ProofStream
+    from stark_brainfuck_amd.vm import VirtualMachine
+    g = json.load(open(os.path.join(GOLDEN, "stark_%s.json" % name)))
+    proof = open(os.path.join(GOLDEN, "stark_%s_proof.bin" % name), "rb").read()
+    program = VirtualMachine.compile(g["program"])
+    running_time, input_symbols, output_symbols = VirtualMachine.run(program, input_data=list(g["input"]))
+    _, mm, _, _, _ = VirtualMachine.simulate(program, input_data=list(input_symbols))
+    args = (running_time, len(mm), program, input_symbols, output_symbols)
+    assert _verdict(args, proof, True) == _verdict(args, proof, False) == ("value", True)
+    wrong = (running_time, len(mm), program, input_symbols, list(output_symbols) + ["!"])
+    assert _verdict(wrong, proof, True) == _verdict(wrong, proof, False)
+    P = (1 << 64) - (1 << 32) + 1
+    rnd = random.Random(hash(name) & 0xFFFF)
+    base = ProofStream().deserialize(proof).objects
+    xf = next(o for o in base if isinstance(o, ExtensionFieldElement)).field
+
+    def flip(b):
+        k = rnd.randrange(len(b))
+        return b[:k] + bytes([b[k] ^ (1 << rnd.randrange(8))]) + b[k + 1:]
+
+    def bump(e):
+        """another element in place of e: a limb changed, the same value as v + p, or an element of the other kind"""
+        if isinstance(e, ExtensionFieldElement):
+            limbs = list(e.limbs())
+            how = rnd.randrange(4)
+            if how == 0:
+                limbs[rnd.randrange(3)] = (limbs[rnd.randrange(3)] + 1) % P
+            elif how == 1:
+                k = rnd.randrange(3)
+                if limbs[k] + P < (1 << 64):
+                    limbs[k] += P                           # the same field element in another representation
+                else:
+                    limbs[k] = (limbs[k] + 5) % P
+            elif how == 2:
+                return BaseFieldElement(limbs[0], xf.modulus.coefficients[0].field)
+            else:
+                limbs = [rnd.randrange(P) for _ in range(3)]
+            return xf.from_limbs(limbs)
+        if isinstance(e, BaseFieldElement):
+            return BaseFieldElement((e.value + 1) % P, e.field) if rnd.random() < 0.7 else xf.from_limbs([e.value, 0, 1])
+        return e
+
+    def mutate(o):
+        if isinstance(o, (bytes, bytearray)):
+            return flip(bytes(o))
+        if isinstance(o, (ExtensionFieldElement, BaseFieldElement)):
+            return bump(o)
+        if isinstance(o, tuple) and len(o) == 2 and isinstance(o[0], (bytes, bytearray)):       # (salt, path)
+            if rnd.random() < 0.4:
+                return (flip(o[0]), o[1])
+            return (o[0], mutate(o[1]))
+        if isinstance(o, (list, tuple)) and len(o):
+            items = list(o)
+            how = rnd.randrange(5)
+            if how == 0 and len(items) > 1:
+                del items[rnd.randrange(len(items))]
+            elif how == 1:
+                items.append(items[-1])
+            else:
+                k = rnd.randrange(len(items))
+                items[k] = mutate(items[k])
+            return type(o)(items)
+        return o
+
+    tried = 0
+    for trial in range(70):
+        objs = list(base)
+        how = rnd.randrange(10)
+        if how == 0:
+            del objs[rnd.randrange(len(objs))]
+        elif how == 1:
+            k = rnd.randrange(len(objs))
+            objs.insert(k, objs[k])
+        elif how == 2:
+            i, j = rnd.randrange(len(objs)), rnd.randrange(len(objs))
+            objs[i], objs[j] = objs[j], objs[i]
+        elif how == 3:
+            objs = objs[:rnd.randrange(1, len(objs))]
+        else:
+            k = rnd.randrange(min(len(objs), 8)) if rnd.random() < 0.3 else rnd.randrange(len(objs))
+            objs[k] = mutate(objs[k])
+        ps = ProofStream()
+        ps.objects = objs
+        try:
+            data = ps.serialize()
+        except TypeError:
+            continue
+        tried += 1
+        a, b = _verdict(args, data, True), _verdict(args, data, False)
+        assert a == b, (trial, how, a, b)
+    assert tried >= 50
+
+
 @pytest.mark.parametrize("tag", ["d16_t2", "d64_t8", "d1024_t4", "test_fri_valid", "test_fri_disturbed", "d16_t2_prepushed"])
 def test_fri_verify_on_the_host_golden_transcripts(tag):
     """Fri.verify (fri.py:201-319) on the transcripts the reference's Fri.prove wrote, read from their bytes, without a GPU: the verdict
