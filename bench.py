@@ -1001,7 +1001,15 @@ def bench_stark(code=None, label="Hello World!"):
     t0 = time.perf_counter()
     ok = BrainfuckStark(running_time, len(matrices[1]), program, inputs, outputs).verify(proof)
     verify_ms = (time.perf_counter() - t0) * 1e3
-    return {"ms": statistics.median(times[1:]) * 1e3, "program": label, "running_time": running_time,
+    busy = None
+    bpath = os.path.join(ROOT, "profiles", "prove_busy.json")
+    if code == HELLO_WORLD and os.path.exists(bpath):
+        # GPU-busy share of the proof: the kernels + copies of one proof from the tracked rocprofv3 timeline (static, profiles/prove_busy.json)
+        # over THIS run's wall clock -- what of the proof's latency is the device, the rest being host work and round trips in front of it
+        rec = json.load(open(bpath))
+        busy = {"gpu_busy_frac": min(1.0, rec["kernel_and_copy_busy_us"] * 1e-3 / (statistics.median(times[1:]) * 1e3)),
+                "kernel_and_copy_busy_us_static": rec["kernel_and_copy_busy_us"], "static": "profiles/prove_busy.json"}
+    return {"ms": statistics.median(times[1:]) * 1e3, "gpu_busy": busy, "program": label, "running_time": running_time,
             "fri_domain_length": stark.fri.domain.length, "proof_bytes": len(proof), "verified": bool(ok),
             "trace_ms": trace_ms, "verify_ms": verify_ms,
             "breakdown_ms": {k: round(v * 1e3, 2) for k, v in timing.items()}, "breakdown_run_ms": staged_ms,
