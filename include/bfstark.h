@@ -555,7 +555,8 @@ int bfs_stark_finish(void* session, void* ps, const uint64_t* terminal_handles, 
  * The reference's verifier (brainfuck_stark.py:343-579, fri.py:201-319) as two calls on the native object graph of the proof, so that a proof is
  * checked without one host-language object per pulled item:
  *   bfs_stark_verify_begin   reads the two roots and the five terminals, draws the eleven challenges (Fiat-Shamir at the reference's read
- *                            positions) and offers the later prefix hashes to the helper threads.  out_challenges: 11 x 3 limbs,
+ *                            positions) and offers the prefix hashes FRI will ask for to the helper threads (params may be NULL: none offered;
+ *                            only its protocol parameters are read here).  out_challenges: 11 x 3 limbs,
  *                            out_terminals: 5 x 3 limbs (canonical residues).
  *   [caller]                 the degree bounds of the 151 terms (symbolic; they depend on challenges and terminals)
  *   bfs_stark_verify_finish  weights, indices, opened rows with their salted paths, the constraints at the opened points, the inner product
@@ -574,7 +575,7 @@ typedef struct bfs_stark_verify_params {
     const uint64_t* input; size_t n_input;             /* input / output symbols as code points */
     const uint64_t* output; size_t n_output;
 } bfs_stark_verify_params;
-int bfs_stark_verify_begin(void* ps, uint64_t* out_challenges, uint64_t* out_terminals, int* verdict);
+int bfs_stark_verify_begin(void* ps, const bfs_stark_verify_params* params, uint64_t* out_challenges, uint64_t* out_terminals, int* verdict);
 int bfs_stark_verify_finish(void* ps, const bfs_stark_verify_params* params, const uint64_t* shifts, uint32_t num_terms, int* verdict);
 
 #ifdef __cplusplus

@@ -134,7 +134,7 @@ _SIGNATURES = {
     "bfs_difference_combine_rows": (ci, [vp, vp, u32, u64, u64, vp, vp, vp, u64, u64, vp]),
     "bfs_zerofier_inverses_rows": (ci, [u32, u64, u64, u32, ctypes.POINTER(u32), ctypes.POINTER(u64), vp, u64, u64, vp]),
     "bfs_air_counts": (ci, [ci, ctypes.POINTER(ci)]),
-    "bfs_stark_verify_begin": (ci, [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(ci)]),
+    "bfs_stark_verify_begin": (ci, [vp, vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(ci)]),
     "bfs_stark_verify_finish": (ci, [vp, vp, ctypes.POINTER(u64), u32, ctypes.POINTER(ci)]),
     "bfs_stark_session_new": (vp, []),
     "bfs_stark_session_free": (None, [vp]),

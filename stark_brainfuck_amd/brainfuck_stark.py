@@ -788,17 +788,6 @@ class BrainfuckStark:
             return None
         lib = _lib.load()
         n = self.fri.domain.length
-        out_ch, out_tm, verdict = (_u64 * 33)(), (_u64 * 15)(), ctypes.c_int(3)
-        _lib.check(lib.bfs_stark_verify_begin(t.handle, out_ch, out_tm, ctypes.byref(verdict)))
-        if verdict.value == 2:
-            raise AssertionError(lib.bfs_last_error().decode("utf-8", "replace"))
-        if verdict.value != 1:
-            return None if verdict.value == 3 else False
-        challenges = tuple((out_ch[3 * i], out_ch[3 * i + 1], out_ch[3 * i + 2]) for i in range(11))
-        terminals = [(out_tm[3 * i], out_tm[3 * i + 1], out_tm[3 * i + 2]) for i in range(5)]
-        bounds = [t_.interpolant_degree() for t_ in self.tables for _ in range(t_.base_width)]
-        bounds += [t_.interpolant_degree() for t_ in self.tables for _ in range(t_.full_width - t_.base_width)]
-        bounds += self._quotient_degree_bounds_cached(challenges, terminals)
         unit_distances = list(set(table.unit_distance(n) for table in self.tables))
         if len(unit_distances) > 8:
             return None
@@ -817,6 +806,17 @@ class BrainfuckStark:
         params.program, params.program_len = ctypes.cast(words, ctypes.c_void_p), len(self.program)
         params.input, params.n_input = ctypes.cast(ins, ctypes.c_void_p), len(self.input_symbols)
         params.output, params.n_output = ctypes.cast(outs, ctypes.c_void_p), len(self.output_symbols)
+        out_ch, out_tm, verdict = (_u64 * 33)(), (_u64 * 15)(), ctypes.c_int(3)
+        _lib.check(lib.bfs_stark_verify_begin(t.handle, ctypes.byref(params), out_ch, out_tm, ctypes.byref(verdict)))
+        if verdict.value == 2:
+            raise AssertionError(lib.bfs_last_error().decode("utf-8", "replace"))
+        if verdict.value != 1:
+            return None if verdict.value == 3 else False
+        challenges = tuple((out_ch[3 * i], out_ch[3 * i + 1], out_ch[3 * i + 2]) for i in range(11))
+        terminals = [(out_tm[3 * i], out_tm[3 * i + 1], out_tm[3 * i + 2]) for i in range(5)]
+        bounds = [t_.interpolant_degree() for t_ in self.tables for _ in range(t_.base_width)]
+        bounds += [t_.interpolant_degree() for t_ in self.tables for _ in range(t_.full_width - t_.base_width)]
+        bounds += self._quotient_degree_bounds_cached(challenges, terminals)
         shifts = (_u64 * len(bounds))(*[self.max_degree - b for b in bounds])
         _lib.check(lib.bfs_stark_verify_finish(t.handle, ctypes.byref(params), shifts, len(bounds), ctypes.byref(verdict)))
         if verdict.value == 2:

@@ -7,7 +7,7 @@
 // rounds are known when the commit phase starts, so they are absorbed here, side by side, while the first rounds run.
 //
 // The pool is created on first use and never destroyed (threads parked on a condition variable cost nothing); a forked child
-// gets a fresh one (pthread_atfork handlers keep the pool's guard consistent across the fork).  BFS_HELPER_THREADS=0 switches it off (callers fall back to doing the work themselves).
+// gets a fresh one (pthread_atfork handlers keep the pool's guard consistent across the fork).  BFS_HELPER_THREADS (default 8) sets their number, 0 switches it off (callers fall back to doing the work themselves).
 #pragma once
 #include <pthread.h>
 #include <unistd.h>
@@ -38,7 +38,7 @@ class HelperPool {
         }
         const pid_t me = getpid();
         if (st.pool == nullptr || st.owner != me) {
-            int want = 4;
+            int want = 8;
             if (const char* e = getenv("BFS_HELPER_THREADS")) want = atoi(e);
             const int cores = (int)std::thread::hardware_concurrency();
             if (cores > 0 && want > cores - 1) want = cores - 1;

@@ -872,6 +872,14 @@ struct Transcript {
     };
     std::unordered_map<size_t, std::shared_ptr<PrefixHash>> prefetched;
     bool loaded_from_bytes = false;
+    // hashes nobody asked for are withdrawn with the stream: a helper that gets to one later finds it taken and moves on (a verifier that
+    // runs proof after proof would otherwise queue its next proof's hashes behind the last one's leftovers)
+    ~Transcript() {
+        for (auto& kv : prefetched) {
+            int expected = 0;
+            (void)kv.second->state.compare_exchange_strong(expected, 2);
+        }
+    }
     // offers the hashes over objects[:counts[i]] to the helper pool; returns how many were offered (0: no helpers, or not a loaded stream)
     size_t prefetch_fiat_shamir(const size_t* counts, size_t n, size_t num_bytes) {
         if (!loaded_from_bytes || num_bytes == 0 || num_bytes > 64) return 0;

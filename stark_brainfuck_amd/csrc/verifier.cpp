@@ -407,25 +407,24 @@ int guarded(F&& body, int* verdict) {
 
 extern "C" {
 
-int bfs_stark_verify_begin(void* ps, uint64_t* out_challenges, uint64_t* out_terminals, int* verdict) {
+int bfs_stark_verify_begin(void* ps, const bfs_stark_verify_params* params, uint64_t* out_challenges, uint64_t* out_terminals, int* verdict) {
     Transcript* t = (Transcript*)ps;
     if (!t || !t->loaded_from_bytes) { set_error("bfs_stark_verify_begin: the stream was not read by bfs_ps_loads"); return BFS_ERR_BAD_ARG; }
     return guarded([&]() {
         Reader rd{t};
         Begin b;
         read_begin(rd, b);
-        // Fiat-Shamir ahead of time: the checks ask right before / after a top-level digest (a Merkle root) and after a codeword; those
-        // prefixes go to the helper threads now, the long ones first (a position that was not foreseen is hashed when it is asked for)
-        {
+        // Fiat-Shamir ahead of time.  The read positions at which FRI asks are known from the protocol parameters alone: behind the
+        // openings (four objects per opened row, two per combination leaf) it asks before every round's root and once behind the last
+        // codeword -- each time over ~50 KB.  Exactly those prefixes go to the helper threads now, in the order they will be needed; the
+        // three early positions (1, 7, 8 objects) are a block or two each and are hashed when asked for.
+        if (params != nullptr) {
+            u32 rounds = 0;
+            for (u64 len = 1ull << params->log_n; len > params->expansion_factor; len /= 2) ++rounds;
+            const size_t p0 = 8 + (size_t)params->security_level * (1 + params->num_distances) * 4 + (size_t)params->security_level * 2;
             std::vector<size_t> at;
-            for (size_t k = 0; k < t->objects.size(); ++k) {
-                const Ref& o = t->objects[k];
-                if (o->kind == rp::K_BYTES && o->nbytes() == 64) { if (k) at.push_back(k); at.push_back(k + 1); }
-                else if (o->kind == rp::K_LIST && !o->items.empty() && o->items[0]->kind == rp::K_INSTANCE && o->items[0]->role == rp::R_XFE) at.push_back(k + 1);
-            }
-            std::sort(at.begin(), at.end());
-            at.erase(std::unique(at.begin(), at.end()), at.end());
-            std::reverse(at.begin(), at.end());
+            for (u32 r = 0; r <= rounds; ++r)
+                if (p0 + r <= t->objects.size()) at.push_back(p0 + r);
             if (!at.empty()) (void)t->prefetch_fiat_shamir(at.data(), at.size(), 32);
         }
         memcpy(out_challenges, b.challenges, sizeof b.challenges);
