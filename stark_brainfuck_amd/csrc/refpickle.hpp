@@ -210,6 +210,31 @@ class Pickler {
         return out_;
     }
 
+    // pickle.dumps(items[:count]) without building that list: the verifier's prefix hashes run on helper threads, and copying a thousand
+    // shared pointers per prefix there meant a thousand contended reference-count updates on nodes every other thread is walking too
+    std::string dumps_prefix(const std::vector<Ref>& items, size_t count) {
+        if (count > items.size()) count = items.size();
+        Node list_object;                                   // stands for the list itself: the first memo slot
+        list_object.kind = K_LIST;
+        out_.clear();
+        memo_.clear();
+        memo_next_ = 0;
+        int_marks.clear();
+        frame_start_ = NPOS;
+        framing_ = false;
+        const unsigned char proto[2] = {0x80, 4};
+        write(proto, 2);
+        framing_ = true;
+        op(0x5d);  // EMPTY_LIST
+        memo_put(&list_object);
+        save_list_items(items.data(), count);
+        op(0x2e);  // STOP
+        commit_frame();
+        framing_ = false;
+        memo_.clear();                                      // (holds the address of a stack object)
+        return out_;
+    }
+
     // ---- incremental pickling of a growing list (the proof stream): pickle.dumps(objects) for objects[:k] is a prefix-stable
     // byte string -- memo indices are handed out in order, so the encoding of the first k objects never changes -- followed by
     // APPENDS STOP and the frame length patched in.  Valid from two objects on (a one-element list has no MARK, _pickle.c
@@ -442,6 +467,23 @@ class Pickler {
         write(b, 2 + (size_t)nn);
     }
 
+    // the items of a list as _pickle.c's batch_list_exact writes them: one item -> APPEND, more -> MARK ... APPENDS in batches of 1000
+    void save_list_items(const Ref* items, size_t len) {
+        if (len == 1) { save(items[0].get()); op(0x61); }  // APPEND
+        else if (len > 1) {
+            size_t total = 0;
+            do {
+                size_t batch = 0;
+                op(0x28);  // MARK
+                while (total < len) {
+                    save(items[total].get());
+                    ++total;
+                    if (++batch == BATCH) break;
+                }
+                op(0x65);  // APPENDS
+            } while (total < len);
+        }
+    }
     void save(const Node* n) {
         opcode_boundary();
         if (n->kind == K_INT) { save_long(n->ival); return; }
@@ -468,21 +510,7 @@ class Pickler {
             case K_LIST: {
                 op(0x5d);  // EMPTY_LIST
                 memo_put(n);
-                size_t len = n->items.size();
-                if (len == 1) { save(n->items[0].get()); op(0x61); }  // APPEND
-                else if (len > 1) {
-                    size_t total = 0;
-                    do {
-                        size_t batch = 0;
-                        op(0x28);  // MARK
-                        while (total < len) {
-                            save(n->items[total].get());
-                            ++total;
-                            if (++batch == BATCH) break;
-                        }
-                        op(0x65);  // APPENDS
-                    } while (total < len);
-                }
+                save_list_items(n->items.data(), n->items.size());
                 break;
             }
             case K_TUPLE: {
@@ -852,17 +880,16 @@ struct Transcript {
     // computed ahead by the helper threads.  Jobs are OFFERS (helper_pool.hpp): whoever needs a result first computes it; a job owns
     // the objects of its prefix, so it outlives the stream if it has to.
     struct PrefixHash {
-        std::vector<Ref> prefix;
+        std::shared_ptr<const std::vector<Ref>> all;                 // the stream's objects (one shared copy for every job of a stream) ...
+        size_t count = 0;                                            // ... of which this job hashes the first `count`
         size_t num_bytes = 0;
         unsigned char out[64];
         std::atomic<int> state{0};                                   // 0 offered, 1 somebody is computing, 2 done
         void run() {
             int expected = 0;
             if (state.compare_exchange_strong(expected, 1)) {
-                Ref lst = mk(K_LIST);
-                lst->items = prefix;
                 Pickler p(nullptr);                                  // (streams read from bytes hold no compact elements: no World needed)
-                const std::string s = p.dumps(lst);
+                const std::string s = p.dumps_prefix(*all, count);
                 shake256(s.data(), s.size(), out, num_bytes);
                 state.store(2, std::memory_order_release);
                 return;
@@ -871,6 +898,7 @@ struct Transcript {
         }
     };
     std::unordered_map<size_t, std::shared_ptr<PrefixHash>> prefetched;
+    std::shared_ptr<const std::vector<Ref>> prefetch_objects;
     bool loaded_from_bytes = false;
     // hashes nobody asked for are withdrawn with the stream: a helper that gets to one later finds it taken and moves on (a verifier that
     // runs proof after proof would otherwise queue its next proof's hashes behind the last one's leftovers)
@@ -886,11 +914,13 @@ struct Transcript {
         HelperPool* pool = HelperPool::get();
         if (pool == nullptr) return 0;
         std::vector<std::function<void()>> work;
+        if (!prefetch_objects) prefetch_objects = std::make_shared<const std::vector<Ref>>(objects);      // (a loaded stream does not change)
         for (size_t i = 0; i < n; ++i) {
             const size_t k = counts[i] < objects.size() ? counts[i] : objects.size();
             if (prefetched.count(k)) continue;
             std::shared_ptr<PrefixHash> job = std::make_shared<PrefixHash>();
-            job->prefix.assign(objects.begin(), objects.begin() + k);
+            job->all = prefetch_objects;
+            job->count = k;
             job->num_bytes = num_bytes;
             prefetched[k] = job;
             work.push_back([job] { int s = job->state.load(); if (s == 0) job->run(); });

@@ -1,5 +1,6 @@
 // transcript.cpp -- C ABI over rp::Transcript (proof stream / Fiat-Shamir, host side).
 // Declarations and reference citations: include/bfstark.h ("proof stream").
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/bfstark.h"
@@ -22,23 +23,9 @@ static int bad_handle(uint64_t h) {
 extern "C" {
 
 void* bfs_ps_new(void) { return new Transcript(); }
-void bfs_ps_free(void* ps) {
-    // a stream read from a proof holds thousands of nodes; taking it apart is ~0.4 ms of a 2-4 ms verification and nobody waits for
-    // it: the helper threads do it when there are any (a prover's own, small streams are freed here)
-    Transcript* t = T(ps);
-    if (t && t->loaded_from_bytes) {
-        if (HelperPool* pool = HelperPool::get()) {
-            std::vector<std::function<void()>> job;
-            job.emplace_back([t] { delete t; });
-            pool->submit(std::move(job));
-            return;
-        }
-    }
-    delete t;
-}
+void bfs_ps_free(void* ps) { delete T(ps); }      // (handing a loaded stream's teardown to a helper thread was measured: the cross-thread
+                                                   //  frees made the NEXT verification 2-3 x slower -- tools/verify_time.py, profiles/r05/README.md)
 
-// ProofStream.deserialize (ip.py:27-30) without Python objects in between: the pickle of a LIST is read into a new stream whose objects
-// are the list's items, with the identities (shared coefficient objects, BaseField instances, repeated nodes) the writer's objects had.
 // The result is only handed out if serialising it gives the input back byte for byte; otherwise (an opcode or an object kind outside
 // what the reference's proofs contain, or a pickle some other writer laid out differently) NULL with bfs_last_error() saying why --
 // the caller falls back to CPython's unpickler + bfs_ps_obj_*.
