@@ -20,11 +20,12 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-enum Op { ADD_U32, XOR_B32, ADD_CO_PAIR, LSHL_ADD_U64, CNDMASK, MAD_U64_U32, SUBB_SGPR, MUL_LO_U32, ALIGNBIT, ADD_LAZY4, OPS };
+enum Op { ADD_U32, XOR_B32, ADD_CO_PAIR, LSHL_ADD_U64, CNDMASK, MAD_U64_U32, SUBB_SGPR, MUL_LO_U32, ALIGNBIT, ADD_LAZY4, PERM_B32, ALIGNBYTE, LSHL_OR, XOR3, ADD3, LSHLREV, CNDMASK_CMP, OPS };
 static const char* NAMES[OPS] = {"v_add_u32", "v_xor_b32", "v_add_co_u32 + v_addc_co_u32 (vcc)", "v_lshl_add_u64", "v_cndmask_b32 (vcc)",
                                  "v_mad_u64_u32", "v_sub_co + s_nop 1 + v_subb_co (SGPR pair)", "v_mul_lo_u32", "v_alignbit_b32",
-                                 "gl_add_lazy shape: add_co, addc_co, cndmask, add_co... (4 instr)"};
-static const int INSTR_PER_STEP[OPS] = {1, 1, 2, 1, 1, 1, 2, 1, 1, 4};
+                                 "gl_add_lazy shape: add_co, addc_co, cndmask, add_co... (4 instr)", "v_perm_b32", "v_alignbyte_b32", "v_lshl_or_b32",
+                                 "v_bitop3_b32 (three-input xor)", "v_add3_u32", "v_lshlrev_b32", "v_cmp_lt_u32 + v_cndmask_b32 (vcc written every time)"};
+static const int INSTR_PER_STEP[OPS] = {1, 1, 2, 1, 1, 1, 2, 1, 1, 4, 1, 1, 1, 1, 1, 1, 2};
 
 // one step = the class applied to chain k.  Everything is inline asm (volatile) so the compiler neither folds nor reorders the work;
 // the loop is unrolled by hand through the macro below.
@@ -46,6 +47,13 @@ __device__ __forceinline__ void step(uint32_t& lo, uint32_t& hi, uint32_t c) {
                                              : "+v"(lo), "+v"(hi) : "v"(c) : "s42", "s43");
     else if (OP == MUL_LO_U32) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(lo) : "v"(c));
     else if (OP == ALIGNBIT) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(lo) : "v"(hi));
+    else if (OP == PERM_B32) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(lo) : "v"(hi), "v"(c));
+    else if (OP == ALIGNBYTE) asm volatile("v_alignbyte_b32 %0, %0, %1, 3" : "+v"(lo) : "v"(hi));
+    else if (OP == LSHL_OR) asm volatile("v_lshl_or_b32 %0, %0, 8, %1" : "+v"(lo) : "v"(hi));
+    else if (OP == XOR3) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96" : "+v"(lo) : "v"(hi), "v"(c));
+    else if (OP == ADD3) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(lo) : "v"(hi), "v"(c));
+    else if (OP == LSHLREV) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(lo));
+    else if (OP == CNDMASK_CMP) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(lo) : "v"(hi), "v"(c) : "vcc");
     else if (OP == ADD_LAZY4) asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %2, vcc\n\tv_cndmask_b32 %0, %0, %2, vcc\n\tv_add_co_u32 %0, vcc, %0, %1"
                                            : "+v"(lo), "+v"(hi) : "v"(c) : "vcc");
 }
@@ -127,5 +135,12 @@ int main() {
     sweep<MUL_LO_U32>(d_cycles, d_sink, num_cu);
     sweep<ALIGNBIT>(d_cycles, d_sink, num_cu);
     sweep<ADD_LAZY4>(d_cycles, d_sink, num_cu);
+    sweep<PERM_B32>(d_cycles, d_sink, num_cu);
+    sweep<ALIGNBYTE>(d_cycles, d_sink, num_cu);
+    sweep<LSHL_OR>(d_cycles, d_sink, num_cu);
+    sweep<XOR3>(d_cycles, d_sink, num_cu);
+    sweep<ADD3>(d_cycles, d_sink, num_cu);
+    sweep<LSHLREV>(d_cycles, d_sink, num_cu);
+    sweep<CNDMASK_CMP>(d_cycles, d_sink, num_cu);
     return 0;
 }
