@@ -289,6 +289,16 @@ int bfs_merkle_build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_
  * next, brainfuck_stark.py:179, 198) in the read-back the call ends with anyway.  h_root may be NULL. */
 int bfs_merkle_build_rows_root(const bfs_row_column* columns, uint32_t ncols, uint64_t n, uint64_t limb_stride, const uint8_t* salts,
                                int salts_on_device, uint8_t* d_nodes, uint8_t h_root[64], void* stream);
+/* The flattened template of one row pattern of a column layout (csrc/rows.hip; `code` = 2 bits per extension column, how many
+ * coefficients its element stores; d_values are not looked at): what tools/gen_rows.py unrolls into csrc/rows_generated.hpp and what
+ * the tests compare that header with.  out_header = {steps, integers, constant bytes of the tuple pickle, bytes of the salt pickle};
+ * a step is two words (kind | a << 32, data: csrc/rows_core.hpp RowStep); out_ints[k] = column | limb << 8 of the k-th integer of
+ * the row; *out_hash = the number a generated kernel is matched by.  Host only, no GPU work. */
+int bfs_row_template_steps(const bfs_row_column* columns, uint32_t ncols, uint32_t code, int salted, uint32_t out_header[4],
+                           uint64_t* out_steps, uint32_t steps_cap, uint32_t* out_ints, uint32_t ints_cap, uint64_t* out_hash);
+/* How many leaf launches of this process went through a kernel of csrc/rows_generated.hpp (the tests check that the prover's two
+ * layouts do and that other layouts do not). */
+uint64_t bfs_row_generated_launches(void);
 /* nwords (a multiple of 8) pseudo-random words in HBM: 64-byte block j = BLAKE2b-512(seed || j).  For salts that never visit
  * the host (the reference draws os.urandom(24) per leaf, salted_merkle.py:25; the caller seeds this from os.urandom(32)). */
 int bfs_random_fill(const uint8_t seed[32], uint64_t* d_out, uint64_t nwords, void* stream);

@@ -95,6 +95,8 @@ _SIGNATURES = {
                                      ctypes.POINTER(u64), u32, ctypes.POINTER(u64), u32, ctypes.POINTER(u64), vp]),
     "bfs_merkle_build_rows_range": (ci, [vp, u32, u64, u64, vp, ci, vp, vp]),
     "bfs_merkle_build_rows_root": (ci, [vp, u32, u64, u64, vp, ci, vp, vp, vp]),
+    "bfs_row_template_steps": (ci, [vp, u32, u32, ci, vp, vp, u32, vp, u32, vp]),
+    "bfs_row_generated_launches": (u64, []),
     "bfs_random_fill": (ci, [ctypes.c_char_p, vp, u64, vp]),
     "bfs_xfe_sample_fill": (ci, [ctypes.c_char_p, vp, u64, u64, vp]),
     "bfs_xfe_fold": (ci, [vp, u64, vp, u64, u32, ctypes.POINTER(u64), u64, u64, vp]),

@@ -13,6 +13,7 @@
 //      frame length patched in) which a wave walks in lockstep -- and feeds the bytes straight into BLAKE2b: a 200-byte buffer per
 //      lane in LDS, compressed by the whole wave whenever the lane furthest ahead has filled it.  The preimage never exists in memory.
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -23,6 +24,7 @@
 #include "leaf_encode.hpp"
 #include "refpickle.hpp"
 #include "rows_core.hpp"
+#include "rows_generated.hpp"
 #include "runtime.hpp"
 
 namespace bfs {
@@ -61,6 +63,7 @@ struct RowArgs {
     u64* digests;                // n x 8 words
     u64* pattern_set;            // pattern kernel output: open-addressing set of the codes present (PATTERN_SLOTS entries, ~0 = empty)
     u32* error;                  // [0]: a row without a template, [1]: the pattern set overflowed
+    u32 skip, skip_code;         // interpreter kernel, skip != 0: rows of pattern skip_code were hashed by a generated kernel
 };
 
 // 2 bits per extension column: how many coefficients its element of row i stores (trailing zero limbs are dropped).  The top limbs
@@ -133,6 +136,7 @@ __global__ void __launch_bounds__(LEAF_THREADS, BFS_ROW_WAVES) row_leaves_kernel
     const u64 i = (u64)blockIdx.x * LEAF_THREADS + lane;
     if (i >= a.n) return;
     const u32 code = row_pattern(a, i);
+    if (a.skip && code == a.skip_code) return;
     u32 mine = ~0u;
     for (u32 t = 0; t < a.num_templates; ++t)
         if (a.templates[t].code == code) mine = t;
@@ -241,6 +245,108 @@ __global__ void __launch_bounds__(LEAF_THREADS, BFS_ROW_WAVES) row_leaves_kernel
     }
 }
 
+// ---- the same walk as straight-line code, for the layouts rows_generated.hpp knows ----------------------------------------------
+// row_leaves_kernel spends a third of its issue time on the scalar control flow of the interpreter: one taken branch per ten vector
+// instructions, each of which restarts the wave's instruction fetch (profiles/r05/ab_rows_stalls.txt).  For a template known when the
+// library is built, tools/gen_rows.py unrolls the walk: constants are immediates, every store of a segment has a fixed offset from the
+// lane's position, and the only branch per segment is the (almost never taken) "is some lane full?".  The compression stays ONE site:
+// Layout::segments is a coroutine -- it returns with `resume` = the next segment when the wave must compress, and is entered again
+// through its switch.  Lanes whose row has another pattern than the layout's (a shorter extension element) leave at once: the
+// interpreter kernel, launched behind this one when the remembered pattern set has more than one entry, hashes them.
+#ifndef BFS_ROWGEN_PREFETCH
+#define BFS_ROWGEN_PREFETCH 4          // integers of the row requested ahead of the one being written
+#endif
+template <class G>
+struct RowGenLane {
+    RowLane st8;
+    unsigned char* buf;
+    const RowArgs& a;
+    u64 i;
+    u32 tuple_len;
+    u32 variant;                // which of the layout's patterns the rows are (wave-uniform: a kernel argument)
+    u64 r[BFS_ROWGEN_PREFETCH];
+    __device__ __forceinline__ RowGenLane(const RowArgs& a_, unsigned char* buf_, u64 i_, u32 variant_) : buf(buf_), a(a_), i(i_), tuple_len(0), variant(variant_) {}
+    __device__ __forceinline__ u64 row_int(u32 packed) const {
+        const GlobalWords col = (GlobalWords)((ConstColumns)a.columns)[packed & 0xFF];
+        return col[(u64)((packed >> 8) & 0xFF) * a.limb_stride + i];
+    }
+    // (the constant is made where it is stored: left to itself the compiler hoists all of them out of the loop around the compression
+    // site, as loop invariants, and then spills them -- 428 bytes of scratch per lane)
+    __device__ __forceinline__ void st(u32 off, u64 data) {
+        u32 lo = (u32)data, hi = (u32)(data >> 32);
+        asm volatile("" : "+v"(lo), "+v"(hi));
+        row_store8(buf + st8.pos + off, lo | ((u64)hi << 32));
+    }
+    __device__ __forceinline__ void adv(u32 n) { st8.pos += n; }
+    __device__ __forceinline__ void framelen(u32 off) { row_store8(buf + st8.pos + off, (u64)tuple_len - 11); }
+    __device__ __forceinline__ void salt(u32 off, u32 w) { row_store8(buf + st8.pos + off, a.salts[3 * i + w]); }
+    // integer K of the row (V < 0: of the part all variants share; else of variant V's own part)
+    template <u32 K, int V = -1> __device__ __forceinline__ void integer() {
+        constexpr u32 D = BFS_ROWGEN_PREFETCH;
+        const u64 v = r[K % D];
+        if constexpr (V >= 0) {
+            if constexpr (K + D < G::NUM_INTS[V >= 0 ? V : 0]) r[K % D] = row_int(G::INTS[V >= 0 ? V : 0][K + D]);
+        } else if constexpr (K + D < G::COMMON_INTS) {
+            r[K % D] = row_int(G::INTS[0][K + D]);
+        } else {
+            if (K + D < G::NUM_INTS[variant]) r[K % D] = row_int(G::INTS[variant][K + D]);      // (wave-uniform)
+        }
+        u64 lo, hi;
+        u32 len;
+        if (__all(v >= (1ull << 31))) row_long1_opcode(v, lo, hi, len);     // field elements are almost never small
+        else row_int_opcode(v, lo, hi, len);
+        row_store8(buf + st8.pos, lo);
+        row_store8(buf + st8.pos + 8, hi);      // (zeros above the opcode's length; what follows overwrites them)
+        st8.pos += len;
+    }
+    __device__ __forceinline__ bool full() const { return __any(st8.pos > ROW_LANE_BYTES - 16); }
+    __device__ __forceinline__ void finish() { row_lane_finish(st8, buf); }
+};
+
+template <class G>
+__global__ void __launch_bounds__(LEAF_THREADS, BFS_ROW_WAVES) row_leaves_generated_kernel(const RowArgs a, const u32 variant_, const u32 others_follow) {
+    __shared__ __attribute__((aligned(16))) unsigned char blk[ROW_LANE_BYTES * LEAF_THREADS];
+    const u32 lane = threadIdx.x;
+    const u64 i = (u64)blockIdx.x * LEAF_THREADS + lane;
+    if (i >= a.n) return;
+    const u32 variant = uniform32(variant_);
+    RowGenLane<G> c(a, blk + ROW_LANE_BYTES * lane, i, variant);
+    // pass 1: the length of the tuple pickle, all integers of the row requested at once.  A row is this kernel's when it has the
+    // variant's pattern, i.e. stores exactly the integers the variant lists: the top coefficient of every listed element is not zero
+    // (a limb below a listed one may be), and every extension element the variant does not list in full is zero above what is listed.
+    {
+        if (row_pattern(a, i) != G::CODES[variant]) {
+            if (!others_follow) atomicOr(a.error, 1u);
+            return;
+        }
+        const u32 nints = G::NUM_INTS[variant];
+        u64 w[G::MAX_INTS];
+#pragma unroll
+        for (u32 q = 0; q < G::MAX_INTS; ++q) w[q] = c.row_int(q < G::COMMON_INTS ? G::INTS[0][q] : G::INTS[variant][q]);   // (padded with the last one)
+        u32 int_bytes = 0;
+#pragma unroll
+        for (u32 q = 0; q < G::MAX_INTS; ++q) int_bytes += (q < G::COMMON_INTS || q < nints) ? pickle_int_len(w[q]) : 0u;
+        c.tuple_len = G::TUPLE_CONST_BYTES[variant] + int_bytes;
+#pragma unroll
+        for (u32 q = 0; q < BFS_ROWGEN_PREFETCH; ++q) c.r[q] = w[q < G::COMMON_INTS ? q : 0];
+        static_assert(BFS_ROWGEN_PREFETCH <= G::COMMON_INTS, "the first integers are the same in every variant");
+    }
+    row_lane_init(c.st8, c.tuple_len + G::SALT_BYTES);
+    u32 resume = 0;
+    while (true) {
+        resume = uniform32(resume);             // (the same in every lane; the compiler cannot tell)
+        if (resume < G::NUM_SEGMENTS) G::segments(c, resume);
+        const bool at_end = uniform32(resume) >= G::NUM_SEGMENTS;
+        // ---- the compression site
+        const bool want = at_end ? row_lane_wants_end(c.st8) : row_lane_wants_mid(c.st8, true);
+        if (at_end && !__any(want)) break;
+        if (want) row_lane_compress(c.st8, c.buf, at_end);
+    }
+    u64* out = a.digests + i * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] = c.st8.h[j];
+}
+
 // Salts can also be made on the device: 64-byte block j of the stream is BLAKE2b-512(seed || j), seed = 32 bytes of os.urandom.
 // (The reference draws urandom(24) per leaf, salted_merkle.py:25; any cryptographic stream serves.  Tests that need the
 // reference's exact bytes pass host salts instead.)
@@ -277,9 +383,13 @@ struct HostTemplates {
     std::vector<u32> ints;           // idem
     std::vector<RowSeg> segs;        // scratch of build_template
     std::vector<u64> pool;           // idem
+    int generated = -1;              // the layout of rows_generated.hpp one of the templates is (by hash), or -1 ...
+    u32 generated_variant = 0;       // ... which of its patterns ...
+    u32 generated_code = 0;          // ... and the pattern itself
 };
 
 static std::mutex g_template_mu;
+static std::atomic<u64> g_generated_launches{0};      // how often a kernel of rows_generated.hpp was used (the tests ask)
 static std::map<std::string, std::shared_ptr<const HostTemplates>> g_template_cache;
 static std::map<std::string, std::vector<u32>> g_last_codes;      // column layout -> the row patterns its last commitment had
 
@@ -376,9 +486,57 @@ static int build_template(const bfs_row_column* cols, u32 ncols, u32 code, bool 
     return BFS_OK;
 }
 
+// What a template IS, as one number: FNV-1a over its steps, the integers they name and its two lengths.  A generated leaf kernel
+// (rows_generated.hpp) carries the hash of the template it was unrolled from and is used for exactly the templates that hash alike.
+static u64 template_hash(const HostTemplates& ht, const RowTemplate& t) {
+    u64 h = 0xcbf29ce484222325ull;
+    auto mix = [&h](u64 v) { for (int b = 0; b < 8; ++b) { h ^= (v >> (8 * b)) & 0xFF; h *= 0x100000001b3ull; } };
+    mix(t.num_steps); mix(t.num_ints); mix(t.tuple_const_bytes); mix(t.salt_bytes);
+    for (u32 k = 0; k < t.num_steps; ++k) { const RowStep& st = ht.steps[t.first_step + k]; mix(st.kind | ((u64)st.a << 32)); mix(st.data); }
+    for (u32 k = 0; k < t.num_ints; ++k) mix(ht.ints[t.first_int + k]);
+    return h;
+}
+
+template <class G>
+static bool generated_match(HostTemplates& ht, int layout) {
+    for (const RowTemplate& t : ht.templates) {
+        const u64 h = template_hash(ht, t);
+        for (u32 v = 0; v < G::NUM_VARIANTS; ++v)
+            if (h == G::HASHES[v] && t.code == G::CODES[v]) {
+                ht.generated = layout; ht.generated_variant = v; ht.generated_code = t.code;
+                return true;
+            }
+    }
+    return false;
+}
+// one of the templates is a pattern of a layout rows_generated.hpp has a kernel for? (the first that is)
+static void find_generated(HostTemplates& ht) {
+    static_assert(rowgen::NUM_LAYOUTS == 2, "one line per generated layout");
+    if (generated_match<rowgen::Layout0>(ht, 0)) return;
+    generated_match<rowgen::Layout1>(ht, 1);
+}
+
 }  // namespace bfs
 
 using namespace bfs;
+
+extern "C" uint64_t bfs_row_generated_launches(void) { return g_generated_launches.load(std::memory_order_relaxed); }
+
+// tools/gen_rows.py and the tests: the flattened template of one row pattern of a column layout (d_values are not looked at).
+// out_header = {num_steps, num_ints, tuple_const_bytes, salt_bytes}; a step is two words: kind | a << 32, data.
+extern "C" int bfs_row_template_steps(const bfs_row_column* columns, uint32_t ncols, uint32_t code, int salted, uint32_t out_header[4],
+                                      uint64_t* out_steps, uint32_t steps_cap, uint32_t* out_ints, uint32_t ints_cap, uint64_t* out_hash) {
+    if (ncols == 0 || ncols > ROW_MAX_COLS) { set_error("bfs_row_template_steps: 1..%d columns", ROW_MAX_COLS); return BFS_ERR_BAD_ARG; }
+    HostTemplates ht;
+    BFS_TRY(build_template(columns, ncols, code, salted != 0, ht));
+    const RowTemplate& t = ht.templates[0];
+    if (t.num_steps > steps_cap || t.num_ints > ints_cap) { set_error("bfs_row_template_steps: %u steps, %u integers do not fit", t.num_steps, t.num_ints); return BFS_ERR_BAD_ARG; }
+    out_header[0] = t.num_steps; out_header[1] = t.num_ints; out_header[2] = t.tuple_const_bytes; out_header[3] = t.salt_bytes;
+    for (u32 k = 0; k < t.num_steps; ++k) { out_steps[2 * k] = ht.steps[k].kind | ((u64)ht.steps[k].a << 32); out_steps[2 * k + 1] = ht.steps[k].data; }
+    for (u32 k = 0; k < t.num_ints; ++k) out_ints[k] = ht.ints[k];
+    if (out_hash) *out_hash = template_hash(ht, t);
+    return BFS_OK;
+}
 
 extern "C" int bfs_random_fill(const uint8_t seed[32], uint64_t* d_out, uint64_t nwords, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
@@ -524,6 +682,7 @@ static int build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n,
         if (!cached) {
             std::shared_ptr<HostTemplates> fresh(new HostTemplates());
             for (u32 code : codes) BFS_TRY(build_template(columns, ncols, code, salted, *fresh));
+            find_generated(*fresh);
             std::lock_guard<std::mutex> lock(g_template_mu);
             if (g_template_cache.size() >= 256) g_template_cache.clear();
             g_template_cache[key] = fresh;
@@ -545,9 +704,33 @@ static int build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n,
         a.steps = (const RowStep*)(tb + tbytes);
         a.ints = (const u32*)(tb + tbytes + sbytes);
 
-        // 3. leaf digests, then the tree
-        hipLaunchKernelGGL(row_leaves_kernel, dim3((u32)((n + LEAF_THREADS - 1) / LEAF_THREADS)), dim3(LEAF_THREADS), 0, stream, a);
-        BFS_HIP(hipGetLastError());
+        // 3. leaf digests, then the tree.  A layout rows_generated.hpp knows goes through its straight-line kernel; rows of any other
+        // pattern of that layout (and every other layout) through the interpreter.  BFS_ROWS_GENERATED=0: the interpreter only.
+        static const bool use_generated = [] { const char* e = getenv("BFS_ROWS_GENERATED"); return !(e && e[0] == '0'); }();
+        const dim3 grid((u32)((n + LEAF_THREADS - 1) / LEAF_THREADS)), block(LEAF_THREADS);
+        const int gen = use_generated ? ht.generated : -1;
+        static const bool log_rows = [] { const char* e = getenv("BFS_ROWS_LOG"); return e && e[0] == '1'; }();
+        if (log_rows) {
+            std::string line;
+            for (const RowTemplate& t : ht.templates) { char b[16]; snprintf(b, sizeof b, " %x", t.code); line += b; }
+            fprintf(stderr, "[bfs] row leaves: %u columns (%u extension), %llu rows, patterns%s%s, generated layout %d\n", ncols, a.n_ext,
+                    (unsigned long long)n, line.c_str(), guessed ? " (remembered)" : "", gen);
+        }
+        const u32 others = ht.templates.size() > 1 ? 1u : 0u;
+        a.skip = 0;
+        if (gen == 0) hipLaunchKernelGGL(row_leaves_generated_kernel<rowgen::Layout0>, grid, block, 0, stream, a, ht.generated_variant, others);
+        else if (gen == 1) hipLaunchKernelGGL(row_leaves_generated_kernel<rowgen::Layout1>, grid, block, 0, stream, a, ht.generated_variant, others);
+        static_assert(rowgen::NUM_LAYOUTS == 2, "one launch per generated layout");
+        if (gen >= 0) {
+            BFS_HIP(hipGetLastError());
+            g_generated_launches.fetch_add(1, std::memory_order_relaxed);
+            a.skip = 1;
+            a.skip_code = ht.generated_code;
+        }
+        if (gen < 0 || others) {
+            hipLaunchKernelGGL(row_leaves_kernel, grid, block, 0, stream, a);
+            BFS_HIP(hipGetLastError());
+        }
         BFS_TRY(merkle_inner_launch((u64*)d_nodes, depth, n, stream, nullptr, 0));
         // error word and root in one copy: nodes[1] is the root (heap order), digests of 8 words
         BFS_HIP(hipMemcpyAsync(back, d_err, 16, hipMemcpyDeviceToHost, stream));

@@ -351,3 +351,74 @@ def test_row_lanes_walk_a_template_block_synchronously(emu, seed):
         assert out[l].tobytes() == hashlib.blake2b(pre).digest(), "lane %d, %d bytes" % (l, len(pre))
     if mode == 2 and nints >= 8:
         assert skew.value > 56, "the alternating rows should put lanes more than a buffer's slack apart"
+
+
+def test_generated_row_header_is_what_the_generator_writes_today():
+    """csrc/rows_generated.hpp against tools/gen_rows.py (which asks the library for the templates: bfs_row_template_steps)"""
+    import subprocess
+    import sys
+    header = os.path.join(ROOT, "stark_brainfuck_amd", "csrc", "rows_generated.hpp")
+    before = open(header).read()
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rows.py")], check=True, capture_output=True)
+    assert open(header).read() == before, "rows_generated.hpp is stale: run tools/gen_rows.py"
+
+
+@pytest.mark.parametrize("layout,variant,n_ext,n_base", [(0, 0, 1, 16)] + [(1, v, 9, 0) for v in range(9)])
+def test_generated_row_walks_against_the_oracle_pickles(emu, oracle, layout, variant, n_ext, n_base):
+    """csrc/rows_generated.hpp (tools/gen_rows.py: the zipped-row template walk unrolled for the prover's two column layouts and the
+    row patterns they come in), compiled for the host and driven like row_leaves_generated_kernel drives it (tests/emu/emu_rowgen.cpp):
+    64 lanes in lockstep, every digest against BLAKE2b of the oracle's pickle of the same row (look-alike classes, CPython's pickle:
+    brainfuck_stark.py:178-179 / 197-198 with salted_merkle.py:32-35).  Integers of every opcode width, neighbouring lanes blocks
+    apart.  Also: the library matches its own template of the pattern by the hash the header carries."""
+    u32 = ctypes.c_uint32
+    emu.emu_rowgen_leaves.argtypes = [u32, u32, vp, vp, u32, vp, vp, vp]
+    info = (u32 * 5)()
+    assert emu.emu_rowgen_leaves(layout, variant, None, None, 0, None, info, None) == 0
+    nints, code = info[1], info[4]
+    stored = [(code >> (2 * e)) & 3 for e in range(n_ext)]        # coefficients per extension element
+    assert nints == sum(stored) + n_base
+    lanes = 64
+    widths = [1, 255, 256, 65535, 65536, (1 << 31) - 1, 1 << 31, (1 << 40) - 1, 1 << 47, (1 << 48) + 9, (1 << 56) - 1, 1 << 56, (1 << 63) - 1, 1 << 63, P - 1]
+    for mode in range(3):
+        rng = np.random.default_rng(SEED + 100 * layout + 10 * variant + mode)
+        values = np.zeros((lanes, nints), dtype=np.uint64)
+        for l in range(lanes):
+            for j in range(nints):
+                if mode == 0:
+                    values[l, j] = int(rng.integers(1, P, dtype=np.uint64))
+                elif mode == 1:
+                    values[l, j] = widths[int(rng.integers(0, len(widths)))]
+                else:
+                    values[l, j] = 5 if l % 2 else P - 1 - j
+        salts = rng.integers(0, 1 << 63, (lanes, 3), dtype=np.uint64)
+        out = np.zeros((lanes, 8), dtype=np.uint64)
+        sites = u32()
+        rc = emu.emu_rowgen_leaves(layout, variant, values.ctypes.data, salts.ctypes.data, lanes, out.ctypes.data, None, ctypes.byref(sites))
+        assert rc == 0, rc
+        longest = 0
+        for l in range(lanes):
+            v = [int(x) for x in values[l]]
+            row, at = [], 0
+            for k in stored:
+                row.append(oracle.make_xfe(v[at:at + k] + [0] * (3 - k)))
+                at += k
+            row += [oracle.make_bfe(x) for x in v[at:]]
+            pre = oracle.salted_leaf_bytes(tuple(row), salts[l].tobytes())
+            longest = max(longest, len(pre))
+            assert out[l].tobytes() == hashlib.blake2b(pre).digest(), "mode %d lane %d, %d bytes" % (mode, l, len(pre))
+        assert sites.value >= (longest + 127) // 128
+        if mode == 2:
+            assert sites.value > (longest + 127) // 128, "lanes blocks apart: some compressions must run without the short rows"
+    from stark_brainfuck_amd import _lib
+    lib = _lib.load()
+    cols = (_lib.RowColumn * (n_ext + n_base))()
+    for c in range(n_ext + n_base):
+        cols[c].d_values, cols[c].is_ext, cols[c].field_id = None, int(c < n_ext), 0
+    hdr = (u32 * 4)()
+    steps = np.zeros(2 * 4096, dtype=np.uint64)
+    ints = np.zeros(256, dtype=np.uint32)
+    h = ctypes.c_uint64()
+    _lib.check(lib.bfs_row_template_steps(cols, n_ext + n_base, code, 1, hdr, steps.ctypes.data, 4096, ints.ctypes.data, 256, ctypes.byref(h)))
+    header = open(os.path.join(ROOT, "stark_brainfuck_amd", "csrc", "rows_generated.hpp")).read()
+    assert "0x%016xull" % h.value in header
+    assert [hdr[1], hdr[2], hdr[3]] == [info[1], info[2], info[3]]

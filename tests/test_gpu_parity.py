@@ -1082,6 +1082,89 @@ def test_zipped_rows_edge_shapes(sb, oracle, n, n_ext, n_base):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_ext,n_base", [(1, 16), (9, 0)])
+def test_zipped_rows_generated_layouts(sb, oracle, n_ext, n_base):
+    """the prover's two column layouts go through the straight-line kernels of csrc/rows_generated.hpp (tools/gen_rows.py): every
+    leaf digest against the oracle's pickles, for (a) rows of random field elements, (b) rows whose integers have every opcode width
+    -- one-byte values next to nine-byte ones, so the lanes of a wave drift whole blocks apart -- but whose extension elements still
+    store three coefficients, (c) the same with some top limbs zero: those rows are another pattern, the generated kernel leaves
+    them to the interpreter kernel launched behind it (first through the fallback of a remembered pattern set that lacks them),
+    (d) a layout one column wider, which must NOT take a generated kernel."""
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.device import DeviceBuffer
+    lib = _lib.load()
+    P = (1 << 64) - (1 << 32) + 1
+    n, npo2 = 1000, 1024
+    rng = np.random.default_rng(900 + n_ext)
+    widths = [1, 200, 60000, (1 << 31) - 1, 1 << 31, (1 << 40) + 5, (1 << 48) - 1, 1 << 55, (1 << 56) - 1, 1 << 56, (1 << 63) - 1, 1 << 63, P - 1]
+
+    def commit(ext, base, expect_generated):
+        bufs = [DeviceBuffer.from_numpy(np.ascontiguousarray(e).reshape(-1)) for e in ext] + [DeviceBuffer.from_numpy(np.ascontiguousarray(b)) for b in base]
+        rc = (_lib.RowColumn * len(bufs))()
+        for k, b in enumerate(bufs):
+            rc[k].d_values, rc[k].is_ext, rc[k].field_id = b.ptr, int(k < len(ext)), 0
+        nodes = DeviceBuffer(2 * npo2 * 8)
+        salts = rng.integers(0, 256, 24 * n, dtype=np.uint8).tobytes()
+        keep = ctypes.create_string_buffer(salts, len(salts))
+        before = lib.bfs_row_generated_launches()
+        _lib.check(lib.bfs_merkle_build_rows(rc, len(bufs), n, ctypes.cast(keep, ctypes.c_void_p), 0, nodes.ptr, 0))
+        assert (lib.bfs_row_generated_launches() > before) == expect_generated
+        rows = [tuple([oracle.make_xfe([int(e[0, i]), int(e[1, i]), int(e[2, i])]) for e in ext] + [oracle.make_bfe(int(b[i])) for b in base])
+                for i in range(n)]
+        pre = [oracle.salted_leaf_bytes(r, salts[24 * i:24 * i + 24]) for i, r in enumerate(rows)]
+        got = nodes.to_numpy(8 * n, offset=8 * npo2).tobytes()
+        bad = [i for i in range(n) if got[64 * i:64 * i + 64] != hashlib.blake2b(pre[i]).digest()]
+        assert not bad, "leaf digests differ at rows %s" % bad[:8]
+        assert nodes.to_numpy(8, offset=8).tobytes() == oracle.MerkleOracle(pre).root()
+        return pre
+
+    # (a) random field elements; for the extension commitment also the patterns of its last two columns the header has variants for
+    # (the evaluation columns of the input and output tables: zero without symbols, a base-field constant with one)
+    ext = [rng.integers(1, P, (3, n), dtype=np.uint64) for _ in range(n_ext)]
+    base = [rng.integers(0, P, n, dtype=np.uint64) for _ in range(n_base)]
+    commit(ext, base, True)
+    if n_ext == 9:
+        for k7, k8 in [(0, 3), (0, 1), (1, 0), (3, 1), (0, 0), (1, 1)]:
+            e = [x.copy() for x in ext]
+            e[7][k7:] = 0
+            e[8][k8:] = 0
+            commit(e, base, True)
+            commit(e, base, True)             # (the second time through the remembered pattern set)
+        e = [x.copy() for x in ext]
+        e[7][2:] = 0                          # two stored coefficients: no variant for that ...
+        commit(e, base, True)                 # ... (found out by the generated kernel the remembered pattern set stood for) ...
+        commit(e, base, False)                # ... so the interpreter alone
+        commit(ext, base, True)
+    # (b) every opcode width, neighbouring rows far apart; top limbs stay non-zero
+    ext = [np.zeros((3, n), dtype=np.uint64) for _ in range(n_ext)]
+    base = [np.zeros(n, dtype=np.uint64) for _ in range(n_base)]
+    for i in range(n):
+        kind = i % 4
+        for c, col in enumerate([e[j] for e in ext for j in range(3)] + base):
+            if kind == 0:
+                col[i] = 7
+            elif kind == 1:
+                col[i] = P - 1 - c
+            elif kind == 2:
+                col[i] = widths[(i + c) % len(widths)]
+            else:
+                col[i] = widths[int(rng.integers(0, len(widths)))] if c < (i % 27) else 3
+    pre = commit(ext, base, True)
+    lengths = {len(p) for p in pre}
+    assert max(lengths) - min(lengths) >= 9 * (3 * n_ext + n_base) - 20
+    # (c) rows of other patterns among them: a zero element, two stored coefficients, one
+    for e in ext[:2]:
+        e[:, 5] = 0
+        e[2, 100:140] = 0
+        e[1:, 700] = 0
+    ext[-1][2, 256:512] = 0               # a whole workgroup of the generated kernel with nothing to do
+    commit(ext, base, True)               # (remembered set: one pattern; rows without a template -> collected, hashed again)
+    commit(ext, base, True)               # (remembered set: all of them; generated kernel + interpreter, no fallback)
+    # (d) one base column more: not a layout the header knows
+    commit(ext, base + [rng.integers(0, P, n, dtype=np.uint64)], False)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("salted", [True, False])
 def test_zipped_rows_lanes_far_apart(sb, oracle, salted):
     """the leaf kernel compresses wave-synchronously: every lane has a 24-word block buffer and the wave compresses when the lane

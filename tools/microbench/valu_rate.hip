@@ -20,12 +20,14 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at line %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
-enum Op { ADD_U32, XOR_B32, ADD_CO_PAIR, LSHL_ADD_U64, CNDMASK, MAD_U64_U32, SUBB_SGPR, MUL_LO_U32, ALIGNBIT, ADD_LAZY4, PERM_B32, ALIGNBYTE, LSHL_OR, XOR3, ADD3, LSHLREV, CNDMASK_CMP, OPS };
+enum Op { ADD_U32, XOR_B32, ADD_CO_PAIR, LSHL_ADD_U64, CNDMASK, MAD_U64_U32, SUBB_SGPR, MUL_LO_U32, ALIGNBIT, ADD_LAZY4, PERM_B32, ALIGNBYTE, LSHL_OR, XOR3, ADD3, LSHLREV, CNDMASK_CMP, MIX_XA, MIX_G, OPS };
 static const char* NAMES[OPS] = {"v_add_u32", "v_xor_b32", "v_add_co_u32 + v_addc_co_u32 (vcc)", "v_lshl_add_u64", "v_cndmask_b32 (vcc)",
                                  "v_mad_u64_u32", "v_sub_co + s_nop 1 + v_subb_co (SGPR pair)", "v_mul_lo_u32", "v_alignbit_b32",
                                  "gl_add_lazy shape: add_co, addc_co, cndmask, add_co... (4 instr)", "v_perm_b32", "v_alignbyte_b32", "v_lshl_or_b32",
-                                 "v_bitop3_b32 (three-input xor)", "v_add3_u32", "v_lshlrev_b32", "v_cmp_lt_u32 + v_cndmask_b32 (vcc written every time)"};
-static const int INSTR_PER_STEP[OPS] = {1, 1, 2, 1, 1, 1, 2, 1, 1, 4, 1, 1, 1, 1, 1, 1, 2};
+                                 "v_bitop3_b32 (three-input xor)", "v_add3_u32", "v_lshlrev_b32", "v_cmp_lt_u32 + v_cndmask_b32 (vcc written every time)",
+                                 "mix: v_xor_b32, v_alignbit_b32 alternating (class prices 2 + 4)",
+                                 "mix, a quarter of BLAKE2b's G: v_lshl_add_u64, v_xor_b32 x 2, v_alignbit_b32 x 2 (class prices 4 + 2 + 2 + 4 + 4)"};
+static const int INSTR_PER_STEP[OPS] = {1, 1, 2, 1, 1, 1, 2, 1, 1, 4, 1, 1, 1, 1, 1, 1, 2, 2, 5};
 
 // one step = the class applied to chain k.  Everything is inline asm (volatile) so the compiler neither folds nor reorders the work;
 // the loop is unrolled by hand through the macro below.
@@ -54,6 +56,13 @@ __device__ __forceinline__ void step(uint32_t& lo, uint32_t& hi, uint32_t c) {
     else if (OP == ADD3) asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(lo) : "v"(hi), "v"(c));
     else if (OP == LSHLREV) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(lo));
     else if (OP == CNDMASK_CMP) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %2, vcc" : "+v"(lo) : "v"(hi), "v"(c) : "vcc");
+    else if (OP == MIX_XA) asm volatile("v_xor_b32 %0, %0, %2\n\tv_alignbit_b32 %1, %1, %0, 7" : "+v"(lo), "+v"(hi) : "v"(c));
+    else if (OP == MIX_G) {
+        uint64_t x = ((uint64_t)hi << 32) | lo, y = c;
+        asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(x) : "v"(y));
+        lo = (uint32_t)x; hi = (uint32_t)(x >> 32);
+        asm volatile("v_xor_b32 %0, %0, %2\n\tv_xor_b32 %1, %1, %2\n\tv_alignbit_b32 %0, %0, %1, 24\n\tv_alignbit_b32 %1, %1, %0, 24" : "+v"(lo), "+v"(hi) : "v"(c));
+    }
     else if (OP == ADD_LAZY4) asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %2, vcc\n\tv_cndmask_b32 %0, %0, %2, vcc\n\tv_add_co_u32 %0, vcc, %0, %1"
                                            : "+v"(lo), "+v"(hi) : "v"(c) : "vcc");
 }
@@ -117,7 +126,7 @@ void sweep(uint64_t* d_cycles, uint32_t* d_sink, int num_cu) {
     for (int w : {1, 2, 4, 6, 8}) run<OP>(w, d_cycles, d_sink, num_cu);
 }
 
-int main() {
+int main(int argc, char** argv) {
     hipDeviceProp_t prop;
     CK(hipGetDeviceProperties(&prop, 0));
     const int num_cu = prop.multiProcessorCount;
@@ -125,6 +134,13 @@ int main() {
     uint64_t* d_cycles; uint32_t* d_sink;
     CK(hipMalloc(&d_cycles, 8 * 4 * num_cu * sizeof(uint64_t)));
     CK(hipMalloc(&d_sink, (size_t)8 * 4 * num_cu * 64 * sizeof(uint32_t)));
+    if (argc > 1 && argv[1][0] == 'm') {        // "mix": do the class prices add up when the classes alternate?
+        sweep<XOR_B32>(d_cycles, d_sink, num_cu);
+        sweep<ALIGNBIT>(d_cycles, d_sink, num_cu);
+        sweep<MIX_XA>(d_cycles, d_sink, num_cu);
+        sweep<MIX_G>(d_cycles, d_sink, num_cu);
+        return 0;
+    }
     sweep<ADD_U32>(d_cycles, d_sink, num_cu);
     sweep<XOR_B32>(d_cycles, d_sink, num_cu);
     sweep<ADD_CO_PAIR>(d_cycles, d_sink, num_cu);
