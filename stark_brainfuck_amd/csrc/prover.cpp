@@ -24,7 +24,10 @@
 #include "runtime.hpp"
 
 #include <chrono>
+#include <condition_variable>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -89,11 +92,51 @@ struct StarkSession {
     // The commitment to the zipped extension rows is the first thing bfs_stark_finish needs and depends on nothing the caller does
     // between the two calls, so bfs_stark_commit hands it to a thread of its own: the GPU hashes rows while the caller's interpreter
     // makes terminal objects and degree bounds.  Joined by bfs_stark_finish (or by whatever ends the session first).
+    // The thread is the session's own and lives as long as the session (a thread per proof cost its creation on the critical path of
+    // every small proof): it sleeps on a condition variable between proofs.
     std::thread ext_tree_thread;
+    std::mutex ext_mu;
+    std::condition_variable ext_cv;
+    std::function<void()> ext_job;          // posted by bfs_stark_commit, taken by the thread
+    bool ext_busy = false, ext_quit = false;
     int ext_tree_rc = BFS_OK;
     std::string ext_tree_error;
     uint8_t ext_root[64];
-    void join_ext_tree() { if (ext_tree_thread.joinable()) ext_tree_thread.join(); }
+    void post_ext_tree(std::function<void()> job) {
+        std::unique_lock<std::mutex> lock(ext_mu);
+        ext_cv.wait(lock, [this] { return !ext_busy; });
+        ext_job = std::move(job);
+        ext_busy = true;
+        if (!ext_tree_thread.joinable())
+            ext_tree_thread = std::thread([this] {
+                std::unique_lock<std::mutex> l(ext_mu);
+                for (;;) {
+                    ext_cv.wait(l, [this] { return ext_quit || ext_job; });
+                    if (ext_quit) return;
+                    std::function<void()> job = std::move(ext_job);
+                    ext_job = nullptr;
+                    l.unlock();
+                    job();
+                    l.lock();
+                    ext_busy = false;
+                    ext_cv.notify_all();
+                }
+            });
+        ext_cv.notify_all();
+    }
+    void join_ext_tree() {                  // (waits for the posted commitment; the thread itself stays)
+        std::unique_lock<std::mutex> lock(ext_mu);
+        ext_cv.wait(lock, [this] { return !ext_busy; });
+    }
+    void stop_ext_thread() {
+        {
+            std::unique_lock<std::mutex> lock(ext_mu);
+            ext_cv.wait(lock, [this] { return !ext_busy; });
+            ext_quit = true;
+        }
+        ext_cv.notify_all();
+        if (ext_tree_thread.joinable()) ext_tree_thread.join();
+    }
     // Side streams.  At the sizes where this driver matters the kernels of a proof are small (10-20 us, a handful of workgroups) and
     // queue faster than they run, so independent chains -- the randomizer's sampling + transform, each table's interpolation +
     // randomizer correction -- run side by side instead of one after the other: fork / join with events around them.
@@ -123,7 +166,7 @@ struct StarkSession {
         if (fork_ev) { (void)hipEventDestroy(fork_ev); fork_ev = nullptr; }
         if (rand_ev) { (void)hipEventDestroy(rand_ev); rand_ev = nullptr; }
     }
-    ~StarkSession() { join_ext_tree(); drop_streams(); }
+    ~StarkSession() { stop_ext_thread(); drop_streams(); }
 };
 
 u64 padding_length(u64 rows) {                              // table.py: rows to add so that the count becomes a power of two (0 and 2^k stay)
@@ -230,6 +273,9 @@ int bfs_stark_commit(void* session, void* ps, const bfs_stark_params* params, co
     DeviceBlock rpoly;
     BFS_TRY(rpoly.get(3 * count * 8, stream));
     BFS_TRY(S.randomizer_cw.get(3 * n * 8, stream));
+    const u64 salt_words = (3 * n + 7) / 8 * 8;
+    if (rnd->base_salt_seed) BFS_TRY(S.base_salts_dev.get(salt_words * 8, stream));
+    if (rnd->ext_salt_seed) BFS_TRY(S.ext_salts_dev.get(salt_words * 8, stream));
     BFS_HIP(hipEventRecord(S.fork_ev, stream));             // (the blocks above may have been released on `stream` by work still queued there)
     hipStream_t rs = S.aux[2];
     BFS_HIP(hipStreamWaitEvent(rs, S.fork_ev, 0));
@@ -239,7 +285,10 @@ int bfs_stark_commit(void* session, void* ps, const bfs_stark_params* params, co
         BFS_TRY(bfs_memcpy_h2d(rpoly.ptr, rnd->randomizer_limbs, 3 * count * 8, rs));
     } else { set_error("bfs_stark_commit: no randomizer polynomial"); return BFS_ERR_BAD_ARG; }
     BFS_TRY(bfs_gl_ntt(rpoly.words(), count, count, S.randomizer_cw.words(), n, P.log_n, 3, omega, offset, 1, rs));
-    BFS_HIP(hipEventRecord(S.rand_ev, rs));                 // joined in front of the base commitment, which reads the codeword
+    // the salts of both commitments are expanded from their seeds here too, next to the transforms: nothing depends on them until the leaf kernels
+    if (rnd->base_salt_seed) BFS_TRY(bfs_random_fill(rnd->base_salt_seed, S.base_salts_dev.words(), salt_words, rs));
+    if (rnd->ext_salt_seed) BFS_TRY(bfs_random_fill(rnd->ext_salt_seed, S.ext_salts_dev.words(), salt_words, rs));
+    BFS_HIP(hipEventRecord(S.rand_ev, rs));                 // joined in front of the base commitment, which reads the codeword (and the salts)
 
     // ---- padding (host) into pinned staging, one upload for all tables; the scan masks ride along
     u64 trace_words = 0, mask_bytes = 0;
@@ -321,10 +370,7 @@ int bfs_stark_commit(void* session, void* ps, const bfs_stark_params* params, co
     BFS_TRY(S.base_nodes.get(2 * n * 64, stream));
     uint8_t root[64];
     if (rnd->base_salt_seed) {
-        const u64 words = (3 * n + 7) / 8 * 8;
-        BFS_TRY(S.base_salts_dev.get(words * 8, stream));
-        BFS_TRY(bfs_random_fill(rnd->base_salt_seed, S.base_salts_dev.words(), words, stream));
-        S.base_salts_on_device = true;
+        S.base_salts_on_device = true;                      // (filled on the randomizer's stream, joined above)
         BFS_TRY(bfs_merkle_build_rows_root(cols, nc, n, n, (const uint8_t*)S.base_salts_dev.ptr, 1, (uint8_t*)S.base_nodes.ptr, root, stream));
     } else if (rnd->base_salts) {
         S.base_salts_host.assign(rnd->base_salts, rnd->base_salts + 24 * n);
@@ -463,10 +509,7 @@ int bfs_stark_commit(void* session, void* ps, const bfs_stark_params* params, co
     // ---- commitment to the zipped extension rows (brainfuck_stark.py:197-198), on a thread of its own (see StarkSession)
     BFS_TRY(S.ext_nodes.get(2 * n * 64, stream));
     if (S.have_ext_salt_seed) {
-        const u64 words = (3 * n + 7) / 8 * 8;
-        BFS_TRY(S.ext_salts_dev.get(words * 8, stream));
-        BFS_TRY(bfs_random_fill(S.ext_salt_seed, S.ext_salts_dev.words(), words, stream));
-        S.ext_salts_on_device = true;
+        S.ext_salts_on_device = true;                       // (filled at the start of the call, on the randomizer's stream)
     } else {
         S.ext_salts_on_device = false;
     }
@@ -475,7 +518,7 @@ int bfs_stark_commit(void* session, void* ps, const bfs_stark_params* params, co
         BFS_HIP(hipGetDevice(&dev));
         StarkSession* sp = &S;
         S.ext_tree_rc = BFS_OK;
-        S.ext_tree_thread = std::thread([sp, dev, n, stream] {
+        S.post_ext_tree([sp, dev, n, stream] {
             StarkSession& T = *sp;
             if (hipSetDevice(dev) != hipSuccess) { T.ext_tree_rc = BFS_ERR_HIP; T.ext_tree_error = "hipSetDevice failed on the commitment thread"; return; }
             bfs_row_column cols[32];
