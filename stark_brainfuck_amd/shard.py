@@ -6,7 +6,21 @@ independently).  The only exchange is the "final transcript reduction": every ra
 roots of its columns and receives all of them (one all_gather over RCCL/xGMI; `gloo` in the CPU tests).  Field
 elements are never summed across ranks -- ncclSum on uint64 would not be reduction mod p.
 """
+import contextvars
+
 import numpy as np
+
+# the shared_randomness block this context (thread / task) is inside, if any: its collectives ask it whether a peer has failed
+_current_block = contextvars.ContextVar("bfs_shared_randomness_block", default=None)
+
+
+def check_peers():
+    """in front of every collective of a cooperative proof: if a rank of this shared_randomness block has left it through an exception
+    (it said so in the process group's store -- out of band, it takes part in no further collective), raise here instead of entering a
+    collective that rank will never join.  Outside a block, or without a store: nothing."""
+    block = _current_block.get()
+    if block is not None:
+        block.raise_if_a_peer_failed()
 
 
 def assign_columns(num_columns, world_size, rank):
@@ -37,6 +51,7 @@ def gather_roots(local_roots, num_columns, world_size, rank, group=None, device=
     if device is not None:
         send = send.to(device)
     recv = [torch.empty_like(send) for _ in range(world_size)]
+    check_peers()
     dist.all_gather(recv, send, group=group)
     out = [None] * num_columns
     for r in range(world_size):
@@ -92,6 +107,7 @@ def exchange_rows(local_columns, planes, n, world_size, rank, group=None, device
     in_splits = [my_words] * world_size
     out_splits = [sum(planes[c] for c in assign_columns(num_columns, world_size, r)) * m for r in range(world_size)]
     recv = torch.empty(sum(out_splits), dtype=torch.int64, device=send.device)
+    check_peers()
     dist.all_to_all_single(recv, send.contiguous(), out_splits, in_splits, group=group)
     out, pos = [None] * num_columns, 0
     for r in range(world_size):
@@ -123,6 +139,7 @@ def all_gather_rows(ptr, n, planes, stride, world_size, rank, group=None, device
     lib = _lib.load()
     stream = current_stream() if stream is None else stream
     _lib.check(lib.bfs_stream_synchronize(stream))                 # the kernels that wrote this rank's rows
+    check_peers()
     if device is not None:
         for p in range(planes):
             whole = torch.as_tensor(_DeviceWords(ptr + 8 * p * stride, n), device=device)
@@ -173,6 +190,7 @@ class ShardedZippedMerkle:
             if device is not None:
                 send = send.to(device)
             recv = [torch.empty_like(send) for _ in range(world_size)]
+            check_peers()
             dist.all_gather(recv, send, group=group)
             roots = [r.cpu().numpy().tobytes() for r in recv]
         # heap of the top levels: top[G + r] = subtree root of rank r, top[k] = H(top[2k] || top[2k+1])   (merkle.py:35-41)
@@ -207,6 +225,7 @@ class ShardedZippedMerkle:
             salt, path = self.subtree.open(index - self.first)
             box = [(bytes(salt), [bytes(p) for p in path])]
         if self.world_size > 1:
+            check_peers()
             dist.broadcast_object_list(box, src=owner, group=self.group)
         salt, path = box[0]
         return salt, path + self.top_path(index)
@@ -325,15 +344,41 @@ class shared_randomness:
     the ranks of `group` (randomness.override: a context variable, so another prover thread of the same process keeps its own source
     and the module-level `urandom` names are left alone).  On a clean exit the ranks compare how far each one read the stream: the
     proofs can only agree if every rank drew the same bytes in the same order, and a divergence here would otherwise show up as
-    mismatched collectives later."""
+    mismatched collectives later.
+
+    A rank that leaves the block through an exception takes part in NO further collective (its peers may be inside another one: on
+    RCCL a mismatched collective hangs or returns garbage -- round-4 advice); it says so in the process group's store instead, under a
+    key of this block.  The peers look at that key in front of every collective of the block (check_peers) and while they wait for
+    each other at its end, and raise.  A peer that is already inside a collective the failed rank never joins still waits for the
+    backend's timeout, as it always did.  Without a store (a process group made from one is rare) the closing gather is the old one."""
+    _entered = {}                   # ranks of the group -> blocks entered so far (the ranks of a group enter its blocks in the same order)
+    closing_timeout_s = 600.0
 
     def __init__(self, world_size, rank, group=None, seed=None):
         self.world_size, self.rank, self.group, self.seed = world_size, rank, group, seed
+        self._store = None
+
+    def _open_store(self):
+        try:
+            import torch.distributed as dist
+            from torch.distributed import distributed_c10d as c10d
+            ranks = tuple(dist.get_process_group_ranks(self.group if self.group is not None else dist.group.WORLD))
+            serial = shared_randomness._entered.get(ranks, 0)
+            shared_randomness._entered[ranks] = serial + 1
+            return c10d.PrefixStore("bfs-shared-randomness/%s/%d/" % ("-".join(map(str, ranks)), serial), c10d._get_default_store())
+        except Exception:
+            return None
+
+    def raise_if_a_peer_failed(self):
+        if self._store is not None and self._store.check(["failed"]):
+            raise RuntimeError("rank(s) [%s] left the shared-randomness block with an exception" % self._store.get("failed").decode())
 
     def __enter__(self):
         import os
         from . import randomness
         seed = self.seed
+        if self.world_size > 1:
+            self._store = self._open_store()
         if seed is None:
             box = [os.urandom(32) if self.rank == 0 else None]
             if self.world_size > 1:
@@ -343,14 +388,33 @@ class shared_randomness:
         self._stream = _SharedStream(seed)
         self._override = randomness.override(self._stream)
         self._override.__enter__()
+        self._token = _current_block.set(self)
         return self._stream
 
     def __exit__(self, exc_type, exc, tb):
+        _current_block.reset(self._token)
         self._override.__exit__(exc_type, exc, tb)
         if self.world_size > 1:
-            # every rank reports (left cleanly?, stream position), whether or not it is leaving through an exception: a rank that
-            # failed must turn into an error on the others here instead of leaving them blocked in this gather (round-3 advice)
             import torch.distributed as dist
+            if self._store is not None:
+                import time
+                if exc_type is not None:
+                    try:
+                        self._store.set("failed", str(self.rank))
+                    except Exception:               # the process group itself is gone: keep the original error
+                        pass
+                    return False
+                # wait until every rank is here (then the closing gather is matched by construction) or one has failed
+                self._store.add("arrived", 1)
+                deadline = time.monotonic() + self.closing_timeout_s
+                while self._store.add("arrived", 0) < self.world_size:
+                    self.raise_if_a_peer_failed()
+                    if time.monotonic() > deadline:
+                        raise RuntimeError("shared-randomness block: not every rank arrived at its end within %.0f s" % self.closing_timeout_s)
+                    time.sleep(1e-4)
+                self.raise_if_a_peer_failed()
+            # every rank reports (left cleanly?, stream position); without a store a rank that failed still takes part, so that its
+            # peers get an error here instead of blocking (round-3 advice)
             reports = [None] * self.world_size
             try:
                 dist.all_gather_object(reports, (exc_type is None, self._stream._pos), group=self.group)

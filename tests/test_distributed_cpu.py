@@ -271,9 +271,58 @@ def _failing_rank_worker(rank, world, port, q):
     q.put((rank, outcome))
 
 
+def _failing_rank_mid_block_worker(rank, world, port, q):
+    import sys
+    import time
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from stark_brainfuck_amd import shard
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    outcome, entered = "clean", False
+    try:
+        with shard.shared_randomness(world, rank) as stream:
+            stream(16)
+            if rank == 1:
+                raise ValueError("rank 1 fails before the block's collective")
+            time.sleep(1.0)                  # rank 1 has long left; this rank now reaches a collective of the block
+            shard.check_peers()
+            entered = True                   # (not reached: the all_gather below would wait for a rank that never comes)
+            dist.all_gather([torch.zeros(1) for _ in range(world)], torch.zeros(1))
+    except ValueError:
+        outcome = "own error"
+    except RuntimeError as e:
+        outcome = "told: " + str(e)
+    # the process group is intact: no rank is stuck in, or has skipped, a collective
+    dist.barrier()
+    with shard.shared_randomness(world, rank) as stream:      # and the next block of the same group starts from a clean slate
+        stream(8)
+    dist.destroy_process_group()
+    q.put((rank, outcome, entered))
+
+
+def test_a_failing_rank_issues_no_collective_and_its_peers_find_out_in_front_of_theirs():
+    """round-4 advice: a rank that leaves the shared-randomness block through an exception must not issue the closing gather while
+    its peers may be inside another collective of the block (on RCCL a mismatched collective); it flags the failure in the process
+    group's store, and a peer raises in front of its next collective of the block (shard.check_peers) instead of entering it"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_failing_rank_mid_block_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {r: (o, e) for r, o, e in (q.get(timeout=120) for _ in procs)}
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert got[1] == ("own error", False)
+    assert got[0][0].startswith("told:") and "[1]" in got[0][0] and got[0][1] is False, got
+
+
 def test_a_failing_rank_in_shared_randomness_becomes_an_error_on_the_others():
-    """a rank that leaves the shared-randomness block through an exception still takes part in the closing gather, and the ranks that
-    left cleanly raise instead of blocking in it (round-3 advice)"""
+    """a rank that leaves the shared-randomness block through an exception turns into an error on the ranks that left it cleanly,
+    which raise at the end of the block instead of blocking there (round-3 advice; since round 5 through the store, not a gather)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
