@@ -62,43 +62,49 @@ __device__ __forceinline__ void blake2b_init_quad(const QuadLane& q, u64& hl, u6
     hh = q.iv_d;
 }
 
+// the four message words lane j needs in round R: column step (x, y), diagonal step (x, y)
+struct QuadWords { u64 cx, cy, dx, dy; };
 template <int R>
-__device__ __forceinline__ void blake2b_round_quad(u64& a, u64& b, u64& c, u64& d, const u64* m, u32 j4) {
-    {
-        const u64 mx = m[__builtin_amdgcn_ubfe(sigma_pack<R, 0>(), j4, 4)];
-        const u64 my = m[__builtin_amdgcn_ubfe(sigma_pack<R, 1>(), j4, 4)];
-        BFS_B2_G(a, b, c, d, mx, my);
-    }
+__device__ __forceinline__ QuadWords quad_words(const u64* m, u32 j4) {
+    QuadWords w;
+    w.cx = m[__builtin_amdgcn_ubfe(sigma_pack<R, 0>(), j4, 4)];
+    w.cy = m[__builtin_amdgcn_ubfe(sigma_pack<R, 1>(), j4, 4)];
+    w.dx = m[__builtin_amdgcn_ubfe(sigma_pack<R, 2>(), j4, 4)];
+    w.dy = m[__builtin_amdgcn_ubfe(sigma_pack<R, 3>(), j4, 4)];
+    __builtin_amdgcn_sched_barrier(0);       // (left to itself the scheduler sinks the reads back to where the words are used)
+    return w;
+}
+
+__device__ __forceinline__ void blake2b_round_quad(u64& a, u64& b, u64& c, u64& d, const QuadWords& w) {
+    BFS_B2_G(a, b, c, d, w.cx, w.cy);
     b = quad_perm64<0x39>(b);  // lane j takes b of lane j+1
     c = quad_perm64<0x4E>(c);  // lane j takes c of lane j+2
     d = quad_perm64<0x93>(d);  // lane j takes d of lane j+3
-    {
-        const u64 mx = m[__builtin_amdgcn_ubfe(sigma_pack<R, 2>(), j4, 4)];
-        const u64 my = m[__builtin_amdgcn_ubfe(sigma_pack<R, 3>(), j4, 4)];
-        BFS_B2_G(a, b, c, d, mx, my);
-    }
+    BFS_B2_G(a, b, c, d, w.dx, w.dy);
     b = quad_perm64<0x93>(b);
     c = quad_perm64<0x4E>(c);
     d = quad_perm64<0x39>(d);
 }
 
-// (hl, hh) <- F((hl, hh), m, t, last) for the hash owned by this quad; m: 16 message words (LDS)
+// (hl, hh) <- F((hl, hh), m, t, last) for the hash owned by this quad; m: 16 message words (LDS).  The words of round R + 1 are
+// requested before round R is computed: a quad kernel runs ONE wave per SIMD, so nothing else hides the LDS latency of a read that
+// is issued where its value is needed (~40 reads per compression).
 __device__ __forceinline__ void blake2b_compress_quad(const QuadLane& q, u64& hl, u64& hh, const u64* m, u64 t, bool last) {
     u64 a = hl, b = hh, c = q.iv_c, d = q.iv_d;
     if (q.j4 == 0) d ^= t;               // v12 ^= t0
     if (q.j4 == 8 && last) d = ~d;       // v14 = ~v14 on the final block
-    blake2b_round_quad<0>(a, b, c, d, m, q.j4);
-    blake2b_round_quad<1>(a, b, c, d, m, q.j4);
-    blake2b_round_quad<2>(a, b, c, d, m, q.j4);
-    blake2b_round_quad<3>(a, b, c, d, m, q.j4);
-    blake2b_round_quad<4>(a, b, c, d, m, q.j4);
-    blake2b_round_quad<5>(a, b, c, d, m, q.j4);
-    blake2b_round_quad<6>(a, b, c, d, m, q.j4);
-    blake2b_round_quad<7>(a, b, c, d, m, q.j4);
-    blake2b_round_quad<8>(a, b, c, d, m, q.j4);
-    blake2b_round_quad<9>(a, b, c, d, m, q.j4);
-    blake2b_round_quad<10>(a, b, c, d, m, q.j4);
-    blake2b_round_quad<11>(a, b, c, d, m, q.j4);
+    QuadWords w0 = quad_words<0>(m, q.j4), w1;
+#define BFS_B2_QUAD_PAIR(R0, R1, R2)                                  \
+    w1 = quad_words<R1>(m, q.j4); blake2b_round_quad(a, b, c, d, w0); \
+    w0 = quad_words<R2>(m, q.j4); blake2b_round_quad(a, b, c, d, w1);
+    BFS_B2_QUAD_PAIR(0, 1, 2)
+    BFS_B2_QUAD_PAIR(2, 3, 4)
+    BFS_B2_QUAD_PAIR(4, 5, 6)
+    BFS_B2_QUAD_PAIR(6, 7, 8)
+    BFS_B2_QUAD_PAIR(8, 9, 10)
+    w1 = quad_words<11>(m, q.j4); blake2b_round_quad(a, b, c, d, w0);
+    blake2b_round_quad(a, b, c, d, w1);
+#undef BFS_B2_QUAD_PAIR
     hl ^= a ^ c;
     hh ^= b ^ d;
 }
