@@ -307,6 +307,28 @@ int bfs_random_fill(const uint8_t seed[32], uint64_t* d_out, uint64_t nwords, vo
  * of 27 pseudo-random bytes.  For the randomizer polynomial of brainfuck_stark.py:162-165 without the host in the loop. */
 int bfs_xfe_sample_fill(const uint8_t seed[32], uint64_t* d_out, uint64_t count, uint64_t limb_stride, void* stream);
 
+/* ---- trace tables: padding on the device -------------------------------------------------------------------- */
+/*
+ * bfs_trace_pad: Table.pad of every trace table (table.py:25 with processor_table.py:24-35, instruction_table.py:19-25,
+ * memory_table.py:40-44, io_table.py:17-21) on rows that are already in HBM, ROW-major as the virtual machine wrote them
+ * (rows x row_stride words, the first `width` of a row are used): d_out receives the padded table COLUMN-major (width x height
+ * words, residues reduced mod p), the masks one byte per row for the scans of the table's extension:
+ *   kind 0 processor   (width >= 7): d_mask0 = current instruction != 0, d_mask1 = it is ',', d_mask2 = it is '.'
+ *   kind 1 instruction (width >= 2): d_mask0 = rows of the running product, d_mask1 = rows of the running evaluation
+ *   kind 2 memory      (width >= 4): d_mask0 = non-dummy rows
+ *   kind 3 / 4 input / output: padding rows are zero rows, no masks.
+ * Stream-ordered; at most five tables per call.
+ */
+typedef struct bfs_trace_pad_table {
+    const uint64_t* d_rows;
+    uint64_t rows, row_stride, height;
+    uint64_t* d_out;
+    uint8_t *d_mask0, *d_mask1, *d_mask2;
+    int32_t kind;
+    uint32_t width;
+} bfs_trace_pad_table;
+int bfs_trace_pad(const bfs_trace_pad_table* tables, uint32_t count, void* stream);
+
 /* ---- FRI ---------------------------------------------------------------------------------------------------- */
 /*
  * bfs_xfe_fold: one split-and-fold round (fri.py:127-128) of a limb-major extension codeword of length 2^log_n:

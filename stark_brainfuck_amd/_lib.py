@@ -96,6 +96,7 @@ _SIGNATURES = {
     "bfs_merkle_build_rows_range": (ci, [vp, u32, u64, u64, vp, ci, vp, vp]),
     "bfs_merkle_build_rows_root": (ci, [vp, u32, u64, u64, vp, ci, vp, vp, vp]),
     "bfs_row_template_steps": (ci, [vp, u32, u32, ci, vp, vp, u32, vp, u32, vp]),
+    "bfs_trace_pad": (ci, [vp, u32, vp]),
     "bfs_row_generated_launches": (u64, []),
     "bfs_random_fill": (ci, [ctypes.c_char_p, vp, u64, vp]),
     "bfs_xfe_sample_fill": (ci, [ctypes.c_char_p, vp, u64, u64, vp]),
@@ -154,6 +155,12 @@ class GatherRequest(ctypes.Structure):
 class RowColumn(ctypes.Structure):
     """bfs_row_column (include/bfstark.h)"""
     _fields_ = [("d_values", vp), ("is_ext", ctypes.c_int32), ("field_id", ctypes.c_int32)]
+
+
+class TracePadTable(ctypes.Structure):
+    """bfs_trace_pad_table (include/bfstark.h)"""
+    _fields_ = [("d_rows", vp), ("rows", u64), ("row_stride", u64), ("height", u64), ("d_out", vp), ("d_mask0", vp), ("d_mask1", vp),
+                ("d_mask2", vp), ("kind", ctypes.c_int32), ("width", u32)]
 
 
 class CombSource(ctypes.Structure):

@@ -23,10 +23,12 @@
 #include "blake2b.hpp"
 #include "runtime.hpp"
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -188,32 +190,6 @@ Xfe xfe_pow(Xfe a, u64 e) {
     return acc;
 }
 
-// column-major padded copy of a table (base_width x height words) in pinned staging memory
-void pad_table(int t, const bfs_stark_table_in& in, u64 height, u64* out) {
-    const u32 w = BASE_W[t];
-    const u64 rows = in.rows;
-    for (u64 r = 0; r < rows; ++r) {
-        const u64* row = in.values + r * in.row_stride;
-        for (u32 c = 0; c < w; ++c) out[(u64)c * height + r] = row[c] % GL_P;
-    }
-    if (rows == height) return;
-    u64 last[8] = {0};
-    if (rows) for (u32 c = 0; c < w; ++c) last[c] = in.values[(rows - 1) * in.row_stride + c] % GL_P;
-    for (u64 r = rows; r < height; ++r) {
-        const u64 j = r - rows + 1;                         // the j-th padding row
-        for (u32 c = 0; c < w; ++c) out[(u64)c * height + r] = 0;
-        if (t == 0) {                                       // processor_table.py:24-35: the cycle count keeps counting, ip / mp / mv / mvi stay
-            out[0 * height + r] = gl_add(last[0], j % GL_P);
-            out[1 * height + r] = last[1]; out[4 * height + r] = last[4]; out[5 * height + r] = last[5]; out[6 * height + r] = last[6];
-        } else if (t == 1) {                                // instruction_table.py:19-25: the last address repeats
-            out[0 * height + r] = rows ? last[0] : 0;
-        } else if (t == 2) {                                // memory_table.py:40-44: dummy rows, the cycle counts up
-            out[0 * height + r] = gl_add(last[0], j % GL_P);
-            out[1 * height + r] = last[1]; out[2 * height + r] = last[2]; out[3 * height + r] = 1;
-        }
-    }
-}
-
 int check_session(void* s, const char* who) {
     if (!s) { set_error("%s: null session", who); return BFS_ERR_BAD_ARG; }
     return BFS_OK;
@@ -232,6 +208,9 @@ int bfs_stark_commit(void* session, void* ps, const bfs_stark_params* params, co
     StarkSession& S = *(StarkSession*)session;
     hipStream_t stream = (hipStream_t)stream_;
     const double t0 = now_ms();
+    static const bool trace_marks = [] { const char* e = getenv("BFS_STARK_MARKS"); return e && e[0] == '1'; }();
+    double t_last = t0;
+    auto mark = [&](const char* what) { if (trace_marks) { const double t = now_ms(); fprintf(stderr, "[bfs mark] %-28s %.3f ms\n", what, t - t_last); t_last = t; } };
     S.join_ext_tree();                                     // (a commit that was never finished)
     S.P = *params;
     S.stream = stream;
@@ -289,45 +268,51 @@ int bfs_stark_commit(void* session, void* ps, const bfs_stark_params* params, co
     if (rnd->base_salt_seed) BFS_TRY(bfs_random_fill(rnd->base_salt_seed, S.base_salts_dev.words(), salt_words, rs));
     if (rnd->ext_salt_seed) BFS_TRY(bfs_random_fill(rnd->ext_salt_seed, S.ext_salts_dev.words(), salt_words, rs));
     BFS_HIP(hipEventRecord(S.rand_ev, rs));                 // joined in front of the base commitment, which reads the codeword (and the salts)
+    mark("randomizer + salts queued");
 
-    // ---- padding (host) into pinned staging, one upload for all tables; the scan masks ride along
-    u64 trace_words = 0, mask_bytes = 0;
-    for (int t = 0; t < NT; ++t) trace_words += (u64)BASE_W[t] * S.height[t];
+    // ---- the rows as the virtual machine wrote them go up in one copy; padding, transposition and the scan masks happen on the device
+    // (bfs_trace_pad: the host loops cost 0.3-0.6 ms of a 14 ms proof with the GPU waiting)
+    u64 trace_words = 0, mask_bytes = 0, raw_words = 0;
+    for (int t = 0; t < NT; ++t) { trace_words += (u64)BASE_W[t] * S.height[t]; raw_words += tables[t].rows * tables[t].row_stride; }
     // masks: processor active / reads / writes, instruction product / evaluation rows, memory non-dummy rows
     const u64 hp = S.height[0], hi = S.height[1], hm = S.height[2];
     mask_bytes = 3 * hp + 2 * hi + hm;
     PinnedBlock stage;
-    BFS_TRY(stage.get(trace_words * 8 + ((mask_bytes + 7) & ~7ull)));
-    u64* st = (u64*)stage.ptr;
-    u64* table_stage[NT];
+    BFS_TRY(stage.get(raw_words * 8));
+    DeviceBlock raw, padded;
+    BFS_TRY(raw.get(raw_words * 8, stream));
+    BFS_TRY(padded.get(trace_words * 8 + ((mask_bytes + 7) & ~7ull), stream));
     {
         u64 at = 0;
-        for (int t = 0; t < NT; ++t) { table_stage[t] = st + at; pad_table(t, tables[t], S.height[t], table_stage[t]); at += (u64)BASE_W[t] * S.height[t]; }
+        for (int t = 0; t < NT; ++t) {
+            const u64 words = tables[t].rows * tables[t].row_stride;
+            if (words) memcpy((u64*)stage.ptr + at, tables[t].values, words * 8);
+            at += words;
+        }
+        if (raw_words) BFS_HIP(hipMemcpyAsync(raw.ptr, stage.ptr, raw_words * 8, hipMemcpyHostToDevice, stream));
+        uint8_t* mk = (uint8_t*)(padded.words() + trace_words);
+        bfs_trace_pad_table pt[NT];
+        u64 raw_at = 0, out_at = 0;
+        for (int t = 0; t < NT; ++t) {
+            pt[t] = bfs_trace_pad_table{raw.words() + raw_at, tables[t].rows, tables[t].row_stride, S.height[t], padded.words() + out_at, nullptr, nullptr, nullptr, t, BASE_W[t]};
+            raw_at += tables[t].rows * tables[t].row_stride;
+            out_at += (u64)BASE_W[t] * S.height[t];
+        }
+        pt[0].d_mask0 = mk; pt[0].d_mask1 = mk + hp; pt[0].d_mask2 = mk + 2 * hp;
+        pt[1].d_mask0 = mk + 3 * hp; pt[1].d_mask1 = mk + 3 * hp + hi;
+        pt[2].d_mask0 = mk + 3 * hp + 2 * hi;
+        BFS_TRY(bfs_trace_pad(pt, NT, stream));
     }
-    uint8_t* mk = (uint8_t*)(st + trace_words);
-    uint8_t *m_active = mk, *m_reads = mk + hp, *m_writes = mk + 2 * hp, *m_prod = mk + 3 * hp, *m_eval = mk + 3 * hp + hi, *m_mem = mk + 3 * hp + 2 * hi;
-    for (u64 r = 0; r < hp; ++r) {                          // processor_table.py:329-427: padding rows (ci = 0) leave the products alone
-        const u64 ci = table_stage[0][2 * hp + r];
-        m_active[r] = ci != 0; m_reads[r] = ci == (u64)','; m_writes[r] = ci == (u64)'.';
-    }
-    for (u64 r = 0; r < hi; ++r) {                          // instruction_table.py:197-214
-        const bool same = r > 0 && table_stage[1][r] == table_stage[1][r - 1];
-        m_prod[r] = (table_stage[1][hi + r] != 0) && same;
-        m_eval[r] = !same;
-    }
-    for (u64 r = 0; r < hm; ++r) m_mem[r] = table_stage[2][3 * hm + r] == 0;       // memory_table.py:172-206: dummy rows leave the product alone
-    DeviceBlock upload;                                     // traces of all tables + masks, one copy
-    BFS_TRY(upload.get(trace_words * 8 + ((mask_bytes + 7) & ~7ull), stream));
-    BFS_HIP(hipMemcpyAsync(upload.ptr, stage.ptr, trace_words * 8 + ((mask_bytes + 7) & ~7ull), hipMemcpyHostToDevice, stream));
-    // (the upload block becomes the session's trace storage: tables point into it)
+    // (the padded block becomes the session's trace storage: tables point into it)
     S.trace[0].release();
-    S.trace[0].ptr = upload.ptr; S.trace[0].stream = stream; upload.ptr = nullptr;
+    S.trace[0].ptr = padded.ptr; S.trace[0].stream = stream; padded.ptr = nullptr;
     u64* d_trace[NT];
     {
         u64 at = 0;
         for (int t = 0; t < NT; ++t) { d_trace[t] = S.trace[0].words() + at; at += (u64)BASE_W[t] * S.height[t]; }
     }
     const uint8_t* d_masks = (const uint8_t*)(S.trace[0].words() + trace_words);
+    mark("rows copied, padding queued");
     const double t_pad = now_ms();
 
     // ---- base LDE (table.py:112-148 for every table; one coset transform for all columns)

@@ -276,3 +276,81 @@ extern "C" int bfs_xfe_scan_device(int kind, const uint64_t* d_x1, const uint64_
     }
     return BFS_OK;
 }
+
+
+// ---- padding of the trace tables on the device (round 5) -----------------------------------------------------------------------------
+// Table.pad (/root/reference/code/table.py:25 with processor_table.py:24-35, instruction_table.py:19-25, memory_table.py:40-44,
+// io_table.py:17-21) brings a table to a power-of-two height; the prover then wants the padded table COLUMN-major (one codeword per
+// column) and, for the scans above, a byte per row saying whether the row takes part.  Doing that on the host cost 0.3-0.6 ms of a
+// 14 ms proof with the GPU waiting (scalar loops over 10^6 words): the host now only copies the rows it was given into pinned memory,
+// and this kernel transposes, reduces mod p, appends the padding rows and writes the masks.  One thread per row.
+namespace bfs {
+
+struct PadTables { bfs_trace_pad_table t[5]; u32 count; };
+
+__global__ void trace_pad_kernel(const PadTables a) {
+    const bfs_trace_pad_table& T = a.t[blockIdx.y];
+    const u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blockIdx.y >= a.count || r >= T.height) return;
+    const u64 rows = T.rows, h = T.height;
+    const u32 w = T.width;
+    auto canonical = [](u64 v) { return v >= GL_P ? v - GL_P : v; };
+    u64 v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (r < rows) {
+        for (u32 c = 0; c < w; ++c) v[c] = canonical(T.d_rows[r * T.row_stride + c]);
+    } else if (rows && T.kind <= 2) {
+        u64 last[8];
+        for (u32 c = 0; c < w; ++c) last[c] = canonical(T.d_rows[(rows - 1) * T.row_stride + c]);
+        const u64 j = (r - rows + 1) % GL_P;                    // the j-th padding row
+        if (T.kind == 0) { v[0] = gl_add(last[0], j); v[1] = last[1]; v[4] = last[4]; v[5] = last[5]; v[6] = last[6]; }   // the cycle count keeps counting; ip, mp, mv, mvi stay
+        else if (T.kind == 1) v[0] = last[0];                   // the last address repeats
+        else { v[0] = gl_add(last[0], j); v[1] = last[1]; v[2] = last[2]; v[3] = 1; }                                      // dummy rows, the cycle counts up
+    } else if (T.kind == 2) {
+        v[0] = (r + 1) % GL_P; v[3] = 1;                        // (a memory table without rows: "last" is the zero row)
+    } else if (T.kind == 0) {
+        v[0] = (r + 1) % GL_P;
+    }
+    for (u32 c = 0; c < w; ++c) T.d_out[(u64)c * h + r] = v[c];
+    if (T.kind == 0) {
+        T.d_mask0[r] = v[2] != 0; T.d_mask1[r] = v[2] == (u64)','; T.d_mask2[r] = v[2] == (u64)'.';
+    } else if (T.kind == 1) {
+        bool same = false;
+        if (r > 0) {
+            const u64 above = r - 1 < rows ? canonical(T.d_rows[(r - 1) * T.row_stride]) : (rows ? canonical(T.d_rows[(rows - 1) * T.row_stride]) : 0);
+            same = v[0] == above;
+        }
+        T.d_mask0[r] = v[1] != 0 && same;                       // product rows
+        T.d_mask1[r] = !same;                                   // evaluation rows
+    } else if (T.kind == 2) {
+        T.d_mask0[r] = v[3] == 0;                               // non-dummy rows
+    }
+}
+
+}  // namespace bfs
+
+extern "C" int bfs_trace_pad(const bfs_trace_pad_table* tables, uint32_t count, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (count == 0) return BFS_OK;
+    if (count > 5) { bfs::set_error("bfs_trace_pad: at most 5 tables"); return BFS_ERR_BAD_ARG; }
+    bfs::PadTables a{};
+    a.count = count;
+    u64 tallest = 0;
+    for (uint32_t k = 0; k < count; ++k) {
+        const bfs_trace_pad_table& t = tables[k];
+        if (t.width == 0 || t.width > 8 || t.rows > t.height || (t.rows && (t.row_stride < t.width || t.d_rows == nullptr)) || (t.height && t.d_out == nullptr)) {
+            bfs::set_error("bfs_trace_pad: table %u: width 1..8, rows <= height, row_stride >= width", k);
+            return BFS_ERR_BAD_ARG;
+        }
+        if (t.kind < 0 || t.kind > 4 || (t.kind == 0 && (t.width < 7 || !t.d_mask0 || !t.d_mask1 || !t.d_mask2)) || (t.kind == 1 && (t.width < 2 || !t.d_mask0 || !t.d_mask1)) ||
+            (t.kind == 2 && (t.width < 4 || !t.d_mask0))) {
+            bfs::set_error("bfs_trace_pad: table %u: kind 0..4 with its width and masks", k);
+            return BFS_ERR_BAD_ARG;
+        }
+        a.t[k] = t;
+        tallest = t.height > tallest ? t.height : tallest;
+    }
+    if (tallest == 0) return BFS_OK;
+    hipLaunchKernelGGL(bfs::trace_pad_kernel, dim3((u32)((tallest + 255) / 256), count), dim3(256), 0, stream, a);
+    BFS_HIP(hipGetLastError());
+    return BFS_OK;
+}

@@ -408,3 +408,99 @@ def test_one_transform_for_all_tables_equals_one_per_table(code, inputs, monkeyp
         assert (kept_a[k] is None) == (kept_b[k] is None) and (kept_a[k] is None or np.array_equal(kept_a[k], kept_b[k]))
     assert moduli_a == moduli_b
     assert any(a.any() for a in base_a) and any(a.any() for a in ext_a)
+
+
+@pytest.mark.gpu
+def test_trace_padding_on_the_device():
+    """bfs_trace_pad (csrc/scan.hip): the trace tables go up as the virtual machine wrote them (row-major, unpadded) and are padded,
+    transposed and reduced on the device, with the scan masks of their extensions.  Against the reference's rules restated here in
+    numpy -- Table.pad: processor_table.py:24-35 (the cycle count keeps counting; ip, mp, mv, mvi stay), instruction_table.py:19-25
+    (the last address repeats), memory_table.py:40-44 (dummy rows: cycle counting up, mp / mv kept, dummy = 1), io_table.py:17-21
+    (zero rows) -- for real traces and for synthetic rows with residues >= p, tables without rows, with one row, and with exactly a
+    power of two of rows."""
+    import ctypes
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.device import DeviceBuffer
+    from stark_brainfuck_amd.vm import VirtualMachine
+    lib = _lib.load()
+    P = (1 << 64) - (1 << 32) + 1
+    WIDTH = [7, 3, 4, 1, 1]
+
+    def npo2(k):
+        h = 1
+        while h < k:
+            h <<= 1
+        return h if k else 0
+
+    def expect(kind, rows, width, height):
+        k = rows.shape[0]
+        vals = [[int(v) % P for v in r[:width]] for r in rows]
+        out = [[0] * height for _ in range(width)]
+        for r in range(k):
+            for c in range(width):
+                out[c][r] = vals[r][c]
+        last = vals[-1] if k else [0] * width
+        for r in range(k, height):
+            j = r - k + 1
+            if kind == 0:
+                out[0][r] = (last[0] + j) % P
+                for c in (1, 4, 5, 6):
+                    out[c][r] = last[c]
+            elif kind == 1:
+                out[0][r] = last[0]
+            elif kind == 2:
+                out[0][r], out[1][r], out[2][r], out[3][r] = (last[0] + j) % P, last[1], last[2], 1
+        masks = []
+        if kind == 0:
+            masks = [[int(v != 0) for v in out[2]], [int(v == ord(",")) for v in out[2]], [int(v == ord(".")) for v in out[2]]]
+        elif kind == 1:
+            same = [r > 0 and out[0][r] == out[0][r - 1] for r in range(height)]
+            masks = [[int(out[1][r] != 0 and same[r]) for r in range(height)], [int(not s) for s in same]]
+        elif kind == 2:
+            masks = [[int(v == 0) for v in out[3]]]
+        return out, masks
+
+    def check(tables, heights):
+        """tables: five (rows x stride) uint64 arrays"""
+        bufs, outs, masks, structs = [], [], [], (_lib.TracePadTable * 5)()
+        for t, (rows, h) in enumerate(zip(tables, heights)):
+            raw = DeviceBuffer.from_numpy(np.ascontiguousarray(rows).reshape(-1)) if rows.size else None
+            out = DeviceBuffer(max(WIDTH[t] * h, 1))
+            mk = [DeviceBuffer(max((h + 7) // 8, 1)) for _ in range(3)]
+            bufs.append(raw)
+            outs.append(out)
+            masks.append(mk)
+            s = structs[t]
+            s.d_rows, s.rows, s.row_stride, s.height = (raw.ptr if raw else None), rows.shape[0], (rows.shape[1] if rows.size else 0), h
+            s.d_out, s.d_mask0, s.d_mask1, s.d_mask2, s.kind, s.width = out.ptr, mk[0].ptr, mk[1].ptr, mk[2].ptr, t, WIDTH[t]
+        _lib.check(lib.bfs_trace_pad(structs, 5, 0))
+        for t, (rows, h) in enumerate(zip(tables, heights)):
+            want, want_masks = expect(t, rows, WIDTH[t], h)
+            if h:
+                got = outs[t].to_numpy(WIDTH[t] * h).reshape(WIDTH[t], h)
+                assert got.tolist() == want, "table %d" % t
+            for k, wm in enumerate(want_masks):
+                got = masks[t][k].to_numpy((h + 7) // 8).view(np.uint8)[:h] if h else np.zeros(0, dtype=np.uint8)
+                assert got.tolist() == wm, "table %d mask %d" % (t, k)
+
+    # real traces: a program that reads and writes, one that does neither
+    for code, inp in ((",[.,]", "hello\x00"), ("++[>+++<-]>.", ""), ("+", "")):
+        program = VirtualMachine.compile(code)
+        pm, mm, im, inm, om = VirtualMachine.simulate(program, input_data=inp)
+        tables = [np.ascontiguousarray(m.values) if len(m) else np.zeros((0, w), dtype=np.uint64) for m, w in zip((pm, im, mm, inm, om), WIDTH)]
+        check(tables, [npo2(len(t)) for t in tables])
+    # synthetic rows: residues next to 0 and p and beyond p, wider rows than the table uses, every shape of (rows, height)
+    rng = np.random.default_rng(77)
+    edge = np.array([0, 1, 44, 46, P - 1, P, P + 5, (1 << 64) - 1], dtype=np.uint64)
+    for shape in ([0, 0, 0, 0, 0], [1, 1, 1, 1, 1], [256, 128, 512, 2, 4], [300, 5, 1000, 3, 0], [70000, 70001, 140000, 0, 1]):
+        tables = []
+        for t, k in enumerate(shape):
+            stride = WIDTH[t] + int(rng.integers(0, 3))
+            rows = rng.integers(0, 1 << 63, (k, stride), dtype=np.uint64)
+            pick = rng.integers(0, 3, (k, stride))
+            rows = np.where(pick == 0, edge[rng.integers(0, len(edge), (k, stride))], rows)
+            if t == 1 and k:
+                rows[:, 0] = np.sort(rng.integers(0, max(k // 3, 1), k).astype(np.uint64))      # repeated addresses, as in a real table
+            tables.append(rows)
+        check(tables, [npo2(k) for k in shape])
+        check(tables, [2 * npo2(k) if k else 4 for k in shape])          # taller than the rows ask for (IO tables: zero rows)
