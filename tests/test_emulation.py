@@ -357,6 +357,8 @@ def test_generated_row_header_is_what_the_generator_writes_today():
     """csrc/rows_generated.hpp against tools/gen_rows.py (which asks the library for the templates: bfs_row_template_steps)"""
     import subprocess
     import sys
+    from stark_brainfuck_amd import build
+    build.build_library()                 # (no-op when current: the generator reads the templates through the library)
     header = os.path.join(ROOT, "stark_brainfuck_amd", "csrc", "rows_generated.hpp")
     before = open(header).read()
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_rows.py")], check=True, capture_output=True)
@@ -409,7 +411,8 @@ def test_generated_row_walks_against_the_oracle_pickles(emu, oracle, layout, var
         assert sites.value >= (longest + 127) // 128
         if mode == 2:
             assert sites.value > (longest + 127) // 128, "lanes blocks apart: some compressions must run without the short rows"
-    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd import _lib, build
+    build.build_library()
     lib = _lib.load()
     cols = (_lib.RowColumn * (n_ext + n_base))()
     for c in range(n_ext + n_base):
