@@ -64,6 +64,8 @@ struct RowArgs {
     u64* pattern_set;            // pattern kernel output: open-addressing set of the codes present (PATTERN_SLOTS entries, ~0 = empty)
     u32* error;                  // [0]: a row without a template, [1]: the pattern set overflowed
     u32 skip, skip_code;         // interpreter kernel, skip != 0: rows of pattern skip_code were hashed by a generated kernel
+    const u64* block0_states;    // generated kernels: BLAKE2b's state behind block 0 of the preimage, 8 words per possible length of the
+                                 // row's integers (2 .. 11 bytes each), first entry = all of them two bytes long
 };
 
 // 2 bits per extension column: how many coefficients its element of row i stores (trailing zero limbs are dropped).  The top limbs
@@ -332,7 +334,17 @@ __global__ void __launch_bounds__(LEAF_THREADS, BFS_ROW_WAVES) row_leaves_genera
         static_assert(BFS_ROWGEN_PREFETCH <= G::COMMON_INTS, "the first integers are the same in every variant");
     }
     row_lane_init(c.st8, c.tuple_len + G::SALT_BYTES);
+    // Block 0 is constants and the frame length (the first integer of a row comes ~50 bytes later): its compression is a table look-up by
+    // length, and the walk starts with the bytes of the segment that straddles byte 128.
     u32 resume = 0;
+    {
+        const u64* ms = a.block0_states + (size_t)(c.tuple_len - G::TUPLE_CONST_BYTES[variant] - 2 * G::NUM_INTS[variant]) * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) c.st8.h[j] = ms[j];
+        c.st8.consumed = 128;
+        c.st8.hashed_any = 1;
+        G::enter_after_block0(c, resume);
+    }
     while (true) {
         resume = uniform32(resume);             // (the same in every lane; the compiler cannot tell)
         if (resume < G::NUM_SEGMENTS) G::segments(c, resume);
@@ -386,6 +398,7 @@ struct HostTemplates {
     int generated = -1;              // the layout of rows_generated.hpp one of the templates is (by hash), or -1 ...
     u32 generated_variant = 0;       // ... which of its patterns ...
     u32 generated_code = 0;          // ... and the pattern itself
+    std::vector<u64> block0_states;  // ... and BLAKE2b's state behind block 0 of its rows, per length of the row's integers (RowArgs::block0_states)
 };
 
 static std::mutex g_template_mu;
@@ -504,6 +517,21 @@ static bool generated_match(HostTemplates& ht, int layout) {
         for (u32 v = 0; v < G::NUM_VARIANTS; ++v)
             if (h == G::HASHES[v] && t.code == G::CODES[v]) {
                 ht.generated = layout; ht.generated_variant = v; ht.generated_code = t.code;
+                // every length the row's integers can have together: 2 .. 11 bytes each (leaf_encode.hpp: pickle_int_len)
+                const u32 n = G::NUM_INTS[v];
+                ht.block0_states.resize((size_t)(9 * n + 1) * 8);
+                for (u32 extra = 0; extra <= 9 * n; ++extra) {
+                    const u64 tuple_len = (u64)G::TUPLE_CONST_BYTES[v] + 2 * n + extra;
+                    unsigned char block[128];
+                    memcpy(block, G::BLOCK0, 128);
+                    const u64 frame = tuple_len - 11;                       // (as SEG_FRAMELEN writes it: rows_core.hpp)
+                    memcpy(block + 3, &frame, 8);
+                    u64 m[16], st[8];
+                    memcpy(m, block, 128);
+                    blake2b_init(st);
+                    blake2b_compress(st, m, 128, false);
+                    memcpy(&ht.block0_states[(size_t)extra * 8], st, 64);
+                }
                 return true;
             }
     }
@@ -689,16 +717,19 @@ static int build_rows(const bfs_row_column* columns, uint32_t ncols, uint64_t n,
             cached = fresh;
         }
         const HostTemplates& ht = *cached;
-        const size_t tbytes = ht.templates.size() * sizeof(RowTemplate), sbytes = ht.steps.size() * sizeof(RowStep), ibytes = ht.ints.size() * sizeof(u32);
+        const size_t tbytes = ht.templates.size() * sizeof(RowTemplate), sbytes = ht.steps.size() * sizeof(RowStep);
+        const size_t ibytes = (ht.ints.size() * sizeof(u32) + 7) & ~(size_t)7, mbytes = ht.block0_states.size() * sizeof(u64);
         void* tw = nullptr;
-        BFS_TRY(workspace(6, tbytes + sbytes + ibytes + 64, stream, &tw));
+        BFS_TRY(workspace(6, tbytes + sbytes + ibytes + mbytes + 64, stream, &tw));
         char* tb = (char*)tw;
         PinnedLease tstage;
-        BFS_TRY(tstage.get(tbytes + sbytes + ibytes + 64));
+        BFS_TRY(tstage.get(tbytes + sbytes + ibytes + mbytes + 64));
         memcpy(tstage.host, ht.templates.data(), tbytes);
         memcpy((char*)tstage.host + tbytes, ht.steps.data(), sbytes);
-        memcpy((char*)tstage.host + tbytes + sbytes, ht.ints.data(), ibytes);
-        BFS_HIP(hipMemcpyAsync(tb, tstage.host, tbytes + sbytes + ibytes, hipMemcpyHostToDevice, stream));
+        memcpy((char*)tstage.host + tbytes + sbytes, ht.ints.data(), ht.ints.size() * sizeof(u32));
+        if (mbytes) memcpy((char*)tstage.host + tbytes + sbytes + ibytes, ht.block0_states.data(), mbytes);
+        BFS_HIP(hipMemcpyAsync(tb, tstage.host, tbytes + sbytes + ibytes + mbytes, hipMemcpyHostToDevice, stream));
+        a.block0_states = (const u64*)(tb + tbytes + sbytes + ibytes);
         a.templates = (const RowTemplate*)tb;
         a.num_templates = (u32)ht.templates.size();
         a.steps = (const RowStep*)(tb + tbytes);

@@ -61,7 +61,24 @@ int run(uint32_t variant, const uint64_t* values, const uint64_t* salts, uint32_
         c[l].tuple_len = G::TUPLE_CONST_BYTES[variant] + ib;
         row_lane_init(c[l].st8, c[l].tuple_len + G::SALT_BYTES);
     }
+    // block 0: constants and the frame length -- the kernel takes BLAKE2b's state behind it from a table the host makes exactly like this
+    // (csrc/rows.hip, generated_match), and starts the walk with what the straddling segment appends beyond byte 128
     uint32_t resume = 0, sites = 0;
+    for (uint32_t l = 0; l < lanes; ++l) {
+        unsigned char block[128];
+        memcpy(block, G::BLOCK0, 128);
+        const uint64_t frame = (uint64_t)c[l].tuple_len - 11;
+        memcpy(block + 3, &frame, 8);
+        uint64_t m[16];
+        memcpy(m, block, 128);
+        blake2b_compress(c[l].st8.h, m, 128, false);
+        c[l].st8.consumed = 128;
+        c[l].st8.hashed_any = 1;
+        unsigned r = 0;
+        G::enter_after_block0(c[l], r);
+        if (c[l].error) return c[l].error;
+        resume = r;
+    }
     while (true) {
         if (resume < G::NUM_SEGMENTS) {
             unsigned next = resume;

@@ -408,9 +408,10 @@ def test_generated_row_walks_against_the_oracle_pickles(emu, oracle, layout, var
             pre = oracle.salted_leaf_bytes(tuple(row), salts[l].tobytes())
             longest = max(longest, len(pre))
             assert out[l].tobytes() == hashlib.blake2b(pre).digest(), "mode %d lane %d, %d bytes" % (mode, l, len(pre))
-        assert sites.value >= (longest + 127) // 128
+        blocks_walked = (longest + 127) // 128 - 1              # (block 0 is a table look-up, not a compression of the walk)
+        assert sites.value >= blocks_walked
         if mode == 2:
-            assert sites.value > (longest + 127) // 128, "lanes blocks apart: some compressions must run without the short rows"
+            assert sites.value > blocks_walked, "lanes blocks apart: some compressions must run without the short rows"
     from stark_brainfuck_amd import _lib, build
     build.build_library()
     lib = _lib.load()

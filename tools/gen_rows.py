@@ -15,6 +15,10 @@ that a lane that was not "full" (rows_core.hpp: position <= ROW_LANE_BYTES - 16)
 segment the wave asks whether some lane is full and, if so, leaves for the one compression site and comes back to the
 next segment.  An integer is a segment of its own (two stores, 0 and 8; up to 11 bytes).
 
+Block 0 of the preimage (128 bytes: constants and the frame length, no integer yet) is emitted too: the library tabulates
+BLAKE2b's state behind it per frame length and the kernels start the walk behind it (BLOCK0, AFTER_BLOCK0,
+enter_after_block0).
+
     python tools/gen_rows.py            (needs the built library: python -c "import __graft_entry__ as g; g.build()")
 """
 import ctypes
@@ -127,6 +131,32 @@ def statement(seg, variant):
     return " ".join(parts)
 
 
+def constant_prefix(steps):
+    """the preimage bytes in front of the row's first integer, the eight bytes of the frame length as zeros"""
+    out = bytearray()
+    for kind, a, data in steps:
+        if kind == SEG_CONST:
+            out += data.to_bytes(8, "little")[:a]
+        elif kind == SEG_FRAMELEN:
+            out += bytes(8)
+        else:
+            break
+    return bytes(out)
+
+
+def segment_bytes(seg):
+    """bytes a segment of constants appends (None for an integer)"""
+    n = 0
+    for u in seg:
+        if u[0] == "st":
+            n = u[1] + u[3]
+        elif u[0] in ("framelen", "salt"):
+            n = u[1] + 8
+        else:
+            return None
+    return n
+
+
 def ints_in(segs):
     return sum(1 for seg in segs for u in seg if u[0] == "int")
 
@@ -193,6 +223,31 @@ def main():
             padded = v[3] + [v[3][-1]] * (max_ints - len(v[3]))
             w.append("        {%s}," % ", ".join("0x%x" % x for x in padded))
         w.append("    };")
+        # block 0 of the preimage is constant but for the frame length (the first integer comes later, in every variant alike): its
+        # BLAKE2b state is tabulated per length on the host, and the walk starts behind it
+        prefixes = [constant_prefix(template(lib, _lib.RowColumn, layout, salted, v[0])[2]) for v in variants]
+        assert all(len(q) >= 128 and q[:128] == prefixes[0][:128] for q in prefixes), "block 0 must be the same constant in every variant"
+        block0 = prefixes[0][:128]
+        assert block0[3:11] == bytes(8) and block0[2] == 0x95
+        cum, k = 0, 0
+        while True:
+            nb = segment_bytes(variants[0][2][k])
+            assert nb is not None and k < common, "block 0 ends inside the shared constants"
+            if cum + nb >= 128:
+                break
+            cum += nb
+            k += 1
+        leftover = prefixes[0][128:cum + nb]                    # what segment k appends behind byte 128
+        assert len(leftover) < 16
+        w.append("    // block 0 (128 bytes, frame length at 3..10 zero) as little-endian words; the host tabulates BLAKE2b's state behind it per frame length")
+        w.append("    static constexpr unsigned long long BLOCK0[16] = {%s};" % ", ".join("0x%016xull" % int.from_bytes(block0[8 * i:8 * i + 8], "little") for i in range(16)))
+        w.append("    static constexpr unsigned AFTER_BLOCK0 = %du;        // the segment the walk goes on with" % (k + 1))
+        w.append("    // a lane that starts behind block 0: the %d bytes segment %d appends beyond byte 128" % (len(leftover), k))
+        parts = []
+        for i in range(0, len(leftover), 8):
+            parts.append("c.st(%d, 0x%xull);" % (i, int.from_bytes(leftover[i:i + 8], "little")))
+        parts.append("c.adv(%d);" % len(leftover))
+        w.append("    template <class C> static __device__ __forceinline__ void enter_after_block0(C& c, unsigned& resume) { %s resume = AFTER_BLOCK0; }" % " ".join(parts))
         w.append("    template <class C> static __device__ __forceinline__ void segments(C& c, unsigned& resume) {")
         w.append("        switch (resume) {")
         for si in range(common):
