@@ -1034,8 +1034,8 @@ def stark_roofline(stark):
         r = valu_roofline(instr, ms * 1e-3, what)
         r["stage_ms"] = ms
         return r
-    return {"zipped_row_commitments": stage(["row_leaves_kernel", "row_pattern_kernel"], b["base_tree"] + b["ext_tree"],
-                                            "static SQ_INSTS_VALU of row_leaves + row_pattern (profiles/prover_valu.json) over base_tree + ext_tree of this run"),
+    return {"zipped_row_commitments": stage(["row_leaves_kernel", "row_leaves_generated_kernel", "row_pattern_kernel"], b["base_tree"] + b["ext_tree"],
+                                            "static SQ_INSTS_VALU of the row-leaf kernels (profiles/prover_valu.json) over base_tree + ext_tree of this run"),
             "combination": stage(["air_combine_kernel", "zerofier_inverses_kernel", "difference_combine_kernel"], b["combination"],
                                  "static SQ_INSTS_VALU of air_combine<TABLE> + zerofier_inverses + difference_combine over this run's combination stage"),
             "static": "profiles/prover_valu.json"}
