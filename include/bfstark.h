@@ -302,9 +302,10 @@ uint64_t bfs_row_generated_launches(void);
 /* nwords (a multiple of 8) pseudo-random words in HBM: 64-byte block j = BLAKE2b-512(seed || j).  For salts that never visit
  * the host (the reference draws os.urandom(24) per leaf, salted_merkle.py:25; the caller seeds this from os.urandom(32)). */
 int bfs_random_fill(const uint8_t seed[32], uint64_t* d_out, uint64_t nwords, void* stream);
-/* `count` pseudo-random extension elements (limb planes `limb_stride` words apart) in HBM: limb j of element i = the first 9
- * bytes of BLAKE2b-512(seed || 3 i + j) as a big-endian integer mod p, i.e. ExtensionField.sample (extension_field.py:100-111)
- * of 27 pseudo-random bytes.  For the randomizer polynomial of brainfuck_stark.py:162-165 without the host in the loop. */
+/* `count` pseudo-random extension elements (limb planes `limb_stride` words apart) in HBM: ExtensionField.sample
+ * (extension_field.py:100-111) of 27 bytes per element, element i taking bytes [27 i, 27 i + 27) of the stream made of the first 63
+ * bytes of every block BLAKE2b-512(seed || b), b = 0, 1, ... (limb j = the j-th run of 9 bytes as a big-endian integer mod p).  For
+ * the randomizer polynomial of brainfuck_stark.py:162-165 without the host in the loop. */
 int bfs_xfe_sample_fill(const uint8_t seed[32], uint64_t* d_out, uint64_t count, uint64_t limb_stride, void* stream);
 
 /* ---- trace tables: padding on the device -------------------------------------------------------------------- */

@@ -373,19 +373,27 @@ __global__ void random_fill_kernel(u64 s0, u64 s1, u64 s2, u64 s3, u64* out, u64
     for (int k = 0; k < 8; ++k) out[8 * j + k] = h[k];
 }
 
-// ExtensionField.sample (extension_field.py:100-111) of 27 pseudo-random bytes, on the device: limb j of element i is the
-// big-endian integer of the first 9 bytes of BLAKE2b-512(seed || 3 i + j), reduced mod p (2^64 = 2^32 - 1).
+// ExtensionField.sample (extension_field.py:100-111) of 27 pseudo-random bytes per element, on the device.  The byte stream is the first
+// 63 bytes of every 64-byte block BLAKE2b-512(seed || b), b = 0, 1, ...; element i takes stream bytes [27 i, 27 i + 27): limb j is the
+// big-endian integer of its j-th run of 9 bytes, reduced mod p (2^64 = 2^32 - 1) -- seven limbs per compression.
 __global__ void xfe_sample_kernel(u64 s0, u64 s1, u64 s2, u64 s3, u64* out, u64 count, u64 stride) {
-    const u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 3 * count) return;
-    u64 m[16] = {s0, s1, s2, s3, t, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const u64 b = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (7 * b >= 3 * count) return;
+    u64 m[16] = {s0, s1, s2, s3, b, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     u64 h[8];
     blake2b_init(h);
     blake2b_compress(h, m, 40, true);
-    const u64 top = h[0] & 0xFF;                                  // first byte = most significant
-    const u64 low = __builtin_bswap64((h[0] >> 8) | (h[1] << 56));   // bytes 1..8 as a big-endian integer
-    const u64 v = gl_add(gl_mul(top, GL_EPS), low >= GL_P ? low - GL_P : low);
-    out[(t % 3) * stride + t / 3] = v;
+#pragma unroll
+    for (u32 k = 0; k < 7; ++k) {
+        const u64 limb = 7 * b + k;
+        if (limb >= 3 * count) break;
+        // bytes 9 k .. 9 k + 8 of the block: the first is the most significant
+        const u32 at = 9 * k, w = (at + 1) / 8, sh = 8 * ((at + 1) % 8);
+        const u64 top = (h[at / 8] >> (8 * (at % 8))) & 0xFF;
+        const u64 low = __builtin_bswap64(sh ? (h[w] >> sh) | (h[w + 1] << (64 - sh)) : h[w]);      // bytes 1..8 as a big-endian integer
+        const u64 v = gl_add(gl_mul(top, GL_EPS), low >= GL_P ? low - GL_P : low);
+        out[(limb % 3) * stride + limb / 3] = v;
+    }
 }
 
 // ---- host: one template per pattern -------------------------------------------------------------------------------
@@ -583,7 +591,8 @@ extern "C" int bfs_xfe_sample_fill(const uint8_t seed[32], uint64_t* d_out, uint
     if (count == 0) return BFS_OK;
     u64 s[4];
     memcpy(s, seed, 32);
-    hipLaunchKernelGGL(xfe_sample_kernel, dim3((u32)((3 * count + 255) / 256)), dim3(256), 0, stream, s[0], s[1], s[2], s[3], d_out, count, limb_stride);
+    const u64 blocks = (3 * count + 6) / 7;
+    hipLaunchKernelGGL(xfe_sample_kernel, dim3((u32)((blocks + 255) / 256)), dim3(256), 0, stream, s[0], s[1], s[2], s[3], d_out, count, limb_stride);
     BFS_HIP(hipGetLastError());
     return BFS_OK;
 }

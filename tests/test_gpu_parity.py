@@ -997,20 +997,28 @@ def test_ntt_batch_larger_than_grid_limit(sb, oracle):
 
 
 def test_device_side_sampling_of_the_randomizer_polynomial(sb):
-    """bfs_xfe_sample_fill: ExtensionField.sample of 27 pseudo-random bytes per element, bytes = BLAKE2b(seed || counter)"""
+    """bfs_xfe_sample_fill: ExtensionField.sample (extension_field.py:100-111) of 27 pseudo-random bytes per element; the byte stream
+    is the first 63 bytes of every BLAKE2b-512(seed || block counter), element i takes bytes [27 i, 27 i + 27)"""
     from stark_brainfuck_amd import _lib
     from stark_brainfuck_amd.device import DeviceBuffer
     lib = _lib.load()
     P = (1 << 64) - (1 << 32) + 1
-    seed, count = bytes(range(100, 132)), 1000
-    buf = DeviceBuffer(3 * count)
-    _lib.check(lib.bfs_xfe_sample_fill(seed, buf.ptr, count, count, 0))
-    got = buf.to_numpy(3 * count).reshape(3, count)
-    for i in (0, 1, 2, 499, 999):
-        for j in range(3):
-            digest = hashlib.blake2b(seed + (3 * i + j).to_bytes(8, "little")).digest()
-            assert int(got[j, i]) == int.from_bytes(digest[:9], "big") % P
-    assert (got < np.uint64(P)).all() and len(set(got.reshape(-1).tolist())) == 3 * count
+    seed = bytes(range(100, 132))
+    for count in (1, 2, 3, 7, 1000, 4099):
+        buf = DeviceBuffer(3 * count)
+        _lib.check(lib.bfs_xfe_sample_fill(seed, buf.ptr, count, count, 0))
+        got = buf.to_numpy(3 * count).reshape(3, count)
+        blocks = (27 * count + 62) // 63
+        stream = b"".join(hashlib.blake2b(seed + b.to_bytes(8, "little")).digest()[:63] for b in range(blocks))
+        for i in sorted({0, 1, 2, count // 2, count - 1}):
+            if i >= count:
+                continue
+            chunk = stream[27 * i:27 * i + 27]
+            for j in range(3):
+                assert int(got[j, i]) == int.from_bytes(chunk[9 * j:9 * j + 9], "big") % P, (count, i, j)
+        assert (got < np.uint64(P)).all()
+        if count >= 1000:
+            assert len(set(got.reshape(-1).tolist())) == 3 * count
 
 
 def test_zipped_rows_remembered_patterns_and_the_fallback(sb, oracle):
