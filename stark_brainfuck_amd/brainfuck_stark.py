@@ -223,7 +223,7 @@ class BrainfuckStark:
         def salts(tree):
             if getattr(tree, "_salt_cache", None) is not None:
                 return ctypes.c_void_p(tree._salt_base), 1
-            return ctypes.cast(tree._salt_host, ctypes.c_void_p), 0
+            return ctypes.c_void_p(ctypes.addressof(tree._salt_host)), 0
         base_arr, ext_arr = requests(base_row), requests(ext_row)
         mods = (_u64 * max(len(moduli), 1))(*[0 if m is None else int(m) for m in moduli])
         idx = (_u64 * len(indices))(*indices)
@@ -339,12 +339,14 @@ class BrainfuckStark:
                 return None                                                     # (the Python path raises where the reference would)
         # ---- every random draw of prove(), in its order, from the sources the Python path reads (tests replace them module by module)
         rnd = _lib.StarkRandomness()
-        keep = []                                                               # buffers the structure points at
+        keep = []                                                               # buffers the structure points at (ADDRESSES go into it:
+        # ctypes.cast(buffer, c_void_p) puts the buffer into its own _objects dictionary -- a reference cycle, and a 24 n-byte salt
+        # buffer per commitment then lives until the cyclic collector happens to run: a soak grew by 5 MB per proof that way)
         draw = random_source(urandom)
         count = self.max_degree + 1
         if draw is os.urandom or getattr(draw, "expand_on_device", False):
             keep.append(ctypes.create_string_buffer(draw(32), 32))
-            rnd.randomizer_seed = ctypes.cast(keep[-1], ctypes.c_void_p)
+            rnd.randomizer_seed = ctypes.addressof(keep[-1])
         else:
             keep.append(np.ascontiguousarray(sample_ext_many(draw(3 * 9 * count), count, 9), dtype=np.uint64))
             rnd.randomizer_limbs = keep[-1].ctypes.data
@@ -358,17 +360,17 @@ class BrainfuckStark:
             return [int.from_bytes(source(24), "big") for _ in range(count)]
         base_rand = [v % P_GOLDILOCKS for v in draws(tdraw, sum(t.base_width for t in self.tables[:3] if t.height))]
         keep.append((_u64 * max(len(base_rand), 1))(*base_rand))
-        rnd.base_randomizers = ctypes.cast(keep[-1], ctypes.c_void_p)
+        rnd.base_randomizers = ctypes.addressof(keep[-1])
 
         def salts(field_seed, field_data):
             sdraw = random_source(salted_mod.urandom)
             if sdraw is os.urandom or getattr(sdraw, "expand_on_device", False):
                 keep.append(ctypes.create_string_buffer(sdraw(32), 32))
-                setattr(rnd, field_seed, ctypes.cast(keep[-1], ctypes.c_void_p))
+                setattr(rnd, field_seed, ctypes.addressof(keep[-1]))
             else:
                 data = sdraw(24 * n)
                 keep.append(ctypes.create_string_buffer(data, len(data)))
-                setattr(rnd, field_data, ctypes.cast(keep[-1], ctypes.c_void_p))
+                setattr(rnd, field_data, ctypes.addressof(keep[-1]))
         salts("base_salt_seed", "base_salts")
         initials = [sample_ext(draw(3 * 8)) for _ in self.permutation_arguments]
         rnd.initials = (_u64 * 6)(*[v for i in initials for v in i])
@@ -376,7 +378,7 @@ class BrainfuckStark:
         ext_rand = [c % P_GOLDILOCKS for v in draws(tdraw, sum(t.full_width - t.base_width for t in self.tables[:3] if t.height))
                     for c in (v >> 128, (v >> 64) & mask64, v & mask64)]
         keep.append((_u64 * max(len(ext_rand), 1))(*ext_rand))
-        rnd.ext_randomizers = ctypes.cast(keep[-1], ctypes.c_void_p)
+        rnd.ext_randomizers = ctypes.addressof(keep[-1])
         salts("ext_salt_seed", "ext_salts")
 
         params = _lib.StarkParams(n.bit_length() - 1, self.expansion_factor, self.num_colinearity_checks, self.security_level,
@@ -803,9 +805,9 @@ class BrainfuckStark:
         params.omicrons = (_u64 * 5)(*[t_.omicron.value for t_ in self.tables])
         params.num_distances = len(unit_distances)
         params.distances = (_u64 * 8)(*(unit_distances + [0] * (8 - len(unit_distances))))
-        params.program, params.program_len = ctypes.cast(words, ctypes.c_void_p), len(self.program)
-        params.input, params.n_input = ctypes.cast(ins, ctypes.c_void_p), len(self.input_symbols)
-        params.output, params.n_output = ctypes.cast(outs, ctypes.c_void_p), len(self.output_symbols)
+        params.program, params.program_len = ctypes.addressof(words), len(self.program)
+        params.input, params.n_input = ctypes.addressof(ins), len(self.input_symbols)
+        params.output, params.n_output = ctypes.addressof(outs), len(self.output_symbols)
         out_ch, out_tm, verdict = (_u64 * 33)(), (_u64 * 15)(), ctypes.c_int(3)
         _lib.check(lib.bfs_stark_verify_begin(t.handle, ctypes.byref(params), out_ch, out_tm, ctypes.byref(verdict)))
         if verdict.value == 2:

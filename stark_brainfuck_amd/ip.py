@@ -69,23 +69,21 @@ class NativeTranscript:
     def scan(self, objs):
         """note which BaseFieldElement objects are coefficients of more than one extension element: those elements must be
         built over explicit coefficient objects so that the second occurrence becomes a back-reference, as in pickle."""
-        seen = {}
-
-        def walk(o):
+        # (a loop with its own stack: a nested function that calls itself is a reference cycle -- function, closure cell, function --
+        # that also holds `self`, so every call kept a transcript and its native object graph alive until the cyclic collector ran)
+        seen, uses = set(), self._coefficient_uses
+        stack = list(objs)[::-1]
+        while stack:
+            o = stack.pop()
             if isinstance(o, ExtensionFieldElement):
-                if id(o) in seen:
-                    return
-                seen[id(o)] = 1
-                for c in o.polynomial.coefficients:
-                    self._coefficient_uses[id(c)] = self._coefficient_uses.get(id(c), 0) + 1
+                if id(o) not in seen:
+                    seen.add(id(o))
+                    for c in o.polynomial.coefficients:
+                        uses[id(c)] = uses.get(id(c), 0) + 1
             elif isinstance(o, (list, tuple)):
-                if id(o) in seen:
-                    return
-                seen[id(o)] = 1
-                for x in o:
-                    walk(x)
-        for o in objs:
-            walk(o)
+                if id(o) not in seen:
+                    seen.add(id(o))
+                    stack.extend(reversed(o))
 
     def _field_id(self, field):
         """BaseField instances are distinguished by identity, like pickle does: 1 = the one inside the xfield's modulus,

@@ -120,7 +120,7 @@ class ZippedSaltedMerkle(SaltedMerkle):
             keep = ctypes.create_string_buffer(salts, len(salts))
             self._salt_host = keep                   # bfs_stark_push_openings reads opened salts from here
             root = ctypes.create_string_buffer(64)
-            _lib.check(lib.bfs_merkle_build_rows_root(cols, len(columns), n, limb_stride, ctypes.cast(keep, ctypes.c_void_p), 0,
+            _lib.check(lib.bfs_merkle_build_rows_root(cols, len(columns), n, limb_stride, ctypes.addressof(keep), 0,        # (not ctypes.cast: it makes `keep` part of a reference cycle)
                                                       self._nodes.ptr, root, stream))
             self._root = root.raw
 

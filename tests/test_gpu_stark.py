@@ -504,3 +504,62 @@ def test_trace_padding_on_the_device():
             tables.append(rows)
         check(tables, [npo2(k) for k in shape])
         check(tables, [2 * npo2(k) if k else 4 for k in shape])          # taller than the rows ask for (IO tables: zero rows)
+
+
+@pytest.mark.gpu
+def test_proving_in_a_loop_does_not_grow_the_process(monkeypatch):
+    """a prover that runs for hours must not depend on Python's cyclic collector to give memory back: with the collector switched
+    off, 150 proofs + verifications -- production path and Python stages, with the operating system's randomness and with a replaced
+    urandom (explicit 24 n-byte salt buffers) -- leave the resident set where it was.  (Round 5: `ctypes.cast(buffer, c_void_p)` makes
+    the buffer part of a reference cycle, and a nested function that calls itself held every transcript; a soak grew by 5 MB per proof
+    and lost its box after twenty minutes.  tools/leak_probe.py is the long form of this test.)"""
+    import gc
+    from stark_brainfuck_amd import brainfuck_stark, salted_merkle, table
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    code = "++++[>++++[>++<-]<-]>>."
+    program = VirtualMachine.compile(code)
+    rt, inp, out = VirtualMachine.run(program)
+    m = VirtualMachine.simulate(program, input_data=inp)
+
+    class Stream:
+        def __init__(self, tag):
+            self.tag, self.pos, self.buf = tag, 0, b""
+
+        def __call__(self, n):
+            end = self.pos + n
+            if end > len(self.buf):
+                self.buf = hashlib.shake_256(b"loop" + self.tag).digest(max(2 * end, 1 << 16))
+            o = self.buf[self.pos:end]
+            self.pos = end
+            return o
+
+    def rss():
+        return int(open("/proc/self/statm").read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 2**20
+
+    def one(k):
+        keep, replaced = bool(k & 1), bool(k & 2)
+        if replaced:
+            s = Stream(str(k).encode())
+            for mod in (brainfuck_stark, salted_merkle, table):
+                monkeypatch.setattr(mod, "urandom", s)
+        else:
+            monkeypatch.undo()
+        stark = BrainfuckStark(rt, len(m[1]), program, inp, out)
+        stark.keep_intermediates = keep
+        proof = stark.prove(program, *m)
+        assert BrainfuckStark(rt, len(m[1]), program, inp, out).verify(proof) is True
+
+    for k in range(8):              # pools, caches, templates: everything that is made once
+        one(k)
+    gc.collect()
+    gc.disable()
+    try:
+        before = rss()
+        for k in range(150):
+            one(k)
+        grown = rss() - before
+    finally:
+        gc.enable()
+        monkeypatch.undo()
+    assert grown < 24, "150 proofs grew the process by %.0f MiB with the cyclic collector off" % grown

@@ -52,6 +52,7 @@ def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     t0, count, shapes = time.time(), 0, set()
+    last_log = t0
     while time.time() - t0 < budget:
         code = random_program(rng)
         inp = [chr(int(c)) for c in rng.integers(1, 127, code.count(",") + 3)]
@@ -87,6 +88,38 @@ def main():
         assert wrong is False, "accepted a false claim: %r" % code
         count += 1
         shapes.add(tuple(t.height for t in stark.tables) + (stark.fri.domain.length,))
+        if os.environ.get("SOAK_MEMLOG") and time.time() - last_log >= 30:
+            # resident set of this process and free device memory: a soak must not grow either without bound
+            last_log = time.time()
+            rss = int(open("/proc/self/statm").read().split()[1]) * os.sysconf("SC_PAGE_SIZE") / 2**20
+            try:
+                import torch
+                free, total = torch.cuda.mem_get_info()
+                dev = "device free %.1f of %.1f GiB" % (free / 2**30, total / 2**30)
+            except Exception as e:
+                dev = "device memory: %s" % e
+            print("[mem] %5.0f s  %6d proofs  %d shapes  rss %.0f MiB  %s" % (time.time() - t0, count, len(shapes), rss, dev), flush=True)
+            if os.environ.get("SOAK_GC"):
+                import gc
+                print("      gc.collect(): %d unreachable" % gc.collect(), flush=True)
+            if os.environ.get("SOAK_MEMLOG") == "2":            # who holds it: Python allocations by source line, the C heap, the mappings
+                import ctypes, gc, tracemalloc
+                gc.collect()
+                if tracemalloc.is_tracing():
+                    snap = tracemalloc.take_snapshot()
+                    for st in snap.statistics("lineno")[:6]:
+                        print("      %s" % st, flush=True)
+                else:
+                    tracemalloc.start()
+                kinds = {}
+                name = None
+                for line in open("/proc/self/smaps"):
+                    f = line.split()
+                    if "-" in f[0] and ":" not in f[0] and len(f) >= 5:
+                        name = f[5] if len(f) > 5 else "[anon]"
+                    elif f[0] == "Rss:":
+                        kinds[name] = kinds.get(name, 0) + int(f[1])
+                print("      mappings (MiB): %s" % ", ".join("%s %d" % (k, v // 1024) for k, v in sorted(kinds.items(), key=lambda kv: -kv[1])[:5]), flush=True)
     print("%d random programs in %.0f s: both prover paths byte-identical, verify() accepted every proof and rejected every altered claim; "
           "%d distinct (table heights, FRI domain) shapes, FRI domains %d..%d" % (count, time.time() - t0, len(shapes),
           min(s[-1] for s in shapes), max(s[-1] for s in shapes)))
