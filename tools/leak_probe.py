@@ -131,5 +131,29 @@ if os.environ.get("PROBE_PYTHON_STAGES", "1") == "1":
     leg("Python stages + intermediates, replaced urandom", prove(True, True))
 proof = p.proof
 leg("verify()", lambda: BrainfuckStark(rt, len(m[1]), program, inp, out).verify(proof))
+# the hot-path entry points through the reference's own call surface (the Python mirror), collector off: nothing may wait for it
+if os.environ.get("PROBE_API", "1") == "1":
+    import stark_brainfuck_amd as sb
+    from stark_brainfuck_amd.algebra import BaseField, BaseFieldElement
+    from stark_brainfuck_amd.extension_field import ExtensionField
+    from stark_brainfuck_amd.fri import Fri
+    from stark_brainfuck_amd.ip import ProofStream
+    from stark_brainfuck_amd.merkle import Merkle
+    from stark_brainfuck_amd.ntt import fast_coset_evaluate, ntt
+    from stark_brainfuck_amd.univariate import Polynomial
+    field, xfield = BaseField.main(), ExtensionField.main()
+    nn = 1 << 12
+    omega = field.primitive_nth_root(nn)
+    values = [BaseFieldElement((i * i + 7) % field.p, field) for i in range(nn)]
+    poly = Polynomial(values[:nn // 4])
+    fri = Fri(field.generator(), omega, nn, 4, 2, xfield)
+    xcoeffs = [xfield.sample(bytes([i % 251, 1, 2, 3] * 8)) for i in range(nn // 4)]
+    codeword = fri.domain.xevaluate(Polynomial(xcoeffs))
+    gc.disable()
+    leg("ntt(2^12) through the mirror", lambda: ntt(omega, values))
+    leg("fast_coset_evaluate(2^10 -> 2^12)", lambda: fast_coset_evaluate(poly, field.generator(), omega, nn))
+    leg("Merkle(2^12 extension leaves) + root + open", lambda: Merkle(codeword).open(5))
+    leg("Fri.prove(2^12 extension codeword)", lambda: fri.prove(codeword, ProofStream()))
+    gc.enable()
 gc.collect()
 print("after gc.collect(): rss %.0f MiB" % rss())
