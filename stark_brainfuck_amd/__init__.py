@@ -10,7 +10,8 @@ All bulk work runs in hand-written HIP kernels behind the C ABI of libbfstark_hi
 no CPU fallback -- importing the compute entry points without the built library raises BackendUnavailable.
 """
 from .algebra import BaseField, BaseFieldElement, xgcd
-from .univariate import Polynomial, colinear, test_colinearity
+from .univariate import Polynomial, colinear        # (the reference's name for it, `test_colinearity`, stays in .univariate only: a star-import
+#                                                       of it into a test module makes pytest collect it -- SURVEY.md 4)
 from .extension_field import ExtensionField, ExtensionFieldElement
 from .arrays import BaseArray, XArray
 from .ntt import (ntt, intt, fast_multiply, fast_coset_evaluate, fast_coset_interpolate, batch_inverse,
@@ -21,7 +22,7 @@ from .ip import ProofStream, reference_pickle
 from .fri import Fri
 from ._lib import BackendUnavailable
 
-__all__ = ["BaseField", "BaseFieldElement", "xgcd", "Polynomial", "colinear", "test_colinearity", "ExtensionField",
+__all__ = ["BaseField", "BaseFieldElement", "xgcd", "Polynomial", "colinear", "ExtensionField",
            "ExtensionFieldElement", "BaseArray", "XArray", "ntt", "intt", "fast_multiply", "fast_coset_evaluate",
            "fast_coset_interpolate", "batch_inverse", "fast_coset_divide", "Merkle", "SaltedMerkle", "ProofStream",
            "reference_pickle", "Fri", "BackendUnavailable"]

@@ -257,26 +257,38 @@ class BrainfuckStark:
         # would walk all of them (measured: 20 ms pauses on a 17 ms proof).  gc.freeze() parks everything that exists now in a
         # permanent generation for the duration of the call; objects made by the proof itself are collected as usual.
         import gc
+        from . import debug_checks
+        # DEBUG (the reference's switch, brainfuck_stark.py:251-290, table.py:170-176 / 219-234 / 264-284) or BFS_DEBUG=1: every
+        # quotient and every term of the combination is interpolated and its degree asserted (debug_checks.py).  The checks need the
+        # quotient codewords in HBM, i.e. the path that keeps intermediates; the proof bytes are the same.
+        debug = debug_checks.enabled() and not self.keep_intermediates
+        if debug:
+            self.keep_intermediates = True
         gc.freeze()
         try:
             return self._prove(program, processor_matrix, memory_matrix, instruction_matrix, input_matrix, output_matrix, proof_stream)
         finally:
             gc.unfreeze()
+            if debug:
+                self.keep_intermediates = False
+                self._last = {k: v for k, v in getattr(self, "_last", {}).items()
+                              if k in ("challenges", "terminals", "indices", "weights_seed", "quotient_degree_bounds")}
 
     # ---- the production path: the stages between the Fiat-Shamir points run natively (csrc/prover.cpp), two calls per proof
     native_stages = True            # False: every stage is driven from Python (the path below; what the tests compare the native one with)
 
-    _thread_sessions = None         # threading.local: one native session per proving THREAD (created on first use, freed with the thread)
+    # one native session per proving THREAD (made on a thread's first proof, freed with the thread).  The threading.local itself is made
+    # HERE, once, when the class is defined: made lazily, two threads entering their first prove() together could each create one, and the
+    # loser's holder -- referenced from nothing but its own frame -- was finalised (bfs_stark_session_free) while the thread still proved
+    # with the freed session (round-5 advice).
+    _thread_sessions = __import__("threading").local()
 
     @staticmethod
     def _native_session():
         """the calling thread's bfs_stark session.  A session owns side streams, events and scratch buffers (csrc/prover.cpp), which
         cost far more to make than a small proof takes, so it belongs to the thread, not to the BrainfuckStark object: provers are
         made per claim (running time, program, symbols) and thrown away, threads stay."""
-        import threading
         import weakref
-        if BrainfuckStark._thread_sessions is None:
-            BrainfuckStark._thread_sessions = threading.local()
         local = BrainfuckStark._thread_sessions
         holder = getattr(local, "holder", None)
         if holder is None:
@@ -632,6 +644,15 @@ class BrainfuckStark:
             for pa in self.permutation_arguments:
                 quotient_buffers.append((pa.quotient(domain), 1))
                 quotient_degree_bounds.append(pa.quotient_degree_bound())
+            from . import debug_checks
+            if debug_checks.enabled():
+                # the reference checks each table's quotients inside all_quotients (before the terminals are pushed) ...
+                supports = [debug_checks.check_table_quotients(table, buf, n, domain.omega.value)
+                            for table, (buf, _) in zip(self.tables, quotient_buffers)]
+                supports += [debug_checks.support(buf.ptr, 3, count, n, domain.omega.value) for buf, count in quotient_buffers[len(self.tables):]]
+                # ... and the terms of the combination while it assembles them (after the weights are sampled; nothing in between
+                # depends on the outcome, so both sets run here)
+                debug_checks.check_terms(self, n, domain.omega.value, base_degree_bounds, extension_degree_bounds, supports, quotient_degree_bounds)
 
         lap("quotients")
         terminal_objects = self._terminal_objects(terminals)          # :223-224
@@ -854,7 +875,11 @@ class BrainfuckStark:
         base_root = proof_stream.pull()
         challenges = tuple(BrainfuckStark._sample_weights(11, proof_stream.verifier_fiat_shamir()))
         extension_root = proof_stream.pull()
-        terminals = [limbs(proof_stream.pull()) for _ in range(5)]
+        terminal_objects = [proof_stream.pull() for _ in range(5)]
+        terminals = [limbs(t) for t in terminal_objects]
+        # ... and as STORED, for the three evaluation arguments at the end: the reference compares the pulled object with a computed
+        # element through Polynomial.__eq__ / BaseFieldElement.__eq__, i.e. the coefficient values as they were pickled (round-5 advice)
+        stored_terminals = [tuple(t.limbs()) if hasattr(t, "limbs") else (t.value, 0, 0) for t in terminal_objects]
 
         base_degree_bounds = [t.interpolant_degree() for t in self.tables for _ in range(t.base_width)]
         extension_degree_bounds = [t.interpolant_degree() for t in self.tables for _ in range(t.full_width - t.base_width)]
@@ -952,5 +977,5 @@ class BrainfuckStark:
 
         verdict = self.fri.verify(proof_stream, combination_root)
         for ea in self.evaluation_arguments:
-            verdict = verdict and tuple(ea.select_terminal(terminals)) == tuple(ea.compute_terminal(challenges))
+            verdict = verdict and tuple(ea.select_terminal(stored_terminals)) == tuple(ea.compute_terminal(challenges))
         return bool(verdict)

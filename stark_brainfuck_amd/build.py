@@ -143,6 +143,62 @@ def build_library(force=False, verbose=False, extra_flags=()):
     return LIB
 
 
+# ---- hardening build (round-5 verdict, next #3): the host units that read attacker-controlled bytes, under ASan + UBSan ----
+# verify() hands the bytes of a proof to csrc/refpickle.hpp (through transcript.cpp: bfs_ps_loads) and walks the object graph in
+# csrc/verifier.cpp; the reference does the same with CPython's pickle.loads (ip.py:27-30).  `build_sanitized()` compiles exactly those
+# units (plus capi.cpp, whose error string they write) with -fsanitize=address,undefined and links them with the product's other objects
+# into libbfstark_hip_asan.so; tests/test_sanitized_parsers.py and tools/fuzz_proofs.py load it through BFS_LIB_PATH with the ASan
+# runtime preloaded.  Host side only: device code is compiled as in the product.
+SANITIZED_UNITS = ("transcript.cpp", "verifier.cpp", "capi.cpp")
+SAN_FLAGS = ["-Xarch_host", "-fsanitize=address,undefined", "-Xarch_host", "-fno-sanitize-recover=undefined",
+             "-Xarch_host", "-fno-omit-frame-pointer", "-Xarch_host", "-g"]
+LIB_ASAN = os.path.join(HERE, "libbfstark_hip_asan.so")
+
+
+def asan_runtime():
+    """path of the shared ASan runtime of the compiler that built the library (to LD_PRELOAD into the Python that loads it)"""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    clang = os.path.join(os.path.dirname(os.path.realpath(hipcc)), "..", "lib", "llvm", "bin", "clang")
+    if not os.path.exists(clang):
+        clang = "/opt/rocm/lib/llvm/bin/clang"
+    out = subprocess.run([clang, "-print-file-name=libclang_rt.asan-x86_64.so"], stdout=subprocess.PIPE, text=True).stdout.strip()
+    if not os.path.isabs(out) or not os.path.exists(out):
+        raise RuntimeError("no shared ASan runtime next to %s" % clang)
+    return out
+
+
+def build_sanitized(force=False, fuzzer=False):
+    """fuzzer: the sanitized units also carry libFuzzer's coverage counters (-fsanitize=fuzzer-no-link), for tools/fuzz_ps_loads.cpp"""
+    build_library()
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    san_dir = os.path.join(OBJ, "asan_fuzzer" if fuzzer else "asan")
+    os.makedirs(san_dir, exist_ok=True)
+    compile_flags = [f for f in FLAGS if f != "-shared"] + SAN_FLAGS + (["-Xarch_host", "-fsanitize=fuzzer-no-link"] if fuzzer else [])
+    key = content_key(_deps(), [hipcc] + compile_flags + list(SANITIZED_UNITS))
+    if not force and is_current(LIB_ASAN, key):
+        return LIB_ASAN
+    objects = []
+    for src in sources():
+        base = os.path.basename(src)
+        if base in SANITIZED_UNITS:
+            obj = os.path.join(san_dir, base + ".o")
+            res = subprocess.run([hipcc] + compile_flags + ["-c", "-o", obj, src], cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if res.returncode != 0:
+                sys.stderr.write(res.stdout)
+                raise RuntimeError("hipcc failed building the sanitized " + base)
+        else:
+            obj = os.path.join(OBJ, base + ".o")
+        objects.append(obj)
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-fsanitize=address,undefined", "-shared-libsan", "-o", LIB_ASAN + ".tmp"] + objects
+    res = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if res.returncode != 0:
+        sys.stderr.write(res.stdout)
+        raise RuntimeError("hipcc failed linking libbfstark_hip_asan.so")
+    os.replace(LIB_ASAN + ".tmp", LIB_ASAN)
+    record(LIB_ASAN, key)
+    return LIB_ASAN
+
+
 def build_listings(force=False, extra_flags=()):
     """gfx950 assembly listings of the device code, one per .hip unit, in _build/listings/<unit>-gfx950.s: a separate device-only -S
     pass with the library's flags (the product build keeps no temporaries).  tools/isa_hazards.py and tools/isa_mix.py read them;
@@ -189,6 +245,10 @@ def build_fastlist(force=False):
 
 
 if __name__ == "__main__":
+    if "--sanitize" in sys.argv:
+        print("built", build_sanitized(force="--force" in sys.argv, fuzzer="--fuzzer" in sys.argv))
+        print("preload", asan_runtime())
+        sys.exit(0)
     build_library(force="--force" in sys.argv, verbose="--verbose" in sys.argv or True,
                   extra_flags=["-Rpass-analysis=kernel-resource-usage"] if "--resources" in sys.argv else [])
     print("built", LIB)

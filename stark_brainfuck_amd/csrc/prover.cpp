@@ -247,9 +247,14 @@ int bfs_stark_commit(void* session, void* ps, const bfs_stark_params* params, co
     BFS_TRY(S.ensure_streams());
     // an error between a fork and its join leaves work on the side streams that the pool's stream-ordered reuse knows nothing about:
     // every early return waits for the device before the session's blocks go back
+    // The stage's own blocks are DECLARED IN FRONT of the guard so that they are destroyed after it: on an early return the guard's
+    // device synchronisation comes first and only then do the pinned staging block and the device blocks go back to their pools (declared
+    // behind the guard -- as rpoly, stage, raw and padded were -- they were released while the copy out of `stage` and work forked onto the
+    // side streams could still be in flight, and another prover thread could be handed the pinned block mid-copy: round-5 advice).
+    DeviceBlock rpoly, raw, padded;
+    PinnedBlock stage;
     struct Guard { bool ok = false; ~Guard() { if (!ok) (void)hipDeviceSynchronize(); } } guard;
     const u64 count = P.max_degree + 1;
-    DeviceBlock rpoly;
     BFS_TRY(rpoly.get(3 * count * 8, stream));
     BFS_TRY(S.randomizer_cw.get(3 * n * 8, stream));
     const u64 salt_words = (3 * n + 7) / 8 * 8;
@@ -277,9 +282,7 @@ int bfs_stark_commit(void* session, void* ps, const bfs_stark_params* params, co
     // masks: processor active / reads / writes, instruction product / evaluation rows, memory non-dummy rows
     const u64 hp = S.height[0], hi = S.height[1], hm = S.height[2];
     mask_bytes = 3 * hp + 2 * hi + hm;
-    PinnedBlock stage;
     BFS_TRY(stage.get(raw_words * 8));
-    DeviceBlock raw, padded;
     BFS_TRY(raw.get(raw_words * 8, stream));
     BFS_TRY(padded.get(trace_words * 8 + ((mask_bytes + 7) & ~7ull), stream));
     {

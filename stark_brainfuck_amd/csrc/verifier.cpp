@@ -106,7 +106,8 @@ Xfe xfe_pow_u(Xfe a, u64 e) {
 
 struct Begin {
     Ref base_root, ext_root;
-    Xfe terminals[5];
+    Xfe terminals[5];          // reduced: what the reference's arithmetic sees
+    Xfe terminals_stored[5];   // as stored: what its comparisons see (Polynomial.__eq__ / BaseFieldElement.__eq__ compare .value, algebra.py:48-49)
     u64 challenges[33];
 };
 
@@ -116,7 +117,11 @@ void read_begin(Reader& rd, Begin& b) {
     rd.fiat_shamir(seed);
     if (bfs_sample_weights(seed, 32, 11, b.challenges) != BFS_OK) throw Fallback{};
     b.ext_root = bytes_of(rd.pull());
-    for (int k = 0; k < 5; ++k) b.terminals[k] = xfe_value_of(rd.pull());
+    for (int k = 0; k < 5; ++k) {
+        const Ref t = rd.pull();
+        b.terminals[k] = xfe_value_of(t);
+        b.terminals_stored[k] = Xfe{{t->limbs[0], t->limbs[1], t->limbs[2]}};
+    }
 }
 
 // fri.py:201-319 (stark_brainfuck_amd/fri.py: Fri.verify), on the reader's stream
@@ -367,8 +372,11 @@ int verify_finish(Transcript* t, const bfs_stark_verify_params& P, const u64* sh
         for (size_t i = 0; i < count; ++i) acc = xfe_add_base(xfe_mul(acc, point), s[i] % GL_P);
         return acc;
     };
-    verdict = verdict && xfe_eq(b.terminals[2], horner_symbols(P.input, P.n_input, C(8)));
-    verdict = verdict && xfe_eq(b.terminals[3], horner_symbols(P.output, P.n_output, C(9)));
+    // `ea.select_terminal(terminals) == ea.compute_terminal(challenges)` (brainfuck_stark.py:574-577) compares the terminal OBJECT of the
+    // proof with a computed (canonical) element, coefficient values as stored: a terminal whose limb is written as v + p is unequal in the
+    // reference although every other use of it reduces -- so the three comparisons below take the stored limbs (round-5 advice)
+    verdict = verdict && xfe_eq(b.terminals_stored[2], horner_symbols(P.input, P.n_input, C(8)));
+    verdict = verdict && xfe_eq(b.terminals_stored[3], horner_symbols(P.output, P.n_output, C(9)));
     {
         const Xfe a = C(0), bb = C(1), c = C(2), eta = C(10);
         Xfe acc{{0, 0, 0}};
@@ -380,7 +388,7 @@ int verify_finish(Transcript* t, const bfs_stark_verify_params& P, const u64* sh
             }
             acc = xfe_add(xfe_mul(acc, eta), row);
         }
-        verdict = verdict && xfe_eq(b.terminals[4], acc);
+        verdict = verdict && xfe_eq(b.terminals_stored[4], acc);
     }
     return verdict ? V_TRUE : V_FALSE;
 }

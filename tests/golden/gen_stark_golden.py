@@ -15,11 +15,13 @@ re-implementation consumes the same stream through its injectable `urandom`.
 import sys
 sys.dont_write_bytecode = True
 import os, json, hashlib, struct, time
+import multiprocessing          # (imported BEFORE os.urandom is replaced: the module draws its process authentication key from os.urandom on import)
+_REAL_URANDOM = os.urandom
 
 REF = os.environ.get("BFS_REFERENCE", "/root/reference/code")
 sys.path.insert(0, REF)
 sys.setrecursionlimit(100000)
-HERE = os.path.dirname(os.path.abspath(__file__))
+HERE = os.environ.get("BFS_GOLDEN_OUT") or os.path.dirname(os.path.abspath(__file__))
 
 
 class Stream:
@@ -153,6 +155,9 @@ def main():
         return r
     bs.BrainfuckStark.sample_indices = staticmethod(cap_si)
 
+    workers = int(os.environ.get("BFS_GOLDEN_WORKERS", "1"))
+    if workers > 1:
+        install_parallel_quotients(table_mod, workers, rec)
     ps = ProofStream()
     t0 = time.time()
     proof = stark.prove(program, pm, mm, im, inm, om, proof_stream=ps)
@@ -183,6 +188,126 @@ def main():
             f.write(proof)
     print(json.dumps({k: rec[k] for k in ("name", "running_time", "max_degree", "fri_domain_length", "table_heights", "prove_seconds",
                                           "verify", "proof_len", "urandom_calls")}))
+
+
+# ---- BFS_GOLDEN_WORKERS=N: the reference's quotient stage on N processes ------------------------------------------------------------
+# Nine tenths of the reference's proving time is Table.all_quotients (table.py:155-301): for every constraint and every point of the FRI
+# domain one MPolynomial.evaluate on boxed elements -- a pure function of the codewords, the challenges and the terminals (no randomness,
+# nothing else reads its intermediate state).  A proof at FRI domain 2^16 takes a CPython process more than eight hours that way, one at
+# 2^17 (the reference's own Hello-World test, test_brainfuck_stark.py:165-222) twice that.  With N > 1 this script forks N workers at each
+# table's boundary / transition / terminal quotient call.  EVERY worker runs the reference's UNMODIFIED method over all constraints and
+# all points; what differs is that the constraint objects it iterates over are gates: a gate forwards `evaluate(point)` to the reference's
+# MPolynomial for the (constraint, point) pairs of the worker's share and answers the field's zero for the rest, so each worker pays
+# for its share only.  The parent assembles every quotient codeword from the shares.  No arithmetic of the reference is restated or
+# replaced, and the result is checked where it can be: `gen_stark_golden.py plus1 ...` with BFS_GOLDEN_WORKERS=4 writes the same
+# stark_plus1_proof.bin, byte for byte, and the same digests of every quotient codeword, as the sequential run did (tests/golden/README).
+_JOB = None
+
+
+class _Gate:
+    """stands where a constraint (MPolynomial) stands in the list a quotient method iterates over"""
+
+    def __init__(self, mpo, ranges, calls_per_point, zero):
+        self.mpo, self.ranges, self.calls_per_point, self.zero, self.calls = mpo, ranges, calls_per_point, zero, 0
+
+    def evaluate(self, point):
+        i = self.calls // self.calls_per_point
+        self.calls += 1
+        for a, b in self.ranges:
+            if a <= i < b:
+                return self.mpo.evaluate(point)
+        return self.zero
+
+    def __getattr__(self, name):          # anything else a method asks of a constraint goes to the constraint
+        return getattr(self.mpo, name)
+
+
+def _quotient_worker(share):
+    """in a forked child: the reference's method on gated constraints; returns {(l, a, b): values}"""
+    self, method_name, original, args, constraints_attr, constraints, calls_per_point, zero = _JOB
+    mine = {}
+    for l, a, b in share:
+        mine.setdefault(l, []).append((a, b))
+    gates = [_Gate(mpo, mine.get(l, []), calls_per_point, zero) for l, mpo in enumerate(constraints)]
+    setattr(self, constraints_attr, lambda *unused: gates)          # the instance attribute shadows the class's method in this process only
+    codewords = original(self, *args)
+    return {(l, a, b): codewords[l][a:b] for l, a, b in share}
+
+
+def install_parallel_quotients(table_mod, workers, rec):
+    ctx = multiprocessing.get_context("fork")
+    log = rec.setdefault("parallel_quotients", {"workers": workers, "calls": []})
+
+    def wrap(method_name, constraints_attr, calls_per_point, constraint_args):
+        original = getattr(table_mod.Table, method_name)
+
+        def parallel(self, domain, codewords, challenges, *rest):
+            global _JOB
+            constraints = getattr(self, constraints_attr)(*constraint_args(challenges, rest))
+            n = domain.length
+            weight = [max(1, len(c.dictionary)) for c in constraints]
+            if n < 64 or not constraints or self.height == 0:
+                return original(self, domain, codewords, challenges, *rest)
+            # pieces of roughly equal cost (terms x points), dealt to the workers largest first
+            total = sum(weight) * n
+            piece = max(64, total // (workers * 6))
+            pieces = []
+            for l, w in enumerate(weight):
+                step = max(16, min(n, piece // w))
+                for a in range(0, n, step):
+                    pieces.append((w * (min(n, a + step) - a), l, a, min(n, a + step)))
+            pieces.sort(reverse=True)
+            shares, load = [[] for _ in range(workers)], [0] * workers
+            for cost, l, a, b in pieces:
+                k = load.index(min(load))
+                shares[k].append((l, a, b))
+                load[k] += cost
+            # checkpoint (BFS_GOLDEN_CKPT=<dir>): a table's finished quotient codewords are pickled; a run that was interrupted and is
+            # started again with the same name recomputes the cheap early stages (deterministic: same randomness stream) and picks
+            # the quotients up from there.  The file records the digest of the inputs it belongs to.
+            ckpt = os.environ.get("BFS_GOLDEN_CKPT")
+            ckpt_file = None
+            if ckpt:
+                import pickle
+                key = hashlib.sha256(repr((rec["name"], type(self).__name__, method_name, n, sha_elems(codewords[0]), sha_elems(codewords[-1]),
+                                           [xl3(c) for c in challenges], [xl3(t) for r in rest for t in r])).encode()).hexdigest()[:16]
+                ckpt_file = os.path.join(ckpt, "%s_%s_%s_%s.pkl" % (rec["name"], type(self).__name__, method_name, key))
+                if os.path.exists(ckpt_file):
+                    with open(ckpt_file, "rb") as f:
+                        out = pickle.load(f)
+                    print("[parallel] %s.%s: from checkpoint %s" % (type(self).__name__, method_name, ckpt_file), file=sys.stderr, flush=True)
+                    log["calls"].append({"table": type(self).__name__, "method": method_name, "from_checkpoint": True})
+                    return out
+            t0 = time.time()
+            _JOB = (self, method_name, original, (domain, codewords, challenges) + tuple(rest), constraints_attr, constraints, calls_per_point, self.field.zero())
+            stream_urandom, os.urandom = os.urandom, _REAL_URANDOM          # the pool's own needs must not draw from the proof's randomness
+            try:
+                with ctx.Pool(workers) as pool:
+                    parts = pool.map(_quotient_worker, shares, chunksize=1)
+            finally:
+                os.urandom = stream_urandom
+            _JOB = None
+            out = [[None] * n for _ in constraints]
+            for part in parts:
+                for (l, a, b), values in part.items():
+                    out[l][a:b] = values
+            assert all(v is not None for cw in out for v in cw)
+            if ckpt_file:
+                import pickle
+                os.makedirs(ckpt, exist_ok=True)
+                with open(ckpt_file + ".tmp", "wb") as f:
+                    pickle.dump(out, f, protocol=4)
+                os.replace(ckpt_file + ".tmp", ckpt_file)
+            log["calls"].append({"table": type(self).__name__, "method": method_name, "constraints": len(constraints), "points": n,
+                                 "seconds": round(time.time() - t0, 1), "pieces": len(pieces)})
+            print("[parallel] %s.%s: %d constraints x %d points on %d workers, %.1f s" % (type(self).__name__, method_name, len(constraints), n, workers, time.time() - t0),
+                  file=sys.stderr, flush=True)
+            return out
+        setattr(table_mod.Table, method_name, parallel)
+
+    wrap("boundary_quotients", "boundary_constraints_ext", 1, lambda challenges, rest: (challenges,))
+    wrap("transition_quotients", "transition_constraints_ext", 2, lambda challenges, rest: (challenges,))
+    wrap("terminal_quotients", "terminal_constraints_ext", 1, lambda challenges, rest: (challenges,) + tuple(rest))
 
 
 def rle(xs):

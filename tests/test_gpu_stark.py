@@ -208,6 +208,46 @@ def test_prove_then_verify_fresh_randomness():
     assert BrainfuckStark(running_time, len(mm), program, input_symbols, output_symbols).verify(proof_b) is True
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("native_prove", ["1", "0"])
+def test_terminal_stored_as_v_plus_p_is_rejected_as_the_reference_rejects_it(native_prove, monkeypatch):
+    """round-5 advice: `ea.select_terminal(terminals) == ea.compute_terminal(challenges)` (brainfuck_stark.py:574-577) compares the terminal
+    OBJECT with a computed element, coefficient values as stored (univariate.py:67-74, algebra.py:48-49).  A prover that writes the zero
+    input-evaluation terminal as the one-coefficient polynomial [p] makes a proof in which everything else checks -- Fiat-Shamir hashes the
+    same pickle on both sides, every arithmetic use reduces -- and the reference returns False on the comparison (degree 0 against -1).
+    Both verifier routes here must say False too (they said True while they compared reduced limbs); the same claim proved with the
+    canonical object is accepted.  tests/golden/noncanonical_terminal.json records the reference's own verdict on such a proof."""
+    from stark_brainfuck_amd import BaseFieldElement, ExtensionFieldElement, Polynomial
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    monkeypatch.setenv("BFS_NATIVE_PROVE", native_prove)
+    program = VirtualMachine.compile("++>+<[->+<]>.")
+    running_time, input_symbols, output_symbols = VirtualMachine.run(program, input_data=[])
+    matrices = VirtualMachine.simulate(program, input_data=[])
+    args = (running_time, len(matrices[1]), program, input_symbols, output_symbols)
+    honest = BrainfuckStark(*args).prove(program, *matrices)
+    assert BrainfuckStark(*args).verify(honest) is True
+    P = (1 << 64) - (1 << 32) + 1
+    plain = BrainfuckStark._terminal_objects
+
+    def with_noncanonical_zero(self, terminals):
+        objs = plain(self, terminals)
+        assert not any(terminals[2]), "this program reads nothing: its input evaluation terminal is zero"
+        objs[2] = ExtensionFieldElement(Polynomial([BaseFieldElement(P, VirtualMachine.field)]), self.xfield)      # 0, stored as p
+        return objs
+    monkeypatch.setattr(BrainfuckStark, "_terminal_objects", with_noncanonical_zero)
+    crafted = BrainfuckStark(*args).prove(program, *matrices)
+    monkeypatch.setattr(BrainfuckStark, "_terminal_objects", plain)
+    assert crafted != honest
+    for native_verify in ("1", "0"):
+        monkeypatch.setenv("BFS_NATIVE_VERIFY", native_verify)
+        assert BrainfuckStark(*args).verify(crafted) is False, native_verify
+        assert BrainfuckStark(*args).verify(honest) is True, native_verify
+    out = os.environ.get("BFS_WRITE_NONCANONICAL_PROOF")
+    if out:                                                              # tools: the bytes go to the build container, where the reference judges them
+        open(out, "wb").write(crafted)
+
+
 WRAPPING_PROGRAMS = [
     "[->+<][>]+>[-]+++++[>+[>+<-]<-]-++++.----",      # the one tools/soak_stark.py found in round 4 (cells pass through p - 1)
     "-+.", "--++.", "->-<+.>++.", "+[-]-[+]+.", "-[>-<+]>+.", "++[>--<-]>++++.", "-->-<[>+<+]>+++.", "->->-<<+[>+>+<<-]>>+.",

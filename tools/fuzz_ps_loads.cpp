@@ -1,0 +1,100 @@
+// fuzz_ps_loads.cpp -- libFuzzer entry for the native proof reader and verifier (round-5 verdict, next #3: the long form of
+// tests/test_sanitized_parsers.py).  One input = the bytes of a proof as a hostile prover would send them; the reference hands such
+// bytes to pickle.loads (/root/reference/code/ip.py:27-30), here they go to bfs_ps_loads (csrc/refpickle.hpp through transcript.cpp)
+// and, when the reader takes them, through everything a verifier does with the stream: re-serialisation, per-object pickles,
+// Fiat-Shamir over every prefix, and bfs_stark_verify_begin / _finish (csrc/verifier.cpp) under the protocol parameters of the claim the
+// corpus proof was made for.
+//
+//   python -m stark_brainfuck_amd.build --sanitize --fuzzer        # reader + verifier with ASan, UBSan and coverage counters
+//   python tools/fuzz_proofs.py --write-params plus1 /tmp/plus1.params    # the claim's parameters as a flat file (and the degree shifts)
+//   /opt/rocm/lib/llvm/bin/clang++ -g -O1 -fsanitize=fuzzer,address,undefined -I include tools/fuzz_ps_loads.cpp \
+//        stark_brainfuck_amd/libbfstark_hip_asan.so -Wl,-rpath,$PWD/stark_brainfuck_amd -o tools/tmp/fuzz_ps_loads
+//   mkdir -p tools/tmp/corpus && cp tests/golden/stark_plus1_proof.bin tools/tmp/corpus/
+//   BFS_FUZZ_PARAMS=/tmp/plus1.params ASAN_OPTIONS=detect_leaks=0 tools/tmp/fuzz_ps_loads -max_len=65536 -timeout=10 tools/tmp/corpus
+//
+// An ACCEPTED input that is not byte-identical to a corpus proof is reported by abort() (a re-encoding of the same object stream is
+// accepted by the reference too; BFS_FUZZ_ALLOW_ACCEPT=1 skips the abort for such campaigns).
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "bfstark.h"
+
+namespace {
+struct Params {
+    bool loaded = false;
+    bfs_stark_verify_params p{};
+    std::vector<uint64_t> program, input, output, shifts;
+};
+Params& params() {
+    static Params P;
+    static bool tried = false;
+    if (tried) return P;
+    tried = true;
+    const char* path = getenv("BFS_FUZZ_PARAMS");
+    if (!path) return P;
+    FILE* f = fopen(path, "rb");
+    if (!f) { fprintf(stderr, "fuzz_ps_loads: cannot read %s\n", path); return P; }
+    std::vector<uint64_t> w;
+    uint64_t v;
+    while (fread(&v, 8, 1, f) == 1) w.push_back(v);
+    fclose(f);
+    // layout written by tools/fuzz_proofs.py --write-params: log_n, expansion, colinearity checks, security level, offset, omega,
+    // heights[5], lengths[5], omicrons[5], num_distances, distances[8], then program / input / output / shifts, each as (count, words...)
+    size_t k = 0;
+    auto next = [&]() { return k < w.size() ? w[k++] : 0; };
+    P.p.log_n = (uint32_t)next(); P.p.expansion_factor = (uint32_t)next(); P.p.num_colinearity_checks = (uint32_t)next(); P.p.security_level = (uint32_t)next();
+    P.p.offset = next(); P.p.omega = next();
+    for (int i = 0; i < 5; ++i) P.p.heights[i] = next();
+    for (int i = 0; i < 5; ++i) P.p.lengths[i] = next();
+    for (int i = 0; i < 5; ++i) P.p.omicrons[i] = next();
+    P.p.num_distances = (uint32_t)next();
+    for (int i = 0; i < 8; ++i) P.p.distances[i] = next();
+    for (std::vector<uint64_t>* dst : {&P.program, &P.input, &P.output, &P.shifts}) {
+        const uint64_t n = next();
+        for (uint64_t i = 0; i < n; ++i) dst->push_back(next());
+    }
+    P.p.program = P.program.data(); P.p.program_len = P.program.size();
+    P.p.input = P.input.data(); P.p.n_input = P.input.size();
+    P.p.output = P.output.data(); P.p.n_output = P.output.size();
+    P.loaded = k == w.size() && P.p.log_n >= 2;
+    return P;
+}
+}  // namespace
+
+extern "C" int LLVMFuzzerTestOneInput(const uint8_t* data, size_t size) {
+    void* ps = bfs_ps_loads(data, size);
+    if (!ps) return 0;
+    const size_t n = bfs_ps_num_objects(ps);
+    // what a verifier does with a stream it has read: the bytes of prefixes (Fiat-Shamir) and of single objects (Merkle leaves)
+    std::vector<uint8_t> buf(size + 4096);
+    size_t need = 0;
+    (void)bfs_ps_serialize(ps, n, buf.data(), buf.size(), &need);
+    unsigned char seed[32];
+    for (size_t k = 0; k <= n && k < 64; ++k) (void)bfs_ps_fiat_shamir(ps, k, seed, sizeof seed);
+    for (size_t k = 0; k < n && k < 256; ++k) {
+        const uint64_t h = bfs_ps_object_at(ps, k);
+        if (h) (void)bfs_ps_obj_dumps(ps, h, buf.data(), buf.size(), &need);
+    }
+    Params& P = params();
+    if (P.loaded) {
+        uint64_t challenges[33], terminals[15];
+        int verdict = 3;
+        if (bfs_stark_verify_begin(ps, &P.p, challenges, terminals, &verdict) == BFS_OK && verdict == 1) {
+            verdict = 3;
+            if (bfs_stark_verify_finish(ps, &P.p, P.shifts.data(), (uint32_t)P.shifts.size(), &verdict) == BFS_OK && verdict == 1 &&
+                !getenv("BFS_FUZZ_ALLOW_ACCEPT")) {
+                // accepted: fine for the corpus proof itself (the driver marks it by BFS_FUZZ_ACCEPT_SIZE), a finding otherwise
+                const char* ok = getenv("BFS_FUZZ_ACCEPT_SIZE");
+                if (!ok || (size_t)atoll(ok) != size) {
+                    fprintf(stderr, "fuzz_ps_loads: a %zu-byte input was ACCEPTED by the native verifier\n", size);
+                    abort();
+                }
+            }
+        }
+    }
+    bfs_ps_free(ps);
+    return 0;
+}
