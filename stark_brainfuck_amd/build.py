@@ -189,7 +189,7 @@ def build_sanitized(force=False, fuzzer=False):
         else:
             obj = os.path.join(OBJ, base + ".o")
         objects.append(obj)
-    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-fsanitize=address,undefined", "-shared-libsan", "-o", LIB_ASAN + ".tmp"] + objects
+    cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-fsanitize=address,undefined", "-o", LIB_ASAN + ".tmp"] + objects
     res = subprocess.run(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         sys.stderr.write(res.stdout)

@@ -21,18 +21,51 @@ from .extension_field import ExtensionFieldElement
 from .univariate import Polynomial
 
 
-def _base_value(x):
-    """int value of a root/offset given as int, BaseFieldElement or a lifted ExtensionFieldElement."""
+def _is_genuine_extension(x):
+    """an ExtensionFieldElement with a non-zero X or X^2 coefficient"""
+    return isinstance(x, ExtensionFieldElement) and any(c.value % _P for c in x.polynomial.coefficients[1:])
+
+
+def _base_value(x, not_a_root=None):
+    """int value of a root / offset given as int, BaseFieldElement or a lifted ExtensionFieldElement.
+
+    A transform ROOT that is a genuine extension element cannot be what the reference's assertions ask for: p^3 - 1 =
+    (p - 1)(p^2 + p + 1) with p^2 + p + 1 odd, so every element of power-of-two order of the cubic extension lies in the base field
+    and `root ^ n == one` fails for anything else (ntt.py:11-12, 29-30, 46-47, 192-193).  `not_a_root` is that assertion's message
+    (tests/golden/polyxo.json has the reference's).  Coset OFFSETS may be any extension element: _offset below."""
     if isinstance(x, int):
         return x
     if isinstance(x, BaseFieldElement):
         return x.value
     if isinstance(x, ExtensionFieldElement):
+        if _is_genuine_extension(x):
+            raise AssertionError(not_a_root or "supplied root does not have supplied order")
         c = x.polynomial.coefficients
-        if len(c) > 1:
-            raise NotImplementedError("transform roots / offsets must lie in the base field (fri.py:37 lifts them)")
         return c[0].value if c else 0
     raise TypeError("not a field element: %r" % type(x))
+
+
+_P = (1 << 64) - (1 << 32) + 1
+
+
+def _offset_powers(offset, count, inverse=False):
+    """XArray of offset^k (offset^-k), k < count, for a genuine extension offset: Polynomial.scale (univariate.py:168-169) multiplies
+    coefficient k by factor^k.  The powers are a short host loop over this package's own field arithmetic (a correct, slow path: the
+    reference's callers only ever pass lifted base offsets, which ride in the transform's first pass instead)."""
+    step = offset.inverse() if inverse else offset
+    acc = offset.field.one()
+    soa = np.zeros((3, count), dtype=np.uint64)
+    for k in range(count):
+        limbs = acc.limbs()
+        soa[0, k], soa[1, k], soa[2, k] = limbs[0], limbs[1], limbs[2]
+        acc = acc * step
+    return XArray.from_numpy(soa, offset.field)
+
+
+def _scale_by_powers(arr, offset, count, inverse=False):
+    """arr[k] *= offset^(+-k) in place, k < count (arr: XArray)"""
+    pw = _offset_powers(offset, count, inverse)
+    _lib.check(_lib.load().bfs_xfe_mul_pointwise(arr.ptr, arr.stride, pw.ptr, pw.stride, arr.ptr, arr.stride, count, current_stream()))
 
 
 def _log2(n):
@@ -72,7 +105,7 @@ def ntt(primitive_root, values):
     if n <= 1:
         return values                                       # ntt.py:8-9 returns its argument
     as_list = isinstance(values, list)
-    out = _transform(_to_array(values), n, n, _base_value(primitive_root), 1, 1)
+    out = _transform(_to_array(values), n, n, _base_value(primitive_root, "primitive root must be nth root of unity, where n is %d" % n), 1, 1)
     return out.to_elements() if as_list else out
 
 
@@ -158,8 +191,12 @@ def fast_coset_evaluate(polynomial, offset, generator, order):
     assert len(coeffs) <= order, "polynomial has more coefficients than the evaluation domain has points"
     if not coeffs:
         return [offset.field.zero() for _ in range(order)]  # ntt of `order` zeros (ntt.py:166-167)
+    if _is_genuine_extension(offset):
+        src = _coeff_array(coeffs, True)
+        _scale_by_powers(src, offset, len(coeffs))
+        return _transform(src, len(coeffs), order, _base_value(generator, "primitive root must be nth root of unity, where n is %d" % order), 1, 1).to_elements()
     src = _coeff_array(coeffs)
-    out = _transform(src, len(coeffs), order, _base_value(generator), _base_value(offset), 1)
+    out = _transform(src, len(coeffs), order, _base_value(generator, "primitive root must be nth root of unity, where n is %d" % order), _base_value(offset), 1)
     return out.to_elements()
 
 
@@ -178,6 +215,11 @@ def fast_coset_interpolate(offset, generator, values):
     # done as intt, then a coset "scale" pass (bfs_gl_scale)
     arr = _to_array(values)
     out = _transform(arr, n, n, lib.bfs_gl_inv(w), 1, lib.bfs_gl_inv(n))
+    if _is_genuine_extension(offset):
+        if not isinstance(out, XArray):
+            out = _coeff_array(out.to_elements(), True)
+        _scale_by_powers(out, offset, n, inverse=True)
+        return Polynomial(out.to_elements())
     oinv = lib.bfs_gl_inv(_base_value(offset))
     batch = 3 if isinstance(out, XArray) else out.batch
     _lib.check(lib.bfs_gl_scale(out.ptr, out.ptr, n, n, batch, oinv, current_stream()))
@@ -215,16 +257,22 @@ def fast_coset_divide(lhs, rhs, offset, primitive_root, root_order):
     order = root_order
     while degree < order // 2:
         w, order = lib.bfs_gl_mul(w, w), order // 2
-    off = _base_value(offset)
     lco, rco = lhs.coefficients[:lhs.degree() + 1], rhs.coefficients[:rhs.degree() + 1]
-    as_x = _is_xlist(lco) or _is_xlist(rco)
+    xoff = _is_genuine_extension(offset)
+    as_x = _is_xlist(lco) or _is_xlist(rco) or xoff
     la, ra = _coeff_array(lco, as_x), _coeff_array(rco, as_x)
+    if xoff:
+        _scale_by_powers(la, offset, la.n)
+        _scale_by_powers(ra, offset, ra.n)
+    off = 1 if xoff else _base_value(offset)
     lc = _transform(la, la.n, order, w, off, 1)
     rc = _transform(ra, ra.n, order, w, off, 1)
     _inverse_in_place(rc, order)
     _hadamard(lc, rc, order)
     quo = _transform(lc, order, order, lib.bfs_gl_inv(w), 1, lib.bfs_gl_inv(order))
-    if as_x:
+    if xoff:
+        _scale_by_powers(quo, offset, order, inverse=True)
+    elif as_x:
         _lib.check(lib.bfs_gl_scale(quo.ptr, quo.ptr, order, quo.stride, 3, lib.bfs_gl_inv(off), current_stream()))
     else:
         _lib.check(lib.bfs_gl_scale(quo.ptr, quo.ptr, order, order, 1, lib.bfs_gl_inv(off), current_stream()))

@@ -328,6 +328,47 @@ def gen_polyx():
     dump("polyx.json", out)
 
 
+def gen_polyxo():
+    """The call surface of ntt.py with arguments that do NOT come from the base field (round-5 verdict, next #7).
+    * A transform ROOT must be a 2^k-th root of unity.  p^3 - 1 = (p - 1)(p^2 + p + 1) and p^2 + p + 1 is odd, so the 2-part of the
+      cubic extension's multiplicative group is that of the base field: every root of unity of power-of-two order is a lifted base
+      element, and an extension element with a non-zero X or X^2 coefficient fails the reference's own assertions -- recorded here.
+    * A coset OFFSET may be any non-zero extension element: fast_coset_evaluate / _interpolate / _divide scale by its powers
+      (univariate.py:168-169) before / after the transform -- recorded on generic offsets."""
+    out = {}
+    def XP(seed, n, limbs=3):
+        return [[felt(seed, 3 * i + k) if k < limbs else 0 for k in range(3)] for i in range(n)]
+    not_a_root = X([felt(SEED + 1801, 0), felt(SEED + 1801, 1), 0])
+    vals8 = [X(v) for v in XP(SEED + 1802, 8)]
+    w8 = XF.lift(BF.primitive_nth_root(8))
+    out["extension_root"] = {
+        "root": xl3(not_a_root), "values": [xl3(v) for v in vals8],
+        "ntt": assertion_message(lambda: refntt.ntt(not_a_root, vals8)),
+        "intt": assertion_message(lambda: refntt.intt(not_a_root, vals8)),
+        "fast_multiply": assertion_message(lambda: refntt.fast_multiply(Polynomial(vals8), Polynomial(vals8), not_a_root, 16)),
+        "fast_coset_divide": assertion_message(lambda: refntt.fast_coset_divide(Polynomial(vals8), Polynomial(vals8[:3]), w8, not_a_root, 16)),
+        "lifted_root_values_ntt": [xl3(v) for v in refntt.ntt(w8, vals8)]}
+    cases = []
+    for (n, deg, seed) in [(64, 20, 1), (64, 63, 2), (128, 70, 3), (1024, 300, 4)]:
+        w = XF.lift(BF.primitive_nth_root(n))
+        offset = X(XP(SEED + 1810 + seed, 1)[0])
+        pc = XP(SEED + 1820 + seed, deg + 1)
+        poly = Polynomial([X(v) for v in pc])
+        values = refntt.fast_coset_evaluate(poly, offset, w, n)
+        back = refntt.fast_coset_interpolate(offset, w, values)
+        rec = {"order": n, "offset": xl3(offset), "poly": pc, "values_sha": sha_xfe_soa(values), "values_head": [xl3(v) for v in values[:4]],
+               "interpolated_back": [xl3(c) for c in back.coefficients]}
+        if deg < n // 2:
+            dc = XP(SEED + 1830 + seed, 7)
+            divisor = Polynomial([X(v) for v in dc])
+            prod = poly * divisor
+            q = refntt.fast_coset_divide(prod, divisor, offset, w, n)
+            rec["divisor"], rec["product"], rec["quotient"] = dc, [xl3(c) for c in prod.coefficients], [xl3(c) for c in q.coefficients]
+        cases.append(rec)
+    out["extension_offset"] = cases
+    dump("polyxo.json", out)
+
+
 def leaf_record(obj, limbs):
     bs = pickle.dumps(obj)
     return {"limbs": limbs, "pickle": bs.hex(), "blake2b": hashlib.blake2b(bs).hexdigest()}
@@ -552,7 +593,7 @@ def gen_fri20():
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "small"
     if what == "small":
-        gen_field(); gen_ntt(); gen_poly(); gen_poly2(); gen_polyx(); gen_pickle(); gen_merkle(); gen_fri()
+        gen_field(); gen_ntt(); gen_poly(); gen_poly2(); gen_polyx(); gen_polyxo(); gen_pickle(); gen_merkle(); gen_fri()
     else:
         {"field": gen_field, "ntt": gen_ntt, "poly": gen_poly, "pickle": gen_pickle, "merkle": gen_merkle,
-         "fri": gen_fri, "ntt20": gen_ntt20, "fri20": gen_fri20, "poly2": gen_poly2, "polyx": gen_polyx}[what]()
+         "fri": gen_fri, "ntt20": gen_ntt20, "fri20": gen_fri20, "poly2": gen_poly2, "polyx": gen_polyx, "polyxo": gen_polyxo}[what]()

@@ -466,6 +466,46 @@ def test_fast_family_over_the_extension_field_goldens(sb):
             assert [_xl3(x) for x in sb.fast_evaluate(_xpoly(sb, XF, c["poly"]), D, w, N)] == c["poly_evaluated"]
 
 
+def test_roots_and_offsets_outside_the_base_field_goldens(sb):
+    """ntt.py's call surface with arguments that do not come from the base field (tests/golden/polyxo.json, the reference's outputs): a
+    genuine extension element is never a 2^k-th root of unity (the 2-part of p^3 - 1 is that of p - 1), so every transform meets the
+    reference's own assertion, message for message; a coset OFFSET may be any extension element, and fast_coset_evaluate / _interpolate /
+    _divide give the reference's values."""
+    import hashlib
+    import struct
+    g = load_golden("polyxo.json")
+    XF = sb.ExtensionField.main()
+    BF = XF._base()
+    e = g["extension_root"]
+    bad = XF.from_limbs(e["root"])
+    vals = [XF.from_limbs(l) for l in e["values"]]
+    w8 = XF.lift(BF.primitive_nth_root(8))
+    assert [_xl3(x) for x in sb.ntt(w8, vals)] == e["lifted_root_values_ntt"]
+    for name, call in (("ntt", lambda: sb.ntt(bad, vals)), ("intt", lambda: sb.intt(bad, vals)),
+                       ("fast_multiply", lambda: sb.fast_multiply(sb.Polynomial(vals), sb.Polynomial(vals), bad, 16)),
+                       ("fast_coset_divide", lambda: sb.fast_coset_divide(sb.Polynomial(vals), sb.Polynomial(vals[:3]), w8, bad, 16))):
+        with pytest.raises(AssertionError) as info:
+            call()
+        assert str(info.value) == e[name], name
+    for c in g["extension_offset"]:
+        n = c["order"]
+        w = XF.lift(BF.primitive_nth_root(n))
+        offset = XF.from_limbs(c["offset"])
+        poly = _xpoly(sb, XF, c["poly"])
+        values = sb.fast_coset_evaluate(poly, offset, w, n)
+        l3 = [_xl3(v) for v in values]
+        h = hashlib.sha256()
+        for k in range(3):
+            h.update(struct.pack("<%dQ" % n, *[t[k] for t in l3]))
+        assert l3[:4] == c["values_head"] and h.hexdigest() == c["values_sha"], n
+        back = sb.fast_coset_interpolate(offset, w, values)
+        got = [_xl3(x) for x in back.coefficients]
+        assert got[:len(c["interpolated_back"])] == c["interpolated_back"] and not any(any(t) for t in got[len(c["interpolated_back"]):])
+        if "quotient" in c:
+            q = sb.fast_coset_divide(_xpoly(sb, XF, c["product"]), _xpoly(sb, XF, c["divisor"]), offset, w, n)
+            assert [_xl3(x) for x in q.coefficients] == c["quotient"]
+
+
 def test_interpolate_columns_shape_through_the_reference_call(sb):
     """Table.interpolate_columns of the reference (table.py:112-136) written out against this package: omicron powers plus one odd
     power of omega, lifted; the interpolant must agree with the rank-one form the prover uses (bfs_poly_randomize)."""

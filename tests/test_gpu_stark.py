@@ -208,44 +208,65 @@ def test_prove_then_verify_fresh_randomness():
     assert BrainfuckStark(running_time, len(mm), program, input_symbols, output_symbols).verify(proof_b) is True
 
 
+def _debug_cases():
+    path = os.path.join(GOLDEN, "debug_checks.json")
+    return json.load(open(path))["cases"] if os.path.exists(path) else []
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("native_prove", ["1", "0"])
-def test_terminal_stored_as_v_plus_p_is_rejected_as_the_reference_rejects_it(native_prove, monkeypatch):
-    """round-5 advice: `ea.select_terminal(terminals) == ea.compute_terminal(challenges)` (brainfuck_stark.py:574-577) compares the terminal
-    OBJECT with a computed element, coefficient values as stored (univariate.py:67-74, algebra.py:48-49).  A prover that writes the zero
-    input-evaluation terminal as the one-coefficient polynomial [p] makes a proof in which everything else checks -- Fiat-Shamir hashes the
-    same pickle on both sides, every arithmetic use reduces -- and the reference returns False on the comparison (degree 0 against -1).
-    Both verifier routes here must say False too (they said True while they compared reduced limbs); the same claim proved with the
-    canonical object is accepted.  tests/golden/noncanonical_terminal.json records the reference's own verdict on such a proof."""
-    from stark_brainfuck_amd import BaseFieldElement, ExtensionFieldElement, Polynomial
+@pytest.mark.parametrize("case", _debug_cases(), ids=lambda c: c["tag"])
+def test_debug_degree_checks_stop_where_the_reference_stops(case, monkeypatch):
+    """DEBUG mode (stark_brainfuck_amd/debug_checks.py; brainfuck_stark.py:251-290, table.py:170-176 / 219-234 / 264-284): with `DEBUG` in
+    the environment prove() interpolates every quotient and every term of the combination and asserts the degrees the reference asserts.
+    tests/golden/debug_checks.json (gen_debug_golden.py) holds what the REFERENCE did, under DEBUG=1, with a clean trace and with one cell
+    of a trace matrix changed: a clean trace passes every check and gives the proof the reference gave; a corrupted one is stopped by an
+    AssertionError in the same function, for the same table, at the same constraint."""
+    from stark_brainfuck_amd import brainfuck_stark, salted_merkle, table
     from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
     from stark_brainfuck_amd.vm import VirtualMachine
-    monkeypatch.setenv("BFS_NATIVE_PROVE", native_prove)
-    program = VirtualMachine.compile("++>+<[->+<]>.")
-    running_time, input_symbols, output_symbols = VirtualMachine.run(program, input_data=[])
-    matrices = VirtualMachine.simulate(program, input_data=[])
-    args = (running_time, len(matrices[1]), program, input_symbols, output_symbols)
-    honest = BrainfuckStark(*args).prove(program, *matrices)
-    assert BrainfuckStark(*args).verify(honest) is True
+    g = json.load(open(os.path.join(GOLDEN, "debug_checks.json")))
     P = (1 << 64) - (1 << 32) + 1
-    plain = BrainfuckStark._terminal_objects
-
-    def with_noncanonical_zero(self, terminals):
-        objs = plain(self, terminals)
-        assert not any(terminals[2]), "this program reads nothing: its input evaluation terminal is zero"
-        objs[2] = ExtensionFieldElement(Polynomial([BaseFieldElement(P, VirtualMachine.field)]), self.xfield)      # 0, stored as p
-        return objs
-    monkeypatch.setattr(BrainfuckStark, "_terminal_objects", with_noncanonical_zero)
-    crafted = BrainfuckStark(*args).prove(program, *matrices)
-    monkeypatch.setattr(BrainfuckStark, "_terminal_objects", plain)
-    assert crafted != honest
-    for native_verify in ("1", "0"):
-        monkeypatch.setenv("BFS_NATIVE_VERIFY", native_verify)
-        assert BrainfuckStark(*args).verify(crafted) is False, native_verify
-        assert BrainfuckStark(*args).verify(honest) is True, native_verify
-    out = os.environ.get("BFS_WRITE_NONCANONICAL_PROOF")
-    if out:                                                              # tools: the bytes go to the build container, where the reference judges them
-        open(out, "wb").write(crafted)
+    program = VirtualMachine.compile(g["program"])
+    running_time, input_symbols, output_symbols = VirtualMachine.run(program, input_data=[])
+    matrices = dict(zip(("processor", "memory", "instruction", "input", "output"), VirtualMachine.simulate(program, input_data=[])))
+    assert {k: [m.values.shape[0], m.values.shape[1] if m.values.shape[0] else 0] for k, m in matrices.items()} == g["shapes"]
+    if case["matrix"]:
+        v = matrices[case["matrix"]].values
+        v[case["row"], case["column"]] = (int(v[case["row"], case["column"]]) + case["add"]) % P
+    stream = Stream(("debug-" + case["tag"]).encode())
+    for mod in (brainfuck_stark, salted_merkle, table):
+        monkeypatch.setattr(mod, "urandom", stream)
+    monkeypatch.setenv("DEBUG", "1")
+    stark = BrainfuckStark(running_time, len(matrices["memory"]), program, input_symbols, output_symbols)
+    assert stark.fri.domain.length == g["fri_domain_length"]
+    args = (program, matrices["processor"], matrices["memory"], matrices["instruction"], matrices["input"], matrices["output"])
+    if case["outcome"] == "passed":
+        proof = stark.prove(*args)
+        assert stream.pos == case["urandom_bytes"]
+        assert len(proof) == case["proof_len"] and hashlib.sha256(proof).hexdigest() == case["proof_sha256"]
+        assert stark.keep_intermediates is False and "quotient_buffers" not in stark._last
+        monkeypatch.delenv("DEBUG")
+        assert stark.verify(proof) is True
+        return
+    with pytest.raises(AssertionError) as info:
+        stark.prove(*args)
+    function, table_name, index = info.value.where
+    assert function == case["function"], (info.value.where, case)
+    if "table" in case:
+        assert table_name == case["table"]
+    want = case.get("index_l", case.get("index_i"))
+    if function != "prove" and want is not None:
+        assert index == want, (info.value.where, case)
+    # without DEBUG the same trace goes through (the prover does not check its witness), and the proof is rejected
+    monkeypatch.delenv("DEBUG")
+    stream2 = Stream(("debug-" + case["tag"]).encode())
+    for mod in (brainfuck_stark, salted_merkle, table):
+        monkeypatch.setattr(mod, "urandom", stream2)
+    bad = BrainfuckStark(running_time, len(matrices["memory"]), program, input_symbols, output_symbols).prove(*args)
+    try:
+        assert BrainfuckStark(running_time, len(matrices["memory"]), program, input_symbols, output_symbols).verify(bad) is False
+    except AssertionError:
+        pass
 
 
 WRAPPING_PROGRAMS = [

@@ -690,6 +690,33 @@ def test_verify_on_the_host_accepts_reference_proofs_and_rejects_tampering(name)
         pass
 
 
+@pytest.mark.parametrize("native", ["1", "0"])
+def test_terminal_stored_as_v_plus_p_gets_the_reference_verdict(native, monkeypatch):
+    """round-5 advice.  tests/golden/noncanonical_terminal_proof.bin was written by the REFERENCE's prover (gen_noncanonical_terminal.py)
+    with the zero input-evaluation terminal pushed as the one-coefficient polynomial [p]: Fiat-Shamir, Merkle paths, the AIR, FRI -- all
+    consistent, every arithmetic use of the terminal reduces -- and the reference's verify says False, because `ea.select_terminal(terminals)
+    == ea.compute_terminal(challenges)` (brainfuck_stark.py:574-577) compares stored coefficient values (univariate.py:67-74, algebra.py:
+    48-49).  Both routes here must say False as well (they said True while they compared reduced limbs); the honest proof of the same
+    claim, made in the same run of the reference, is accepted."""
+    from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark
+    from stark_brainfuck_amd.vm import VirtualMachine
+    path = os.path.join(GOLDEN, "noncanonical_terminal.json")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    g = json.load(open(path))
+    assert g["honest"]["reference_verify"] is True and g["crafted"]["reference_verify"] is False
+    monkeypatch.setenv("BFS_NATIVE_VERIFY", native)
+    program = VirtualMachine.compile(g["program"])
+    running_time, input_symbols, output_symbols = VirtualMachine.run(program, input_data=list(g["input"]))
+    _, mm, _, _, _ = VirtualMachine.simulate(program, input_data=list(input_symbols))
+    args = (running_time, len(mm), program, input_symbols, output_symbols)
+    crafted = open(os.path.join(GOLDEN, "noncanonical_terminal_proof.bin"), "rb").read()
+    honest = open(os.path.join(GOLDEN, "noncanonical_terminal_honest_proof.bin"), "rb").read()
+    assert hashlib.sha256(crafted).hexdigest() == g["crafted"]["proof_sha256"]
+    assert BrainfuckStark(*args).verify(honest) is True
+    assert BrainfuckStark(*args).verify(crafted) is False
+
+
 def _verdict(stark_args, proof, native):
     """('value', bool) / ('assert', message) / ('error', exception type) of BrainfuckStark(*stark_args).verify(proof) on one of the two routes"""
     from stark_brainfuck_amd.brainfuck_stark import BrainfuckStark

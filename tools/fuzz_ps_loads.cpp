@@ -7,10 +7,14 @@
 //
 //   python -m stark_brainfuck_amd.build --sanitize --fuzzer        # reader + verifier with ASan, UBSan and coverage counters
 //   python tools/fuzz_proofs.py --write-params plus1 /tmp/plus1.params    # the claim's parameters as a flat file (and the degree shifts)
-//   /opt/rocm/lib/llvm/bin/clang++ -g -O1 -fsanitize=fuzzer,address,undefined -I include tools/fuzz_ps_loads.cpp \
-//        stark_brainfuck_amd/libbfstark_hip_asan.so -Wl,-rpath,$PWD/stark_brainfuck_amd -o tools/tmp/fuzz_ps_loads
+//   /opt/rocm/lib/llvm/bin/clang++ -g -O1 -fsanitize=fuzzer,address,undefined -mllvm -asan-globals=0 -I include tools/fuzz_ps_loads.cpp \
+//        -ldl -o tools/tmp/fuzz_ps_loads
 //   mkdir -p tools/tmp/corpus && cp tests/golden/stark_plus1_proof.bin tools/tmp/corpus/
-//   BFS_FUZZ_PARAMS=/tmp/plus1.params ASAN_OPTIONS=detect_leaks=0 tools/tmp/fuzz_ps_loads -max_len=65536 -timeout=10 tools/tmp/corpus
+//   ASAN_OPTIONS=detect_leaks=0 BFS_LIB_PATH=$PWD/stark_brainfuck_amd/libbfstark_hip_asan.so BFS_FUZZ_PARAMS=/tmp/plus1.params \
+//   BFS_FUZZ_ACCEPT_SIZE=<bytes of the corpus proof> tools/tmp/fuzz_ps_loads -max_len=65536 -timeout=10 -max_total_time=600 tools/tmp/corpus
+// (The library is opened with dlopen at the first input, as the Python binding does; the executable carries the sanitizer runtime the
+//  library's instrumented units resolve against.  -asan-globals=0: ROCm 7.2's clang registers the harness' own string literals twice
+//  and ASan then reports them as an ODR violation before main; the harness has nothing worth guarding.)
 //
 // An ACCEPTED input that is not byte-identical to a corpus proof is reported by abort() (a re-encoding of the same object stream is
 // accepted by the reference too; BFS_FUZZ_ALLOW_ACCEPT=1 skips the abort for such campaigns).
@@ -20,9 +24,38 @@
 #include <cstring>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "bfstark.h"
 
 namespace {
+struct Api {
+    void* (*ps_loads)(const uint8_t*, size_t);
+    void (*ps_free)(void*);
+    size_t (*ps_num_objects)(void*);
+    uint64_t (*ps_object_at)(void*, size_t);
+    int (*ps_serialize)(void*, size_t, uint8_t*, size_t, size_t*);
+    int (*ps_fiat_shamir)(void*, size_t, uint8_t*, size_t);
+    int (*ps_obj_dumps)(void*, uint64_t, uint8_t*, size_t, size_t*);
+    int (*verify_begin)(void*, const bfs_stark_verify_params*, uint64_t*, uint64_t*, int*);
+    int (*verify_finish)(void*, const bfs_stark_verify_params*, const uint64_t*, uint32_t, int*);
+};
+const Api& api() {
+    static Api a = [] {
+        const char* path = getenv("BFS_LIB_PATH");
+        void* h = dlopen(path ? path : "libbfstark_hip_asan.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) { fprintf(stderr, "fuzz_ps_loads: %s\n", dlerror()); abort(); }
+        Api r;
+#define SYM(field, name) r.field = (decltype(r.field))dlsym(h, name); if (!r.field) { fprintf(stderr, "fuzz_ps_loads: no %s\n", name); abort(); }
+        SYM(ps_loads, "bfs_ps_loads") SYM(ps_free, "bfs_ps_free") SYM(ps_num_objects, "bfs_ps_num_objects") SYM(ps_object_at, "bfs_ps_object_at")
+        SYM(ps_serialize, "bfs_ps_serialize") SYM(ps_fiat_shamir, "bfs_ps_fiat_shamir") SYM(ps_obj_dumps, "bfs_ps_obj_dumps")
+        SYM(verify_begin, "bfs_stark_verify_begin") SYM(verify_finish, "bfs_stark_verify_finish")
+#undef SYM
+        return r;
+    }();
+    return a;
+}
+
 struct Params {
     bool loaded = false;
     bfs_stark_verify_params p{};
@@ -65,26 +98,26 @@ Params& params() {
 }  // namespace
 
 extern "C" int LLVMFuzzerTestOneInput(const uint8_t* data, size_t size) {
-    void* ps = bfs_ps_loads(data, size);
+    void* ps = api().ps_loads(data, size);
     if (!ps) return 0;
-    const size_t n = bfs_ps_num_objects(ps);
+    const size_t n = api().ps_num_objects(ps);
     // what a verifier does with a stream it has read: the bytes of prefixes (Fiat-Shamir) and of single objects (Merkle leaves)
     std::vector<uint8_t> buf(size + 4096);
     size_t need = 0;
-    (void)bfs_ps_serialize(ps, n, buf.data(), buf.size(), &need);
+    (void)api().ps_serialize(ps, n, buf.data(), buf.size(), &need);
     unsigned char seed[32];
-    for (size_t k = 0; k <= n && k < 64; ++k) (void)bfs_ps_fiat_shamir(ps, k, seed, sizeof seed);
+    for (size_t k = 0; k <= n && k < 64; ++k) (void)api().ps_fiat_shamir(ps, k, seed, sizeof seed);
     for (size_t k = 0; k < n && k < 256; ++k) {
-        const uint64_t h = bfs_ps_object_at(ps, k);
-        if (h) (void)bfs_ps_obj_dumps(ps, h, buf.data(), buf.size(), &need);
+        const uint64_t h = api().ps_object_at(ps, k);
+        if (h) (void)api().ps_obj_dumps(ps, h, buf.data(), buf.size(), &need);
     }
     Params& P = params();
     if (P.loaded) {
         uint64_t challenges[33], terminals[15];
         int verdict = 3;
-        if (bfs_stark_verify_begin(ps, &P.p, challenges, terminals, &verdict) == BFS_OK && verdict == 1) {
+        if (api().verify_begin(ps, &P.p, challenges, terminals, &verdict) == BFS_OK && verdict == 1) {
             verdict = 3;
-            if (bfs_stark_verify_finish(ps, &P.p, P.shifts.data(), (uint32_t)P.shifts.size(), &verdict) == BFS_OK && verdict == 1 &&
+            if (api().verify_finish(ps, &P.p, P.shifts.data(), (uint32_t)P.shifts.size(), &verdict) == BFS_OK && verdict == 1 &&
                 !getenv("BFS_FUZZ_ALLOW_ACCEPT")) {
                 // accepted: fine for the corpus proof itself (the driver marks it by BFS_FUZZ_ACCEPT_SIZE), a finding otherwise
                 const char* ok = getenv("BFS_FUZZ_ACCEPT_SIZE");
@@ -95,6 +128,6 @@ extern "C" int LLVMFuzzerTestOneInput(const uint8_t* data, size_t size) {
             }
         }
     }
-    bfs_ps_free(ps);
+    api().ps_free(ps);
     return 0;
 }
