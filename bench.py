@@ -149,13 +149,33 @@ def main():
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
+        # A communicator that does not come up must FAIL the job, loudly and soon, not hang it: a rank stuck inside RCCL's bootstrap cannot
+        # be interrupted from Python, so a watchdog thread ends the process (exit status 3, a line on stderr saying which rank waited for
+        # what) when rendezvous + the first collective have not finished within BFS_BENCH_COMM_TIMEOUT_S (120 s; they take < 5 s on a
+        # healthy node).  torch.distributed.run then tears the other ranks down and the driver sees a non-zero exit.
+        import datetime
+        import threading
+        limit = float(os.environ.get("BFS_BENCH_COMM_TIMEOUT_S", "120"))
+        stage = ["rendezvous (init_process_group)"]
+
+        def give_up():
+            sys.stderr.write("bench.py: rank %d of %d (device %d): the %s communicator did not come up within %.0f s, stuck in %s -- aborting\n"
+                             % (rank, world, local_rank, backend, limit, stage[0]))
+            sys.stderr.flush()
+            os._exit(3)
+        watchdog = threading.Timer(limit, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         try:
             if backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                        timeout=datetime.timedelta(seconds=limit))
             else:
-                dist.init_process_group(backend, rank=rank, world_size=world)
+                dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=limit))
+            stage[0] = "the first collective (barrier: RCCL builds its rings here)"
             dist.barrier()             # RCCL builds its communicators on the first collective (100s of ms): pay that here, not
             torch.cuda.synchronize()   # between the clock spin-up and the timed region, where the idle GPU would clock down again
+            watchdog.cancel()
         finally:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
@@ -455,6 +475,10 @@ def main():
             line["single_column_2p24"] = bench_single_column(lib, _lib, d_in, d_out, n, log_n, root, stream)
             line["single_column_2p24_ms"] = line["single_column_2p24"]["ms"]
             line["pcie_inclusive_2p24"] = bench_pcie_inclusive(lib, _lib, d_in, d_out, n, log_n, root, stream)
+            # the other configurations BASELINE.json names, as scalars beside the headline (round-5 verdict, next #4)
+            line["other_shapes"] = bench_other_shapes(lib, _lib, d_in, d_out, n, cols, root, stream)
+            for k in ("ntt_2p20_fwd_inv_us", "lde_2p24_x4_ms", "intt_8x2p24_ms"):
+                line[k] = line["other_shapes"][k]["value"]
         if not args.no_fri:
             line["fri_prove_ms"] = max(fri_all)
             line["fri_prove"] = mine
@@ -613,6 +637,56 @@ def bench_single_column(lib, _lib, d_in, d_out, n, log_n, root, stream, steps=20
     gbs = 16.0 * n / per / 1e6
     return {"ms": per, "elements_per_s": n / per * 1e3, "algorithmic_GBps": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS, "steps": steps,
             "note": "forward NTT of one column, batch 1, HIP events over %d back-to-back transforms" % steps}
+
+
+def _timed(lib, _lib, stream, call, steps, warm=10):
+    for _ in range(warm):
+        call()
+    e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+    lib.bfs_event_create(ctypes.byref(e0)); lib.bfs_event_create(ctypes.byref(e1))
+    lib.bfs_event_record(e0, stream)
+    for _ in range(steps):
+        call()
+    lib.bfs_event_record(e1, stream)
+    _lib.check(lib.bfs_stream_synchronize(stream))
+    ms = ctypes.c_float()
+    _lib.check(lib.bfs_event_elapsed_ms(e0, e1, ctypes.byref(ms)))
+    lib.bfs_event_destroy(e0); lib.bfs_event_destroy(e1)
+    return ms.value / steps
+
+
+def bench_other_shapes(lib, _lib, d_in, d_out, n, cols, root, stream):
+    """BASELINE.json's other NTT shapes on the buffers of the headline step, HIP events, `frac` on 16 bytes per OUTPUT element:
+       ntt_2p20_fwd_inv_us   config 2: one 2^20 column forward, then inverse (ntt.py:4-42; the reference: 242.7 s + 236.2 s)
+       lde_2p24_x4_ms        the shape Table.lde makes (table.py:138-149 -> fri.py:26-30): four columns of 2^22 coefficients, zero-padded and
+                             evaluated on the coset of 2^24 points (ntt.py:164-168) in one call
+       intt_8x2p24_ms        the inverse of the headline step: eight 2^24 columns, omega^-1, n^-1 folded in (ntt.py:26-42)"""
+    out = {}
+    n20 = 1 << 20
+    w20, w20i, n20i = lib.bfs_gl_primitive_root(20), lib.bfs_gl_inv(lib.bfs_gl_primitive_root(20)), lib.bfs_gl_inv(n20)
+
+    def pair20():
+        _lib.check(lib.bfs_gl_ntt(d_in.ptr, n20, n20, d_out.ptr, n20, 20, 1, w20, 1, 1, stream))
+        _lib.check(lib.bfs_gl_ntt(d_out.ptr, n20, n20, d_out.ptr + 8 * n20, n20, 20, 1, w20i, 1, n20i, stream))
+    ms = _timed(lib, _lib, stream, pair20, 200)
+    out["ntt_2p20_fwd_inv_us"] = {"value": ms * 1e3, "frac": 2 * 16.0 * n20 / ms / 1e6 / HBM_PEAK_GBS,
+                                  "reference_seconds": [242.7, 236.2], "note": "one column, forward + inverse, 200 pairs back to back"}
+    quarter = n // 4
+    lde_cols = min(4, cols)
+
+    def lde():
+        _lib.check(lib.bfs_gl_ntt(d_in.ptr, quarter, n, d_out.ptr, n, 24, lde_cols, root, 7, 1, stream))
+    ms = _timed(lib, _lib, stream, lde, 30)
+    out["lde_2p24_x4_ms"] = {"value": ms, "frac": 16.0 * n * lde_cols / ms / 1e6 / HBM_PEAK_GBS, "columns": lde_cols,
+                             "note": "2^22 coefficients per column, zero padding and coset shift fused into the first pass; frac on 16 B per output element (the algorithmic bytes are 8 * 2^22 + 8 * 2^24 per column: %.3f on those)"
+                                     % ((8.0 * quarter + 8.0 * n) * lde_cols / ms / 1e6 / HBM_PEAK_GBS)}
+    wi, ni = lib.bfs_gl_inv(root), lib.bfs_gl_inv(n)
+
+    def inverse():
+        _lib.check(lib.bfs_gl_ntt(d_in.ptr, n, n, d_out.ptr, n, 24, cols, wi, 1, ni, stream))
+    ms = _timed(lib, _lib, stream, inverse, 20)
+    out["intt_8x2p24_ms"] = {"value": ms, "frac": 16.0 * n * cols / ms / 1e6 / HBM_PEAK_GBS, "columns": cols}
+    return out
 
 
 def bench_pcie_inclusive(lib, _lib, d_in, d_out, n, log_n, root, stream, reps=5):

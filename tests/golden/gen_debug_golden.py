@@ -69,14 +69,17 @@ def main():
                 proof = stark.prove(program, matrices["processor"], matrices["memory"], matrices["instruction"], matrices["input"], matrices["output"])
             out["outcome"] = "passed"
             out["proof_sha256"], out["proof_len"], out["urandom_bytes"] = hashlib.sha256(proof).hexdigest(), len(proof), stream.pos
-        except AssertionError as e:
+        except (AssertionError, AttributeError) as e:
+            # (AttributeError: the dump that table.py:219-234 prints in front of its assert(False) reads `self.terminal_index`, which the
+            #  processor and instruction tables do not have -- the reference stops there, one line before the assertion it was heading for)
             frames = traceback.extract_tb(e.__traceback__)
             tb = e.__traceback__
             while tb.tb_next is not None:
                 tb = tb.tb_next
             frame = tb.tb_frame
             loc = frame.f_locals
-            out["outcome"] = "assertion"
+            out["outcome"] = "assertion" if isinstance(e, AssertionError) else "stopped in the failure dump in front of assert(False)"
+            out["exception"] = type(e).__name__
             out["message"] = str(e)
             out["function"] = frame.f_code.co_name
             out["file"] = os.path.basename(frame.f_code.co_filename)

@@ -311,6 +311,25 @@ def test_bench_with_eight_ranks_on_one_gpu():
     assert line["guard"]["columns_round_tripped"] == 1 and line["roots_sha256"]
 
 
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_bench_fails_loudly_when_the_communicator_does_not_come_up(backend):
+    """round-5 verdict, next #8: a rank whose peers never arrive must end with a non-zero status and a line on stderr that names the rank
+    and the stage it was stuck in, within the limit (BFS_BENCH_COMM_TIMEOUT_S, 120 s by default; 8 s here) -- not hang the scaling run.
+    Rank 0 of a two-rank job is started alone: the rendezvous can never complete."""
+    import time
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BFS_BENCH_BACKEND=backend, BFS_BENCH_DEVICE="0", BFS_BENCH_COMM_TIMEOUT_S="8",
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.pop("TORCHELASTIC_RUN_ID", None)
+    t0 = time.time()
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--log-n", "16", "--no-cpu",
+                          "--no-fri", "--no-stark"], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    took = time.time() - t0
+    assert res.returncode != 0, res.stdout[-1000:]
+    assert took < 120, took
+    assert "did not come up within" in res.stderr or "imeout" in res.stderr, res.stderr[-2000:]
+    assert not [l for l in res.stdout.splitlines() if l.startswith("{")], "no JSON line may be printed by a job that did not run"
+
+
 def test_plain_bench_command_launches_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher around it (what a driver that reuses its N = 1 command line runs): bench.py starts
     the two ranks itself under torch.distributed.run and rank 0's JSON line arrives on the caller's stdout; the cooperative proof runs as
@@ -354,7 +373,9 @@ def _rccl_worker(rank, world, port, q):
     _lib.check(_lib.load().bfs_set_device(rank))
     dev = torch.device("cuda", rank)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    out = {"rank": rank}
+    props = torch.cuda.get_device_properties(rank)
+    out = {"rank": rank, "rccl_ranks_seen": dist.get_world_size(), "device": rank, "name": props.name,
+           "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")) or None}
     # (1) gather_roots: the all-gather of 64-byte roots (5 columns over `world` ranks: uneven)
     roots = {c: bytes([c + 1]) * 64 for c in shard.assign_columns(5, world, rank)}
     out["roots_ok"] = shard.gather_roots(roots, 5, world, rank, device=dev) == [bytes([c + 1]) * 64 for c in range(5)]
@@ -462,6 +483,28 @@ def test_collectives_and_cooperative_proof_over_rccl_one_rank_per_gpu():
         for p in procs:                 # a rank stuck in a collective must not outlive the test
             if p.is_alive():
                 p.kill()
+    # what the first multi-GPU box should put on record (pytest -s / the captured output of a failure): who was in the job
+    print("rccl_ranks_seen", sorted({o["rccl_ranks_seen"] for o in got}), "ranks", world, "devices",
+          [(o["rank"], o["device"], o.get("pci_bus_id"), o.get("uuid")) for o in sorted(got, key=lambda o: o["rank"])])
+    assert all(o["rccl_ranks_seen"] == world for o in got)
+    ids = [o.get("uuid") or (o["device"], o.get("pci_bus_id")) for o in got]
+    assert len(set(map(str, ids))) == world, "ranks must sit on distinct GPUs: %r" % ids
     for o in got:
         assert o["roots_ok"] and o["zipped_ok"] and o["rows_ok"] and o["proof_ok"] and o["fresh_verified"], o
     assert len({o["fresh_sha"] for o in got}) == 1
+    # bench.py as the driver runs it, at N = 1 and at N = world, on this box: the N-rank line must name `world` ranks and distinct
+    # devices, and its whole-job value must agree with N x the one-GPU value (strong scaling over 8 columns: >= 0.6 x linear -- the
+    # step is HBM / issue bound per GPU and shares nothing but the 64-byte roots)
+    import json
+    import subprocess
+    import sys
+    lines = {}
+    for gpus in (1, world):
+        res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "10", "--warmup", "2", "--no-fri", "--no-stark",
+                              "--no-cpu", "--no-single", "--no-concurrent", "--no-cooperative"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-3000:]
+        lines[gpus] = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+        print("bench --gpus %d: value %.4g %s, ms_per_step %.4f, rccl_ranks_seen %s" % (gpus, lines[gpus]["value"], lines[gpus]["unit"],
+                                                                                          lines[gpus]["ms_per_step"], lines[gpus].get("rccl_ranks_seen")))
+    assert lines[world]["n_gpus"] == world and lines[world].get("rccl_ranks_seen") == world
+    assert lines[world]["value"] >= 0.6 * world * lines[1]["value"], (lines[1]["value"], lines[world]["value"])
