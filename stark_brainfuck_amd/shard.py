@@ -351,40 +351,49 @@ class shared_randomness:
     key of this block.  The peers look at that key in front of every collective of the block (check_peers) and while they wait for
     each other at its end, and raise.  A peer that is already inside a collective the failed rank never joins still waits for the
     backend's timeout, as it always did.  Without a store (a process group made from one is rare) the closing gather is the old one."""
-    _entered = {}                   # ranks of the group -> blocks entered so far (the ranks of a group enter its blocks in the same order)
     closing_timeout_s = 600.0
 
     def __init__(self, world_size, rank, group=None, seed=None):
         self.world_size, self.rank, self.group, self.seed = world_size, rank, group, seed
         self._store = None
 
-    def _open_store(self):
+    def _open_store(self, block_id):
+        """the block's corner of the process group's store.  `block_id` is a nonce that rank 0 drew and broadcast in __enter__: the ranks
+        agree on it by construction, whatever blocks a rank skipped or entered from other threads before (a per-process serial number,
+        as in round 5, drifts apart for the rest of the process as soon as one rank raises in front of a block -- round-5 advice)."""
         try:
-            import torch.distributed as dist
             from torch.distributed import distributed_c10d as c10d
-            ranks = tuple(dist.get_process_group_ranks(self.group if self.group is not None else dist.group.WORLD))
-            serial = shared_randomness._entered.get(ranks, 0)
-            shared_randomness._entered[ranks] = serial + 1
-            return c10d.PrefixStore("bfs-shared-randomness/%s/%d/" % ("-".join(map(str, ranks)), serial), c10d._get_default_store())
+            return c10d.PrefixStore("bfs-shared-randomness/%s/" % block_id, c10d._get_default_store())
         except Exception:
             return None
 
     def raise_if_a_peer_failed(self):
-        if self._store is not None and self._store.check(["failed"]):
-            raise RuntimeError("rank(s) [%s] left the shared-randomness block with an exception" % self._store.get("failed").decode())
+        if self._store is not None and self._store.add("failed_count", 0) > 0:
+            failed = [str(r) for r in range(self.world_size) if self._store.check(["failed/%d" % r])]
+            raise RuntimeError("rank(s) [%s] left the shared-randomness block with an exception" % ", ".join(failed))
+
+    def _forget_keys(self):
+        """a block that ended cleanly leaves nothing behind in the store (rank 0, once every rank is through with the keys)"""
+        if self._store is None or self.rank != 0:
+            return
+        for key in ["arrived", "failed_count", "compared"] + ["failed/%d" % r for r in range(self.world_size)]:
+            try:
+                self._store.delete_key(key)
+            except Exception:       # a store without delete_key (FileStore): the keys are a few bytes under a unique prefix
+                return
 
     def __enter__(self):
         import os
         from . import randomness
         seed = self.seed
         if self.world_size > 1:
-            self._store = self._open_store()
-        if seed is None:
-            box = [os.urandom(32) if self.rank == 0 else None]
-            if self.world_size > 1:
-                import torch.distributed as dist
-                dist.broadcast_object_list(box, src=0, group=self.group)
-            seed = box[0]
+            import torch.distributed as dist
+            box = [(os.urandom(32) if seed is None else seed, os.urandom(12).hex()) if self.rank == 0 else None]
+            dist.broadcast_object_list(box, src=0, group=self.group)
+            seed, block_id = box[0] if seed is None else (seed, box[0][1])
+            self._store = self._open_store(block_id)
+        elif seed is None:
+            seed = os.urandom(32)
         self._stream = _SharedStream(seed)
         self._override = randomness.override(self._stream)
         self._override.__enter__()
@@ -399,8 +408,9 @@ class shared_randomness:
             if self._store is not None:
                 import time
                 if exc_type is not None:
-                    try:
-                        self._store.set("failed", str(self.rank))
+                    try:                            # one key per rank, and a counter the peers poll: two failing ranks do not overwrite each other
+                        self._store.set("failed/%d" % self.rank, "1")
+                        self._store.add("failed_count", 1)
                     except Exception:               # the process group itself is gone: keep the original error
                         pass
                     return False
@@ -428,4 +438,15 @@ class shared_randomness:
                     raise RuntimeError("rank(s) %r left the shared-randomness block with an exception" % (failed,))
                 positions = [p for _, p in reports]
                 assert len(set(positions)) == 1, "the ranks read the shared random stream to different positions: %r" % (positions,)
+                if self._store is not None:
+                    try:
+                        if self._store.add("compared", 1) >= self.world_size or self.rank == 0:
+                            # (rank 0 waits for the others to be past their last read of the block's keys)
+                            import time
+                            deadline = time.monotonic() + 5.0
+                            while self.rank == 0 and self._store.add("compared", 0) < self.world_size and time.monotonic() < deadline:
+                                time.sleep(1e-4)
+                            self._forget_keys()
+                    except Exception:
+                        pass
         return False
