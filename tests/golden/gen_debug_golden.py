@@ -89,6 +89,8 @@ def main():
             for name in ("l", "i"):
                 if name in loc and isinstance(loc[name], int):
                     out["index_" + name] = loc[name]
+            if "qc" in loc and "quotient_codewords" in loc:          # table.py:170-176 walks the codewords themselves: which one it was at
+                out["index_qc"] = next(k for k, cw in enumerate(loc["quotient_codewords"]) if cw is loc["qc"])
             out["stack"] = [f.name for f in frames]
         out["seconds"] = round(time.time() - t0, 1)
         out["debug_lines_printed"] = sink.getvalue().count("\n")

@@ -254,7 +254,9 @@ def test_debug_degree_checks_stop_where_the_reference_stops(case, monkeypatch):
     assert function == case["function"], (info.value.where, case)
     if "table" in case:
         assert table_name == case["table"]
-    want = case.get("index_l", case.get("index_i"))
+    # which constraint: the loop variable of the reference's frame -- `qc`'s position in boundary_quotients (its `l` is left over from the loop
+    # that made the codewords), `l` in transition_quotients, `i` in terminal_quotients
+    want = case.get("index_qc") if function == "boundary_quotients" else case.get("index_l", case.get("index_i"))
     if function != "prove" and want is not None:
         assert index == want, (info.value.where, case)
     # without DEBUG the same trace goes through (the prover does not check its witness), and the proof is rejected
