@@ -248,56 +248,77 @@ def install_parallel_quotients(table_mod, workers, rec):
             weight = [max(1, len(c.dictionary)) for c in constraints]
             if n < 64 or not constraints or self.height == 0:
                 return original(self, domain, codewords, challenges, *rest)
-            # pieces of roughly equal cost (terms x points), dealt to the workers largest first
+            # pieces of roughly equal cost (terms x points).  The work goes out in ROUNDS of about ten minutes per worker; after every
+            # round the partial result is pickled (BFS_GOLDEN_CKPT=<dir>), so that a run that was interrupted and is started again with
+            # the same name recomputes only the cheap early stages (deterministic: same randomness stream) and the round it was in.  The
+            # worker count is read again in front of every round (BFS_GOLDEN_WORKERS_FILE: a file holding the number), so that cores
+            # freed by another run can be put to use without a restart.  The checkpoint's name carries a digest of the call's inputs.
             total = sum(weight) * n
-            piece = max(64, total // (workers * 6))
+            round_cost = int(os.environ.get("BFS_GOLDEN_ROUND_COST", "500000"))       # ~1.1 ms of CPython per term and point
+            piece = max(64, min(total // (workers * 6), round_cost // 4))
             pieces = []
             for l, w in enumerate(weight):
                 step = max(16, min(n, piece // w))
                 for a in range(0, n, step):
                     pieces.append((w * (min(n, a + step) - a), l, a, min(n, a + step)))
             pieces.sort(reverse=True)
-            shares, load = [[] for _ in range(workers)], [0] * workers
-            for cost, l, a, b in pieces:
-                k = load.index(min(load))
-                shares[k].append((l, a, b))
-                load[k] += cost
-            # checkpoint (BFS_GOLDEN_CKPT=<dir>): a table's finished quotient codewords are pickled; a run that was interrupted and is
-            # started again with the same name recomputes the cheap early stages (deterministic: same randomness stream) and picks
-            # the quotients up from there.  The file records the digest of the inputs it belongs to.
             ckpt = os.environ.get("BFS_GOLDEN_CKPT")
             ckpt_file = None
+            out = [[None] * n for _ in constraints]
+            done = set()
+            import pickle
             if ckpt:
-                import pickle
                 key = hashlib.sha256(repr((rec["name"], type(self).__name__, method_name, n, sha_elems(codewords[0]), sha_elems(codewords[-1]),
                                            [xl3(c) for c in challenges], [xl3(t) for r in rest for t in r])).encode()).hexdigest()[:16]
                 ckpt_file = os.path.join(ckpt, "%s_%s_%s_%s.pkl" % (rec["name"], type(self).__name__, method_name, key))
                 if os.path.exists(ckpt_file):
                     with open(ckpt_file, "rb") as f:
-                        out = pickle.load(f)
-                    print("[parallel] %s.%s: from checkpoint %s" % (type(self).__name__, method_name, ckpt_file), file=sys.stderr, flush=True)
-                    log["calls"].append({"table": type(self).__name__, "method": method_name, "from_checkpoint": True})
-                    return out
+                        done, out = pickle.load(f)
+                    print("[parallel] %s.%s: %d of %d pieces from checkpoint %s" % (type(self).__name__, method_name, len(done), len(pieces), ckpt_file),
+                          file=sys.stderr, flush=True)
             t0 = time.time()
-            _JOB = (self, method_name, original, (domain, codewords, challenges) + tuple(rest), constraints_attr, constraints, calls_per_point, self.field.zero())
-            stream_urandom, os.urandom = os.urandom, _REAL_URANDOM          # the pool's own needs must not draw from the proof's randomness
-            try:
-                with ctx.Pool(workers) as pool:
-                    parts = pool.map(_quotient_worker, shares, chunksize=1)
-            finally:
-                os.urandom = stream_urandom
-            _JOB = None
-            out = [[None] * n for _ in constraints]
-            for part in parts:
-                for (l, a, b), values in part.items():
-                    out[l][a:b] = values
+            todo = [p for p in pieces if p[1:] not in done]
+            rounds = 0
+            while todo:
+                wf = os.environ.get("BFS_GOLDEN_WORKERS_FILE")
+                now = workers
+                if wf and os.path.exists(wf):
+                    try:
+                        now = max(1, int(open(wf).read().split()[0]))
+                    except (ValueError, IndexError):
+                        now = workers
+                shares, load = [[] for _ in range(now)], [0] * now
+                rest_todo = []
+                for cost, l, a, b in todo:
+                    k = load.index(min(load))
+                    if load[k] >= round_cost:
+                        rest_todo.append((cost, l, a, b))
+                        continue
+                    shares[k].append((l, a, b))
+                    load[k] += cost
+                todo = rest_todo
+                shares = [sh for sh in shares if sh]
+                _JOB = (self, method_name, original, (domain, codewords, challenges) + tuple(rest), constraints_attr, constraints, calls_per_point, self.field.zero())
+                stream_urandom, os.urandom = os.urandom, _REAL_URANDOM          # the pool's own needs must not draw from the proof's randomness
+                try:
+                    with ctx.Pool(len(shares)) as pool:
+                        parts = pool.map(_quotient_worker, shares, chunksize=1)
+                finally:
+                    os.urandom = stream_urandom
+                _JOB = None
+                for part in parts:
+                    for (l, a, b), values in part.items():
+                        out[l][a:b] = values
+                        done.add((l, a, b))
+                rounds += 1
+                if ckpt_file:
+                    os.makedirs(ckpt, exist_ok=True)
+                    with open(ckpt_file + ".tmp", "wb") as f:
+                        pickle.dump((done, out), f, protocol=4)
+                    os.replace(ckpt_file + ".tmp", ckpt_file)
+                print("[parallel] %s.%s: round %d on %d workers done, %d of %d pieces, %.0f s so far" % (type(self).__name__, method_name, rounds, len(shares),
+                                                                                                          len(done), len(pieces), time.time() - t0), file=sys.stderr, flush=True)
             assert all(v is not None for cw in out for v in cw)
-            if ckpt_file:
-                import pickle
-                os.makedirs(ckpt, exist_ok=True)
-                with open(ckpt_file + ".tmp", "wb") as f:
-                    pickle.dump(out, f, protocol=4)
-                os.replace(ckpt_file + ".tmp", ckpt_file)
             log["calls"].append({"table": type(self).__name__, "method": method_name, "constraints": len(constraints), "points": n,
                                  "seconds": round(time.time() - t0, 1), "pieces": len(pieces)})
             print("[parallel] %s.%s: %d constraints x %d points on %d workers, %.1f s" % (type(self).__name__, method_name, len(constraints), n, workers, time.time() - t0),
