@@ -453,6 +453,17 @@ class BrainfuckStark:
 
     _bounds_cache = {}
 
+    def _quotient_degree_bounds_verifier(self, challenges, terminals):
+        """the same for verify(): the challenges are Fiat-Shamir outputs, the terminals are the PROVER's, chosen after it has seen the
+        challenges.  A terminal made from them (the product of two challenges, say) can cancel a monomial of a terminal constraint while
+        looking as sampled as any other value; the reference expands symbolically every time and would then shift that quotient by a
+        different amount than the generic bounds say (round-5 advice).  So the terminal constraints -- the only ones the terminals enter
+        -- take the exact expansion here (nine small constraints, ~50 us); boundary and transition bounds depend on the challenges
+        alone and keep their per-shape memory."""
+        out = [b for table in self.tables for b in table.all_quotient_degree_bounds(challenges, terminals, exact_terminals=True)]
+        out += [pa.quotient_degree_bound() for pa in self.permutation_arguments]
+        return out
+
     def _quotient_degree_bounds_cached(self, challenges, terminals):
         """all quotient degree bounds of a proof (:203-221) -- Table.all_quotient_degree_bounds of every table, then the permutation
         arguments -- remembered per SHAPE of the inputs.  Which monomials of the composed constraints survive depends on the numeric
@@ -839,7 +850,7 @@ class BrainfuckStark:
         terminals = [(out_tm[3 * i], out_tm[3 * i + 1], out_tm[3 * i + 2]) for i in range(5)]
         bounds = [t_.interpolant_degree() for t_ in self.tables for _ in range(t_.base_width)]
         bounds += [t_.interpolant_degree() for t_ in self.tables for _ in range(t_.full_width - t_.base_width)]
-        bounds += self._quotient_degree_bounds_cached(challenges, terminals)
+        bounds += self._quotient_degree_bounds_verifier(challenges, terminals)
         shifts = (_u64 * len(bounds))(*[self.max_degree - b for b in bounds])
         _lib.check(lib.bfs_stark_verify_finish(t.handle, ctypes.byref(params), shifts, len(bounds), ctypes.byref(verdict)))
         if verdict.value == 2:
@@ -909,7 +920,7 @@ class BrainfuckStark:
                 rows[idx] = row + [limbs(e) for e in element]
 
         quotient_bounds = {t: (t.boundary_quotient_degree_bounds(challenges), t.transition_quotient_degree_bounds(challenges),
-                               t.terminal_quotient_degree_bounds(challenges, terminals)) for t in self.tables}
+                               t.terminal_quotient_degree_bounds(challenges, terminals, exact=True)) for t in self.tables}      # (exact: see _quotient_degree_bounds_verifier)
         for index in indices:
             x = offset * pow(omega, index, P) % P
 

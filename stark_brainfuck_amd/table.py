@@ -688,8 +688,10 @@ class Table:
         memo = {}            # sub-expressions (deselectors, instruction zerofier, row differences) are shared between constraints
         return [air.total_degrees(air.expand(e, nvars, challenges, terminals, params, memo)) for e in dict(self.air.all())[kind]]
 
-    def _degree_bounds(self, kind, challenges, terminals):
-        """symbolic degree bounds of the constraints composed with the interpolants (multivariate.py:144-170).  Which
+    def _degree_bounds(self, kind, challenges, terminals, exact=False):
+        """exact: never take the generic shortcut (the verifier's terminals come from the prover, who chooses them AFTER it has seen the
+        challenges and could make one cancel a leading monomial while still looking sampled -- round-5 advice).
+        symbolic degree bounds of the constraints composed with the interpolants (multivariate.py:144-170).  Which
         monomials survive depends on the numeric challenges only through cancellations; for values that look sampled (pairwise
         distinct, zero or with more than 32 significant bits) the surviving set is the generic one except with probability
         ~2^-160, so it is computed once per zero pattern and reused.  Crafted values (the constructor's all-ones challenges,
@@ -707,7 +709,7 @@ class Table:
         rest = [tuple(v) for v in list(terminals) + list(params)]
         rest_nonzero = [v for v in rest if any(v)]
         values = seen[1] + rest
-        generic = (seen[3] and len(set(rest_nonzero)) == len(rest_nonzero) and seen[2].isdisjoint(rest_nonzero)
+        generic = (not exact and seen[3] and len(set(rest_nonzero)) == len(rest_nonzero) and seen[2].isdisjoint(rest_nonzero)
                    and all(v[0] >> 32 or v[1] or v[2] for v in rest_nonzero))
         if generic:
             key = (type(self).__name__, self.table_index, kind, tuple(any(v) for v in values))
@@ -739,12 +741,12 @@ class Table:
     def transition_quotient_degree_bounds(self, challenges):
         return [b - self.height + 1 for b in self._degree_bounds("transition", challenges, [air.X0] * 5)]
 
-    def terminal_quotient_degree_bounds(self, challenges, terminals):
-        return [b - 1 for b in self._degree_bounds("terminal", challenges, terminals)]
+    def terminal_quotient_degree_bounds(self, challenges, terminals, exact=False):
+        return [b - 1 for b in self._degree_bounds("terminal", challenges, terminals, exact)]
 
-    def all_quotient_degree_bounds(self, challenges, terminals):
+    def all_quotient_degree_bounds(self, challenges, terminals, exact_terminals=False):
         return (self.boundary_quotient_degree_bounds(challenges) + self.transition_quotient_degree_bounds(challenges)
-                + self.terminal_quotient_degree_bounds(challenges, terminals))
+                + self.terminal_quotient_degree_bounds(challenges, terminals, exact_terminals))
 
     def num_quotients(self, challenges=None, terminals=None):
         return sum(len(c) for _, c in self.air.all())
