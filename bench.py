@@ -389,7 +389,7 @@ def main():
         "data": "synthetic (splitmix64 mod p, seed 0x5EED)",
         "config": {"workload": "forward NTT of %d independent 2^%d-point base-field columns resident in HBM (BASELINE config 5)" % (total_cols, log_n),
                    "log_n": log_n, "total_columns": total_cols, "columns_per_gpu": shard.columns_per_rank(total_cols, world),
-                   "parallelism": "column c on rank c mod %d (shard.assign_columns), no data-path collective; roots all-gathered after the timed region" % world},
+                   "parallelism": "column c on rank c mod %d, no data-path collective; roots all-gathered after the timed region" % world},
         "roots_sha256": __import__("hashlib").sha256(b"".join(world_roots)).hexdigest() if world_roots else None,
         "guard": guard,
         "rccl_ranks_seen": ranks_seen, "collective_backend": (backend if dist is not None else None), "rank_devices": rank_devices,
@@ -441,7 +441,7 @@ def main():
             if t.get("log_n") == log_n and t.get("columns") == cols:
                 traffic = t["hbm_bytes_per_launch"]
                 static = {"file": "profiles/ntt_traffic.json", "taken_at": t.get("source_commit"), "kernel_sources_sha16": t.get("kernel_sources_sha16"),
-                          "current_sources_sha16": kernel_sources_sha16(), "fields": ["traffic", "valu.wave_instructions_per_step"]}
+                          "current_sources_sha16": kernel_sources_sha16()}          # (static: roofline.traffic and valu.wave_instructions_per_step)
                 static["stale"] = bool(static["kernel_sources_sha16"]) and static["kernel_sources_sha16"] != static["current_sources_sha16"]
                 if not static["stale"]:
                     del static["current_sources_sha16"]          # (equal: said once)
@@ -525,7 +525,7 @@ def route_probe_info(lib):
     us, route, probes = (ctypes.c_float * 4)(), ctypes.c_int(-1), ctypes.c_ulonglong(0)
     if lib.bfs_ntt_route_probe_info(us, ctypes.byref(route), ctypes.byref(probes)) != 0 or probes.value == 0:
         return {"probes": 0}
-    return {"probes": int(probes.value), "passes_0_1_us": {"direct": us[0], "buffer0": us[1], "buffer1": us[2], "buffer2": us[3]},
+    return {"probes": int(probes.value), "passes_0_1_us": [round(us[0], 1), round(us[1], 1), round(us[2], 1), round(us[3], 1)],       # direct, buffers 0-2
             "chosen": "direct" if route.value < 0 else "buffer%d" % route.value}
 
 
@@ -1157,7 +1157,7 @@ def cpu_baseline(log_n):
             # the reference itself cannot travel to the GPU box; its own figure, measured in the build container (BASELINE.md section 2,
             # tests/golden/ntt20.json ref_seconds): CPython 3.10, 1 core, ntt.py on 2^20 elements in 242.7 s
             "reference_python": {"value": 4320.0, "unit": "elements/s", "cores": 1,
-                                 "provenance": "BASELINE.md: the reference's ntt.py, n = 2^20, 242.7 s, CPython 3.10.12, build container"}}
+                                 "provenance": "BASELINE.md: ntt.py, n = 2^20, 242.7 s, build container"}}
 
 
 def sample_clock_under_load(gpu_index, delay_s=3.0):
@@ -1201,7 +1201,7 @@ def cpu_baseline_python():
         o.ntt_python(wm, v)
         dt = time.perf_counter() - t0
         py.append({"log_n": lg, "seconds": round(dt, 3), "elements_per_s": round(m / dt, 1)})
-    return {"kind": "port of ntt.py:4-23 on boxed elements, pure Python (oracle.ntt_python), 1 core, timed here", "runs": py}
+    return {"kind": "oracle.ntt_python (ntt.py:4-23 on boxed elements), 1 core, timed here", "runs": py}
 
 
 if __name__ == "__main__":
