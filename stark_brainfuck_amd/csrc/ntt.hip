@@ -607,6 +607,26 @@ int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_str
     const u64* in_end = d_in + (u64)(batch - 1) * in_stride + n_in;
     const u64* out_end = d_out + (u64)(batch - 1) * out_stride + n;
     const bool overlap = p.npass > 1 && n_in != 0 && d_in < out_end && d_out < in_end;
+    // Zero-padded transforms whose coefficients fill at most 1/16 of the domain (every trace column's low-degree extension): the
+    // expansion plan starts at the second digit and saves a pass (ntt_plan.hpp: ntt_make_expand_plan; BFS_NTT_EXPAND=0: never)
+    static const bool allow_expand = [] { const char* e = getenv("BFS_NTT_EXPAND"); return !(e && e[0] == '0'); }();
+    NttPlan xp;
+    if (allow_expand && !overlap && ntt_make_expand_plan(log_n, n_in, root, p, xp)) {
+        for (u32 t = 1; t < xp.npass; ++t) {
+            const u32 S = xp.pass_bits[t];
+            const u32 grid_x = (u32)((n >> S) >> xp.logC[t]);
+            if (t == 1) {
+                PassArgs a = ntt_pass_args(xp, t, d_in, d_out, in_stride, out_stride, n_in, tb, shift != 1, shift, post_scale);
+                a.streaming = streaming;
+                BFS_TRY(dispatch_multi<PASS_EXPAND>(a, S, grid_x, batch, stream));
+            } else {
+                PassArgs a = ntt_pass_args(xp, t, d_out, d_out, out_stride, out_stride, n, tb, shift != 1, shift, post_scale);
+                a.streaming = streaming;
+                BFS_TRY(dispatch_multi<PASS_COLUMN>(a, S, grid_x, batch, stream));
+            }
+        }
+        return BFS_OK;
+    }
     // Large out-of-place transforms: which buffer pass 0 writes to is chosen by measurement (ntt_route above)
     int route = -1;
     if (!overlap && p.npass > 1) BFS_TRY(ntt_route(p, tb, d_in, n_in, in_stride, d_out, out_stride, batch, root, shift, post_scale, streaming, stream, &route));

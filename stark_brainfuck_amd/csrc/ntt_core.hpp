@@ -114,6 +114,32 @@ BFS_HD void dif(u64* x) {
     }
 }
 
+// dif<Q> for inputs of which only registers 0 .. LIVE-1 can be non-zero -- a zero-padded transform whose input fills a fraction of the
+// domain (the shape Table.lde makes: table.py:138-149 evaluates an interpolant of degree ~ n/4 .. n/64 on the FRI domain, ntt.py:164-168).
+// While the upper half of a level's block is zero (LIVE <= Q/2) the level neither adds nor subtracts: x[I] stays and x[I + Q/2] is x[I]
+// times its shift twiddle; once the block is full the network is the ordinary dif<Q> -- the very calls dif<16> ends in, so the rule which
+// sums may stay unreduced is the same.  LIVE = 1 (n_in <= n/16): every output is a copy of x[0]; LIVE = 4: nine shifts and four dif<4>
+// instead of 32 sums and 18 shifts.  Registers >= LIVE hold zeros on entry (they were loaded as such) and are overwritten.
+template <int Q, int LIVE, bool OUT_LAZY, int I = 0>
+BFS_HD void dif_sparse_level(u64* x) {
+    if constexpr (I < LIVE && I < Q / 2) {
+        x[I + Q / 2] = mul_pow2<(192 / Q) * I>(x[I]);
+        dif_sparse_level<Q, LIVE, OUT_LAZY, I + 1>(x);
+    }
+}
+template <int Q, int LIVE, bool OUT_LAZY>
+BFS_HD void dif_sparse(u64* x) {
+    if constexpr (Q >= 2) {
+        if constexpr (LIVE > Q / 2) {
+            dif<Q, OUT_LAZY>(x);
+        } else {
+            dif_sparse_level<Q, LIVE, OUT_LAZY>(x);
+            dif_sparse<Q / 2, LIVE, OUT_LAZY>(x);
+            dif_sparse<Q / 2, LIVE, OUT_LAZY>(x + Q / 2);
+        }
+    }
+}
+
 constexpr u32 cx_bitrev(u32 v, int bits) {
     u32 r = 0;
     for (int i = 0; i < bits; ++i) r |= ((v >> i) & 1u) << (bits - 1 - i);
@@ -161,7 +187,13 @@ struct NttTables {
 // PASS_SINGLE: the whole transform in one tile (n <= 4096, one column, natural order in and out)
 // PASS_FIRST:  pass 0 of a multi-pass plan: column tile in, transposed rows out
 // PASS_COLUMN: passes 1.. of a multi-pass plan: column tile in, the same slots out
-enum { PASS_COLUMN = 0, PASS_SINGLE = 1, PASS_FIRST = 2 };
+// PASS_EXPAND: the first REAL pass of an expansion plan (ntt_plan.hpp: ntt_make_expand_plan) -- a zero-padded transform whose
+//              coefficients fill at most 2^-e of the domain, e >= 4.  The leading digit of the input index is then zero (but for a few
+//              "extra" coefficients), its transform is a copy, and the pass that would follow it reads the coefficients straight from
+//              the input instead of from the slots a first pass would have written: a column pass whose loads come from `in` (index
+//              (row << tw_shift) + h, the same for all C columns of the tile), whose factor carries the coset shift, and which adds the
+//              extras' rank-one terms to row 0.  One HBM pass and one launch less than the plain plan.
+enum { PASS_COLUMN = 0, PASS_SINGLE = 1, PASS_FIRST = 2, PASS_EXPAND = 3 };
 
 // everything a pass needs, precomputed on the host (ntt_plan.hpp) so that the kernel does no planning arithmetic
 struct PassArgs {
@@ -194,6 +226,11 @@ struct PassArgs {
     //   w_{n1 n2}^(j2 k1)  at pass 2's load from a tile-uniform row (k1) of a product table.
     // Without it (two- and four-pass plans) every pass t >= 1 multiplies row r of column K by w_{N_t}^(r K): a chain gamma * delta^d per thread.
     u32 sched;
+    // expansion plan, PASS_EXPAND only: coefficients [0, n_main) are the main part (n_main <= 2^main_bits = n / n_0), coefficients
+    // 2^main_bits + t, t < extras, the few beyond it (a trace column's randomizers: table.py:112-136 interpolates over height + 1 points)
+    u64 n_main;
+    u32 main_bits, extras;
+    u64 extra_scale;     // s^(2^main_bits): the coset factor of extra t is extra_scale * s^t
     u32 unit0;           // register 0 of stage 1 carries output digit 0, whose inner twiddle is w^0: skip that product unless tw1 has post_scale folded in
     const u64* tw1;      // inner twiddle table after stage 1 (t_in, or t_in_last when that is the pass' last inner twiddle)
     const u64* tw2;      // ... after stage 2 (three-stage tiles)
@@ -337,7 +374,7 @@ BFS_HD void final_store(const PassArgs& a, const TileGeom& g, const u64* x, u32 
     const bool scale = (Cfg::U == 1) && a.post_scale != 1;
     u64* tp;          // per-thread base; the per-register offset below is wave-uniform
     u32 step_log;
-    if constexpr (MODE == PASS_COLUMN) {
+    if constexpr (MODE == PASS_COLUMN || MODE == PASS_EXPAND) {
         tp = g.out + g.row0 + ((u64)klow << a.logL) + c;
         step_log = (u32)kshift + a.logL;
     } else if constexpr (MODE == PASS_FIRST) {
@@ -397,6 +434,15 @@ BFS_HD void ntt_stage1_load(const PassArgs& a, u32 tid, u32 bid_x, u32 bid_y, in
     constexpr int Q = 1 << B1;
     const TileGeom g = tile_geom<Cfg, LOGC, MODE>(a, bid_x, bid_y);
     const Stage1Pos<B1, B2, B3, LOGC, MODE> p = stage1_pos<B1, B2, B3, LOGC, MODE>(a, g, tid, sub);
+    if constexpr (MODE == PASS_EXPAND) {
+        // coefficient (row << tw_shift) + h for row = (d << SH1) | o: one address for all C columns of the tile
+        const u64 i0 = ((u64)p.o << a.tw_shift) + g.h;
+        const u32 sl = Cfg::SH1 + a.tw_shift;
+        const u64* ip = a.in + (u64)bid_y * a.in_batch_stride + i0;
+        BFS_UNROLL
+        for (int d = 0; d < Q; ++d) x[d] = (i0 + ((u64)d << sl) < a.n_main) ? ntt_ld<NT>(ip + ((u64)d << sl)) : 0;
+        return;
+    }
     const u64* tp = g.in + p.idx0;
     if (a.partial) {
         BFS_UNROLL
@@ -437,6 +483,31 @@ BFS_HD void ntt_stage1_values(const PassArgs& a, const u64* tw, const u64* rowtw
     const u64 nmask = (1ull << a.log_n) - 1;
     const Stage1Pos<B1, B2, B3, LOGC, MODE> p = stage1_pos<B1, B2, B3, LOGC, MODE>(a, g, tid, sub);
     const u32 o = p.o, c = p.c;
+    // zero-padded input: element d of a thread is input index idx0 + (d << step_log), which lies beyond n_in for every thread once
+    // d << step_log does -- registers d >= dmax hold zeros in the whole launch (a wave-uniform, in fact launch-uniform, number)
+    u32 dmax = Q;
+    if constexpr (MODE == PASS_EXPAND) {
+        const u32 sl = Cfg::SH1 + a.tw_shift;
+        const u64 live = (a.n_main + ((1ull << sl) - 1)) >> sl;
+        if (live < (u64)Q) dmax = (u32)live;
+    } else if (a.partial) {
+        const u64 live = (a.n_in + ((1ull << p.step_log) - 1)) >> p.step_log;
+        if (live < (u64)Q) dmax = (u32)live;
+    }
+    if constexpr (MODE == PASS_EXPAND) {
+        // The extras.  Coefficient 2^M + t (M = main_bits, t < extras) has leading digit 1 and the rest t: the copy that stands for the
+        // skipped first pass leaves  x_t s^t + x_(2^M + t) s^(2^M + t) w_{n_0}^(k_0)  in the slot of rest t and column k_0, i.e. the main
+        // coefficient plus  s^(2^M) w^(k_0 2^M)  times the extra one, before this pass' own factor s^t w_{N_1}^(row K) multiplies both.  The
+        // planner keeps extras below the stride of register 1, so only register 0 of the threads whose own coefficient index
+        // (o << tw_shift) + h is below `extras` is touched: a handful of threads per transform.
+        const u64 i0 = ((u64)o << a.tw_shift) + g.h;
+        if (a.extras != 0 && i0 < (u64)a.extras) {
+            const u64 e = g.in[(1ull << a.main_bits) + i0];
+            u64 f = tw_pow(a.tb.w_lo, a.tb.w_hi, a.tb.lo_bits, ((g.c0 + c) << a.main_bits) & nmask);
+            if (a.has_coset) f = gl_mul(f, a.extra_scale);
+            x[0] = gl_add(x[0], gl_mul(e, f));
+        }
+    }
     if (rowtw != nullptr) {
         // last pass of a balanced plan: the factors w_{n1 n2}^(j2 k1) of the tile's rows j2 are one row (k1) of a table
         BFS_UNROLL
@@ -453,6 +524,12 @@ BFS_HD void ntt_stage1_values(const PassArgs& a, const u64* tw, const u64* rowtw
             const u64 ks = g.kbase + ((u64)c << a.tw_shift);                 // w^ks = w_{N_t}^K for this thread's column K = c0 + c
             gam = tw_pow(a.tb.w_lo, a.tb.w_hi, a.tb.lo_bits, ((u64)o * ks) & nmask);
             del = tw_pow(a.tb.w_lo, a.tb.w_hi, a.tb.lo_bits, (ks << Cfg::SH1) & nmask);
+            if constexpr (MODE == PASS_EXPAND) {
+                if (a.has_coset) {       // ... times s^j for the coefficient's own index j = (row << tw_shift) + h: a geometric chain in d as well
+                    gam = gl_mul(gam, tw_pow(a.tb.s_lo, a.tb.s_hi, a.tb.lo_bits, ((u64)o << a.tw_shift) + g.h));
+                    del = gl_mul(del, a.coset_delta);
+                }
+            }
         } else {
             gam = tw_pow(a.tb.s_lo, a.tb.s_hi, a.tb.lo_bits, p.idx0);
             del = a.coset_delta;
@@ -460,11 +537,23 @@ BFS_HD void ntt_stage1_values(const PassArgs& a, const u64* tw, const u64* rowtw
         u64 f = gam;
         BFS_UNROLL
         for (int d = 0; d < Q; ++d) {
-            x[d] = gl_mul(x[d], f);
-            if (d + 1 < Q) f = gl_mul_lazy(f, del);   // only ever multiplied again: no canonical form needed
+            if ((u32)d < dmax) {                      // (zeros need neither their factor nor the chain's next step)
+                x[d] = gl_mul(x[d], f);
+                if (d + 1 < Q) f = gl_mul_lazy(f, del);   // only ever multiplied again: no canonical form needed
+            }
         }
     }
-    dif<Q, (Cfg::U >= 2)>(x);          // U >= 2: every output meets an inner twiddle below (the one with a unit twiddle is reduced there)
+    // U >= 2: every output meets an inner twiddle below (the one with a unit twiddle is reduced there)
+    if (Q == 16 && dmax <= 8) {                    // (wave-uniform) zero-padded input: the network for the registers that can be non-zero
+        if constexpr (Q == 16) {
+            if (dmax <= 1) dif_sparse<16, 1, (Cfg::U >= 2)>(x);
+            else if (dmax <= 2) dif_sparse<16, 2, (Cfg::U >= 2)>(x);
+            else if (dmax <= 4) dif_sparse<16, 4, (Cfg::U >= 2)>(x);
+            else dif_sparse<16, 8, (Cfg::U >= 2)>(x);
+        }
+    } else {
+        dif<Q, (Cfg::U >= 2)>(x);
+    }
     if constexpr (Cfg::U == 1) {
         final_store<Cfg, LOGC, MODE, B1, NT>(a, g, x, 0, 0, c, srow);
     } else {

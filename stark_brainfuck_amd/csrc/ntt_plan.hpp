@@ -25,7 +25,11 @@ struct NttPlan {
     u32 lo_bits = 0;
     u32 t_in_log = 0;
     u32 sched = 0;                    // 1: the balanced twiddle schedule of a three-pass plan (PassArgs::sched)
+    // expansion plan (ntt_make_expand_plan): pass 0 is VIRTUAL -- pass_bits[0] = e leading bits of the input index that are zero for
+    // all but `extras` coefficients -- and passes 1.. are real; main_bits = log n - e
+    u32 expand = 0, main_bits = 0, extras = 0;
 };
+constexpr u32 NTT_EXPAND_MAX_EXTRAS = 16;
 
 inline int ntt_check_root(u64 root, u32 log_n) {
     if (log_n == 0) return BFS_OK;  // ntt.py:8-9: length <= 1 returns its input unchecked
@@ -105,6 +109,55 @@ inline bool ntt_make_plan(u32 log_n, u64 root, NttPlan& p) {
                      best[0] + best[1] <= 16 && best[1] + best[2] <= 16;
     p.sched = (can && ntt_schedule_override() != 0) ? 1 : 0;
     return true;
+}
+
+// Expansion plan for a zero-padded transform of n_in coefficients on n = 2^log_n points (fast_coset_evaluate, ntt.py:164-168; the shape
+// Table.lde makes, table.py:138-149: height + 1 coefficients on ~64 height points).  Write the input index as (j_0 | j_1 | ..) with e
+// leading bits j_0: when n_in <= 2^(log n - e) (+ a few extras) every coefficient has j_0 = 0, the first pass' 2^e-point transform of
+// (x, 0, .., 0) is 2^e copies of x, and the plan can start at the second digit: passes over the remaining M = log n - e bits, the first of
+// them reading the coefficients instead of slots (PASS_EXPAND).  Taken when that saves a pass: M <= 8 -> one real pass, M <= 16 -> two.
+// Extras: up to NTT_EXPAND_MAX_EXTRAS coefficients 2^M + t (a trace interpolant has height + num_randomizers coefficients, one or two
+// past a power of two) enter as rank-one terms of the first real pass instead of costing a bit of e.
+inline bool ntt_try_expand_plan(u32 log_n, u32 M, u64 r, const NttPlan& plain, NttPlan& p) {
+    if (M < 5 || M == 9 || M > 16 || log_n < M + 4) return false;   // digits are 5..8 bits (9 = 5 + 4 does not split), at most two real passes; e >= 4 keeps 16 adjacent columns per tile
+    const u32 e = log_n - M;
+    const u32 real = M <= 8 ? 1 : 2;
+    if (real >= plain.npass) return false;                    // taken only when it saves a pass
+    p = plain;
+    p.sched = 0;
+    p.expand = 1;
+    p.main_bits = M;
+    p.extras = (u32)r;
+    p.npass = 1 + real;
+    for (int i = 0; i < 4; ++i) { p.pass_bits[i] = 0; p.logC[i] = 0; }
+    p.pass_bits[0] = e;
+    if (real == 1) {
+        p.pass_bits[1] = M;
+    } else {
+        p.pass_bits[1] = (M + 1) / 2;                          // the larger digit first: its tile has fewer columns, and e >= 4 of them are there
+        p.pass_bits[2] = M - p.pass_bits[1];
+    }
+    u32 done = e;
+    for (u32 t = 1; t < p.npass; ++t) {
+        p.logC[t] = NTT_TILE_LOG - p.pass_bits[t];
+        if (p.logC[t] > done) return false;                    // a tile's columns are values of the finished digits
+        done += p.pass_bits[t];
+    }
+    // an extra's rest index t must belong to register 0 of a thread of the first real pass: t < 2^(SH1 + tw_shift), SH1 = S_1 - 4
+    const u32 reach = (p.pass_bits[1] - 4) + (real == 2 ? p.pass_bits[2] : 0);
+    return r <= (1ull << reach);
+}
+inline bool ntt_make_expand_plan(u32 log_n, u64 n_in, u64 root, const NttPlan& plain, NttPlan& p) {
+    (void)root;
+    if (plain.npass < 2 || n_in == 0 || n_in >= (1ull << log_n)) return false;
+    u32 m0 = 0;
+    while ((2ull << m0) <= n_in) ++m0;                       // 2^m0 <= n_in < 2^(m0 + 1)
+    const u64 r = n_in - (1ull << m0);
+    // the main part 2^m0 with the r coefficients beyond it as extras, else the next sizes up with zero padding inside the main part
+    if (r <= NTT_EXPAND_MAX_EXTRAS && ntt_try_expand_plan(log_n, m0, r, plain, p)) return true;
+    for (u32 M = (r == 0 ? m0 : m0 + 1); M <= 16; ++M)
+        if (M >= 5 && ntt_try_expand_plan(log_n, M, 0, plain, p)) return true;
+    return false;
 }
 
 // product table: out[(a << b_bits) + b] = omega^(a b)
@@ -195,6 +248,24 @@ inline PassArgs ntt_pass_args(const NttPlan& p, u32 t, const u64* in, u64* out, 
     }
     a.uinv = p.uinv;
     a.sched = p.sched;
+    if (p.expand && t == 1) {
+        // the first real pass of an expansion plan reads the coefficients: n_in of them, of which the first n_main are the main part
+        a.main_bits = p.main_bits;
+        a.extras = p.extras;
+        a.n_main = n_in < (1ull << p.main_bits) ? n_in : (1ull << p.main_bits);
+        a.has_coset = has_coset ? 1 : 0;
+        if (has_coset) {
+            const u32 sh1 = S - (S < 4 ? S : 4);
+            a.coset_delta = gl_pow(shift, 1ull << (sh1 + a.tw_shift));
+            a.extra_scale = gl_pow(shift, 1ull << p.main_bits);
+        }
+        a.post_scale = last ? post_scale : 1;
+        a.tb = tb;
+        a.tw1 = last ? tb.t_in_last : tb.t_in;
+        a.tw2 = tb.t_in;
+        a.unit0 = (a.tw1 == tb.t_in || post_scale == 1) ? 1 : 0;
+        return a;
+    }
     a.has_coset = (t == 0 && has_coset) ? 1 : 0;
     a.post_scale = last ? post_scale : 1;
     a.tb = tb;

@@ -60,6 +60,10 @@ static void dispatch_single(const PassArgs& a, u32 S, u32 batch) {
     }
 }
 
+static int emu_allow_expand = 1;
+static unsigned long long emu_expand_plans = 0;
+// 0: zero-padded transforms take the plain plan too; returns how many calls have taken the expansion plan so far
+extern "C" unsigned long long emu_set_expand(int allow) { emu_allow_expand = allow; return emu_expand_plans; }
 static int emu_force_ws = 0;
 extern "C" void emu_set_force_ws(int v) { emu_force_ws = v; }
 // operands that had to be canonical and were not, since the last reset (gl.hpp, BFS_CHECK_CANONICAL)
@@ -95,6 +99,24 @@ extern "C" int emu_gl_ntt(const u64* in, u64 n_in, u64 in_stride, u64* out, u64 
     const u64* in_end = in + (u64)(batch - 1) * in_stride + n_in;
     const u64* out_end = out + (u64)(batch - 1) * out_stride + n;
     const bool overlap = p.npass > 1 && n_in != 0 && ((in < out_end && out < in_end) || emu_force_ws);
+    // the expansion plan of a zero-padded transform (ntt.hip: ntt_launch takes it under the same condition)
+    NttPlan xp;
+    if (emu_allow_expand && !overlap && ntt_make_expand_plan(log_n, n_in, root, p, xp)) {
+        ++emu_expand_plans;
+        for (u32 t = 1; t < xp.npass; ++t) {
+            const u32 S = xp.pass_bits[t];
+            const u32 grid_x = (u32)((n >> S) >> xp.logC[t]);
+            tb.row = nullptr; tb.srow = nullptr;
+            if (t == 1) {
+                PassArgs a = ntt_pass_args(xp, t, in, out, in_stride, out_stride, n_in, tb, coset, shift, post_scale);
+                dispatch_multi<PASS_EXPAND>(a, S, grid_x, batch);
+            } else {
+                PassArgs a = ntt_pass_args(xp, t, out, out, out_stride, out_stride, n, tb, coset, shift, post_scale);
+                dispatch_multi<PASS_COLUMN>(a, S, grid_x, batch);
+            }
+        }
+        return 0;
+    }
     std::vector<u64> ws;
     if (overlap) ws.resize((size_t)n * batch);
     std::vector<std::vector<u64>> rows(p.npass), srows(p.npass);

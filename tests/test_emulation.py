@@ -27,6 +27,8 @@ def emu():
     lib.emu_gl_ntt.argtypes = [vp, u64, u64, vp, u64, ctypes.c_uint32, ctypes.c_uint32, u64, u64, u64]
     lib.emu_set_schedule.argtypes = [ctypes.c_int, ctypes.c_uint32, u64]
     lib.emu_set_force_ws.argtypes = [ctypes.c_int]
+    lib.emu_set_expand.argtypes = [ctypes.c_int]
+    lib.emu_set_expand.restype = ctypes.c_ulonglong
     lib.emu_canonical_violations.argtypes = [ctypes.c_int]
     lib.emu_canonical_violations.restype = ctypes.c_ulonglong
     lib.emu_plan.argtypes = [ctypes.c_uint32, u64, vp, vp, vp, vp]
@@ -120,12 +122,46 @@ def test_zero_padded_inputs_of_every_shape(emu, oracle, logn):
     loads are predicated on n_in and everything above reads as zero."""
     n = 1 << logn
     w = oracle.primitive_nth_root(n)
-    counts = sorted({1, 2, max(1, n // 64), max(1, n // 64) + 1, n // 16, n // 16 + 1, n // 4 - 1, n // 4, n // 4 + 1, n // 2 + 3} & set(range(1, n + 1)))
+    counts = sorted({1, 2, max(1, n // 64), max(1, n // 64) + 1, n // 16, n // 16 + 1, n // 8, n // 8 + 1, n // 4 - 1, n // 4, n // 4 + 1, n // 2, n // 2 + 3} & set(range(1, n + 1)))
     v = oracle.felt_array(SEED + 3 * logn, 0, n)
     for d in counts:
         for shift in (1, 7):
             want = oracle.fast_coset_evaluate(v[:d], shift, w, n)
             assert (emu_ntt(emu, v[:d], logn, w, shift, 1, n_in=d) == want).all(), (logn, d, shift)
+
+
+@pytest.mark.parametrize("logn", [13, 14, 16, 17, 18, 20])
+def test_expansion_plans_of_zero_padded_transforms(emu, oracle, logn):
+    """ntt_make_expand_plan / PASS_EXPAND: when the coefficients fill at most 1/16 of the domain the plan starts at the second digit of the
+    input index -- one real pass for up to 2^8 (+ extras) coefficients, two for up to 2^16 -- and the first real pass reads the coefficients
+    themselves, carries the coset shift and adds the rank-one terms of the few coefficients past the power of two (a trace interpolant has
+    height + 1).  Every count around the plan's thresholds, with and without shift and post-scale, must equal the oracle's
+    fast_coset_evaluate (ntt.py:164-168) and the plain plan's output, and the plan must actually have been taken."""
+    n = 1 << logn
+    w = oracle.primitive_nth_root(n)
+    v = oracle.felt_array(SEED + 5 * logn, 0, n)
+    P = (1 << 64) - (1 << 32) + 1
+    edge = np.array([0, P - 1, 1, P - 2] * (n // 4), dtype=np.uint64)
+    taken = 0
+    counts = set()
+    for M in range(3, min(16, logn - 4) + 1):
+        counts |= {(1 << M) - 1, 1 << M, (1 << M) + 1, (1 << M) + 2, (1 << M) + 16, (1 << M) + 17}
+    counts = sorted(c for c in counts if 1 <= c <= n // 16 + 17)
+    if logn >= 18:                      # (the host emulation walks every tile of every pass: keep the large sizes to the counts next to n / 64 .. n / 16)
+        counts = [c for c in counts if c >= n // 128]
+    for d in counts:
+        for shift, scale, src in ((7, 1, v), (1, 1, edge), (3, oracle.inv(n), v)):
+            before = emu.emu_set_expand(1)
+            got = emu_ntt(emu, src[:d], logn, w, shift, scale, n_in=d)
+            after = emu.emu_set_expand(0)
+            plain = emu_ntt(emu, src[:d], logn, w, shift, scale, n_in=d)
+            emu.emu_set_expand(1)
+            taken += after - before
+            want = oracle.fast_coset_evaluate(src[:d], shift, w, n)
+            if scale != 1:
+                want = oracle.mul_scalar(want, scale) if hasattr(oracle, "mul_scalar") else plain
+            assert (got == want).all() and (got == plain).all(), (logn, d, shift, scale)
+    assert taken >= len(counts), (taken, len(counts))
 
 
 @pytest.mark.parametrize("logn", [13, 16, 17, 20])

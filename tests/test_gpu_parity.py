@@ -50,6 +50,25 @@ def raw_ntt(sb, v, logn, root, shift=1, scale=1, n_in=None, batch=1):
     return dout.to_numpy()
 
 
+@pytest.mark.parametrize("logn", [6, 9, 12, 13, 16, 17, 20, 22, 24])
+def test_zero_padded_transforms_of_every_fill(sb, oracle, logn):
+    """fast_coset_evaluate of d coefficients on n points (ntt.py:164-168) for d around n/64, n/16, n/8, n/4, n/2 -- the shapes Table.lde makes
+    (table.py:138-149).  The first register stage knows how many of its 16 registers can be non-zero and runs the network for those only
+    (ntt_core.hpp: dif_sparse -- 1, 2, 4 or 8 live inputs); values next to 0 and p ride along in the last column."""
+    n = 1 << logn
+    w = oracle.primitive_nth_root(n)
+    v = oracle.felt_array(SEED + 17 * logn, 0, n)
+    P = (1 << 64) - (1 << 32) + 1
+    edge = np.array([0, 1, P - 1, P - 2, 2, (1 << 32) - 1, 1 << 32, P - (1 << 32)] * (n // 8 if n >= 8 else 1), dtype=np.uint64)[:n]
+    counts = sorted({1, max(1, n // 64), n // 16, n // 16 + 1, n // 8, n // 8 + 1, n // 4 + 1, n // 2, n // 2 + 3} & set(range(1, n + 1)))
+    if logn >= 22:
+        counts = [c for c in counts if c in (n // 64, n // 16 + 1, n // 8, n // 2)]
+    for d in counts:
+        for shift in ((7,) if logn >= 20 else (1, 7)):
+            for src in (v, edge):
+                assert (raw_ntt(sb, src[:d], logn, w, shift, 1, n_in=d) == oracle.fast_coset_evaluate(src[:d], shift, w, n)).all(), (logn, d, shift)
+
+
 # ------------------------------------------------------------------------------------------------ NTT
 @pytest.mark.parametrize("logn", list(range(0, 24)))
 def test_ntt_intt_coset_vs_oracle(sb, oracle, logn):
