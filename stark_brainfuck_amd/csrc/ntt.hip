@@ -611,6 +611,8 @@ int ntt_launch(const u64* d_in, u64 n_in, u64 in_stride, u64* d_out, u64 out_str
     // expansion plan starts at the second digit and saves a pass (ntt_plan.hpp: ntt_make_expand_plan; BFS_NTT_EXPAND=0: never)
     static const bool allow_expand = [] { const char* e = getenv("BFS_NTT_EXPAND"); return !(e && e[0] == '0'); }();
     NttPlan xp;
+    static const bool log_plans = getenv("BFS_NTT_PLAN_LOG") != nullptr;
+    if (log_plans) fprintf(stderr, "ntt plan: log_n %u n_in %llu batch %u overlap %d allow %d in %p out %p\n", log_n, (unsigned long long)n_in, batch, (int)overlap, (int)allow_expand, (const void*)d_in, (void*)d_out);
     if (allow_expand && !overlap && ntt_make_expand_plan(log_n, n_in, root, p, xp)) {
         for (u32 t = 1; t < xp.npass; ++t) {
             const u32 S = xp.pass_bits[t];

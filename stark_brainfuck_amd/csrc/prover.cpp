@@ -42,6 +42,13 @@ constexpr int NT = 5;                                       // processor, instru
 constexpr u32 BASE_W[NT] = {7, 3, 4, 1, 1};
 constexpr u32 FULL_W[NT] = {11, 5, 5, 2, 2};
 constexpr u32 NUM_RAND[NT] = {1, 1, 1, 0, 0};               // brainfuck_stark.py:48: one randomizer per column; the IO tables have none
+
+// The coset transform of all tables' coefficient columns (table.py:138-149).  Small domains: ONE call over every column with the largest
+// table's coefficient count (a small proof is a chain of launches; merging them was round 5's gain).  Large domains (>= 2^20 points): one
+// call per run of tables with the same count -- a column's zero padding is what the transform's cost depends on (ntt_plan.hpp: a table
+// with 2^16 + 1 coefficients on 2^22 points takes the two-pass expansion plan, one with 2^17 + 1 the three-pass plan), and a table must not
+// pay for its neighbour's height.  Columns beyond a table's own count are zero in `coeffs` either way: same values.
+constexpr u32 LDE_GROUP_MIN_LOG_N = 20;
 constexpr int NUM_SCANS = 9;
 
 inline double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -202,6 +209,29 @@ extern "C" {
 void* bfs_stark_session_new(void) { return new StarkSession(); }
 void bfs_stark_session_free(void* s) { delete (StarkSession*)s; }
 
+static int lde_all_tables(const StarkSession& S, const u64* coeffs, u64 stride, u64* codewords, u64 n, u32 log_n, u64 omega, u64 offset, u32 planes,
+                          bool extension, hipStream_t stream) {
+    const u32 total = planes * (extension ? S.total_ext : S.total_base);
+    if (total == 0) return BFS_OK;
+    if (log_n < LDE_GROUP_MIN_LOG_N) return bfs_gl_ntt(coeffs, stride, stride, codewords, n, log_n, total, omega, offset, 1, stream);
+    for (int t = 0; t < NT;) {
+        const u64 count = S.height[t] + NUM_RAND[t];                       // a table's interpolant: height + randomizers coefficients (table.py:112-136)
+        int u = t;
+        u32 columns = 0;
+        while (u < NT && S.height[u] + NUM_RAND[u] == count) {
+            columns += planes * (extension ? FULL_W[u] - BASE_W[u] : BASE_W[u]);
+            ++u;
+        }
+        if (columns != 0) {
+            const u64 first = planes * (extension ? S.ext_at[t] : S.base_at[t]);
+            const u64 n_in = count == 0 ? 1 : (count < stride ? count : stride);   // (an empty table's columns are zero: one zero coefficient each)
+            BFS_TRY(bfs_gl_ntt(coeffs + first * stride, n_in, stride, codewords + first * n, n, log_n, columns, omega, offset, 1, stream));
+        }
+        t = u;
+    }
+    return BFS_OK;
+}
+
 int bfs_stark_commit(void* session, void* ps, const bfs_stark_params* params, const bfs_stark_table_in* tables, const bfs_stark_randomness* rnd,
                      uint64_t* out_challenges, uint64_t* out_scan_terminals, uint64_t* out_io_terminals, double* out_ms, void* stream_) {
     BFS_TRY(check_session(session, "bfs_stark_commit"));
@@ -345,7 +375,7 @@ int bfs_stark_commit(void* session, void* ps, const bfs_stark_params* params, co
         }
         for (int t = 0; t < 2; ++t) if (forked[t]) BFS_HIP(hipStreamWaitEvent(stream, S.join_ev[t], 0));
     }
-    BFS_TRY(bfs_gl_ntt(S.coeffs.words(), stride, stride, S.base_cw.words(), n, P.log_n, S.total_base, omega, offset, 1, stream));
+    BFS_TRY(lde_all_tables(S, S.coeffs.words(), stride, S.base_cw.words(), n, P.log_n, omega, offset, /*planes=*/1, /*extension=*/false, stream));
     BFS_HIP(hipStreamWaitEvent(stream, S.rand_ev, 0));      // the randomizer codeword is ready from here on
     rpoly.release();                                        // (stream-ordered behind the join: its transform has run)
     const double t_lde = now_ms();
@@ -488,7 +518,7 @@ int bfs_stark_commit(void* session, void* ps, const bfs_stark_params* params, co
                 S.ext_moduli[col] = modulus;
             }
     }
-    BFS_TRY(bfs_gl_ntt(S.coeffs.words(), stride, stride, S.ext_cw.words(), n, P.log_n, 3 * S.total_ext, omega, offset, 1, stream));
+    BFS_TRY(lde_all_tables(S, S.coeffs.words(), stride, S.ext_cw.words(), n, P.log_n, omega, offset, /*planes=*/3, /*extension=*/true, stream));
     // what bfs_stark_finish needs of the caller's randomness
     S.have_ext_salt_seed = rnd->ext_salt_seed != nullptr;
     if (rnd->ext_salt_seed) memcpy(S.ext_salt_seed, rnd->ext_salt_seed, 32);
