@@ -131,21 +131,27 @@ inline bool ntt_try_expand_plan(u32 log_n, u32 M, u64 r, const NttPlan& plain, N
     p.npass = 1 + real;
     for (int i = 0; i < 4; ++i) { p.pass_bits[i] = 0; p.logC[i] = 0; }
     p.pass_bits[0] = e;
-    if (real == 1) {
-        p.pass_bits[1] = M;
-    } else {
-        p.pass_bits[1] = (M + 1) / 2;                          // the larger digit first: its tile has fewer columns, and e >= 4 of them are there
-        p.pass_bits[2] = M - p.pass_bits[1];
+    // the real digits: one of M bits, or the most balanced pair S_1 + S_2 = M (5..8 bits each) whose tiles find their columns among the
+    // finished digits (C_1 = 2^(12 - S_1) <= 2^e values of k_0, C_2 <= 2^(e + S_1)) and whose first pass reaches the extras: an extra's
+    // rest index t must belong to register 0 of a thread of the first real pass, t < 2^(SH1 + tw_shift) with SH1 = S_1 - 4
+    u32 best1 = 0, best_gap = 99;
+    for (u32 s1 = 5; s1 <= 8; ++s1) {
+        const u32 s2 = real == 1 ? 0 : M - s1;
+        if (real == 1 ? s1 != M : (s2 < 5 || s2 > 8)) continue;
+        if (NTT_TILE_LOG - s1 > e) continue;
+        if (real == 2 && NTT_TILE_LOG - s2 > e + s1) continue;
+        if (r > (1ull << ((s1 - 4) + s2))) continue;
+        const u32 gap = real == 1 ? 0 : (s1 > s2 ? s1 - s2 : s2 - s1);
+        if (gap < best_gap || (gap == best_gap && s1 > best1)) { best_gap = gap; best1 = s1; }
     }
-    u32 done = e;
-    for (u32 t = 1; t < p.npass; ++t) {
-        p.logC[t] = NTT_TILE_LOG - p.pass_bits[t];
-        if (p.logC[t] > done) return false;                    // a tile's columns are values of the finished digits
-        done += p.pass_bits[t];
+    if (best1 == 0) return false;
+    p.pass_bits[1] = best1;
+    p.logC[1] = NTT_TILE_LOG - best1;
+    if (real == 2) {
+        p.pass_bits[2] = M - best1;
+        p.logC[2] = NTT_TILE_LOG - p.pass_bits[2];
     }
-    // an extra's rest index t must belong to register 0 of a thread of the first real pass: t < 2^(SH1 + tw_shift), SH1 = S_1 - 4
-    const u32 reach = (p.pass_bits[1] - 4) + (real == 2 ? p.pass_bits[2] : 0);
-    return r <= (1ull << reach);
+    return true;
 }
 inline bool ntt_make_expand_plan(u32 log_n, u64 n_in, u64 root, const NttPlan& plain, NttPlan& p) {
     (void)root;
