@@ -158,6 +158,8 @@ def main():
     workers = int(os.environ.get("BFS_GOLDEN_WORKERS", "1"))
     if workers > 1:
         install_parallel_quotients(table_mod, workers, rec)
+    if os.environ.get("BFS_GOLDEN_CKPT"):
+        install_early_cache(os.environ["BFS_GOLDEN_CKPT"], name, (stark, program, pm, mm, im, inm, om, VirtualMachine.field), table_mod, fri_mod, rec)
     ps = ProofStream()
     t0 = time.time()
     proof = stark.prove(program, pm, mm, im, inm, om, proof_stream=ps)
@@ -329,6 +331,78 @@ def install_parallel_quotients(table_mod, workers, rec):
     wrap("boundary_quotients", "boundary_constraints_ext", 1, lambda challenges, rest: (challenges,))
     wrap("transition_quotients", "transition_constraints_ext", 2, lambda challenges, rest: (challenges,))
     wrap("terminal_quotients", "terminal_constraints_ext", 1, lambda challenges, rest: (challenges,) + tuple(rest))
+
+
+# ---- BFS_GOLDEN_CKPT=<dir>: the stages in front of the quotients survive an interruption too -------------------------------------------
+# At FRI domain 2^16 the reference spends over two hours between the start of prove() and its first quotient: `fast_interpolate` of every
+# column (table.py:112-136) and the coset evaluations `Domain.evaluate` / `xevaluate` (fri.py:26-37) -- pure functions of their arguments,
+# called in a fixed order; the randomness is drawn OUTSIDE them.  With a checkpoint directory each call's result is pickled under its
+# sequence number, and a run that is started again returns the stored result instead of computing it.  The proof is `pickle.dumps` of
+# objects and pickle memoises by IDENTITY, so a stored result must come back referring to the SAME field objects the live computation would
+# have used: the BaseField / ExtensionField instances reachable from the prover, the program and the trace are numbered by one
+# deterministic traversal and written as persistent ids.  Checked like the parallel quotients: a run of `plus1` resumed from such
+# checkpoints writes the committed stark_plus1_proof.bin byte for byte.
+class _FieldRegistry:
+    def __init__(self, roots):
+        import io, pickle
+        from algebra import BaseField
+        from extension_field import ExtensionField
+        self.pickle, self.io = pickle, io
+        self.objects, seen = [], set()
+        registry = self
+
+        class Scan(pickle.Pickler):
+            def persistent_id(self, obj):
+                if isinstance(obj, (BaseField, ExtensionField)) and id(obj) not in seen:
+                    seen.add(id(obj))
+                    registry.objects.append(obj)
+                return None
+        Scan(io.BytesIO(), protocol=4).dump(roots)
+        self.index = {id(o): i for i, o in enumerate(self.objects)}
+
+    def dump(self, obj, path):
+        registry = self
+
+        class Writer(self.pickle.Pickler):
+            def persistent_id(self, o):
+                return registry.index.get(id(o))
+        with open(path + ".tmp", "wb") as f:
+            Writer(f, protocol=4).dump(obj)
+        os.replace(path + ".tmp", path)
+
+    def load(self, path):
+        registry = self
+
+        class Reader(self.pickle.Unpickler):
+            def persistent_load(self, pid):
+                return registry.objects[pid]
+        with open(path, "rb") as f:
+            return Reader(f).load()
+
+
+def install_early_cache(directory, name, roots, table_mod, fri_mod, rec):
+    os.makedirs(directory, exist_ok=True)
+    registry = _FieldRegistry(roots)
+    state = {"seq": 0}
+    log = rec.setdefault("early_stage_checkpoints", {"fields_numbered": len(registry.objects), "computed": 0, "loaded": 0})
+
+    def cached(label, original):
+        def call(*args, **kwargs):
+            state["seq"] += 1
+            path = os.path.join(directory, "%s_early_%04d_%s.pkl" % (name, state["seq"], label))
+            if os.path.exists(path):
+                log["loaded"] += 1
+                return registry.load(path)
+            t0 = time.time()
+            out = original(*args, **kwargs)
+            registry.dump(out, path)
+            log["computed"] += 1
+            print("[early] %s #%d computed in %.0f s" % (label, state["seq"], time.time() - t0), file=sys.stderr, flush=True)
+            return out
+        return call
+    table_mod.fast_interpolate = cached("fast_interpolate", table_mod.fast_interpolate)
+    fri_mod.Fri.Domain.evaluate = cached("evaluate", fri_mod.Fri.Domain.evaluate)
+    fri_mod.Fri.Domain.xevaluate = cached("xevaluate", fri_mod.Fri.Domain.xevaluate)
 
 
 def rle(xs):
