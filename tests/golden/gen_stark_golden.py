@@ -386,10 +386,28 @@ def install_early_cache(directory, name, roots, table_mod, fri_mod, rec):
     state = {"seq": 0}
     log = rec.setdefault("early_stage_checkpoints", {"fields_numbered": len(registry.objects), "computed": 0, "loaded": 0})
 
+    # BFS_GOLDEN_EARLY_SHARE="h/H": H processes of this script run side by side on the same checkpoint directory; process h computes the
+    # calls whose sequence number is h modulo H and WAITS for the files of the others (the columns of a table are interpolated and evaluated
+    # independently of each other, so the H processes advance together through a table).  Process 0 carries on into the quotients; the
+    # helpers (h > 0) stop at the first of them.
+    share = os.environ.get("BFS_GOLDEN_EARLY_SHARE", "0/1").split("/")
+    mine, parties = int(share[0]), int(share[1])
+    if mine > 0:
+        def helper_is_done(*unused_args, **unused_kwargs):
+            print("[early] helper %d/%d: the early stages are on disk" % (mine, parties), file=sys.stderr, flush=True)
+            os._exit(0)
+        table_mod.Table.all_quotients = helper_is_done
+
     def cached(label, original):
         def call(*args, **kwargs):
             state["seq"] += 1
             path = os.path.join(directory, "%s_early_%04d_%s.pkl" % (name, state["seq"], label))
+            if not os.path.exists(path) and state["seq"] % parties != mine:
+                waited = time.time()
+                while not os.path.exists(path):
+                    time.sleep(1.0)
+                    if time.time() - waited > 6 * 3600:
+                        raise RuntimeError("no other process wrote %s" % path)
             if os.path.exists(path):
                 log["loaded"] += 1
                 return registry.load(path)
