@@ -398,19 +398,39 @@ def install_early_cache(directory, name, roots, table_mod, fri_mod, rec):
             os._exit(0)
         table_mod.Table.all_quotients = helper_is_done
 
+    class _Pending:
+        """the result of a call another process owns, not needed yet: inside Table.lde / ldex the interpolants and codewords of a table's
+        columns are only collected in lists, so a process can run on to the calls it owns and pick the others' results up at the end"""
+        def __init__(self, path):
+            self.path, self.value, self.loaded = path, None, False
+
+        def resolve(self):
+            if not self.loaded:
+                waited = time.time()
+                while not os.path.exists(self.path):
+                    time.sleep(1.0)
+                    if time.time() - waited > 8 * 3600:
+                        raise RuntimeError("no other process wrote %s" % self.path)
+                self.value, self.loaded = registry.load(self.path), True
+                log["loaded"] += 1
+            return self.value
+
+    def settle(seq):
+        for k, item in enumerate(seq):
+            if isinstance(item, _Pending):
+                seq[k] = item.resolve()
+
     def cached(label, original):
         def call(*args, **kwargs):
             state["seq"] += 1
             path = os.path.join(directory, "%s_early_%04d_%s.pkl" % (name, state["seq"], label))
-            if not os.path.exists(path) and state["seq"] % parties != mine:
-                waited = time.time()
-                while not os.path.exists(path):
-                    time.sleep(1.0)
-                    if time.time() - waited > 6 * 3600:
-                        raise RuntimeError("no other process wrote %s" % path)
             if os.path.exists(path):
                 log["loaded"] += 1
                 return registry.load(path)
+            if state["seq"] % parties != mine:
+                pending = _Pending(path)
+                return pending if state.get("collecting", 0) > 0 else pending.resolve()
+            args = tuple(a.resolve() if isinstance(a, _Pending) else a for a in args)
             t0 = time.time()
             out = original(*args, **kwargs)
             registry.dump(out, path)
@@ -418,6 +438,30 @@ def install_early_cache(directory, name, roots, table_mod, fri_mod, rec):
             print("[early] %s #%d computed in %.0f s" % (label, state["seq"], time.time() - t0), file=sys.stderr, flush=True)
             return out
         return call
+    if parties > 1:
+        plain_lde, plain_ldex = table_mod.Table.lde, table_mod.Table.ldex
+
+        def lde(self, domain):
+            state["collecting"] = state.get("collecting", 0) + 1
+            try:
+                out = plain_lde(self, domain)
+            finally:
+                state["collecting"] -= 1
+            settle(self.codewords)                    # (table.py:138-141: `out` IS self.codewords)
+            if out is not self.codewords:
+                settle(out)
+            return out
+
+        def ldex(self, domain, xfield):
+            state["collecting"] = state.get("collecting", 0) + 1
+            try:
+                out = plain_ldex(self, domain, xfield)
+            finally:
+                state["collecting"] -= 1
+            settle(out)                               # the same _Pending objects sit in both lists: each resolves once, to one object
+            settle(self.codewords)
+            return out
+        table_mod.Table.lde, table_mod.Table.ldex = lde, ldex
     table_mod.fast_interpolate = cached("fast_interpolate", table_mod.fast_interpolate)
     fri_mod.Fri.Domain.evaluate = cached("evaluate", fri_mod.Fri.Domain.evaluate)
     fri_mod.Fri.Domain.xevaluate = cached("xevaluate", fri_mod.Fri.Domain.xevaluate)
