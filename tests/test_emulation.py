@@ -149,6 +149,8 @@ def test_expansion_plans_of_zero_padded_transforms(emu, oracle, logn):
     counts = sorted(c for c in counts if 1 <= c <= n // 16 + 17)
     if logn >= 18:                      # (the host emulation walks every tile of every pass: keep the large sizes to the counts next to n / 64 .. n / 16)
         counts = [c for c in counts if c >= n // 128]
+    if logn >= 20:
+        counts = [c for c in counts if c in (n // 64 + 1, n // 32, n // 16 + 16, n // 16 + 17)]
     for d in counts:
         for shift, scale, src in ((7, 1, v), (1, 1, edge), (3, oracle.inv(n), v)):
             before = emu.emu_set_expand(1)

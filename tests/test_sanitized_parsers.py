@@ -45,7 +45,7 @@ def _no_reports(text):
 def test_byte_level_mutants_of_every_golden_proof(san_env):
     names = sorted(os.path.basename(f)[6:-10] for f in glob.glob(os.path.join(GOLDEN, "stark_*_proof.bin")))
     assert len(names) >= 11
-    workers = max(1, min(6, (os.cpu_count() or 2) - 1, len(names)))
+    workers = max(1, min(8, os.cpu_count() or 2, len(names)))
     # longest proofs first, dealt round-robin: the workers finish together
     names.sort(key=lambda n: -os.path.getsize(os.path.join(GOLDEN, "stark_%s_proof.bin" % n)))
     procs = []
