@@ -257,7 +257,23 @@ def lde_tables(tables, domain, extension=False):
         raw = (_u64 * total)()
         _lib.check(lib.bfs_poly_support(coeffs.ptr, stride, n_in, total, raw, stream))
         masks = [int(v) for v in raw]
-    raw_ntt(coeffs.ptr, n_in, stride, out.ptr, n, log_n, total, omega, offset, 1, stream)
+    if log_n < 20:
+        raw_ntt(coeffs.ptr, n_in, stride, out.ptr, n, log_n, total, omega, offset, 1, stream)
+    else:
+        # large domains: one call per run of tables with the same coefficient count (csrc/prover.cpp: lde_all_tables does the same on the
+        # native path) -- a transform's cost depends on its zero padding (ntt_plan.hpp: 2^16 + 1 coefficients on 2^22 points take the
+        # two-pass expansion plan, 2^17 + 1 the plain three passes), and a table must not pay for its neighbour's height
+        k, first = 0, 0
+        while k < len(tables):
+            count = tables[k].height + (1 if tables[k].num_randomizers else 0) if tables[k].height else 0
+            u, cols = k, 0
+            while u < len(tables) and (tables[u].height + (1 if tables[u].num_randomizers else 0) if tables[u].height else 0) == count:
+                cols += widths[u]
+                u += 1
+            if cols:
+                raw_ntt(coeffs.ptr + 8 * first * stride, min(max(count, 1), n_in), stride, out.ptr + 8 * first * n, n, log_n, cols, omega, offset, 1, stream)
+            first += cols
+            k = u
     from .device import DeviceView
     at = 0
     for t, w, d_in in zip(tables, widths, inputs):
