@@ -18,6 +18,7 @@
 #include <atomic>
 #include <functional>
 #include <memory>
+#include <stdexcept>
 #include <thread>
 #include <string>
 #include <unordered_map>
@@ -485,6 +486,7 @@ class Pickler {
         }
     }
     void save(const Node* n) {
+        if (n == nullptr) throw std::runtime_error("a null object in the graph");        // (never from a graph the reader or the C ABI built)
         opcode_boundary();
         if (n->kind == K_INT) { save_long(n->ival); return; }
         uint32_t seen;
@@ -633,6 +635,7 @@ class Unpickler {
     const unsigned char* p_;
     size_t n_, pos_ = 0;
     std::vector<Ref> stack_, memo_;
+    std::vector<Ref> instances_;       // every object NEWOBJ made: each must have received its state by STOP (see there)
     std::vector<size_t> marks_;
     std::string why_;
 
@@ -783,6 +786,7 @@ class Unpickler {
                     if (!pop(b) || !pop(a) || a->kind != K_CLASS || b->kind != K_TUPLE || !b->items.empty()) { why_ = "NEWOBJ"; return Ref(); }
                     Ref inst = mk(K_INSTANCE);
                     inst->cls = a;
+                    instances_.push_back(inst);
                     stack_.push_back(inst);
                     break;
                 }
@@ -820,8 +824,12 @@ class Unpickler {
                 }
                 case 0x2e:                                                                                // STOP
                     if (stack_.size() != 1 || !marks_.empty()) { why_ = "STOP with a stack of the wrong depth"; return Ref(); }
-                    for (const Ref& m : memo_)
-                        if (m->kind == K_INSTANCE && !m->state) { why_ = "an instance without state"; return Ref(); }
+                    // every instance must have been BUILT: the writer dereferences an instance's state.  (Until round 6 only the
+                    // MEMOISED instances were checked here; a stream whose NEWOBJ is followed by neither MEMOIZE nor BUILD -- two byte
+                    // mutations of a proof -- put an instance without state into the graph and the round-trip check of bfs_ps_loads
+                    // crashed on it: found by tests/test_sanitized_parsers.py.)
+                    for (const Ref& m : instances_)
+                        if (!m->state) { why_ = "an instance without state"; return Ref(); }
                     return stack_.back();
                 default: {
                     char buf[48];

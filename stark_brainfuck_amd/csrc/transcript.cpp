@@ -41,7 +41,14 @@ void* bfs_ps_loads(const uint8_t* data, size_t len) {
         t->objects.push_back(item);
     }
     t->loaded_from_bytes = true;
-    const std::string again = t->serialize(t->objects.size());
+    std::string again;
+    try {
+        again = t->serialize(t->objects.size());
+    } catch (const std::exception& e) {       // (the writer refuses a graph it cannot walk: never seen from the reader, kept as a net)
+        delete t;
+        set_error("bfs_ps_loads: %s", e.what());
+        return nullptr;
+    }
     if (again.size() != len || memcmp(again.data(), data, len) != 0) {
         delete t;
         set_error("bfs_ps_loads: the stream does not serialise back to the same %zu bytes", len);

@@ -690,6 +690,28 @@ def test_verify_on_the_host_accepts_reference_proofs_and_rejects_tampering(name)
         pass
 
 
+def test_an_instance_that_was_never_built_is_refused_by_the_native_reader():
+    """found by tests/test_sanitized_parsers.py in round 6: NEWOBJ followed by neither MEMOIZE nor BUILD leaves an instance without state
+    in the graph; only memoised instances were checked at STOP, and the round-trip check of bfs_ps_loads dereferenced the missing state
+    (SIGSEGV on two byte mutations of a reference proof).  The reader refuses such a stream now -- the synthetic one below and the fuzzer's
+    own input (tests/golden/hostile_unbuilt_instance.bin, a mutated reference proof) -- and verify() falls back to the Python route, which
+    rejects it like any other malformed proof."""
+    from stark_brainfuck_amd import _lib
+    from stark_brainfuck_amd.ip import NativeTranscript
+    tiny = b"\x80\x04]\x8c\x07algebra\x8c\tBaseField\x93)\x81a."
+    assert NativeTranscript.from_bytes(tiny) is None
+    assert b"an instance without state" in _lib.load().bfs_last_error()
+    hostile = open(os.path.join(GOLDEN, "hostile_unbuilt_instance.bin"), "rb").read()
+    assert NativeTranscript.from_bytes(hostile) is None
+    assert b"an instance without state" in _lib.load().bfs_last_error()
+    from tools.fuzz_proofs import stark_of
+    for name in ("mul34", "two_io"):
+        try:
+            assert stark_of(name).verify(hostile) is not True
+        except Exception:       # noqa: BLE001 -- the reference's verifier raises on malformed streams too
+            pass
+
+
 @pytest.mark.parametrize("native", ["1", "0"])
 def test_terminal_stored_as_v_plus_p_gets_the_reference_verdict(native, monkeypatch):
     """round-5 advice.  tests/golden/noncanonical_terminal_proof.bin was written by the REFERENCE's prover (gen_noncanonical_terminal.py)

@@ -27,6 +27,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 INTERESTING = [0x00, 0x01, 0x7F, 0x80, 0xFF, 0x2E, 0x28, 0x29, 0x5D, 0x61, 0x65, 0x85, 0x86, 0x87, 0x8A, 0x8B, 0x42, 0x43, 0x8E, 0x94, 0x95,
                0x68, 0x6A, 0x71, 0x72, 0x4A, 0x4B, 0x4D, 0x51, 0x52, 0x62, 0x81, 0x93, 0x8C, 0x58, 0x30, 0x31, 0x32, 0x4E, 0x74, 0x75]
+SAVE_LAST = os.environ.get("BFS_FUZZ_SAVE_LAST")
 WORDS = [0, 1, 2, 0x7FFFFFFF, 0x80000000, 0xFFFFFFFF, 0xFFFFFFFE, 64, 65, 255, 256, 1 << 20, 1 << 24, 1 << 30]
 
 
@@ -108,6 +109,9 @@ def fuzz_one(name, mutants, seed, python_sample, others):
         if mut == proof:
             continue
         stats["mutants"] += 1
+        if SAVE_LAST:
+            with open(SAVE_LAST, "wb") as f:          # a crash leaves the input that caused it behind
+                f.write(mut)
         t = NativeTranscript.from_bytes(mut)
         if t is None and i % 2 == 1:
             # every other mutant is made to REACH the verifier: four out of five random mutants die in the reader's framing checks, so
@@ -120,6 +124,9 @@ def fuzz_one(name, mutants, seed, python_sample, others):
                     ks.append(k)
                     b[k] = b[k] ^ (1 << rnd.randrange(8)) if rnd.random() < 0.6 else rnd.randrange(256)
                 mut = bytes(b)
+                if SAVE_LAST:
+                    with open(SAVE_LAST, "wb") as f:
+                        f.write(mut)
                 t = NativeTranscript.from_bytes(mut) if mut != proof else None
                 if t is not None:
                     stats["steered_into_verifier"] += 1
