@@ -19,7 +19,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
-MUTANTS = int(os.environ.get("BFS_FUZZ_MUTANTS", "2000"))      # per proof; BFS_FUZZ_MUTANTS=5000 is the long form (5.5 min on eight cores, run at the end of round 6)
+MUTANTS = int(os.environ.get("BFS_FUZZ_MUTANTS", "2000"))      # per proof; BFS_FUZZ_MUTANTS=5000 is the long form (about 3 min on eight idle cores; run four times on the last code of round 6)
 REPORT_MARKS = ("ERROR: AddressSanitizer", "runtime error:", "SUMMARY: UndefinedBehaviorSanitizer", "SUMMARY: AddressSanitizer")
 
 
