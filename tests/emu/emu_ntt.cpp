@@ -155,6 +155,15 @@ extern "C" int emu_plan(u32 log_n, u64 root, u32* npass, u32* bits, u32* logc, u
     return 0;
 }
 
+// what ntt_launch decides for a zero-padded transform (no arithmetic): 0 the plain plan, 1 an expansion plan; main_bits / extras as planned
+extern "C" int emu_expand_plan(u32 log_n, u64 n_in, u64 root, u32* main_bits, u32* extras) {
+    NttPlan p, xp;
+    if (!ntt_make_plan(log_n, root, p) || p.npass == 0) return 0;
+    if (!ntt_make_expand_plan(log_n, n_in, root, p, xp)) return 0;
+    *main_bits = xp.main_bits; *extras = xp.extras;
+    return 1;
+}
+
 // the twiddle schedule of three-pass plans: -1 environment, 0 load-time, 1 balanced; returns what a plan for log_n then uses
 extern "C" int emu_set_schedule(int mode, u32 log_n, u64 root) {
     ntt_schedule_override() = mode;
